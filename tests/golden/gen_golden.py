@@ -1,0 +1,351 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the *reference itself* (CoderWZW/ARLib, mounted read-only at
+/root/reference) on CPU in this container and stores inputs + expected outputs as small .npz
+fixtures next to this script.  The reference never travels to the GPU box; these fixtures do.
+
+Only data is written (inputs and expected outputs); no reference source is copied.
+
+Harness-side shims (the reference hard-codes .cuda() and imports numba):
+  * sys.modules['numba'] = stub with an identity `jit`
+  * torch.Tensor.cuda / nn.Module.cuda = identity
+  * SimGCL noise: torch.rand_like is patched *during the reference call* to hand out
+    pre-generated tensors so the product can be fed the same noise.
+
+Usage:  python tests/golden/gen_golden.py            (writes tests/golden/*.npz)
+"""
+import os, sys, types, random, hashlib, tempfile, copy
+from types import SimpleNamespace
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+
+numba_stub = types.ModuleType('numba')
+numba_stub.jit = lambda *a, **k: (lambda f: f)
+sys.modules['numba'] = numba_stub
+
+import numpy as np
+import torch
+import scipy.sparse as sp
+
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.nn.Module.cuda = lambda self, *a, **k: self
+torch.set_num_threads(4)
+
+# the reference writes ./log, ./modelsaved, ./data/... relative to cwd
+SCRATCH = tempfile.mkdtemp(prefix='arl_golden_')
+os.chdir(SCRATCH)
+os.makedirs('data/clean', exist_ok=True)
+os.symlink(os.path.join(REF, 'data/clean/ml-100k'), 'data/clean/ml-100k-ro')
+
+from util.tool import seedSet                      # noqa: E402
+from util.DataLoader import DataLoader             # noqa: E402
+from util import sampler as ref_sampler            # noqa: E402
+from util import loss as ref_loss                  # noqa: E402
+from recommender.GMF import GMF                    # noqa: E402
+from recommender.LightGCN import LightGCN          # noqa: E402
+from recommender.SimGCL import SimGCL              # noqa: E402
+
+
+def rec_args(**kw):
+    a = dict(dataset='ml-100k', data_path=REF + '/data/clean/', training_data='/train.txt',
+             val_data='/val.txt', test_data='/test.txt', model_name='LightGCN', maxEpoch=30,
+             batch_size=2048, emb_size=64, n_layers=3, reg=1e-4, lRate=0.005, dropout=True,
+             dropout_rate=0.3, cuda=True, gpu_id='0', seed=2018, topK='50', load=False, save=False,
+             save_dir='./modelsaved/')
+    a.update(kw)
+    return SimpleNamespace(**a)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print('wrote %s (%.1f KB)' % (name, os.path.getsize(path) / 1024))
+
+
+def sha_batches(batches):
+    h = hashlib.sha256()
+    for u, p, n in batches:
+        h.update(np.asarray([u, p, n], dtype=np.int32).tobytes())
+    return h.hexdigest()
+
+
+# --------------------------------------------------------------------------- dataset (data, not code)
+def gen_dataset():
+    def raw(fn):
+        rows = [l.split() for l in open(REF + '/data/clean/ml-100k/' + fn)]
+        return (np.array([int(r[0]) for r in rows], np.int32), np.array([int(r[1]) for r in rows], np.int32),
+                np.array([float(r[2]) for r in rows], np.float32))
+    tu, ti, tr = raw('train.txt')
+    vu, vi, vr = raw('val.txt')
+    su, si, sr = raw('test.txt')
+    save('ml100k_data.npz', train_u=tu, train_i=ti, train_r=tr, val_u=vu, val_i=vi, val_r=vr,
+         test_u=su, test_i=si, test_r=sr)
+
+
+# --------------------------------------------------------------------------- G1 sampler
+def gen_sampler():
+    args = rec_args()
+    seedSet(2018)
+    data = DataLoader(args)
+    out = {}
+    U, I, nnz = data.training_size()
+    out['sizes'] = np.array([U, I, nnz], np.int64)
+    # internal ids of the file-order training pairs (pre-shuffle)
+    out['pairs0'] = np.array([[data.user[r[0]], data.item[r[1]]] for r in data.training_data], np.int32)
+    random.seed(2018)
+    for ep in range(2):                          # second epoch pins the in-place shuffle carry-over (Q7)
+        bs = list(ref_sampler.next_batch_pairwise(data, 2048))
+        out['ep%d_u' % ep] = np.concatenate([np.asarray(b[0], np.int32) for b in bs])
+        out['ep%d_p' % ep] = np.concatenate([np.asarray(b[1], np.int32) for b in bs])
+        out['ep%d_n' % ep] = np.concatenate([np.asarray(b[2], np.int32) for b in bs])
+        out['ep%d_sha' % ep] = np.frombuffer(sha_batches(bs).encode(), np.uint8)
+        out['ep%d_nb' % ep] = np.array([len(bs), len(bs[-1][0])], np.int64)
+    out['next_random'] = np.array([random.random()], np.float64)
+    st = random.getstate()
+    out['mt_state_after'] = np.array(st[1], np.uint32)
+    # ragged batch size + different seed
+    random.seed(7)
+    bs = list(ref_sampler.next_batch_pairwise(data, 1000))
+    out['b1000_u'] = np.concatenate([np.asarray(b[0], np.int32) for b in bs])
+    out['b1000_p'] = np.concatenate([np.asarray(b[1], np.int32) for b in bs])
+    out['b1000_n'] = np.concatenate([np.asarray(b[2], np.int32) for b in bs])
+    out['b1000_next_random'] = np.array([random.random()], np.float64)
+    save('g1_sampler.npz', **out)
+
+    # heavy-rejection toy: 6 users x 5 items, most users hold 4 of 5 items
+    toy = SimpleNamespace()
+    pairs = [(u, i) for u in range(6) for i in range(5) if (u + i) % 5 != 0 or u == 5]
+    pairs = [p for p in pairs if not (p[0] == 5 and p[1] >= 2)]
+    toy.user, toy.item = {}, {}
+    toy.training_data = []
+    from collections import defaultdict
+    toy.training_set_u = defaultdict(dict)
+    for u, i in pairs:
+        us, it = 'u%d' % u, 'i%d' % i
+        if us not in toy.user: toy.user[us] = len(toy.user)
+        if it not in toy.item: toy.item[it] = len(toy.item)
+        toy.training_data.append([us, it, 1.0])
+        toy.training_set_u[us][it] = 1.0
+    o = {'pairs0': np.array([[toy.user[r[0]], toy.item[r[1]]] for r in toy.training_data], np.int32),
+         'sizes': np.array([len(toy.user), len(toy.item), len(toy.training_data)], np.int64)}
+    random.seed(12345678901234567890)             # > 64-bit seed exercises init_by_array with 3 key words
+    us, ps, ns = [], [], []
+    for ep in range(5):
+        for b in ref_sampler.next_batch_pairwise(toy, 7):
+            us += b[0]; ps += b[1]; ns += b[2]
+    o['u'], o['p'], o['n'] = (np.array(x, np.int32) for x in (us, ps, ns))
+    o['next_random'] = np.array([random.random()], np.float64)
+    save('g1_sampler_toy.npz', **o)
+    return data
+
+
+# --------------------------------------------------------------------------- G2 / G6 losses
+def gen_losses():
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    B, d = 2048, 64
+    for tag, scale, B in (('n', 0.1, 1024), ('sat', 6.0, 256)):   # 'sat' drives |x| > 30: sigmoid saturation + 1e-7 eps
+        u = (torch.randn(B, d, generator=g) * scale).requires_grad_()
+        p = (torch.randn(B, d, generator=g) * scale).requires_grad_()
+        n = (torch.randn(B, d, generator=g) * scale).requires_grad_()
+        l = ref_loss.bpr_loss(u, p, n)
+        r = ref_loss.l2_reg_loss(1e-4, u, p)
+        (l + r).backward()
+        out.update({tag + '_u': u.detach().numpy(), tag + '_p': p.detach().numpy(), tag + '_n': n.detach().numpy(),
+                    tag + '_bpr': np.array([l.item()], np.float32), tag + '_reg': np.array([r.item()], np.float32),
+                    tag + '_du': u.grad.numpy(), tag + '_dp': p.grad.numpy(), tag + '_dn': n.grad.numpy()})
+    # gather form with duplicate indices (scatter-add accumulates duplicates)
+    T = torch.randn(300, d, generator=g) * 0.1
+    T.requires_grad_()
+    B = 2048
+    ui = torch.randint(0, 100, (B,), generator=g)
+    pi = torch.randint(100, 300, (B,), generator=g)
+    ni = torch.randint(100, 300, (B,), generator=g)
+    l = ref_loss.bpr_loss(T[ui], T[pi], T[ni]) + ref_loss.l2_reg_loss(1e-4, T[ui], T[pi])
+    l.backward()
+    out.update(dup_T=T.detach().numpy(), dup_ui=ui.numpy().astype(np.int32), dup_pi=pi.numpy().astype(np.int32),
+               dup_ni=ni.numpy().astype(np.int32), dup_loss=np.array([l.item()], np.float32), dup_dT=T.grad.numpy())
+    save('g2_losses.npz', **out)
+
+    out = {}
+    for tag, n_, d_ in (('a', 700, 64), ('b', 2048, 16), ('c', 33, 16)):
+        v1 = torch.randn(n_, d_, generator=g).requires_grad_()
+        v2 = torch.randn(n_, d_, generator=g).requires_grad_()
+        l = ref_loss.InfoNCE(v1, v2, 0.2)
+        l.backward()
+        out.update({tag + '_v1': v1.detach().numpy(), tag + '_v2': v2.detach().numpy(),
+                    tag + '_loss': np.array([l.item()], np.float32),
+                    tag + '_dv1': v1.grad.numpy(), tag + '_dv2': v2.grad.numpy()})
+    save('g6_infonce.npz', **out)
+
+
+# --------------------------------------------------------------------------- G3 adjacency
+def gen_adj(data):
+    na = data.norm_adj.tocsr()
+    na.sort_indices()
+    out = dict(norm_indptr=na.indptr.astype(np.int64), norm_indices=na.indices.astype(np.int32),
+               norm_data=na.data.astype(np.float32))
+    # _init_uiAdj on a weighted symmetric adjacency with fractional weights and one isolated node
+    rng = np.random.RandomState(5)
+    U_, I_ = 50, 40
+    R = sp.random(U_, I_, density=0.15, random_state=rng, format='lil', dtype=np.float32)
+    R[7, :] = 0                                    # isolated user -> 1/sqrt(0)=inf, no guard (Q15)
+    R = R.tocsr(); R.eliminate_zeros()
+    A = sp.bmat([[None, R], [R.T, None]], format='csr', dtype=np.float32)
+    args = rec_args(emb_size=8, n_layers=2)
+    m = LightGCN(args, data).model
+    with np.errstate(divide='ignore'):
+        m._init_uiAdj(A)
+    t = m.sparse_norm_adj.coalesce()
+    Rc = R.tocoo()
+    out.update(w_R_row=Rc.row.astype(np.int32), w_R_col=Rc.col.astype(np.int32), w_R_val=Rc.data.astype(np.float32),
+               w_shape=np.array([U_, I_], np.int64),
+               w_norm_row=t.indices()[0].numpy().astype(np.int32), w_norm_col=t.indices()[1].numpy().astype(np.int32),
+               w_norm_val=t.values().numpy())
+    save('g3_adj.npz', **out)
+
+
+# --------------------------------------------------------------------------- G4 forward / G5 steps
+def gen_forward_and_steps(data):
+    out = {}
+    seedSet(2018)
+    for L in (1, 2, 3):
+        args = rec_args(emb_size=32, n_layers=L)
+        rec = LightGCN(args, data)
+        if L == 1:
+            out['lgn_user0'] = rec.model.embedding_dict['user_emb'].detach().numpy().copy()
+            out['lgn_item0'] = rec.model.embedding_dict['item_emb'].detach().numpy().copy()
+        with torch.no_grad():       # same tables for every L
+            rec.model.embedding_dict['user_emb'][:] = torch.from_numpy(out['lgn_user0'])
+            rec.model.embedding_dict['item_emb'][:] = torch.from_numpy(out['lgn_item0'])
+            ue, ie = rec.model()
+        out['lgn_L%d_user' % L] = ue.numpy().copy()
+        out['lgn_L%d_item' % L] = ie.numpy().copy()
+    save('g4_forward.npz', **out)
+
+    # --- G5: k training steps, exactly the reference loop body (LightGCN.py:47-64 / GMF.py:39-54)
+    def run_steps(cls, args, k_snap, opt='adam'):
+        seedSet(2018)
+        rec = cls(args, data)
+        model = rec.model
+        if opt == 'adam':
+            optim = torch.optim.Adam(model.parameters(), lr=args.lRate)
+        else:
+            optim = torch.optim.SGD(model.parameters(), lr=args.lRate / 10)     # PGA.py:59
+        o = {'user0': model.embedding_dict['user_emb'].detach().numpy().copy(),
+             'item0': model.embedding_dict['item_emb'].detach().numpy().copy()}
+        losses, bu, bp, bn = [], [], [], []
+        random.seed(2018)
+        d2 = copy.copy(data); d2.training_data = [list(r) for r in data_training0]
+        step = 0
+        done = False
+        while not done:
+            for batch in ref_sampler.next_batch_pairwise(d2, args.batch_size):
+                user_idx, pos_idx, neg_idx = batch
+                rec_user_emb, rec_item_emb = model()
+                user_emb, pos_item_emb, neg_item_emb = rec_user_emb[user_idx], rec_item_emb[pos_idx], rec_item_emb[neg_idx]
+                batch_loss = ref_loss.bpr_loss(user_emb, pos_item_emb, neg_item_emb) + \
+                    ref_loss.l2_reg_loss(args.reg, user_emb, pos_item_emb)
+                optim.zero_grad()
+                batch_loss.backward()
+                if step == 0:
+                    o['grad_user_step0'] = model.embedding_dict['user_emb'].grad.numpy().copy()
+                    o['grad_item_step0'] = model.embedding_dict['item_emb'].grad.numpy().copy()
+                optim.step()
+                losses.append(batch_loss.item())
+                bu.append(np.asarray(user_idx, np.int32)); bp.append(np.asarray(pos_idx, np.int32)); bn.append(np.asarray(neg_idx, np.int32))
+                step += 1
+                if step in k_snap:
+                    o['user_k%d' % step] = model.embedding_dict['user_emb'].detach().numpy().copy()
+                    o['item_k%d' % step] = model.embedding_dict['item_emb'].detach().numpy().copy()
+                    if opt == 'adam' and step == max(k_snap):
+                        st = optim.state[model.embedding_dict['user_emb']]
+                        o['m_user'] = st['exp_avg'].numpy().copy(); o['v_user'] = st['exp_avg_sq'].numpy().copy()
+                        st = optim.state[model.embedding_dict['item_emb']]
+                        o['m_item'] = st['exp_avg'].numpy().copy(); o['v_item'] = st['exp_avg_sq'].numpy().copy()
+                if step >= max(k_snap):
+                    done = True
+                    break
+        o['losses'] = np.array(losses, np.float32)
+        o['batch_u'] = np.concatenate(bu); o['batch_p'] = np.concatenate(bp); o['batch_n'] = np.concatenate(bn)
+        o['batch_sizes'] = np.array([len(x) for x in bu], np.int64)
+        return o
+
+    o = run_steps(LightGCN, rec_args(emb_size=64, n_layers=3), {1, 3, 10})
+    assert abs(o['losses'][0] - 0.6937738) < 1e-5, o['losses'][0]      # SURVEY 8c anchor
+    save('g5_lightgcn_adam.npz', **o)
+    o = run_steps(GMF, rec_args(emb_size=64, model_name='GMF'), {3, 25})   # 25 > one epoch (22 batches)
+    save('g5_gmf_adam.npz', **o)
+    o = run_steps(LightGCN, rec_args(emb_size=16, n_layers=2), {3}, opt='sgd')
+    save('g5_lightgcn_sgd.npz', **o)
+
+
+# --------------------------------------------------------------------------- SimGCL with injected noise
+def gen_simgcl(data):
+    args = rec_args(emb_size=16, n_layers=2, model_name='SimGCL')
+    seedSet(2018)
+    rec = SimGCL(args, data)
+    model = rec.model
+    N = data.user_num + data.item_num
+    g = torch.Generator().manual_seed(77)
+    noises = [torch.rand(N, 16, generator=g) for _ in range(4)]       # 2 views x 2 hops, in call order
+    o = {'user0': model.embedding_dict['user_emb'].detach().numpy().copy(),
+         'item0': model.embedding_dict['item_emb'].detach().numpy().copy(),
+         'noise': torch.stack(noises).numpy()}
+    random.seed(2018)
+    d2 = copy.copy(data); d2.training_data = [list(r) for r in data_training0]
+    batch = next(iter(ref_sampler.next_batch_pairwise(d2, 2048)))
+    user_idx, pos_idx, neg_idx = batch
+    orig = torch.rand_like
+    it = iter(noises)
+    torch.rand_like = lambda x, *a, **k: next(it)
+    try:
+        optim = torch.optim.Adam(model.parameters(), lr=args.lRate)
+        rec_user_emb, rec_item_emb = model()
+        user_emb, pos_item_emb, neg_item_emb = rec_user_emb[user_idx], rec_item_emb[pos_idx], rec_item_emb[neg_idx]
+        rec_loss = ref_loss.bpr_loss(user_emb, pos_item_emb, neg_item_emb)
+        cl_loss = rec.cl_rate * model.cal_cl_loss([user_idx, pos_idx])
+        batch_loss = rec_loss + ref_loss.l2_reg_loss(args.reg, user_emb, pos_item_emb) + cl_loss
+        optim.zero_grad()
+        batch_loss.backward()
+        o['grad_user'] = model.embedding_dict['user_emb'].grad.numpy().copy()
+        o['grad_item'] = model.embedding_dict['item_emb'].grad.numpy().copy()
+        optim.step()
+    finally:
+        torch.rand_like = orig
+    o['rec_loss'] = np.array([rec_loss.item()], np.float32)
+    o['cl_loss'] = np.array([cl_loss.item()], np.float32)
+    o['user_k1'] = model.embedding_dict['user_emb'].detach().numpy().copy()
+    o['item_k1'] = model.embedding_dict['item_emb'].detach().numpy().copy()
+    o['batch_u'] = np.asarray(user_idx, np.int32); o['batch_p'] = np.asarray(pos_idx, np.int32); o['batch_n'] = np.asarray(neg_idx, np.int32)
+    # forward-only outputs (unperturbed + perturbed with noises[0:2]) from the *initial* tables
+    seedSet(2018)
+    rec2 = SimGCL(args, data)
+    with torch.no_grad():
+        u0, i0 = rec2.model()
+        it2 = iter(noises[:2])
+        torch.rand_like = lambda x, *a, **k: next(it2)
+        try:
+            u1, i1 = rec2.model(perturbed=True)
+        finally:
+            torch.rand_like = orig
+    o['fwd_user'] = u0.numpy().copy(); o['fwd_item'] = i0.numpy().copy()
+    o['fwdp_user'] = u1.numpy().copy(); o['fwdp_item'] = i1.numpy().copy()
+    save('g5_simgcl.npz', **o)
+
+
+if __name__ == '__main__':
+    gen_dataset()
+    data = gen_sampler()
+    # the sampler shuffled data.training_data in place; keep a pristine file-order copy for the step fixtures
+    args0 = rec_args()
+    data = DataLoader(args0)
+    data_training0 = [list(r) for r in data.training_data]
+    gen_losses()
+    gen_adj(data)
+    gen_forward_and_steps(data)
+    gen_simgcl(data)
+    print('done; scratch dir', SCRATCH)
