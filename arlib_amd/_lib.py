@@ -1,0 +1,79 @@
+"""ctypes loader for the in-tree libarlib_amd.so (C ABI declared in include/arlib_amd.h).
+
+There is no CPU fallback: if the HIP library is missing every op raises.  Build it with
+`python -c "import __graft_entry__ as g; g.build()"` or `make -C arlib_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libarlib_amd.so')
+ABI_VERSION = 1
+_lib = None
+
+
+class ArlError(RuntimeError):
+    pass
+
+
+class arl_csr(C.Structure):
+    _fields_ = [('n_rows', C.c_int64), ('nnz', C.c_int64), ('rowptr', C.c_void_p), ('col', C.c_void_p), ('val', C.c_void_p),
+                ('chunk', C.c_int32), ('n_chunks', C.c_int64), ('chunk_row', C.c_void_p), ('chunk_begin', C.c_void_p),
+                ('chunk_end', C.c_void_p), ('n_long', C.c_int64), ('long_row', C.c_void_p), ('long_first', C.c_void_p),
+                ('long_count', C.c_void_p), ('partial', C.c_void_p)]
+
+
+_vp, _i64, _i32, _f = C.c_void_p, C.c_int64, C.c_int32, C.c_float
+_SIGS = {
+    'arl_abi_version': (C.c_int, []),
+    'arl_mt_seed': (C.c_int, [_vp, _vp, _i64]),
+    'arl_sampler_shuffle': (C.c_int, [_vp, _vp, _i64]),
+    'arl_sampler_next_batch': (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp]),
+    'arl_norm_adj_values_f32': (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'arl_spmm_csr_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _f, _f, _vp, _vp, _vp]),
+    'arl_spmm_csr_layersum_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _vp, _vp, _vp, _vp]),
+    'arl_spmm_csr_adam_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),
+    'arl_bpr_l2_workspace_bytes': (_i64, [_i64]),
+    'arl_bpr_l2_fwd_bwd_f32': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _f, _f, _vp, _vp, _vp, _vp]),
+    'arl_adam_dense_f32': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i64, _vp]),
+    'arl_sgd_dense_f32': (C.c_int, [_vp, _vp, _i64, _f, _vp]),
+    'arl_gather_rows_f32': (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    'arl_scatter_add_rows_f32': (C.c_int, [_vp, _vp, _i64, _i64, _vp, _f, _vp]),
+    'arl_infonce_workspace_bytes': (_i64, [_i64, _i64]),
+    'arl_infonce_fwd_bwd_f32': (C.c_int, [_vp, _vp, _i64, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    'arl_simgcl_perturb_f32': (C.c_int, [_vp, _vp, _i64, _i64, _f, _vp]),
+    'arl_sddmm_rows_dense_f32': (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp]),
+    'arl_pga_update_f32': (C.c_int, [_vp, _vp, _i64, _vp]),
+    'arl_score_mask_topk_f32': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
+    'arl_topn_project_rows_f32': (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def lib():
+    """Load libarlib_amd.so or fail loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ArlError('arlib_amd: %s is missing -- the HIP extension is the product and there is no CPU fallback. '
+                           'Build it with `make -C arlib_amd/csrc` (hipcc --offload-arch=gfx950).' % LIB_PATH)
+        # torch bundles its own libamdhip64.so (SONAME libamdhip64.so.7).  It must be loaded first so that our NEEDED
+        # entry resolves to that same runtime instance: two HIP runtimes in one process do not share device state.
+        import torch  # noqa: F401
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)            # AttributeError here = ABI mismatch: fail loudly
+            fn.restype, fn.argtypes = res, args
+        if l.arl_abi_version() != ABI_VERSION:
+            raise ArlError('arlib_amd: ABI version mismatch (lib %d, python %d): rebuild' % (l.arl_abi_version(), ABI_VERSION))
+        _lib = l
+    return _lib
+
+
+_ERR = {-1: 'ARL_E_NULL (required pointer is NULL)', -2: 'ARL_E_DIM (unsupported embedding size/shape)',
+        -3: 'ARL_E_RANGE (size outside the int32 index range)', -4: 'ARL_E_ARG (inconsistent arguments)'}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise ArlError('%s failed: %s' % (what, _ERR.get(rc, 'hipError_t %d' % rc)))

@@ -1,0 +1,134 @@
+// arl_host.cpp -- host side of libarlib_amd.so: the bit-exact BPR pair sampler.
+//
+// Replaces util/sampler.py:4-30 (next_batch_pairwise).  The reference draws from CPython's global
+// `random` (MT19937, seeded by util/tool.py:101-108).  To stay a drop-in, the caller hands us
+// random.getstate()[1] (624 words + index), we advance it exactly as CPython would, and the caller
+// puts it back with random.setstate().  Sequential by nature (rejection loops consume a
+// data-dependent number of draws), so this lives on the host and feeds the GPU through pinned
+// buffers; it costs ~10 ns per draw versus ~2.5 us per sample in the reference's Python loop.
+#include <cstdint>
+#include <cstddef>
+#include "arlib_amd.h"
+
+namespace {
+
+// View over a CPython MT19937 state vector (624 words followed by the read position).
+class PyMersenne {
+public:
+    explicit PyMersenne(uint32_t *state) : w_(state), pos_(state[kN]) {}
+    ~PyMersenne() { w_[kN] = pos_; }
+
+    uint32_t next32() {
+        if (pos_ >= kN) refill();
+        uint32_t y = w_[pos_++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        return y ^ (y >> 18);
+    }
+
+    // Random._randbelow_with_getrandbits for n < 2^32: draw bit_length(n) top bits until < n.
+    uint32_t below(uint32_t n) {
+        if (n == 0) return 0;
+        const int shift = __builtin_clz(n);          // 32 - bit_length(n)
+        uint32_t r;
+        do { r = next32() >> shift; } while (r >= n);
+        return r;
+    }
+
+    static void seed_by_array(uint32_t *w, const uint32_t *key, int64_t len) {
+        w[0] = 19650218u;
+        for (uint32_t i = 1; i < kN; ++i) w[i] = 1812433253u * (w[i - 1] ^ (w[i - 1] >> 30)) + i;
+        uint32_t i = 1;
+        int64_t j = 0;
+        for (int64_t k = (len > (int64_t)kN ? len : (int64_t)kN); k > 0; --k) {
+            w[i] = (w[i] ^ ((w[i - 1] ^ (w[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+            if (++i >= kN) { w[0] = w[kN - 1]; i = 1; }
+            if (++j >= len) j = 0;
+        }
+        for (uint32_t k = kN - 1; k > 0; --k) {
+            w[i] = (w[i] ^ ((w[i - 1] ^ (w[i - 1] >> 30)) * 1566083941u)) - i;
+            if (++i >= kN) { w[0] = w[kN - 1]; i = 1; }
+        }
+        w[0] = 0x80000000u;
+        w[kN] = kN;
+    }
+
+private:
+    static constexpr uint32_t kN = 624, kM = 397;
+    static uint32_t twist(uint32_t hi, uint32_t lo, uint32_t far) {
+        const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+        return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    void refill() {
+        for (uint32_t k = 0; k < kN - kM; ++k) w_[k] = twist(w_[k], w_[k + 1], w_[k + kM]);
+        for (uint32_t k = kN - kM; k < kN - 1; ++k) w_[k] = twist(w_[k], w_[k + 1], w_[k + kM - kN]);
+        w_[kN - 1] = twist(w_[kN - 1], w_[0], w_[kM - 1]);
+        pos_ = 0;
+    }
+    uint32_t *w_;
+    uint32_t pos_;
+};
+
+// `item in training_set_u[user]` on the CSR image of the dict-of-dicts (sorted item ids per user).
+inline bool user_has_item(const int64_t *rowptr, const int32_t *items, int64_t rows, int32_t user, int32_t item) {
+    if (user < 0 || user >= rows) return false;
+    const int32_t *lo = items + rowptr[user], *hi = items + rowptr[user + 1];
+    while (lo < hi) {
+        const int32_t *mid = lo + (hi - lo) / 2;
+        if (*mid < item) lo = mid + 1; else hi = mid;
+    }
+    return lo < items + rowptr[user + 1] && *lo == item;
+}
+
+}  // namespace
+
+extern "C" {
+
+int arl_abi_version(void) { return 1; }
+
+int arl_mt_seed(uint32_t *mt_state, const uint32_t *key, int64_t key_len) {
+    if (!mt_state || !key) return ARL_E_NULL;
+    if (key_len < 1) return ARL_E_ARG;
+    PyMersenne::seed_by_array(mt_state, key, key_len);
+    return ARL_OK;
+}
+
+int arl_sampler_shuffle(uint32_t *mt_state, int32_t *pairs, int64_t nnz) {
+    if (!mt_state || (!pairs && nnz > 0)) return ARL_E_NULL;
+    if (nnz < 0 || nnz > 0xFFFFFFFFll) return ARL_E_RANGE;
+    if (mt_state[624] > 624) return ARL_E_ARG;
+    PyMersenne rng(mt_state);
+    // random.shuffle: for i in reversed(range(1, n)): j = randbelow(i + 1); x[i], x[j] = x[j], x[i]
+    int64_t *rows = reinterpret_cast<int64_t *>(pairs);      // one (user,item) pair = 8 bytes
+    const bool aligned = (reinterpret_cast<uintptr_t>(pairs) & 7u) == 0;
+    for (int64_t i = nnz - 1; i >= 1; --i) {
+        const int64_t j = rng.below((uint32_t)(i + 1));
+        if (aligned) {
+            const int64_t t = rows[i]; rows[i] = rows[j]; rows[j] = t;
+        } else {
+            for (int c = 0; c < 2; ++c) { const int32_t t = pairs[2 * i + c]; pairs[2 * i + c] = pairs[2 * j + c]; pairs[2 * j + c] = t; }
+        }
+    }
+    return ARL_OK;
+}
+
+int arl_sampler_next_batch(uint32_t *mt_state, const int32_t *pairs, int64_t begin, int64_t count, int32_t n_items,
+                           const int64_t *memb_rowptr, const int32_t *memb_items, int64_t memb_rows,
+                           int32_t *out_u, int32_t *out_p, int32_t *out_n) {
+    if (!mt_state || !pairs || !out_u || !out_p || !out_n) return ARL_E_NULL;
+    if (memb_rows > 0 && (!memb_rowptr || !memb_items)) return ARL_E_NULL;
+    if (begin < 0 || count < 0 || n_items <= 0) return ARL_E_ARG;
+    if (mt_state[624] > 624) return ARL_E_ARG;
+    PyMersenne rng(mt_state);
+    for (int64_t b = 0; b < count; ++b) {
+        const int32_t user = pairs[2 * (begin + b)], pos = pairs[2 * (begin + b) + 1];
+        int32_t neg;
+        do { neg = (int32_t)rng.below((uint32_t)n_items); }
+        while (user_has_item(memb_rowptr, memb_items, memb_rows, user, neg));
+        out_u[b] = user; out_p[b] = pos; out_n[b] = neg;
+    }
+    return ARL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,908 @@
+// arl_kernels.hip -- gfx950 (MI355X / CDNA4) kernels behind the C ABI in include/arlib_amd.h.
+//
+// Everything here is HBM/L2-bound gather/scatter/streaming work on fp32 rows (no MFMA: these are sparse
+// gathers, not dense contractions).  Design rules used throughout (cdna_hip_programming.md):
+//   * wavefront = 64 lanes; one embedding row of d floats is owned by LPR = d/4 lanes holding a float4
+//     each, so a wave moves 64/LPR rows per 1-KiB dwordx4 load instruction (d = 64 -> 4 rows/instr);
+//   * no LDS round trips for the SpMM: edge (col,val) pairs are loaded coalesced 64 at a time and
+//     broadcast with ds_bpermute (__shfl), partial rows are combined with wave shuffles;
+//   * several independent gathers in flight per lane (UNROLL) to cover Infinity-Cache/HBM latency;
+//   * >> 256 workgroups per launch, 256 threads (4 waves) each, no inter-workgroup communication.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "arlib_amd.h"
+
+#define ARL_LAUNCH_CHECK()                                  \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return (int)e__;             \
+    } while (0)
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__device__ __forceinline__ void fma4(float4 &a, float s, const float4 &x) {
+    a.x = fmaf(s, x.x, a.x); a.y = fmaf(s, x.y, a.y); a.z = fmaf(s, x.z, a.z); a.w = fmaf(s, x.w, a.w);
+}
+__device__ __forceinline__ float4 add4(const float4 &a, const float4 &b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 shfl_xor4(const float4 &a, int off) {
+    return make_float4(__shfl_xor(a.x, off), __shfl_xor(a.y, off), __shfl_xor(a.z, off), __shfl_xor(a.w, off));
+}
+
+// ================================================================================================
+// SpMM  (recommender/LightGCN.py:234 torch.sparse.mm and its backward; A symmetric)
+// ================================================================================================
+struct CsrDev {
+    int n_rows;
+    const int32_t *rowptr, *col;
+    const float *val;
+    int chunk, n_chunks;
+    const int32_t *chunk_row, *chunk_begin, *chunk_end;
+    int n_long;
+    const int32_t *long_row, *long_first, *long_count;
+    float *partial;
+};
+
+enum { EPI_AXPBY = 0, EPI_LAYERSUM = 1, EPI_ADAM = 2 };
+
+struct Epi {
+    float alpha, beta;
+    const float *Z;          // AXPBY / ADAM
+    float *Y;                // AXPBY / LAYERSUM
+    const float *S_in;       // LAYERSUM
+    float *S;
+    float *P, *M, *V;        // ADAM
+    float step_size, inv_bc2_sqrt, b1, b2, eps;
+};
+
+// Accumulate sum_e val[e] * X[col[e], 4q..4q+3] over edges [begin,end) for this lane's column quad.
+// Lanes are split in G = 64/LPR groups; group g takes edges g, g+G, ... of each 64-edge window.
+// Returns the per-lane partial (still split over the G groups).
+template <int LPR, int UNROLL>
+__device__ __forceinline__ float4 spmm_gather(const int32_t *__restrict__ col, const float *__restrict__ val, int begin,
+                                              int end, const float *__restrict__ X, int d, int lane) {
+    constexpr int G = kWave / LPR;
+    const int g = lane / LPR, q = lane % LPR;
+    const bool qact = (q * 4 < d);
+    const float *xq = X + q * 4;
+    float4 acc[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = begin; base < end; base += kWave) {
+        const int e = base + lane;
+        int c = 0;
+        float v = 0.f;
+        if (e < end) { c = col[e]; v = val[e]; }
+        const int cnt = min(kWave, end - base);
+        for (int j = 0; j < cnt; j += G * UNROLL) {
+            int cj[UNROLL];
+            float vj[UNROLL];
+            float4 x[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                // the shuffles run with every lane active (a bpermute reads 0 from a disabled source lane)
+                const int s = j + u * G + g;
+                const int cs = __shfl(c, s & (kWave - 1));
+                const float vs = __shfl(v, s & (kWave - 1));
+                const bool ok = s < cnt;
+                cj[u] = ok ? cs : -1;
+                vj[u] = ok ? vs : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (qact && cj[u] >= 0) x[u] = *reinterpret_cast<const float4 *>(xq + (size_t)cj[u] * d);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) fma4(acc[u], vj[u], x[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 1; u < UNROLL; ++u) acc[0] = add4(acc[0], acc[u]);
+    return acc[0];
+}
+
+template <int LPR>
+__device__ __forceinline__ float4 group_reduce(float4 a) {
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) a = add4(a, shfl_xor4(a, off));
+    return a;
+}
+
+template <int MODE>
+__device__ __forceinline__ void spmm_epilogue(const Epi &ep, int row, int d, int q, float4 a) {
+    const size_t o = (size_t)row * d + q * 4;
+    if (MODE == EPI_AXPBY) {
+        float4 y = make_float4(ep.alpha * a.x, ep.alpha * a.y, ep.alpha * a.z, ep.alpha * a.w);
+        if (ep.Z) {
+            const float4 z = *reinterpret_cast<const float4 *>(ep.Z + o);
+            y.x = fmaf(ep.beta, z.x, y.x); y.y = fmaf(ep.beta, z.y, y.y); y.z = fmaf(ep.beta, z.z, y.z); y.w = fmaf(ep.beta, z.w, y.w);
+        }
+        *reinterpret_cast<float4 *>(ep.Y + o) = y;
+    } else if (MODE == EPI_LAYERSUM) {
+        const float4 s = *reinterpret_cast<const float4 *>(ep.S_in + o);
+        if (ep.Y) *reinterpret_cast<float4 *>(ep.Y + o) = a;
+        *reinterpret_cast<float4 *>(ep.S + o) = add4(s, a);
+    } else {  // EPI_ADAM: torch/optim/adam.py _single_tensor_adam
+        float g[4] = {ep.alpha * a.x, ep.alpha * a.y, ep.alpha * a.z, ep.alpha * a.w};
+        if (ep.Z) {
+            const float4 z = *reinterpret_cast<const float4 *>(ep.Z + o);
+            g[0] = fmaf(ep.beta, z.x, g[0]); g[1] = fmaf(ep.beta, z.y, g[1]); g[2] = fmaf(ep.beta, z.z, g[2]); g[3] = fmaf(ep.beta, z.w, g[3]);
+        }
+        float4 p4 = *reinterpret_cast<const float4 *>(ep.P + o);
+        float4 m4 = *reinterpret_cast<const float4 *>(ep.M + o);
+        float4 v4 = *reinterpret_cast<const float4 *>(ep.V + o);
+        float p[4] = {p4.x, p4.y, p4.z, p4.w}, m[4] = {m4.x, m4.y, m4.z, m4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            m[k] = m[k] + (g[k] - m[k]) * (1.0f - ep.b1);
+            v[k] = v[k] * ep.b2 + (1.0f - ep.b2) * g[k] * g[k];
+            const float denom = sqrtf(v[k]) * ep.inv_bc2_sqrt + ep.eps;
+            p[k] = p[k] - ep.step_size * (m[k] / denom);
+        }
+        *reinterpret_cast<float4 *>(ep.P + o) = make_float4(p[0], p[1], p[2], p[3]);
+        *reinterpret_cast<float4 *>(ep.M + o) = make_float4(m[0], m[1], m[2], m[3]);
+        *reinterpret_cast<float4 *>(ep.V + o) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// One wavefront per task.  Tasks [0, n_chunks) are slices of long rows (heavy; dispatched first) whose
+// partial sums go to A.partial; tasks [n_chunks, n_chunks + n_rows) are whole rows (long rows skip).
+template <int LPR, int MODE>
+__global__ __launch_bounds__(kBlock) void spmm_rows_kernel(CsrDev A, const float *__restrict__ X, int d, Epi ep) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const long long task = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int q = lane % LPR;
+    if (task < A.n_chunks) {
+        const int t = (int)task;
+        float4 a = spmm_gather<LPR, 4>(A.col, A.val, A.chunk_begin[t], A.chunk_end[t], X, d, lane);
+        a = group_reduce<LPR>(a);
+        if (lane < LPR && q * 4 < d) *reinterpret_cast<float4 *>(A.partial + (size_t)t * d + q * 4) = a;
+        return;
+    }
+    const long long r = task - A.n_chunks;
+    if (r >= A.n_rows) return;
+    const int begin = A.rowptr[r], end = A.rowptr[r + 1];
+    if (A.n_chunks > 0 && end - begin > A.chunk) return;       // long row: summed by spmm_long_rows_kernel
+    float4 a = spmm_gather<LPR, 4>(A.col, A.val, begin, end, X, d, lane);
+    a = group_reduce<LPR>(a);
+    if (lane < LPR && q * 4 < d) spmm_epilogue<MODE>(ep, (int)r, d, q, a);
+}
+
+// One wavefront per long row: add its chunk partials in slot order (deterministic) and run the epilogue.
+template <int LPR, int MODE>
+__global__ __launch_bounds__(kBlock) void spmm_long_rows_kernel(CsrDev A, int d, Epi ep) {
+    constexpr int G = kWave / LPR;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int t = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (t >= A.n_long) return;
+    const int g = lane / LPR, q = lane % LPR;
+    const int first = A.long_first[t], cnt = A.long_count[t];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q * 4 < d)
+        for (int s = g; s < cnt; s += G) a = add4(a, *reinterpret_cast<const float4 *>(A.partial + (size_t)(first + s) * d + q * 4));
+    a = group_reduce<LPR>(a);
+    if (lane < LPR && q * 4 < d) spmm_epilogue<MODE>(ep, A.long_row[t], d, q, a);
+}
+
+template <int MODE>
+int launch_spmm(const arl_csr *A, const float *X, int64_t d, const Epi &ep, hipStream_t st) {
+    if (!A || !X || !A->rowptr || (A->nnz > 0 && (!A->col || !A->val))) return ARL_E_NULL;
+    if (d <= 0 || d > 256 || (d & 3)) return ARL_E_DIM;
+    if (A->n_rows < 0 || A->n_rows > 0x7fffffffll || A->nnz > 0x7fffffffll || A->n_chunks > 0x7fffffffll) return ARL_E_RANGE;
+    if (A->n_chunks > 0 && (!A->chunk_row || !A->chunk_begin || !A->chunk_end || !A->partial || A->chunk <= 0)) return ARL_E_NULL;
+    if (A->n_long > 0 && (!A->long_row || !A->long_first || !A->long_count)) return ARL_E_NULL;
+    if ((A->n_chunks > 0) != (A->n_long > 0)) return ARL_E_ARG;
+    if (A->n_rows == 0) return ARL_OK;
+    CsrDev D;
+    D.n_rows = (int)A->n_rows; D.rowptr = A->rowptr; D.col = A->col; D.val = A->val;
+    D.chunk = A->chunk; D.n_chunks = (int)A->n_chunks; D.chunk_row = A->chunk_row; D.chunk_begin = A->chunk_begin;
+    D.chunk_end = A->chunk_end; D.n_long = (int)A->n_long; D.long_row = A->long_row; D.long_first = A->long_first;
+    D.long_count = A->long_count; D.partial = A->partial;
+    const long long tasks = (long long)D.n_rows + D.n_chunks;
+    const unsigned grid = (unsigned)((tasks + kWavesPerBlock - 1) / kWavesPerBlock);
+    const unsigned grid_long = (unsigned)((D.n_long + kWavesPerBlock - 1) / kWavesPerBlock);
+    const int di = (int)d;
+#define ARL_SPMM_CASE(LPRV)                                                                              \
+    do {                                                                                                 \
+        hipLaunchKernelGGL((spmm_rows_kernel<LPRV, MODE>), dim3(grid), dim3(kBlock), 0, st, D, X, di, ep); \
+        ARL_LAUNCH_CHECK();                                                                              \
+        if (D.n_long > 0) {                                                                              \
+            hipLaunchKernelGGL((spmm_long_rows_kernel<LPRV, MODE>), dim3(grid_long), dim3(kBlock), 0, st, D, di, ep); \
+            ARL_LAUNCH_CHECK();                                                                          \
+        }                                                                                                \
+    } while (0)
+    if (d <= 16) ARL_SPMM_CASE(4);
+    else if (d <= 32) ARL_SPMM_CASE(8);
+    else if (d <= 64) ARL_SPMM_CASE(16);
+    else if (d <= 128) ARL_SPMM_CASE(32);
+    else ARL_SPMM_CASE(64);
+#undef ARL_SPMM_CASE
+    return ARL_OK;
+}
+
+// ================================================================================================
+// Degree normalisation (util/DataLoader.py:73-87, recommender/LightGCN.py:212-215)
+// ================================================================================================
+__global__ __launch_bounds__(kBlock) void row_dinv_kernel(int n_rows, const int32_t *__restrict__ rowptr,
+                                                           const float *__restrict__ w, float *__restrict__ dinv) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    float s = 0.f;
+    for (int e = rowptr[r] + lane; e < rowptr[r + 1]; e += kWave) s += w[e];
+    s = wave_sum(s);
+    if (lane == 0) dinv[r] = s > 0.f ? 1.0f / sqrtf(s) : 0.f;
+}
+
+__global__ __launch_bounds__(kBlock) void norm_vals_kernel(int n_rows, const int32_t *__restrict__ rowptr,
+                                                            const int32_t *__restrict__ col, const float *__restrict__ w,
+                                                            const float *__restrict__ dinv, float *__restrict__ val) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const float dr = dinv[r];
+    for (int e = rowptr[r] + lane; e < rowptr[r + 1]; e += kWave) val[e] = (dr * w[e]) * dinv[col[e]];
+}
+
+// ================================================================================================
+// BPR + L2 (util/loss.py:5-9,25-29; gathers recommender/LightGCN.py:51-52)
+// workspace layout (floats): coef[B] | bpr_terms[B] | uu[B] | pp[B]
+// ================================================================================================
+__global__ __launch_bounds__(kBlock) void bpr_fwd_kernel(const float *__restrict__ emb, int d, long long item_off,
+                                                          const int32_t *__restrict__ ui, const int32_t *__restrict__ pi,
+                                                          const int32_t *__restrict__ ni, int B, float *__restrict__ ws) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float *u = emb + (size_t)ui[b] * d, *p = emb + (size_t)(item_off + pi[b]) * d, *n = emb + (size_t)(item_off + ni[b]) * d;
+    float ps = 0.f, ns = 0.f, uu = 0.f, pp = 0.f;
+    for (int k = lane; k < d; k += kWave) {
+        const float uk = u[k], pk = p[k], nk = n[k];
+        ps = fmaf(uk, pk, ps); ns = fmaf(uk, nk, ns); uu = fmaf(uk, uk, uu); pp = fmaf(pk, pk, pp);
+    }
+    ps = wave_sum(ps); ns = wave_sum(ns); uu = wave_sum(uu); pp = wave_sum(pp);
+    if (lane == 0) {
+        const float x = ps - ns;
+        const float s = 1.0f / (1.0f + expf(-x));
+        ws[b] = -(s * (1.0f - s)) / ((1e-7f + s) * (float)B);      // d(mean loss)/dx_b
+        ws[B + b] = -logf(1e-7f + s);
+        ws[2 * B + b] = uu;
+        ws[3 * B + b] = pp;
+    }
+}
+
+// single block: fixed-order tree reduction -> bitwise reproducible loss and norms
+__global__ __launch_bounds__(kBlock) void bpr_finalize_kernel(int B, float reg, const float *__restrict__ ws, float *__restrict__ out) {
+    __shared__ float sh[3][kBlock];
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < B; i += kBlock) { a += ws[B + i]; b += ws[2 * B + i]; c += ws[3 * B + i]; }
+    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b; sh[2][threadIdx.x] = c;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + s]; sh[1][threadIdx.x] += sh[1][threadIdx.x + s]; sh[2][threadIdx.x] += sh[2][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float nu = sqrtf(sh[1][0]), np_ = sqrtf(sh[2][0]);
+        out[0] = sh[0][0] / (float)B;
+        out[1] = reg * (nu + np_);
+        out[2] = nu;
+        out[3] = np_;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void bpr_bwd_kernel(const float *__restrict__ emb, int d, long long item_off,
+                                                          const int32_t *__restrict__ ui, const int32_t *__restrict__ pi,
+                                                          const int32_t *__restrict__ ni, int B, float reg, float upstream,
+                                                          const float *__restrict__ ws, const float *__restrict__ out,
+                                                          float *__restrict__ G) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const size_t ru = (size_t)ui[b] * d, rp = (size_t)(item_off + pi[b]) * d, rn = (size_t)(item_off + ni[b]) * d;
+    const float g = ws[b] * upstream;
+    const float cu = out[2] > 0.f ? upstream * reg / out[2] : 0.f, cp = out[3] > 0.f ? upstream * reg / out[3] : 0.f;
+    for (int k = lane; k < d; k += kWave) {
+        const float uk = emb[ru + k], pk = emb[rp + k], nk = emb[rn + k];
+        atomicAdd(G + ru + k, fmaf(g, pk - nk, cu * uk));
+        atomicAdd(G + rp + k, fmaf(g, uk, cp * pk));
+        atomicAdd(G + rn + k, -g * uk);
+    }
+}
+
+// ================================================================================================
+// Dense optimisers (torch.optim.Adam / SGD)
+// ================================================================================================
+__global__ __launch_bounds__(kBlock) void adam_kernel(float4 *__restrict__ p, const float4 *__restrict__ g, float4 *__restrict__ m,
+                                                       float4 *__restrict__ v, long long n4, float step_size, float inv_bc2_sqrt,
+                                                       float b1, float b2, float eps) {
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (long long)gridDim.x * kBlock) {
+        const float4 g4 = g[i];
+        float4 p4 = p[i], m4 = m[i], v4 = v[i];
+        float gg[4] = {g4.x, g4.y, g4.z, g4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mm[k] = mm[k] + (gg[k] - mm[k]) * (1.0f - b1);
+            vv[k] = vv[k] * b2 + (1.0f - b2) * gg[k] * gg[k];
+            pp[k] = pp[k] - step_size * (mm[k] / (sqrtf(vv[k]) * inv_bc2_sqrt + eps));
+        }
+        p[i] = make_float4(pp[0], pp[1], pp[2], pp[3]); m[i] = make_float4(mm[0], mm[1], mm[2], mm[3]); v[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    }
+}
+// scalar form for the <= 3 trailing elements (or a whole table whose base is not 16-byte aligned)
+__global__ __launch_bounds__(kBlock) void adam_scalar_kernel(float *p, const float *g, float *m, float *v, long long from, long long n,
+                                                              float step_size, float inv_bc2_sqrt, float b1, float b2, float eps) {
+    for (long long i = from + (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] = p[i] - step_size * (mi / (sqrtf(vi) * inv_bc2_sqrt + eps));
+    }
+}
+__global__ __launch_bounds__(kBlock) void sgd_kernel(float *__restrict__ p, const float *__restrict__ g, long long n, float lr) {
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) p[i] = p[i] - lr * g[i];
+}
+
+inline void adam_scalars(float lr, float b1, float b2, int64_t step, float *step_size, float *inv_bc2_sqrt) {
+    const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+    *step_size = (float)((double)lr / bc1);
+    *inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+}
+
+// ================================================================================================
+// gather / scatter-add rows
+// ================================================================================================
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float *__restrict__ src, const int32_t *__restrict__ idx, int n, int d,
+                                                              float *__restrict__ dst) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (t >= n) return;
+    const float *s = src + (size_t)idx[t] * d;
+    for (int k = lane; k < d; k += kWave) dst[(size_t)t * d + k] = s[k];
+}
+__global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(float *__restrict__ dst, const int32_t *__restrict__ idx, int n, int d,
+                                                                   const float *__restrict__ src, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (t >= n) return;
+    float *o = dst + (size_t)idx[t] * d;
+    for (int k = lane; k < d; k += kWave) atomicAdd(o + k, scale * src[(size_t)t * d + k]);
+}
+
+// ================================================================================================
+// InfoNCE (util/loss.py:42-49).  workspace (floats): a[n*d] | b[n*d] | n1[n] | n2[n] | ttl[n] | rowloss[n] | da[n*d] | db[n*d]
+// ================================================================================================
+__global__ __launch_bounds__(kBlock) void nce_normalize_kernel(const float *__restrict__ v, int n, int d, float *__restrict__ y, float *__restrict__ nrm) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = lane; k < d; k += kWave) { const float x = v[(size_t)i * d + k]; s = fmaf(x, x, s); }
+    s = wave_sum(s);
+    const float r = fmaxf(sqrtf(s), 1e-12f);          // F.normalize eps
+    for (int k = lane; k < d; k += kWave) y[(size_t)i * d + k] = v[(size_t)i * d + k] / r;
+    if (lane == 0) nrm[i] = r;
+}
+
+// One block per row i of `a`: s_ij = <a_i, b_j> for all j; ttl_i = sum_j exp(s_ij/tau); rowloss_i = -(s_ii/tau - log ttl_i)
+__global__ __launch_bounds__(kBlock) void nce_rowsum_kernel(const float *__restrict__ a, const float *__restrict__ b, int n, int d, float inv_tau,
+                                                             float *__restrict__ ttl, float *__restrict__ rowloss) {
+    __shared__ float ai[256];
+    __shared__ float red[kBlock];
+    __shared__ float sii_sh;
+    const int i = blockIdx.x;
+    for (int k = threadIdx.x; k < d; k += kBlock) ai[k] = a[(size_t)i * d + k];
+    __syncthreads();
+    float acc = 0.f;
+    for (int j = threadIdx.x; j < n; j += kBlock) {
+        const float *bj = b + (size_t)j * d;
+        float s = 0.f;
+        for (int k = 0; k < d; k += 4) {
+            const float4 x = *reinterpret_cast<const float4 *>(bj + k);
+            s = fmaf(ai[k], x.x, s); s = fmaf(ai[k + 1], x.y, s); s = fmaf(ai[k + 2], x.z, s); s = fmaf(ai[k + 3], x.w, s);
+        }
+        if (j == i) sii_sh = s;
+        acc += expf(s * inv_tau);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) { ttl[i] = red[0]; rowloss[i] = -(sii_sh * inv_tau - logf(red[0])); }
+}
+
+__global__ __launch_bounds__(kBlock) void nce_loss_kernel(const float *__restrict__ rowloss, int n, float *__restrict__ out) {
+    __shared__ float red[kBlock];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += kBlock) a += rowloss[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = red[0] / (float)n;
+}
+
+// One block per row r of the side being differentiated.
+//   ROWSIDE = true : r = i, w_j = (exp(s_ij/tau)/ttl_i - [i==j]) * scale ; dy = sum_j w_j other_j   (other = b, self = a)
+//   ROWSIDE = false: r = j, w_i = (exp(s_ij/tau)/ttl_i - [i==j]) * scale ; dy = sum_i w_i other_i   (other = a, self = b)
+// then back through the row normalisation: dx = (dy - y <y,dy>) / nrm.
+template <bool ROWSIDE>
+__global__ __launch_bounds__(kBlock) void nce_grad_kernel(const float *__restrict__ self, const float *__restrict__ other, const float *__restrict__ ttl,
+                                                           const float *__restrict__ nrm, int n, int d, float inv_tau, float scale,
+                                                           float *__restrict__ dx) {
+    extern __shared__ float shm[];           // y[d] | w[n] | part[kBlock]
+    float *y = shm, *w = shm + 256, *part = w + n;
+    const int r = blockIdx.x;
+    for (int k = threadIdx.x; k < d; k += kBlock) y[k] = self[(size_t)r * d + k];
+    __syncthreads();
+    const float ttl_r = ROWSIDE ? ttl[r] : 0.f;
+    for (int j = threadIdx.x; j < n; j += kBlock) {
+        const float *oj = other + (size_t)j * d;
+        float s = 0.f;
+        for (int k = 0; k < d; k += 4) {
+            const float4 x = *reinterpret_cast<const float4 *>(oj + k);
+            s = fmaf(y[k], x.x, s); s = fmaf(y[k + 1], x.y, s); s = fmaf(y[k + 2], x.z, s); s = fmaf(y[k + 3], x.w, s);
+        }
+        const float t = ROWSIDE ? ttl_r : ttl[j];
+        w[j] = (expf(s * inv_tau) / t - (j == r ? 1.f : 0.f)) * scale;
+    }
+    __syncthreads();
+    // dy[k] = sum_j w[j] * other[j][k]; threads split j into kBlock/dpad slices per column k
+    const int dpad = d <= 64 ? 64 : (d <= 128 ? 128 : 256);
+    const int slices = kBlock / dpad;
+    const int k = threadIdx.x % dpad, sl = threadIdx.x / dpad;
+    float acc = 0.f;
+    if (k < d)
+        for (int j = sl; j < n; j += slices) acc = fmaf(w[j], other[(size_t)j * d + k], acc);
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    float dy = 0.f;
+    if ((int)threadIdx.x < dpad) for (int s = 0; s < slices; ++s) dy += part[s * dpad + threadIdx.x];
+    __syncthreads();
+    // <y, dy>
+    part[threadIdx.x] = ((int)threadIdx.x < d) ? y[threadIdx.x] * dy : 0.f;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) { if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s]; __syncthreads(); }
+    const float dot = part[0];
+    if ((int)threadIdx.x < d) dx[(size_t)r * d + threadIdx.x] = (dy - y[threadIdx.x] * dot) / nrm[r];
+}
+
+// ================================================================================================
+// SimGCL perturbation (recommender/SimGCL.py:203-205)
+// ================================================================================================
+__global__ __launch_bounds__(kBlock) void simgcl_perturb_kernel(float *__restrict__ E, const float *__restrict__ noise, int n, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (r >= n) return;
+    float s = 0.f;
+    for (int k = lane; k < d; k += kWave) { const float x = noise[(size_t)r * d + k]; s = fmaf(x, x, s); }
+    s = wave_sum(s);
+    const float nr = fmaxf(sqrtf(s), 1e-12f);
+    for (int k = lane; k < d; k += kWave) {
+        const float x = E[(size_t)r * d + k];
+        const float sg = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+        E[(size_t)r * d + k] = x + sg * (noise[(size_t)r * d + k] / nr) * eps;
+    }
+}
+
+// ================================================================================================
+// Attack primitives
+// ================================================================================================
+// out[t, j] += <dY[rows[t]], X[col_off+j]>.  Block = 64 items staged in LDS (stride d+1: conflict-free column
+// reads), 4 waves stride over the selected rows; the dY row is wave-uniform (broadcast loads).
+__global__ __launch_bounds__(kBlock) void sddmm_rows_dense_kernel(const float *__restrict__ dY, const float *__restrict__ X, int d,
+                                                                   const int32_t *__restrict__ rows, int n_sel, long long col_off, int n_cols,
+                                                                   float *__restrict__ out) {
+    extern __shared__ float xs[];            // [64][d+1]
+    const int j0 = blockIdx.x * 64;
+    const int ld = d + 1;
+    for (int t = threadIdx.x; t < 64 * d; t += kBlock) {
+        const int jj = t / d, k = t % d;
+        xs[jj * ld + k] = (j0 + jj < n_cols) ? X[(size_t)(col_off + j0 + jj) * d + k] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = j0 + lane;
+    for (int t = wv; t < n_sel; t += kWavesPerBlock) {
+        const float *dy = dY + (size_t)rows[t] * d;
+        float s = 0.f;
+        for (int k = 0; k < d; ++k) s = fmaf(dy[k], xs[lane * ld + k], s);
+        if (j < n_cols) out[(size_t)t * n_cols + j] += s;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void pga_update_kernel(float *__restrict__ S, const float *__restrict__ grad, long long n) {
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+        float s = S[i] - 0.2f * tanhf(grad[i]);
+        if (s > 1.f) s = 1.f;
+        if (s <= 0.f) s = 10e-8f;
+        S[i] = s;
+    }
+}
+
+// ---- streaming score + mask + top-k -------------------------------------------------------------
+// Candidate ordering key: larger score first, then smaller item id.  Packed so that a plain 64-bit unsigned
+// compare orders candidates: high 32 bits = order-preserving map of the float, low 32 bits = ~item.
+__device__ __forceinline__ unsigned long long pack_cand(float s, int item) {
+    unsigned u = __float_as_uint(s);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned)(~(unsigned)item);
+}
+__device__ __forceinline__ float cand_score(unsigned long long c) {
+    unsigned u = (unsigned)(c >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ int cand_item(unsigned long long c) { return (int)(~(unsigned)(c & 0xffffffffu)); }
+
+constexpr int kTU = 16;          // users per block
+constexpr int kTI = 256;         // items per tile (one per thread)
+constexpr int kCap = 512;        // candidate slots per user (>= kTI + 2*k_max)
+
+// bitonic sort (descending) of one user's kCap candidate keys by one wavefront
+__device__ void wave_sort_desc(unsigned long long *c, int lane) {
+    for (int k = 2; k <= kCap; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < kCap; t += kWave) {
+                const int ixj = t ^ j;
+                if (ixj > t) {
+                    const unsigned long long a = c[t], b = c[ixj];
+                    const bool desc = ((t & k) == 0);
+                    if (desc ? (a < b) : (a > b)) { c[t] = b; c[ixj] = a; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void score_mask_topk_kernel(const float *__restrict__ Pu, const float *__restrict__ Pi, int U, int I, int d,
+                                                                  const int32_t *__restrict__ mrp, const int32_t *__restrict__ mcol, int k,
+                                                                  int32_t *__restrict__ top_idx, float *__restrict__ top_val) {
+    extern __shared__ unsigned char smem_raw[];
+    unsigned long long *cand = reinterpret_cast<unsigned long long *>(smem_raw);          // [kTU][kCap]
+    float *us = reinterpret_cast<float *>(cand + kTU * kCap);                               // [kTU][d]
+    unsigned long long *thr = reinterpret_cast<unsigned long long *>(us + kTU * 256);     // [kTU]
+    int *cnt = reinterpret_cast<int *>(thr + kTU);                                          // [kTU]
+    const int u0 = blockIdx.x * kTU;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int t = tid; t < kTU * d; t += kBlock) {
+        const int uu = t / d, kk = t % d;
+        us[uu * 256 + kk] = (u0 + uu < U) ? Pu[(size_t)(u0 + uu) * d + kk] : 0.f;
+    }
+    for (int t = tid; t < kTU * kCap; t += kBlock) cand[t] = 0ull;       // 0 sorts below every real candidate
+    if (tid < kTU) { thr[tid] = 0ull; cnt[tid] = 0; }
+    __syncthreads();
+    for (int i0 = 0; i0 < I; i0 += kTI) {
+        const int item = i0 + tid;
+        if (item < I) {
+            const float *pi = Pi + (size_t)item * d;
+            float sc[kTU];
+#pragma unroll
+            for (int uu = 0; uu < kTU; ++uu) sc[uu] = 0.f;
+            for (int kk = 0; kk < d; kk += 4) {
+                const float4 x = *reinterpret_cast<const float4 *>(pi + kk);
+#pragma unroll
+                for (int uu = 0; uu < kTU; ++uu) {
+                    const float4 y = *reinterpret_cast<const float4 *>(us + uu * 256 + kk);
+                    sc[uu] = fmaf(x.x, y.x, sc[uu]); sc[uu] = fmaf(x.y, y.y, sc[uu]); sc[uu] = fmaf(x.z, y.z, sc[uu]); sc[uu] = fmaf(x.w, y.w, sc[uu]);
+                }
+            }
+#pragma unroll
+            for (int uu = 0; uu < kTU; ++uu) {
+                if (u0 + uu >= U) continue;
+                unsigned long long key = pack_cand(sc[uu], item);
+                if (key > thr[uu]) {
+                    if (mrp) {          // interacted -> -10e8 (only evaluated for the rare candidates that pass the threshold)
+                        int lo = mrp[u0 + uu], hi = mrp[u0 + uu + 1];
+                        const int end = hi;
+                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (mcol[mid] < item) lo = mid + 1; else hi = mid; }
+                        if (lo < end && mcol[lo] == item) key = pack_cand(-10e8f, item);
+                    }
+                    if (key > thr[uu]) {
+                        const int slot = atomicAdd(&cnt[uu], 1);
+                        cand[uu * kCap + slot] = key;       // slot < kCap guaranteed: cnt <= kCap - kTI at tile start
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // compaction: any user whose buffer could overflow in the next tile is sorted and cut to its top k
+        for (int uu = wv; uu < kTU; uu += kWavesPerBlock) {
+            if (cnt[uu] > kCap - kTI) {
+                unsigned long long *c = cand + uu * kCap;
+                for (int t = cnt[uu] + lane; t < kCap; t += kWave) c[t] = 0ull;
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+                wave_sort_desc(c, lane);
+                if (lane == 0) { thr[uu] = c[k - 1]; cnt[uu] = k; }
+            }
+        }
+        __syncthreads();
+    }
+    for (int uu = wv; uu < kTU; uu += kWavesPerBlock) {
+        if (u0 + uu >= U) continue;
+        unsigned long long *c = cand + uu * kCap;
+        for (int t = cnt[uu] + lane; t < kCap; t += kWave) c[t] = 0ull;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        wave_sort_desc(c, lane);
+        for (int t = lane; t < k; t += kWave) {
+            top_idx[(size_t)(u0 + uu) * k + t] = cand_item(c[t]);
+            top_val[(size_t)(u0 + uu) * k + t] = cand_score(c[t]);
+        }
+    }
+}
+
+// per-row top-n by n rounds of block arg-max over a scratch copy (n ~ average user degree, small)
+__global__ __launch_bounds__(kBlock) void topn_project_kernel(const float *__restrict__ M, int cols, int n, float *__restrict__ out,
+                                                               int32_t *__restrict__ idx, float *__restrict__ scratch) {
+    __shared__ unsigned long long best[kBlock];
+    const int r = blockIdx.x;
+    const float *m = M + (size_t)r * cols;
+    float *s = scratch + (size_t)r * cols, *o = out + (size_t)r * cols;
+    for (int j = threadIdx.x; j < cols; j += kBlock) { s[j] = m[j]; o[j] = 0.f; }
+    __syncthreads();
+    for (int t = 0; t < n; ++t) {
+        unsigned long long b = 0ull;
+        for (int j = threadIdx.x; j < cols; j += kBlock) {
+            const float v = s[j];
+            if (v != -INFINITY) { const unsigned long long c = pack_cand(v, j); if (c > b) b = c; }
+        }
+        best[threadIdx.x] = b;
+        __syncthreads();
+        for (int st = kBlock / 2; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st && best[threadIdx.x + st] > best[threadIdx.x]) best[threadIdx.x] = best[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0 && best[0] != 0ull) {
+            const int j = cand_item(best[0]);
+            o[j] = 1.f;
+            if (idx) idx[(size_t)r * n + t] = j;
+            s[j] = -INFINITY;
+        }
+        __syncthreads();
+    }
+}
+
+inline unsigned grid_for(long long work_items, int per_block, unsigned cap = 2048u * 8u) {
+    long long g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int arl_norm_adj_values_f32(int64_t n_rows, const int32_t *rowptr, const int32_t *col, const float *w, float *dinv, float *val,
+                            arl_stream_t stream) {
+    if (!rowptr || !dinv) return ARL_E_NULL;
+    if (n_rows < 0 || n_rows > 0x7fffffffll) return ARL_E_RANGE;
+    if (n_rows == 0) return ARL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((n_rows + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(row_dinv_kernel, dim3(grid), dim3(kBlock), 0, st, (int)n_rows, rowptr, w, dinv);
+    ARL_LAUNCH_CHECK();
+    if (val) {
+        if (!col || !w) return ARL_E_NULL;
+        hipLaunchKernelGGL(norm_vals_kernel, dim3(grid), dim3(kBlock), 0, st, (int)n_rows, rowptr, col, w, dinv, val);
+        ARL_LAUNCH_CHECK();
+    }
+    return ARL_OK;
+}
+
+int arl_spmm_csr_f32(const arl_csr *A, const float *X, int64_t d, float alpha, float beta, const float *Z, float *Y, arl_stream_t stream) {
+    if (!Y) return ARL_E_NULL;
+    if (beta != 0.f && !Z) return ARL_E_NULL;
+    if (Y == X) return ARL_E_ARG;
+    Epi ep = {};
+    ep.alpha = alpha; ep.beta = beta; ep.Z = (beta != 0.f) ? Z : nullptr; ep.Y = Y;
+    return launch_spmm<EPI_AXPBY>(A, X, d, ep, (hipStream_t)stream);
+}
+
+int arl_spmm_csr_layersum_f32(const arl_csr *A, const float *X, int64_t d, const float *S_in, float *S, float *Y, arl_stream_t stream) {
+    if (!S_in || !S) return ARL_E_NULL;
+    if (Y == X) return ARL_E_ARG;
+    Epi ep = {};
+    ep.S_in = S_in; ep.S = S; ep.Y = Y;
+    return launch_spmm<EPI_LAYERSUM>(A, X, d, ep, (hipStream_t)stream);
+}
+
+int arl_spmm_csr_adam_f32(const arl_csr *A, const float *X, int64_t d, float alpha, float beta, const float *Z, float *P, float *M, float *V,
+                          float lr, float beta1, float beta2, float eps, int64_t step, arl_stream_t stream) {
+    if (!P || !M || !V) return ARL_E_NULL;
+    if (beta != 0.f && !Z) return ARL_E_NULL;
+    if (step < 1) return ARL_E_ARG;
+    if (P == X) return ARL_E_ARG;
+    Epi ep = {};
+    ep.alpha = alpha; ep.beta = beta; ep.Z = (beta != 0.f) ? Z : nullptr; ep.P = P; ep.M = M; ep.V = V;
+    ep.b1 = beta1; ep.b2 = beta2; ep.eps = eps;
+    adam_scalars(lr, beta1, beta2, step, &ep.step_size, &ep.inv_bc2_sqrt);
+    return launch_spmm<EPI_ADAM>(A, X, d, ep, (hipStream_t)stream);
+}
+
+int64_t arl_bpr_l2_workspace_bytes(int64_t B) { return B < 0 ? 0 : (int64_t)sizeof(float) * 4 * B; }
+
+int arl_bpr_l2_fwd_bwd_f32(const float *emb, int64_t d, int64_t item_off, const int32_t *u, const int32_t *p, const int32_t *n, int64_t B,
+                           float reg, float upstream, float *loss_out, float *G, void *workspace, arl_stream_t stream) {
+    if (!emb || !u || !p || !n || !loss_out || !workspace) return ARL_E_NULL;
+    if (d <= 0 || B <= 0 || item_off < 0) return ARL_E_ARG;
+    if (B > 0x7fffffffll / 4 || d > 0x7fffffffll) return ARL_E_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+    float *ws = (float *)workspace;
+    const unsigned grid = (unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(bpr_fwd_kernel, dim3(grid), dim3(kBlock), 0, st, emb, (int)d, (long long)item_off, u, p, n, (int)B, ws);
+    ARL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bpr_finalize_kernel, dim3(1), dim3(kBlock), 0, st, (int)B, reg, ws, loss_out);
+    ARL_LAUNCH_CHECK();
+    if (G) {
+        hipLaunchKernelGGL(bpr_bwd_kernel, dim3(grid), dim3(kBlock), 0, st, emb, (int)d, (long long)item_off, u, p, n, (int)B, reg, upstream, ws,
+                           loss_out, G);
+        ARL_LAUNCH_CHECK();
+    }
+    return ARL_OK;
+}
+
+int arl_adam_dense_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps, int64_t step,
+                       arl_stream_t stream) {
+    if (!p || !g || !m || !v) return ARL_E_NULL;
+    if (n < 0 || step < 1) return ARL_E_ARG;
+    if (n == 0) return ARL_OK;
+    float step_size, inv_bc2_sqrt;
+    adam_scalars(lr, beta1, beta2, step, &step_size, &inv_bc2_sqrt);
+    hipStream_t st = (hipStream_t)stream;
+    const bool al = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15u) == 0;
+    const long long n4 = al ? n / 4 : 0;
+    if (n4 > 0) {
+        hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n4, kBlock)), dim3(kBlock), 0, st, (float4 *)p, (const float4 *)g, (float4 *)m, (float4 *)v, n4,
+                           step_size, inv_bc2_sqrt, beta1, beta2, eps);
+        ARL_LAUNCH_CHECK();
+    }
+    if (n4 * 4 < n) {
+        hipLaunchKernelGGL(adam_scalar_kernel, dim3(grid_for(n - n4 * 4, kBlock)), dim3(kBlock), 0, st, p, g, m, v, n4 * 4, (long long)n, step_size,
+                           inv_bc2_sqrt, beta1, beta2, eps);
+        ARL_LAUNCH_CHECK();
+    }
+    return ARL_OK;
+}
+
+int arl_sgd_dense_f32(float *p, const float *g, int64_t n, float lr, arl_stream_t stream) {
+    if (!p || !g) return ARL_E_NULL;
+    if (n < 0) return ARL_E_ARG;
+    if (n == 0) return ARL_OK;
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, p, g, (long long)n, lr);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_gather_rows_f32(const float *src, const int32_t *idx, int64_t n, int64_t d, float *dst, arl_stream_t stream) {
+    if (!src || !idx || !dst) return ARL_E_NULL;
+    if (n < 0 || d <= 0 || n > 0x7fffffffll || d > 0x7fffffffll) return ARL_E_ARG;
+    if (n == 0) return ARL_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, src, idx,
+                       (int)n, (int)d, dst);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_scatter_add_rows_f32(float *dst, const int32_t *idx, int64_t n, int64_t d, const float *src, float scale, arl_stream_t stream) {
+    if (!src || !idx || !dst) return ARL_E_NULL;
+    if (n < 0 || d <= 0 || n > 0x7fffffffll || d > 0x7fffffffll) return ARL_E_ARG;
+    if (n == 0) return ARL_OK;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, dst,
+                       idx, (int)n, (int)d, src, scale);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int64_t arl_infonce_workspace_bytes(int64_t n, int64_t d) { return (n < 0 || d < 0) ? 0 : (int64_t)sizeof(float) * (4 * n * d + 4 * n); }
+
+int arl_infonce_fwd_bwd_f32(const float *v1, const float *v2, int64_t n, int64_t d, float tau, float upstream, float *loss_out, float *dv1,
+                            float *dv2, void *workspace, arl_stream_t stream) {
+    if (!v1 || !v2 || !loss_out || !workspace) return ARL_E_NULL;
+    if ((dv1 == nullptr) != (dv2 == nullptr)) return ARL_E_ARG;
+    if (n <= 0 || n > 8192 || d <= 0 || d > 256 || (d & 3)) return ARL_E_DIM;
+    hipStream_t st = (hipStream_t)stream;
+    float *a = (float *)workspace, *b = a + n * d, *n1 = b + n * d, *n2 = n1 + n, *ttl = n2 + n, *rowloss = ttl + n;
+    const unsigned gw = (unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock);
+    const float inv_tau = 1.0f / tau;
+    hipLaunchKernelGGL(nce_normalize_kernel, dim3(gw), dim3(kBlock), 0, st, v1, (int)n, (int)d, a, n1);
+    ARL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nce_normalize_kernel, dim3(gw), dim3(kBlock), 0, st, v2, (int)n, (int)d, b, n2);
+    ARL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nce_rowsum_kernel, dim3((unsigned)n), dim3(kBlock), 0, st, a, b, (int)n, (int)d, inv_tau, ttl, rowloss);
+    ARL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nce_loss_kernel, dim3(1), dim3(kBlock), 0, st, rowloss, (int)n, loss_out);
+    ARL_LAUNCH_CHECK();
+    if (dv1) {
+        const float scale = upstream / ((float)n * tau);
+        const size_t shm = sizeof(float) * (256 + (size_t)n + kBlock);
+        hipLaunchKernelGGL((nce_grad_kernel<true>), dim3((unsigned)n), dim3(kBlock), shm, st, a, b, ttl, n1, (int)n, (int)d, inv_tau, scale, dv1);
+        ARL_LAUNCH_CHECK();
+        hipLaunchKernelGGL((nce_grad_kernel<false>), dim3((unsigned)n), dim3(kBlock), shm, st, b, a, ttl, n2, (int)n, (int)d, inv_tau, scale, dv2);
+        ARL_LAUNCH_CHECK();
+    }
+    return ARL_OK;
+}
+
+int arl_simgcl_perturb_f32(float *E, const float *noise, int64_t n, int64_t d, float eps, arl_stream_t stream) {
+    if (!E || !noise) return ARL_E_NULL;
+    if (n < 0 || d <= 0 || n > 0x7fffffffll || d > 0x7fffffffll) return ARL_E_ARG;
+    if (n == 0) return ARL_OK;
+    hipLaunchKernelGGL(simgcl_perturb_kernel, dim3((unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, E, noise,
+                       (int)n, (int)d, eps);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_sddmm_rows_dense_f32(const float *dY, const float *X, int64_t d, const int32_t *rows, int64_t n_rows_sel, int64_t col_off, int64_t n_cols,
+                             float *out, arl_stream_t stream) {
+    if (!dY || !X || !rows || !out) return ARL_E_NULL;
+    if (d <= 0 || d > 256 || n_rows_sel < 0 || n_cols < 0 || col_off < 0) return ARL_E_ARG;
+    if (n_cols > 0x7fffffffll || n_rows_sel > 0x7fffffffll) return ARL_E_RANGE;
+    if (n_rows_sel == 0 || n_cols == 0) return ARL_OK;
+    const size_t shm = sizeof(float) * 64 * (size_t)(d + 1);
+    if (shm > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)sddmm_rows_dense_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(sddmm_rows_dense_kernel, dim3((unsigned)((n_cols + 63) / 64)), dim3(kBlock), shm, (hipStream_t)stream, dY, X, (int)d, rows,
+                       (int)n_rows_sel, (long long)col_off, (int)n_cols, out);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_pga_update_f32(float *S, const float *grad, int64_t n, arl_stream_t stream) {
+    if (!S || !grad) return ARL_E_NULL;
+    if (n < 0) return ARL_E_ARG;
+    if (n == 0) return ARL_OK;
+    hipLaunchKernelGGL(pga_update_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, S, grad, (long long)n);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t I, int64_t d, const int32_t *mask_rowptr, const int32_t *mask_col,
+                            int64_t k, int32_t *top_idx, float *top_val, arl_stream_t stream) {
+    if (!Pu || !Pi || !top_idx || !top_val) return ARL_E_NULL;
+    if (mask_rowptr && !mask_col) return ARL_E_NULL;
+    if (d <= 0 || d > 256 || (d & 3)) return ARL_E_DIM;
+    if (k <= 0 || k > 128 || k > I) return ARL_E_ARG;
+    if (U < 0 || I <= 0 || U > 0x7fffffffll || I > 0x7fffffffll) return ARL_E_RANGE;
+    if (U == 0) return ARL_OK;
+    const size_t shm = sizeof(unsigned long long) * kTU * kCap + sizeof(float) * kTU * 256 + sizeof(unsigned long long) * kTU + sizeof(int) * kTU;
+    hipError_t e = hipFuncSetAttribute((const void *)score_mask_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(score_mask_topk_kernel, dim3((unsigned)((U + kTU - 1) / kTU)), dim3(kBlock), shm, (hipStream_t)stream, Pu, Pi, (int)U, (int)I,
+                       (int)d, mask_rowptr, mask_col, (int)k, top_idx, top_val);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_topn_project_rows_f32(const float *M, int64_t rows, int64_t cols, int64_t n, float *out, int32_t *idx, float *scratch, arl_stream_t stream) {
+    if (!M || !out || !scratch) return ARL_E_NULL;
+    if (rows < 0 || cols <= 0 || n < 0 || n > cols || cols > 0x7fffffffll || rows > 0x7fffffffll) return ARL_E_ARG;
+    if (rows == 0) return ARL_OK;
+    hipLaunchKernelGGL(topn_project_kernel, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, M, (int)cols, (int)n, out, idx, scratch);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+}  // extern "C"

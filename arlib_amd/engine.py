@@ -1,0 +1,166 @@
+"""Device-resident training engine for the GMF / LightGCN / SimGCL hot loop.
+
+One `step()` is one iteration of the reference's inner loop (recommender/LightGCN.py:47-64, GMF.py:39-54):
+full-graph propagation, BPR + L2 on the gathered batch rows, backward through the propagation and a dense
+Adam (or SGD) update of both embedding tables -- as 2L SpMM launches, three small loss kernels and (for
+Adam) no separate optimizer launch at all: the update is fused into the epilogue of the last backward hop.
+
+HBM layout (all fp32, row-major, allocated once):
+    E0  [N,d]  the two embedding tables as ONE buffer: users rows [0,U), items rows [U,N)   (torch.cat eliminated)
+    m,v [N,d]  Adam moments
+    S   [N,d]  running layer sum, becomes the propagated output `out` in place
+    Ea,Eb [N,d] ping-pong hop buffers (forward hops, then backward Horner accumulators)
+    G   [N,d]  dL/d(out): zero except <= 3B rows (scatter-added by the BPR kernel)
+Backward uses the symmetry of the normalised adjacency (Horner form):
+    acc = G; repeat L-1 times: acc = G + A acc;  dE0 = (G + A acc) / (L+1).
+"""
+import torch
+
+from . import ops
+
+
+class PropagationEngine:
+    def __init__(self, graph, n_users, n_items, emb_size, n_layers, reg, lr, device, skip_layer0=False,
+                 optimizer='adam', betas=(0.9, 0.999), eps=1e-8, table=None):
+        self.A = graph
+        self.U, self.I, self.d, self.L = int(n_users), int(n_items), int(emb_size), int(n_layers)
+        self.N = self.U + self.I
+        self.reg, self.lr, self.betas, self.eps = float(reg), float(lr), betas, eps
+        self.skip0 = bool(skip_layer0)
+        self.optimizer = optimizer
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise ops._lib.ArlError('PropagationEngine needs a GPU device (no CPU fallback)')
+        if graph is None and self.L > 0:
+            raise ValueError('n_layers > 0 needs a graph')
+        if graph is not None and graph.n_rows != self.N:
+            raise ValueError('graph has %d rows, expected U+I=%d' % (graph.n_rows, self.N))
+        if self.skip0 and self.L < 1:
+            raise ValueError('skip_layer0 needs n_layers >= 1')
+        z = lambda: torch.zeros(self.N, self.d, dtype=torch.float32, device=self.device)
+        self.E0 = z() if table is None else table
+        if self.E0.shape != (self.N, self.d) or self.E0.dtype != torch.float32 or not self.E0.is_contiguous():
+            raise ValueError('table must be contiguous fp32 [U+I, d]')
+        self.m, self.v, self.G = z(), z(), z()
+        if self.L > 0:
+            self.S, self.Ea, self.Eb = z(), z(), z()
+        else:
+            self.S = self.E0
+        self.t = 0
+        self.loss_out = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self._ws = None
+
+    # views with the reference's names
+    @property
+    def user_emb(self):
+        return self.E0[:self.U]
+
+    @property
+    def item_emb(self):
+        return self.E0[self.U:]
+
+    def forward(self, noises=None, eps=0.1, out=None):
+        """Propagated tables [N,d] (recommender/LightGCN.py:230-240; SimGCL.py:198-210 when skip_layer0).
+        `noises`: optional list of L [N,d] tensors (SimGCL perturbed view, injected or from torch.rand)."""
+        L, A = self.L, self.A
+        if L == 0:
+            return self.E0
+        S = self.S if out is None else out
+        if noises is None and not self.skip0:
+            if L == 1:
+                return ops.spmm(A, self.E0, 0.5, 0.5, self.E0, out=S)
+            ops.spmm_layersum(A, self.E0, self.E0, S, self.Ea)
+            cur, nxt = self.Ea, self.Eb
+            for _ in range(L - 2):
+                ops.spmm_layersum(A, cur, S, S, nxt)
+                cur, nxt = nxt, cur
+            s = 1.0 / (L + 1)
+            return ops.spmm(A, cur, s, s, S, out=S)
+        # SimGCL family: mean over hops 1..L, optional perturbation after each hop
+        cur, nxt, x = self.Ea, self.Eb, self.E0
+        for k in range(L):
+            ops.spmm(A, x, out=cur)
+            if noises is not None:
+                ops.simgcl_perturb_(cur, noises[k], eps)
+            if k == 0:
+                if self.skip0:
+                    S.copy_(cur)
+                else:
+                    torch.add(self.E0, cur, out=S)
+            else:
+                S.add_(cur)
+            x, cur, nxt = cur, nxt, cur
+        S.mul_(1.0 / (L if self.skip0 else L + 1))
+        return S
+
+    def backward_to_table(self, G, out=None):
+        """dL/dE0 from dL/d(out) (= G, [N,d]) without touching the optimizer state."""
+        L, A = self.L, self.A
+        if L == 0:
+            return G
+        out = self.Ea if out is None else out
+        if self.skip0:
+            acc = G
+            bufs = [self.Ea, self.Eb]
+            for k in range(L - 1):
+                dst = bufs[k % 2]
+                ops.spmm(A, acc, 1.0, 1.0, G, out=dst)
+                acc = dst
+            dst = self.Eb if acc is self.Ea else self.Ea
+            return ops.spmm(A, acc, 1.0 / L, out=dst)
+        acc = G
+        bufs = [self.Ea, self.Eb]
+        for k in range(L):
+            last = k == L - 1
+            s = 1.0 / (L + 1) if last else 1.0
+            dst = bufs[k % 2]
+            ops.spmm(A, acc, s, s, G, out=dst)
+            acc = dst
+        return acc
+
+    def loss_and_grad_out(self, out, u, p, n):
+        self.G.zero_()
+        if self._ws is None or self._ws.numel() < 4 * u.numel():
+            self._ws = torch.empty(4 * u.numel(), dtype=torch.float32, device=self.device)
+        ops.bpr_l2_fwd_bwd(out, self.U, u, p, n, self.reg, self.G, workspace=self._ws, loss_out=self.loss_out, check_range=False)
+        return self.loss_out
+
+    def grad(self, u, p, n):
+        """(loss_out, dL/dE0) for one batch; no parameter update."""
+        out = self.forward()
+        lo = self.loss_and_grad_out(out, u, p, n)
+        return lo, self.backward_to_table(self.G)
+
+    def step(self, u, p, n):
+        """One training iteration on a device batch (int32 tensors, already range-checked by the caller).
+        Returns the device tensor [bpr, reg_term, ||U_b||, ||P_b||]; loss = [0]+[1] (no host sync here)."""
+        L, A = self.L, self.A
+        out = self.forward()
+        lo = self.loss_and_grad_out(out, u, p, n)
+        self.t += 1
+        if self.optimizer == 'adam' and L > 0 and not self.skip0:
+            acc = self.G
+            bufs = [self.Ea, self.Eb]
+            for k in range(L - 1):
+                dst = bufs[k % 2]
+                ops.spmm(A, acc, 1.0, 1.0, self.G, out=dst)
+                acc = dst
+            s = 1.0 / (L + 1)
+            ops.spmm_adam(A, acc, s, s, self.G, self.E0, self.m, self.v, self.lr, self.t, self.betas, self.eps)
+            return lo
+        g = self.backward_to_table(self.G)
+        self.apply_grad(g)
+        return lo
+
+    def apply_grad(self, g):
+        if self.optimizer == 'adam':
+            ops.adam_dense(self.E0, g, self.m, self.v, self.lr, self.t, self.betas, self.eps)
+        elif self.optimizer == 'sgd':
+            ops.sgd_dense(self.E0, g, self.lr)
+        else:
+            raise ValueError('unknown optimizer %r' % (self.optimizer,))
+
+    # --- accounting: algorithmic bytes of one train step
+    def step_bytes(self, B):
+        E, N, d, L = (self.A.nnz if self.A is not None else 0), self.N, self.d, self.L
+        return L * (16 * E + 8 * N + 24 * N * d) + 28 * N * d + 24 * B * d

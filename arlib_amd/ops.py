@@ -1,0 +1,339 @@
+"""Tensor-level wrappers over the C ABI (include/arlib_amd.h).
+
+PyTorch is plumbing here: device memory, streams, shapes.  Every wrapper validates operand shapes,
+dtypes, devices and contiguity on the host *before* a kernel is launched (a faulting kernel can reset
+the whole GPU host), then passes raw pointers + sizes + the current HIP stream to libarlib_amd.so.
+No op has a CPU fallback.
+"""
+import ctypes as C
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import arl_csr, check
+
+DEFAULT_CHUNK = 512
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype, name, ndim=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s: expected a torch.Tensor' % name)
+    if not t.is_cuda:
+        raise _lib.ArlError('%s: must live on the GPU (no CPU fallback in arlib_amd)' % name)
+    if t.dtype != dtype:
+        raise TypeError('%s: dtype %s, expected %s' % (name, t.dtype, dtype))
+    if not t.is_contiguous():
+        raise ValueError('%s: must be contiguous' % name)
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError('%s: expected %d dims, got %s' % (name, ndim, tuple(t.shape)))
+    return t
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _same_device(*ts):
+    devs = {t.device for t in ts if t is not None}
+    if len(devs) > 1:
+        raise ValueError('tensors on different devices: %s' % devs)
+
+
+# ------------------------------------------------------------------------------------------------ graph
+class CSRGraph:
+    """Device CSR of the normalised (U+I)^2 adjacency plus the long-row plan used by the SpMM kernels.
+
+    rowptr/col/val may be given as numpy arrays or torch tensors; they are validated on the host
+    (monotone rowptr, col in range) because the kernels trust them.
+    """
+
+    def __init__(self, rowptr, col, val, device, chunk=DEFAULT_CHUNK, validate=True):
+        rp = np.ascontiguousarray(rowptr.cpu().numpy() if isinstance(rowptr, torch.Tensor) else rowptr).astype(np.int64)
+        n = len(rp) - 1
+        nnz = int(rp[-1])
+        if n < 0 or rp[0] != 0 or nnz >= 2 ** 31 or n >= 2 ** 31:
+            raise ValueError('CSRGraph: bad rowptr / size out of int32 range')
+        if validate:
+            if np.any(np.diff(rp) < 0):
+                raise ValueError('CSRGraph: rowptr must be non-decreasing')
+        self.device = torch.device(device)
+        self.n_rows, self.nnz, self.chunk = n, nnz, int(chunk)
+        self.rowptr = torch.as_tensor(rp.astype(np.int32)).to(self.device)
+        self.col = (col if isinstance(col, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(col, dtype=np.int32))).to(self.device, torch.int32).contiguous()
+        self.val = (val if isinstance(val, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(val, dtype=np.float32))).to(self.device, torch.float32).contiguous()
+        if self.col.numel() != nnz or self.val.numel() != nnz:
+            raise ValueError('CSRGraph: col/val length != rowptr[-1]')
+        if validate and nnz:
+            lo, hi = int(self.col.min()), int(self.col.max())
+            if lo < 0 or hi >= n:
+                raise ValueError('CSRGraph: column index out of range [0,%d): %d..%d' % (n, lo, hi))
+        # long-row plan (host, once per graph)
+        deg = np.diff(rp)
+        long_rows = np.nonzero(deg > self.chunk)[0] if self.chunk > 0 else np.zeros(0, np.int64)
+        if len(long_rows):
+            nch = (deg[long_rows] + self.chunk - 1) // self.chunk
+            first = np.concatenate([[0], np.cumsum(nch)[:-1]])
+            crow = np.repeat(long_rows, nch)
+            k = np.arange(int(nch.sum())) - np.repeat(first, nch)
+            cbeg = rp[crow] + k * self.chunk
+            cend = np.minimum(cbeg + self.chunk, rp[crow + 1])
+            t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
+            self.chunk_row, self.chunk_begin, self.chunk_end = t(crow), t(cbeg), t(cend)
+            self.long_row, self.long_first, self.long_count = t(long_rows), t(first), t(nch)
+            self.n_chunks, self.n_long = int(nch.sum()), len(long_rows)
+        else:
+            self.chunk_row = self.chunk_begin = self.chunk_end = self.long_row = self.long_first = self.long_count = None
+            self.n_chunks = self.n_long = 0
+        self._partial = None
+        self.dinv = None
+
+    def with_values(self, val):
+        """Same pattern and plan, different edge values (shares index tensors)."""
+        g = object.__new__(CSRGraph)
+        g.__dict__.update(self.__dict__)
+        g.val = _dev(val, torch.float32, 'val', 1)
+        if g.val.numel() != self.nnz:
+            raise ValueError('with_values: wrong length')
+        return g
+
+    def _struct(self, d):
+        if self.n_chunks and (self._partial is None or self._partial.numel() < self.n_chunks * d):
+            self._partial = torch.empty(self.n_chunks * d, dtype=torch.float32, device=self.device)
+        s = arl_csr()
+        s.n_rows, s.nnz = self.n_rows, self.nnz
+        s.rowptr, s.col, s.val = self.rowptr.data_ptr(), self.col.data_ptr(), self.val.data_ptr()
+        s.chunk, s.n_chunks, s.n_long = self.chunk, self.n_chunks, self.n_long
+        if self.n_chunks:
+            s.chunk_row, s.chunk_begin, s.chunk_end = self.chunk_row.data_ptr(), self.chunk_begin.data_ptr(), self.chunk_end.data_ptr()
+            s.long_row, s.long_first, s.long_count = self.long_row.data_ptr(), self.long_first.data_ptr(), self.long_count.data_ptr()
+            s.partial = self._partial.data_ptr()
+        return s
+
+    def spmm_bytes(self, d):
+        """Algorithmic (compulsory) bytes of one SpMM, SURVEY 8d: 8E + 4(N+1) + 8Nd."""
+        return 8 * self.nnz + 4 * (self.n_rows + 1) + 8 * self.n_rows * d
+
+
+def norm_adj_values(rowptr, col, w, n_rows):
+    """val[e] = (dinv[row]*w[e])*dinv[col[e]] on device; returns (val, dinv)."""
+    _dev(rowptr, torch.int32, 'rowptr', 1); _dev(col, torch.int32, 'col', 1); _dev(w, torch.float32, 'w', 1)
+    if rowptr.numel() != n_rows + 1 or col.numel() != w.numel():
+        raise ValueError('norm_adj_values: shape mismatch')
+    dinv = torch.empty(n_rows, dtype=torch.float32, device=w.device)
+    val = torch.empty_like(w)
+    check(_lib.lib().arl_norm_adj_values_f32(n_rows, _ptr(rowptr), _ptr(col), _ptr(w), _ptr(dinv), _ptr(val), _stream()), 'arl_norm_adj_values_f32')
+    return val, dinv
+
+
+def _check_xy(A, X, name='X'):
+    _dev(X, torch.float32, name, 2)
+    if X.shape[0] != A.n_rows:
+        raise ValueError('%s: %d rows, adjacency has %d' % (name, X.shape[0], A.n_rows))
+    d = X.shape[1]
+    if d % 4 or d > 256:
+        raise ValueError('embedding size %d unsupported (multiple of 4, <= 256)' % d)
+    if X.device != A.device:
+        raise ValueError('%s on %s, graph on %s' % (name, X.device, A.device))
+    return d
+
+
+def spmm(A, X, alpha=1.0, beta=0.0, Z=None, out=None):
+    """out = alpha * (A @ X) + beta * Z."""
+    d = _check_xy(A, X)
+    Y = torch.empty_like(X) if out is None else out
+    _check_xy(A, Y, 'out')
+    if Y.shape != X.shape or Y.data_ptr() == X.data_ptr():
+        raise ValueError('spmm: out must have X\'s shape and must not alias X')
+    if beta != 0.0:
+        if Z is None or Z.shape != X.shape:
+            raise ValueError('spmm: Z required with X\'s shape when beta != 0')
+        _check_xy(A, Z, 'Z')
+    s = A._struct(d)
+    check(_lib.lib().arl_spmm_csr_f32(C.byref(s), _ptr(X), d, alpha, beta, _ptr(Z) if beta != 0.0 else None, _ptr(Y), _stream()), 'arl_spmm_csr_f32')
+    return Y
+
+
+def spmm_layersum(A, X, S_in, S, Y=None):
+    """Y = A @ X (optional store); S = S_in + A @ X."""
+    d = _check_xy(A, X)
+    for t, nm in ((S_in, 'S_in'), (S, 'S')):
+        _check_xy(A, t, nm)
+        if t.shape != X.shape:
+            raise ValueError('spmm_layersum: %s shape mismatch' % nm)
+    if Y is not None:
+        _check_xy(A, Y, 'Y')
+        if Y.shape != X.shape or Y.data_ptr() == X.data_ptr():
+            raise ValueError('spmm_layersum: Y must not alias X')
+    if S.data_ptr() == X.data_ptr():
+        raise ValueError('spmm_layersum: S must not alias X')
+    s = A._struct(d)
+    check(_lib.lib().arl_spmm_csr_layersum_f32(C.byref(s), _ptr(X), d, _ptr(S_in), _ptr(S), _ptr(Y), _stream()), 'arl_spmm_csr_layersum_f32')
+    return S
+
+
+def spmm_adam(A, X, alpha, beta, Z, P, M, V, lr, step, betas=(0.9, 0.999), eps=1e-8):
+    """g = alpha*(A@X) + beta*Z ; Adam update of (P, M, V) with g, fused in the SpMM epilogue."""
+    d = _check_xy(A, X)
+    for t, nm in ((P, 'P'), (M, 'M'), (V, 'V')):
+        _check_xy(A, t, nm)
+        if t.shape != X.shape or t.data_ptr() == X.data_ptr():
+            raise ValueError('spmm_adam: %s shape/alias error' % nm)
+    if beta != 0.0:
+        _check_xy(A, Z, 'Z')
+        if Z.shape != X.shape:
+            raise ValueError('spmm_adam: Z shape mismatch')
+    s = A._struct(d)
+    check(_lib.lib().arl_spmm_csr_adam_f32(C.byref(s), _ptr(X), d, alpha, beta, _ptr(Z) if beta != 0.0 else None, _ptr(P), _ptr(M), _ptr(V),
+                                           lr, betas[0], betas[1], eps, int(step), _stream()), 'arl_spmm_csr_adam_f32')
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def _check_idx(t, name, hi, B=None):
+    _dev(t, torch.int32, name, 1)
+    if B is not None and t.numel() != B:
+        raise ValueError('%s: length %d != %d' % (name, t.numel(), B))
+    return t
+
+
+def bpr_l2_fwd_bwd(emb, item_off, u, p, n, reg, G=None, upstream=1.0, workspace=None, loss_out=None, check_range=True):
+    """BPR + L2 on rows gathered from the combined table; returns loss_out = [bpr, reg_term, ||U_b||, ||P_b||] (device).
+    If G is given, the gradient w.r.t. `emb` rows is atomically added into it."""
+    _dev(emb, torch.float32, 'emb', 2)
+    N, d = emb.shape
+    B = u.numel()
+    for t, nm in ((u, 'u'), (p, 'p'), (n, 'n')):
+        _check_idx(t, nm, N, B)
+    if B == 0:
+        raise ValueError('bpr_l2: empty batch')
+    if check_range:   # host-side bounds check (one small sync); hot loops validate once and pass check_range=False
+        mx = torch.stack([u.max(), p.max(), n.max(), -u.min(), -p.min(), -n.min()]).tolist()
+        if mx[0] >= N or max(mx[1], mx[2]) + item_off >= N or max(mx[3:]) > 0:
+            raise IndexError('bpr_l2: batch index out of range')
+    if G is not None:
+        _dev(G, torch.float32, 'G', 2)
+        if G.shape != emb.shape:
+            raise ValueError('bpr_l2: G shape mismatch')
+    need = _lib.lib().arl_bpr_l2_workspace_bytes(B)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need // 4, dtype=torch.float32, device=emb.device)
+    if loss_out is None:
+        loss_out = torch.empty(4, dtype=torch.float32, device=emb.device)
+    check(_lib.lib().arl_bpr_l2_fwd_bwd_f32(_ptr(emb), d, item_off, _ptr(u), _ptr(p), _ptr(n), B, reg, upstream, _ptr(loss_out), _ptr(G),
+                                            _ptr(workspace), _stream()), 'arl_bpr_l2_fwd_bwd_f32')
+    return loss_out
+
+
+def adam_dense(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8):
+    for t, nm in ((p, 'p'), (g, 'g'), (m, 'm'), (v, 'v')):
+        _dev(t, torch.float32, nm)
+        if t.numel() != p.numel():
+            raise ValueError('adam_dense: size mismatch on %s' % nm)
+    check(_lib.lib().arl_adam_dense_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, betas[0], betas[1], eps, int(step), _stream()), 'arl_adam_dense_f32')
+
+
+def sgd_dense(p, g, lr):
+    _dev(p, torch.float32, 'p'); _dev(g, torch.float32, 'g')
+    if g.numel() != p.numel():
+        raise ValueError('sgd_dense: size mismatch')
+    check(_lib.lib().arl_sgd_dense_f32(_ptr(p), _ptr(g), p.numel(), lr, _stream()), 'arl_sgd_dense_f32')
+
+
+def gather_rows(src, idx, check_range=True):
+    _dev(src, torch.float32, 'src', 2); _dev(idx, torch.int32, 'idx', 1)
+    if check_range and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= src.shape[0]):
+        raise IndexError('gather_rows: index out of range')
+    dst = torch.empty(idx.numel(), src.shape[1], dtype=torch.float32, device=src.device)
+    check(_lib.lib().arl_gather_rows_f32(_ptr(src), _ptr(idx), idx.numel(), src.shape[1], _ptr(dst), _stream()), 'arl_gather_rows_f32')
+    return dst
+
+
+def scatter_add_rows(dst, idx, src, scale=1.0, check_range=True):
+    _dev(dst, torch.float32, 'dst', 2); _dev(src, torch.float32, 'src', 2); _dev(idx, torch.int32, 'idx', 1)
+    if src.shape != (idx.numel(), dst.shape[1]):
+        raise ValueError('scatter_add_rows: shape mismatch')
+    if check_range and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= dst.shape[0]):
+        raise IndexError('scatter_add_rows: index out of range')
+    check(_lib.lib().arl_scatter_add_rows_f32(_ptr(dst), _ptr(idx), idx.numel(), dst.shape[1], _ptr(src), scale, _stream()), 'arl_scatter_add_rows_f32')
+    return dst
+
+
+def infonce_fwd_bwd(v1, v2, tau, want_grad=True, upstream=1.0):
+    _dev(v1, torch.float32, 'v1', 2); _dev(v2, torch.float32, 'v2', 2)
+    if v1.shape != v2.shape:
+        raise ValueError('infonce: shape mismatch')
+    n, d = v1.shape
+    if n == 0 or n > 8192 or d % 4 or d > 256:
+        raise ValueError('infonce: unsupported shape %s' % (tuple(v1.shape),))
+    ws = torch.empty(_lib.lib().arl_infonce_workspace_bytes(n, d) // 4, dtype=torch.float32, device=v1.device)
+    loss = torch.empty(1, dtype=torch.float32, device=v1.device)
+    d1 = torch.empty_like(v1) if want_grad else None
+    d2 = torch.empty_like(v2) if want_grad else None
+    check(_lib.lib().arl_infonce_fwd_bwd_f32(_ptr(v1), _ptr(v2), n, d, tau, upstream, _ptr(loss), _ptr(d1), _ptr(d2), _ptr(ws), _stream()), 'arl_infonce_fwd_bwd_f32')
+    return loss, d1, d2
+
+
+def simgcl_perturb_(E, noise, eps):
+    _dev(E, torch.float32, 'E', 2); _dev(noise, torch.float32, 'noise', 2)
+    if E.shape != noise.shape:
+        raise ValueError('simgcl_perturb_: shape mismatch')
+    check(_lib.lib().arl_simgcl_perturb_f32(_ptr(E), _ptr(noise), E.shape[0], E.shape[1], eps, _stream()), 'arl_simgcl_perturb_f32')
+    return E
+
+
+# ------------------------------------------------------------------------------------------------ attack primitives
+def sddmm_rows_dense(dY, X, rows, col_off, n_cols, out=None):
+    _dev(dY, torch.float32, 'dY', 2); _dev(X, torch.float32, 'X', 2); _dev(rows, torch.int32, 'rows', 1)
+    if dY.shape[1] != X.shape[1] or col_off < 0 or col_off + n_cols > X.shape[0]:
+        raise ValueError('sddmm_rows_dense: shape mismatch')
+    if rows.numel() and (int(rows.min()) < 0 or int(rows.max()) >= dY.shape[0]):
+        raise IndexError('sddmm_rows_dense: row out of range')
+    if out is None:
+        out = torch.zeros(rows.numel(), n_cols, dtype=torch.float32, device=X.device)
+    else:
+        _dev(out, torch.float32, 'out', 2)
+        if out.shape != (rows.numel(), n_cols):
+            raise ValueError('sddmm_rows_dense: out shape mismatch')
+    check(_lib.lib().arl_sddmm_rows_dense_f32(_ptr(dY), _ptr(X), X.shape[1], _ptr(rows), rows.numel(), col_off, n_cols, _ptr(out), _stream()), 'arl_sddmm_rows_dense_f32')
+    return out
+
+
+def pga_update_(S, grad):
+    _dev(S, torch.float32, 'S'); _dev(grad, torch.float32, 'grad')
+    if S.shape != grad.shape:
+        raise ValueError('pga_update_: shape mismatch')
+    check(_lib.lib().arl_pga_update_f32(_ptr(S), _ptr(grad), S.numel(), _stream()), 'arl_pga_update_f32')
+    return S
+
+
+def score_mask_topk(Pu, Pi, k, mask_rowptr=None, mask_col=None):
+    _dev(Pu, torch.float32, 'Pu', 2); _dev(Pi, torch.float32, 'Pi', 2)
+    U, d = Pu.shape
+    I = Pi.shape[0]
+    if Pi.shape[1] != d or d % 4 or d > 256 or not (0 < k <= min(128, I)):
+        raise ValueError('score_mask_topk: unsupported shape / k')
+    if mask_rowptr is not None:
+        _dev(mask_rowptr, torch.int32, 'mask_rowptr', 1); _dev(mask_col, torch.int32, 'mask_col', 1)
+        if mask_rowptr.numel() != U + 1:
+            raise ValueError('score_mask_topk: mask_rowptr must have U+1 entries')
+        if int(mask_rowptr[-1]) != mask_col.numel():
+            raise ValueError('score_mask_topk: mask_rowptr[-1] != len(mask_col)')
+    idx = torch.empty(U, k, dtype=torch.int32, device=Pu.device)
+    val = torch.empty(U, k, dtype=torch.float32, device=Pu.device)
+    check(_lib.lib().arl_score_mask_topk_f32(_ptr(Pu), _ptr(Pi), U, I, d, _ptr(mask_rowptr), _ptr(mask_col), k, _ptr(idx), _ptr(val), _stream()), 'arl_score_mask_topk_f32')
+    return idx, val
+
+
+def topn_project_rows(M, n):
+    _dev(M, torch.float32, 'M', 2)
+    rows, cols = M.shape
+    if not (0 <= n <= cols):
+        raise ValueError('topn_project_rows: bad n')
+    out = torch.empty_like(M)
+    idx = torch.empty(rows, max(n, 1), dtype=torch.int32, device=M.device)
+    scratch = torch.empty_like(M)
+    check(_lib.lib().arl_topn_project_rows_f32(_ptr(M), rows, cols, n, _ptr(out), _ptr(idx), _ptr(scratch), _stream()), 'arl_topn_project_rows_f32')
+    return out, idx[:, :n]

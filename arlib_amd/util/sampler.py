@@ -1,0 +1,153 @@
+"""Drop-in for the reference's util/sampler.py:4-30 (next_batch_pairwise), bit-exact.
+
+The sequential MT19937 work (Fisher-Yates shuffle, per-sample rejection sampling) runs in the host part
+of libarlib_amd.so (arlib_amd/csrc/arl_host.cpp).  It consumes CPython's *global* `random` state exactly
+like the reference does: the state is read with random.getstate(), advanced in C, and written back with
+random.setstate(), so code that interleaves other `random` calls stays in lock-step with the reference.
+"""
+import ctypes as C
+import random
+import numpy as np
+
+from .. import _lib
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class MTState:
+    """CPython `random` state as a 625-word uint32 array."""
+
+    def __init__(self, words=None):
+        self.words = np.zeros(625, np.uint32) if words is None else np.ascontiguousarray(words, dtype=np.uint32)
+
+    @classmethod
+    def from_seed(cls, seed):
+        seed = abs(int(seed))
+        key = []
+        while True:
+            key.append(seed & 0xFFFFFFFF)
+            seed >>= 32
+            if not seed:
+                break
+        key = np.array(key, np.uint32)
+        st = cls()
+        _lib.check(_lib.lib().arl_mt_seed(_vp(st.words), _vp(key), len(key)), 'arl_mt_seed')
+        return st
+
+    @classmethod
+    def from_python(cls):
+        return cls(np.array(random.getstate()[1], dtype=np.uint32))
+
+    def to_python(self):
+        st = random.getstate()
+        random.setstate((st[0], tuple(int(x) for x in self.words), st[2]))
+
+
+def build_membership(pairs, n_users):
+    """CSR image of training_set_u (util/DataLoader.py:41): sorted, de-duplicated item ids per user."""
+    pairs = np.asarray(pairs)
+    key = np.unique(pairs[:, 0].astype(np.int64) * (1 << 32) + pairs[:, 1].astype(np.int64))
+    rowptr = np.zeros(n_users + 1, np.int64)
+    np.add.at(rowptr, (key >> 32) + 1, 1)
+    return np.cumsum(rowptr), (key & 0xFFFFFFFF).astype(np.int32)
+
+
+class PairSampler:
+    """Array-native sampler state: `pairs` int32 [nnz,2] (shuffled in place like data.training_data),
+    membership CSR, item count."""
+
+    def __init__(self, pairs, n_items, memb=None, n_users=None):
+        self.pairs = np.ascontiguousarray(pairs, dtype=np.int32)
+        if self.pairs.ndim != 2 or self.pairs.shape[1] != 2:
+            raise ValueError('pairs must be [nnz,2]')
+        self.n_items = int(n_items)
+        if self.pairs.size and (self.pairs.min() < 0 or self.pairs[:, 1].max() >= self.n_items):
+            raise ValueError('pair ids out of range')
+        if memb is None:
+            memb = build_membership(self.pairs, int(n_users if n_users is not None else self.pairs[:, 0].max() + 1))
+        self.memb_rowptr = np.ascontiguousarray(memb[0], dtype=np.int64)
+        self.memb_items = np.ascontiguousarray(memb[1], dtype=np.int32)
+        if len(self.memb_items) == 0:
+            self.memb_items = np.zeros(1, np.int32)
+
+    @property
+    def nnz(self):
+        return self.pairs.shape[0]
+
+    def shuffle(self, mt, also=None):
+        """random.shuffle(training_data).  `also`: optional int32 [nnz,2] array permuted identically."""
+        before = mt.words.copy() if also is not None else None
+        _lib.check(_lib.lib().arl_sampler_shuffle(_vp(mt.words), _vp(self.pairs), self.nnz), 'arl_sampler_shuffle')
+        if also is not None:
+            _lib.check(_lib.lib().arl_sampler_shuffle(_vp(before), _vp(also), self.nnz), 'arl_sampler_shuffle')
+
+    def batch(self, mt, begin, count, out=None):
+        """One batch into `out` (int32 [3,count], e.g. a pinned-host tensor's numpy view) -> rows u, p, n."""
+        if begin < 0 or count < 0 or begin + count > self.nnz:
+            raise IndexError('batch window outside the training pairs')
+        if out is None:
+            out = np.empty((3, count), np.int32)
+        if out.dtype != np.int32 or out.shape != (3, count) or not out.flags.c_contiguous:
+            raise ValueError('out must be C-contiguous int32 [3,count]')
+        _lib.check(_lib.lib().arl_sampler_next_batch(_vp(mt.words), _vp(self.pairs), begin, count, self.n_items, _vp(self.memb_rowptr),
+                                                     _vp(self.memb_items), len(self.memb_rowptr) - 1, _vp(out[0]), _vp(out[1]), _vp(out[2])),
+                   'arl_sampler_next_batch')
+        return out
+
+    def epoch(self, mt, batch_size):
+        """Generator over one epoch: shuffle, then consecutive batches (last one ragged)."""
+        self.shuffle(mt)
+        b = 0
+        while b < self.nnz:
+            cnt = min(batch_size, self.nnz - b)
+            yield self.batch(mt, b, cnt)
+            b += cnt
+
+
+def _shadow(data):
+    """int32 image of data.training_data for the list-based DataLoader API (rebuilt when the list length changed,
+    e.g. after an attack appended fake-user interactions: attack/White/CLeaR.py:190-191)."""
+    sh = getattr(data, '_arl_sampler', None)
+    td = data.training_data
+    if sh is None or sh.nnz != len(td) or sh.n_items != len(data.item):
+        pairs = np.array([[data.user[r[0]], data.item[r[1]]] for r in td], np.int32).reshape(-1, 2)
+        memb = getattr(data, '_arl_memb', None)
+        if memb is None:
+            # training_set_u is fixed at DataLoader construction (util/DataLoader.py:41); users added later have an empty set
+            tsu = data.training_set_u
+            us = [u for u in tsu if len(tsu[u])]
+            mp = np.array([[data.user[u], data.item[i]] for u in us for i in tsu[u]], np.int32).reshape(-1, 2)
+            n_rows = (max(data.user[u] for u in us) + 1) if us else 0
+            memb = build_membership(mp, n_rows) if len(mp) else (np.zeros(1, np.int64), np.zeros(1, np.int32))
+            data._arl_memb = memb
+        sh = PairSampler(pairs, len(data.item), memb)
+        data._arl_sampler = sh
+    return sh
+
+
+def next_batch_pairwise(data, batch_size):
+    """Generator with the reference's signature and semantics (util/sampler.py:4-30): shuffles
+    data.training_data in place, then yields (u_idx, i_idx, j_idx) per batch -- here int32 numpy arrays
+    (index a tensor with them exactly as with the reference's Python lists)."""
+    if hasattr(data, 'pair_sampler'):               # array-native data (arlib_amd.util.synthetic.InteractionData)
+        sh = data.pair_sampler
+        order = None
+    else:
+        sh = _shadow(data)
+        order = np.stack([np.arange(sh.nnz, dtype=np.int32), np.zeros(sh.nnz, np.int32)], 1)
+    mt = MTState.from_python()
+    sh.shuffle(mt, also=order)
+    mt.to_python()
+    if order is not None:                            # keep the Python list in the same (shuffled) order: in-place carry-over
+        td = data.training_data
+        td[:] = [td[k] for k in order[:, 0]]
+    b = 0
+    while b < sh.nnz:
+        cnt = min(batch_size, sh.nnz - b)
+        mt = MTState.from_python()
+        out = sh.batch(mt, b, cnt)
+        mt.to_python()
+        b += cnt
+        yield out[0], out[1], out[2]

@@ -1,0 +1,176 @@
+/*
+ * arlib_amd.h -- C ABI of libarlib_amd.so: the MI355X (gfx950) implementation of ARLib's
+ * embedding-recommender training + white-box attack hot path.
+ *
+ * The reference (CoderWZW/ARLib) is 100 % Python and has no FFI: its "kernels" are implicit ATen ops.
+ * Each entry point below therefore cites the reference Python lines whose device work it replaces
+ * (paths relative to the reference root).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - return 0 on success; negative = argument error (ARL_E_*); positive = hipError_t.
+ *   - never throws across the ABI, never allocates or frees device memory, takes no ownership:
+ *     every buffer and workspace is caller-allocated; sizes of workspaces come from *_workspace_bytes.
+ *   - device entry points are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream) and re-entrant across distinct streams as long as workspaces are distinct.
+ *   - all matrices are row-major fp32; all indices int32; row offsets int32 (nnz < 2^31).
+ *   - "emb" tables are ONE contiguous [N,d] buffer: user rows first, item rows at row offset item_off.
+ *   - d must be a multiple of 4 and <= 256 for the propagation kernels (reference default d = 64).
+ */
+#ifndef ARLIB_AMD_H
+#define ARLIB_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARL_OK 0
+#define ARL_E_NULL (-1)      /* required pointer is NULL                     */
+#define ARL_E_DIM (-2)       /* unsupported embedding size / shape           */
+#define ARL_E_RANGE (-3)     /* size out of the int32 index range            */
+#define ARL_E_ARG (-4)       /* inconsistent arguments                       */
+
+typedef void *arl_stream_t;
+
+/* ABI version; bump on any signature change. */
+int arl_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Host sampler -- replaces util/sampler.py:4-30 (next_batch_pairwise) bit-exactly, including the
+ * CPython `random` MT19937 stream it consumes (util/tool.py:101-108 seedSet -> random.seed).
+ * `mt_state` is random.getstate()[1] as 625 uint32 (624 words + index); it is advanced in place so
+ * the caller can random.setstate() it back and stay in lock-step with the reference.
+ * Not thread-safe per state object.
+ * ---------------------------------------------------------------------------------------------- */
+/* random.seed(int): key = 32-bit little-endian words of abs(seed) */
+int arl_mt_seed(uint32_t *mt_state, const uint32_t *key, int64_t key_len);
+/* util/sampler.py:9   shuffle(training_data) in place; pairs = int32 [nnz][2] (user id, item id) */
+int arl_sampler_shuffle(uint32_t *mt_state, int32_t *pairs, int64_t nnz);
+/* util/sampler.py:12-29  one batch: positives pairs[begin..begin+count), one negative per positive drawn
+ * by choice(item_list) with rejection against training_set_u[user] (given as a CSR with sorted item
+ * ids; users >= memb_rows have an empty set, which is what the reference's defaultdict gives users
+ * injected after DataLoader construction). */
+int arl_sampler_next_batch(uint32_t *mt_state, const int32_t *pairs, int64_t begin, int64_t count,
+                           int32_t n_items, const int64_t *memb_rowptr, const int32_t *memb_items,
+                           int64_t memb_rows, int32_t *out_u, int32_t *out_p, int32_t *out_n);
+
+/* ------------------------------------------------------------------------------------------------
+ * CSR adjacency + long-row plan.  The plan splits rows longer than `chunk` edges into chunk tasks so
+ * a 100k-edge popular-item row does not serialise one wavefront; partial sums go to `partial`
+ * ([n_chunks][d] fp32, caller-allocated) and are combined in chunk order (deterministic).
+ * n_chunks == 0 means "no plan": every row is processed whole.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct arl_csr {
+    int64_t n_rows;
+    int64_t nnz;
+    const int32_t *rowptr;      /* [n_rows+1] device */
+    const int32_t *col;         /* [nnz] device      */
+    const float *val;           /* [nnz] device      */
+    int32_t chunk;              /* rows with more than `chunk` edges are split (0 = never)       */
+    int64_t n_chunks;
+    const int32_t *chunk_row;   /* [n_chunks] device: output row of the task                      */
+    const int32_t *chunk_begin; /* [n_chunks] device: first edge                                  */
+    const int32_t *chunk_end;   /* [n_chunks] device: one past last edge                          */
+    int64_t n_long;
+    const int32_t *long_row;    /* [n_long] device                                                */
+    const int32_t *long_first;  /* [n_long] device: first chunk slot of the row                   */
+    const int32_t *long_count;  /* [n_long] device: number of chunk slots                         */
+    float *partial;             /* [n_chunks * d] device workspace                                */
+} arl_csr;
+
+/* Degree-normalised edge values on device.  Replaces util/DataLoader.py:73-87 (normalize_graph_mat) and
+ * recommender/LightGCN.py:212-215 (_init_uiAdj): val[e] = (dinv[row]*w[e])*dinv[col[e]], dinv = rowsum^-1/2
+ * (0 for an empty row).  dinv: [n_rows] device workspace (kept: PGA re-uses it, attack/White/PGA.py:118-126). */
+int arl_norm_adj_values_f32(int64_t n_rows, const int32_t *rowptr, const int32_t *col, const float *w,
+                            float *dinv, float *val, arl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SpMM family -- replaces torch.sparse.mm(sparse_norm_adj, ego) and its autograd
+ * (recommender/LightGCN.py:234, recommender/SimGCL.py:202) plus the fused neighbours:
+ *   arl_spmm_csr_f32          Y = alpha*(A X) + beta*Z            (Z may be NULL iff beta == 0)
+ *   arl_spmm_csr_layersum_f32 Y = A X ; S = S_in + Y              (torch.stack(...).mean running sum,
+ *                                                                  LightGCN.py:236-237; S may alias S_in)
+ *   arl_spmm_csr_adam_f32     g = alpha*(A X) + beta*Z ; Adam(P,M,V; g)   (last backward hop fused with
+ *                                                                  torch.optim.Adam.step, LightGCN.py:64)
+ * X, Y, Z, S, P, M, V: [n_rows, d] (square adjacency).  Y must not alias X.
+ * ---------------------------------------------------------------------------------------------- */
+int arl_spmm_csr_f32(const arl_csr *A, const float *X, int64_t d, float alpha, float beta, const float *Z,
+                     float *Y, arl_stream_t stream);
+int arl_spmm_csr_layersum_f32(const arl_csr *A, const float *X, int64_t d, const float *S_in, float *S,
+                              float *Y, arl_stream_t stream);
+int arl_spmm_csr_adam_f32(const arl_csr *A, const float *X, int64_t d, float alpha, float beta, const float *Z,
+                          float *P, float *M, float *V, float lr, float beta1, float beta2, float eps,
+                          int64_t step, arl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BPR + un-squared L2 on gathered rows, forward + backward in one call.
+ * Replaces util/loss.py:5-9 (bpr_loss, eps 10e-8), :25-29 (l2_reg_loss), the three gathers
+ * rec_user_emb[user_idx] ... (recommender/LightGCN.py:51-52) and their autograd (index_put accumulate).
+ *   loss_out[0] = mean(-log(1e-7 + sigmoid(<u,p>-<u,n>)))   loss_out[1] = reg*(||U_b||_F + ||P_b||_F)
+ *   loss_out[2] = ||U_b||_F   loss_out[3] = ||P_b||_F
+ *   G[row] += upstream * d(loss)/d(emb[row])  (atomic scatter-add; duplicates accumulate; G pre-zeroed or
+ *   holding other gradient terms).  G may be NULL for forward only.
+ * workspace: arl_bpr_l2_workspace_bytes(B) bytes of device memory.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t arl_bpr_l2_workspace_bytes(int64_t B);
+int arl_bpr_l2_fwd_bwd_f32(const float *emb, int64_t d, int64_t item_off, const int32_t *u, const int32_t *p,
+                           const int32_t *n, int64_t B, float reg, float upstream, float *loss_out, float *G,
+                           void *workspace, arl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense optimisers -- torch.optim.Adam (betas, eps, no weight decay; recommender/LightGCN.py:33,64) and
+ * torch.optim.SGD (attack/White/PGA.py:59) over a whole table.  `step` is the 1-based step count.
+ * ---------------------------------------------------------------------------------------------- */
+int arl_adam_dense_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1,
+                       float beta2, float eps, int64_t step, arl_stream_t stream);
+int arl_sgd_dense_f32(float *p, const float *g, int64_t n, float lr, arl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row gather / scatter-add helpers (advanced indexing of the propagated tables and its backward).
+ *   gather:       dst[t] = src[idx[t]]
+ *   scatter_add:  dst[idx[t]] += scale * src[t]   (atomic; duplicates accumulate)
+ * ---------------------------------------------------------------------------------------------- */
+int arl_gather_rows_f32(const float *src, const int32_t *idx, int64_t n, int64_t d, float *dst, arl_stream_t stream);
+int arl_scatter_add_rows_f32(float *dst, const int32_t *idx, int64_t n, int64_t d, const float *src, float scale,
+                             arl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * InfoNCE forward + backward -- replaces util/loss.py:42-49 and its autograd.
+ *   loss_out[0] = mean_i( -log( exp(<a_i,b_i>/tau) / sum_j exp(<a_i,b_j>/tau) ) ), a,b = row-normalised v1,v2
+ *   dv1, dv2 = upstream * gradients (may be NULL for forward only).   n <= 8192, d <= 256.
+ * workspace: arl_infonce_workspace_bytes(n, d).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t arl_infonce_workspace_bytes(int64_t n, int64_t d);
+int arl_infonce_fwd_bwd_f32(const float *v1, const float *v2, int64_t n, int64_t d, float tau, float upstream,
+                            float *loss_out, float *dv1, float *dv2, void *workspace, arl_stream_t stream);
+
+/* SimGCL perturbation -- recommender/SimGCL.py:203-205: E += sign(E) * normalize(noise, dim=-1) * eps, in place. */
+int arl_simgcl_perturb_f32(float *E, const float *noise, int64_t n, int64_t d, float eps, arl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * White-box attack primitives.
+ * ---------------------------------------------------------------------------------------------- */
+/* Gradient w.r.t. adjacency values restricted to `rows`, dense over the item block (the only entries PGA
+ * uses; replaces autograd.grad(Loss, sparse_norm_adj) + to_dense() + slicing, attack/White/PGA.py:117-134):
+ *   out[t, j] += <dY[rows[t]], X[col_off + j]> ,  0 <= j < n_cols.   out: [n_rows_sel, n_cols]. */
+int arl_sddmm_rows_dense_f32(const float *dY, const float *X, int64_t d, const int32_t *rows, int64_t n_rows_sel,
+                             int64_t col_off, int64_t n_cols, float *out, arl_stream_t stream);
+/* S = S - 0.2*tanh(grad); S>1 -> 1; S<=0 -> 10e-8   (attack/White/PGA.py:135-139) */
+int arl_pga_update_f32(float *S, const float *grad, int64_t n, arl_stream_t stream);
+/* Streaming scores + interacted mask + top-k, never materialising U x I.  Replaces the chunked Pu@Pi.T into a
+ * host buffer, scores[nonzero] = -10e8 and torch.topk (attack/White/DLAttack.py:73-83, CLeaR.py:75-82,
+ * PGA.py:100-102 with mask_rowptr == NULL).  Output sorted by descending score, ties by ascending item id.
+ * k <= 128.  workspace: none. */
+int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t I, int64_t d,
+                            const int32_t *mask_rowptr, const int32_t *mask_col, int64_t k, int32_t *top_idx,
+                            float *top_val, arl_stream_t stream);
+/* Per-row top-n -> {0,1} rows (+ indices, descending value, ties ascending column).  Replaces project()
+ * (attack/White/PGA.py:153-158, CLeaR.py:161-166, DLAttack.py:127-132).  scratch: [rows*cols] fp32. */
+int arl_topn_project_rows_f32(const float *M, int64_t rows, int64_t cols, int64_t n, float *out, int32_t *idx,
+                              float *scratch, arl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARLIB_AMD_H */

@@ -1,0 +1,251 @@
+"""GPU parity tests: every HIP kernel (through the C ABI / ctypes) against the CPU oracle on seeded inputs and
+against the golden fixtures captured from the reference.  Bar: fp32 within 1e-4 rel (north_star), ints bit-exact."""
+import numpy as np
+import pytest
+import torch
+from conftest import golden, rel_err, RTOL
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail('GPU tests need a GPU (run with -m gpu on the MI355X box)')
+    from arlib_amd import ops as _ops
+    return _ops
+
+
+DEV = 'cuda:0'
+
+
+def T(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+
+
+def random_graph(rng, U, I, avg_deg, hot_items=0, hot_deg=0, empty_users=()):
+    """Bipartite interaction list with power-law-ish item popularity, optional very hot items (long rows)
+    and isolated users (empty rows)."""
+    deg = np.clip(rng.poisson(avg_deg, U), 1, I)
+    us = np.repeat(np.arange(U), deg)
+    its = np.floor(I * rng.random(len(us)) ** 2).astype(np.int64)
+    for h in range(hot_items):
+        extra = rng.choice(U, size=min(hot_deg, U), replace=False)
+        us = np.concatenate([us, extra]); its = np.concatenate([its, np.full(len(extra), h)])
+    keep = ~np.isin(us, np.array(list(empty_users), dtype=np.int64))
+    us, its = us[keep], its[keep]
+    key = np.unique(us * I + its)
+    return (key // I).astype(np.int32), (key % I).astype(np.int32)
+
+
+def make_csr(u, i, U, I, w=None):
+    rowptr, col, ww = O.bipartite_csr(u, i, U, I, w)
+    val = O.norm_adj_values(rowptr, col, ww)
+    return rowptr, col, ww, val
+
+
+@pytest.mark.parametrize('d', [16, 32, 64, 128, 24])
+def test_spmm_all_epilogues(ops, d):
+    rng = np.random.default_rng(d)
+    U, I = 3000, 700
+    u, i = random_graph(rng, U, I, 12, hot_items=3, hot_deg=2500, empty_users=(5, 77))
+    rowptr, col, w, val = make_csr(u, i, U, I)
+    N = U + I
+    assert np.diff(rowptr).max() > 4 * 512 and np.diff(rowptr).min() == 0      # long rows and empty rows present
+    A = ops.CSRGraph(rowptr, col, val, DEV, chunk=512)
+    assert A.n_long >= 3
+    X = rng.standard_normal((N, d)).astype(np.float32)
+    Z = rng.standard_normal((N, d)).astype(np.float32)
+    csr = (rowptr, col, val)
+    ref = O.spmm(csr, X)
+    assert rel_err(ops.spmm(A, T(X)).cpu().numpy(), ref) < RTOL
+    assert rel_err(ops.spmm(A, T(X), 0.25, 0.25, T(Z)).cpu().numpy(), O.spmm(csr, X, 0.25, 0.25, Z)) < RTOL
+    # no-plan variant (every row whole) must agree too
+    A0 = ops.CSRGraph(rowptr, col, val, DEV, chunk=0)
+    assert A0.n_chunks == 0
+    assert rel_err(ops.spmm(A0, T(X)).cpu().numpy(), ref) < RTOL
+    # layer-sum epilogue
+    S = T(Z.copy()); Y = torch.empty_like(S)
+    ops.spmm_layersum(A, T(X), S, S, Y)
+    assert rel_err(Y.cpu().numpy(), ref) < RTOL and rel_err(S.cpu().numpy(), Z + ref) < RTOL
+    # fused Adam epilogue == oracle spmm + oracle adam
+    P = rng.standard_normal((N, d)).astype(np.float32) * 0.1
+    M = rng.standard_normal((N, d)).astype(np.float32) * 0.01
+    V = (rng.random((N, d)).astype(np.float32)) * 1e-4
+    g = O.spmm(csr, X, 0.25, 0.25, Z)
+    Pr, Mr, Vr = P.copy(), M.copy(), V.copy()
+    O.adam_step(Pr, g, Mr, Vr, 0.005, 7)
+    Pt, Mt, Vt = T(P), T(M), T(V)
+    ops.spmm_adam(A, T(X), 0.25, 0.25, T(Z), Pt, Mt, Vt, 0.005, 7)
+    assert rel_err(Pt.cpu().numpy(), Pr) < RTOL and rel_err(Mt.cpu().numpy(), Mr) < RTOL and rel_err(Vt.cpu().numpy(), Vr) < RTOL
+
+
+def test_spmm_deterministic_and_linear(ops):
+    rng = np.random.default_rng(3)
+    U, I, d = 5000, 900, 64
+    u, i = random_graph(rng, U, I, 20, hot_items=2, hot_deg=4000)
+    rowptr, col, w, val = make_csr(u, i, U, I)
+    A = ops.CSRGraph(rowptr, col, val, DEV)
+    X1 = torch.randn(U + I, d, device=DEV); X2 = torch.randn(U + I, d, device=DEV)
+    y1 = ops.spmm(A, X1); y1b = ops.spmm(A, X1)
+    assert torch.equal(y1, y1b)                                   # chunk partials are combined in fixed order
+    lin = ops.spmm(A, X1 + 2 * X2)
+    assert rel_err(lin.cpu().numpy(), (y1 + 2 * ops.spmm(A, X2)).cpu().numpy()) < RTOL
+    # symmetry of the normalised adjacency: <y, A x> == <A y, x>
+    a = (X2 * y1).sum().item(); b = (ops.spmm(A, X2) * X1).sum().item()
+    assert abs(a - b) <= 1e-3 * max(abs(a), 1.0)
+
+
+def test_norm_adj_values_golden_and_weighted(ops, ml100k):
+    g = golden('g3_adj.npz')
+    p = ml100k['pairs0']
+    rowptr, col, w = O.bipartite_csr(p[:, 0], p[:, 1], ml100k['U'], ml100k['I'])
+    val, dinv = ops.norm_adj_values(T(rowptr.astype(np.int32)), T(col), T(w), len(rowptr) - 1)
+    assert rel_err(val.cpu().numpy(), g['norm_data']) < 1e-6
+    U, I = (int(x) for x in g['w_shape'])
+    rowptr, col, w = O.bipartite_csr(g['w_R_row'], g['w_R_col'], U, I, g['w_R_val'])
+    val, dinv = ops.norm_adj_values(T(rowptr.astype(np.int32)), T(col), T(w), U + I)
+    assert np.allclose(val.cpu().numpy(), g['w_norm_val'], rtol=1e-5, atol=0)
+    assert dinv[7].item() == 0.0                                  # isolated user: empty row, no inf/NaN
+
+
+@pytest.mark.parametrize('tag', ['n', 'sat'])
+def test_bpr_l2_golden(ops, tag):
+    g = golden('g2_losses.npz')
+    u, p, n = g[tag + '_u'], g[tag + '_p'], g[tag + '_n']
+    B = len(u)
+    emb = T(np.concatenate([u, p, n], 0))
+    G = torch.zeros_like(emb)
+    ar = torch.arange(B, dtype=torch.int32, device=DEV)
+    out = ops.bpr_l2_fwd_bwd(emb, B, ar, ar, ar + B, 1e-4, G).cpu().numpy()
+    assert abs(out[0] - g[tag + '_bpr'][0]) <= RTOL * abs(g[tag + '_bpr'][0])
+    assert abs(out[1] - g[tag + '_reg'][0]) <= RTOL * abs(g[tag + '_reg'][0])
+    Gn = G.cpu().numpy()
+    assert rel_err(Gn[:B], g[tag + '_du']) < RTOL and rel_err(Gn[B:2 * B], g[tag + '_dp']) < RTOL
+    assert rel_err(Gn[2 * B:], g[tag + '_dn']) < RTOL
+
+
+def test_bpr_l2_duplicates_and_ragged(ops):
+    g = golden('g2_losses.npz')
+    emb = T(g['dup_T'])
+    G = torch.zeros_like(emb)
+    out = ops.bpr_l2_fwd_bwd(emb, 0, T(g['dup_ui']), T(g['dup_pi']), T(g['dup_ni']), 1e-4, G).cpu().numpy()
+    assert abs(out[0] + out[1] - g['dup_loss'][0]) <= RTOL * abs(g['dup_loss'][0])
+    assert rel_err(G.cpu().numpy(), g['dup_dT']) < RTOL
+    # ragged batch (B=1, odd d) against the oracle
+    rng = np.random.default_rng(0)
+    e = rng.standard_normal((50, 20)).astype(np.float32)
+    for B in (1, 3, 257):
+        ui = rng.integers(0, 20, B).astype(np.int32); pi = rng.integers(0, 30, B).astype(np.int32); ni = rng.integers(0, 30, B).astype(np.int32)
+        lb, lr_, Gr = O.bpr_l2(e, 20, ui, pi, ni, 1e-3)
+        G = torch.zeros(50, 20, device=DEV)
+        out = ops.bpr_l2_fwd_bwd(T(e), 20, T(ui), T(pi), T(ni), 1e-3, G).cpu().numpy()
+        assert abs(out[0] - lb) <= RTOL * abs(lb) and abs(out[1] - lr_) <= RTOL * abs(lr_)
+        assert rel_err(G.cpu().numpy(), Gr) < RTOL
+    with pytest.raises(IndexError):
+        ops.bpr_l2_fwd_bwd(T(e), 20, T(np.array([25], np.int32)), T(np.array([0], np.int32)), T(np.array([0], np.int32)), 1e-3)
+
+
+def test_adam_sgd_dense(ops):
+    rng = np.random.default_rng(1)
+    for n in (4096, 4099, 3):
+        p = rng.standard_normal(n).astype(np.float32); g = rng.standard_normal(n).astype(np.float32)
+        m = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+        pt, mt, vt = T(p), T(m), T(v)
+        for t in (1, 2, 3):
+            O.adam_step(p, g, m, v, 0.005, t)
+            ops.adam_dense(pt, T(g), mt, vt, 0.005, t)
+        assert rel_err(pt.cpu().numpy(), p) < 1e-6 and rel_err(mt.cpu().numpy(), m) < 1e-6 and rel_err(vt.cpu().numpy(), v) < 1e-6
+        ps = p.copy(); O.sgd_step(ps, g, 0.0005)
+        pt2 = T(p); ops.sgd_dense(pt2, T(g), 0.0005)
+        assert rel_err(pt2.cpu().numpy(), ps) < 1e-6
+
+
+def test_gather_scatter_rows(ops):
+    rng = np.random.default_rng(2)
+    src = rng.standard_normal((100, 64)).astype(np.float32)
+    idx = rng.integers(0, 100, 333).astype(np.int32)
+    assert np.array_equal(ops.gather_rows(T(src), T(idx)).cpu().numpy(), src[idx])
+    add = rng.standard_normal((333, 64)).astype(np.float32)
+    ref = np.zeros((100, 64), np.float64); np.add.at(ref, idx, 0.5 * add.astype(np.float64))
+    dst = torch.zeros(100, 64, device=DEV)
+    ops.scatter_add_rows(dst, T(idx), T(add), 0.5)
+    assert rel_err(dst.cpu().numpy(), ref) < 1e-5
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+def test_infonce_golden(ops, tag):
+    g = golden('g6_infonce.npz')
+    loss, d1, d2 = ops.infonce_fwd_bwd(T(g[tag + '_v1']), T(g[tag + '_v2']), 0.2)
+    assert abs(loss.item() - g[tag + '_loss'][0]) <= RTOL * abs(g[tag + '_loss'][0])
+    assert rel_err(d1.cpu().numpy(), g[tag + '_dv1']) < RTOL and rel_err(d2.cpu().numpy(), g[tag + '_dv2']) < RTOL
+
+
+def test_simgcl_perturb(ops):
+    rng = np.random.default_rng(4)
+    E = rng.standard_normal((500, 64)).astype(np.float32); E[3, 5] = 0.0
+    noise = rng.random((500, 64)).astype(np.float32)
+    out = ops.simgcl_perturb_(T(E), T(noise), 0.1).cpu().numpy()
+    assert rel_err(out, O.simgcl_perturb(E, noise, 0.1)) < 1e-6
+
+
+def test_sddmm_rows_dense_and_pga_update(ops):
+    rng = np.random.default_rng(5)
+    N, d, I, off = 900, 64, 333, 500
+    dY = rng.standard_normal((N, d)).astype(np.float32); X = rng.standard_normal((N, d)).astype(np.float32)
+    rows = np.array([497, 498, 499, 3, 3], np.int32)
+    ref = O.sddmm_rows_dense(dY, X, rows, off, I)
+    out = ops.sddmm_rows_dense(T(dY), T(X), T(rows), off, I)
+    assert rel_err(out.cpu().numpy(), ref) < RTOL
+    out2 = ops.sddmm_rows_dense(T(dY), T(X), T(rows), off, I, out=out)        # accumulates
+    assert rel_err(out2.cpu().numpy(), 2 * ref) < RTOL
+    S = rng.random((5, I)).astype(np.float32); gr = (rng.standard_normal((5, I)) * 3).astype(np.float32)
+    assert rel_err(ops.pga_update_(T(S), T(gr)).cpu().numpy(), O.pga_update(S, gr)) < 1e-6
+    assert ops.pga_update_(T(S), T(gr)).min().item() >= 9.9e-8
+
+
+@pytest.mark.parametrize('U,I,d,k,masked', [(100, 1412, 64, 50, True), (37, 300, 16, 5, False), (70, 5000, 32, 128, True), (17, 60, 64, 50, True)])
+def test_score_mask_topk(ops, U, I, d, k, masked):
+    rng = np.random.default_rng(U + I)
+    Pu = rng.standard_normal((U, d)).astype(np.float32); Pi = rng.standard_normal((I, d)).astype(np.float32)
+    mask = None
+    if masked:
+        deg = rng.integers(0, min(40, I - 1), U)
+        if I <= 64:
+            deg[:] = I - 10            # fewer than k unmasked items: masked (-10e8) entries must appear at the tail
+        cols = [np.sort(rng.choice(I, size=dg, replace=False)) for dg in deg]
+        rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        mask = (rp, np.concatenate(cols).astype(np.int32) if rp[-1] else np.zeros(0, np.int32))
+    ridx, rval = O.score_mask_topk(Pu, Pi, k, mask)
+    if mask is None:
+        idx, val = ops.score_mask_topk(T(Pu), T(Pi), k)
+    else:
+        mc = mask[1] if len(mask[1]) else np.zeros(1, np.int32)
+        idx, val = ops.score_mask_topk(T(Pu), T(Pi), k, T(mask[0].astype(np.int32)), T(mc))
+    idx, val = idx.cpu().numpy(), val.cpu().numpy()
+    assert rel_err(val, rval) < RTOL
+    # indices: identical except where two scores tie within fp32 rounding of the different summation orders
+    same = idx == ridx
+    if not same.all():
+        bad = np.argwhere(~same)
+        for r, c in bad:
+            assert abs(rval[r, c] - val[r, c]) <= 1e-5 * max(1.0, abs(rval[r, c]))
+            assert set(idx[r]) == set(ridx[r]) or abs(rval[r, -1] - val[r, -1]) <= 1e-5 * max(1.0, abs(rval[r, -1]))
+    assert same.mean() > 0.999
+
+
+def test_topn_project_rows(ops):
+    rng = np.random.default_rng(6)
+    M = rng.random((7, 1412)).astype(np.float32)
+    M[2, :] = 1e-7; M[2, 10] = 1.0                                   # massive ties (PGA's clamp floor): lower index first
+    for n in (0, 1, 46):
+        ro, ri = O.topn_project_rows(M, n) if n else (np.zeros_like(M), np.zeros((7, 0), np.int32))
+        out, idx = ops.topn_project_rows(T(M), n)
+        assert np.array_equal(out.cpu().numpy(), ro) and np.array_equal(idx.cpu().numpy(), ri)
+
+
+def test_missing_gpu_tensor_fails_loudly(ops):
+    from arlib_amd._lib import ArlError
+    with pytest.raises(ArlError):
+        ops.sgd_dense(torch.zeros(4), torch.zeros(4), 0.1)
