@@ -13,6 +13,7 @@ from . import _lib
 from ._lib import arl_csr, check
 
 DEFAULT_CHUNK = 512
+EVENT_HOOK = None      # bench.py installs an object with begin(tag)/end(token) to bracket SpMM launches with HIP events
 
 
 def _stream():
@@ -153,7 +154,10 @@ def spmm(A, X, alpha=1.0, beta=0.0, Z=None, out=None):
             raise ValueError('spmm: Z required with X\'s shape when beta != 0')
         _check_xy(A, Z, 'Z')
     s = A._struct(d)
+    tok = EVENT_HOOK.begin('axpby') if EVENT_HOOK is not None else None
     check(_lib.lib().arl_spmm_csr_f32(C.byref(s), _ptr(X), d, alpha, beta, _ptr(Z) if beta != 0.0 else None, _ptr(Y), _stream()), 'arl_spmm_csr_f32')
+    if tok is not None:
+        EVENT_HOOK.end(tok)
     return Y
 
 
@@ -171,7 +175,10 @@ def spmm_layersum(A, X, S_in, S, Y=None):
     if S.data_ptr() == X.data_ptr():
         raise ValueError('spmm_layersum: S must not alias X')
     s = A._struct(d)
+    tok = EVENT_HOOK.begin('layersum') if EVENT_HOOK is not None else None
     check(_lib.lib().arl_spmm_csr_layersum_f32(C.byref(s), _ptr(X), d, _ptr(S_in), _ptr(S), _ptr(Y), _stream()), 'arl_spmm_csr_layersum_f32')
+    if tok is not None:
+        EVENT_HOOK.end(tok)
     return S
 
 
@@ -187,8 +194,11 @@ def spmm_adam(A, X, alpha, beta, Z, P, M, V, lr, step, betas=(0.9, 0.999), eps=1
         if Z.shape != X.shape:
             raise ValueError('spmm_adam: Z shape mismatch')
     s = A._struct(d)
+    tok = EVENT_HOOK.begin('adam') if EVENT_HOOK is not None else None
     check(_lib.lib().arl_spmm_csr_adam_f32(C.byref(s), _ptr(X), d, alpha, beta, _ptr(Z) if beta != 0.0 else None, _ptr(P), _ptr(M), _ptr(V),
                                            lr, betas[0], betas[1], eps, int(step), _stream()), 'arl_spmm_csr_adam_f32')
+    if tok is not None:
+        EVENT_HOOK.end(tok)
 
 
 # ------------------------------------------------------------------------------------------------ losses

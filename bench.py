@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- BPR-train interactions/sec of the LightGCN (d=64, L=3) + BPR + Adam step on the SYN-v1 synthetic
+1M-user x 100K-item graph (BASELINE.json configs[1]), on N MI355X GPUs of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one iteration of the reference's training inner loop (recommender/LightGCN.py:47-64) at the reference's
+default batch size B = 2048: full-graph propagation, BPR + L2 loss on the batch, backward, dense Adam on both tables.
+Batches are produced by the bit-exact host sampler before the timed region and are resident in HBM when it starts.
+Prints ONE JSON line (rank 0).  The CPU baseline leg (rank 0, N=1 only) times the oracle's OpenMP restatement of the
+same step on a bounded number of steps; the oracle is never on the measured GPU path.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--users', type=int, default=1_000_000)
+    ap.add_argument('--items', type=int, default=100_000)
+    ap.add_argument('--mean-deg', type=float, default=32.0)
+    ap.add_argument('--emb', type=int, default=64)
+    ap.add_argument('--layers', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=2048)
+    ap.add_argument('--seed', type=int, default=2018)
+    ap.add_argument('--chunk', type=int, default=512)
+    ap.add_argument('--cpu-baseline', type=int, default=1, help='0 disables the CPU baseline leg')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target seconds of CPU work for the baseline sample')
+    ap.add_argument('--no-kernel-events', action='store_true', help='do not bracket SpMM launches with HIP events')
+    return ap.parse_args()
+
+
+class SpmmEvents:
+    """HIP events around every SpMM-family launch in the timed region (same stream as the kernels)."""
+
+    def __init__(self, torch):
+        self.torch = torch
+        self.recs = []
+        self.on = False
+
+    def begin(self, tag):
+        if not self.on:
+            return None
+        s = self.torch.cuda.Event(enable_timing=True)
+        s.record()
+        return (tag, s)
+
+    def end(self, tok):
+        if tok is None:
+            return
+        e = self.torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.recs.append((tok[0], tok[1], e))
+
+    def summary(self):
+        out = {}
+        for tag, s, e in self.recs:
+            out.setdefault(tag, []).append(s.elapsed_time(e))
+        return {k: (float(np.mean(v)), len(v)) for k, v in out.items()}
+
+
+def cpu_baseline(data, rowptr, col, val_np, E0, batches, args, target_s):
+    """Oracle ('port') timed on the host cores: same graph, same tables, same batches, OpenMP over rows."""
+    from oracle import oracle as O
+    O.build()
+    U, I = data.user_num, data.item_num
+    st = O.TrainState(E0[:U], E0[U:], (rowptr, col, val_np), args.layers, 1e-4, 0.005)
+    st.f32acc = True
+    done, t_used = 0, 0.0
+    max_steps = min(len(batches), 8)
+    while done < max_steps and (t_used < target_s or done < 1):
+        b = batches[done]
+        t0 = time.perf_counter()
+        st.step(b[0], b[1], b[2])
+        t_used += time.perf_counter() - t0
+        done += 1
+    return {'value': args.batch * done / t_used, 'unit': 'interactions/s', 'cores': O.num_threads(), 'kind': 'port',
+            'sample': '%d full training steps of the same workload (same graph, tables and batches), %.1f s of CPU work, '
+                      'oracle/arl_oracle.c with OpenMP over rows' % (done, t_used),
+            'ms_per_step': 1e3 * t_used / done}
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
+        raise SystemExit('WORLD_SIZE %d != --gpus %d' % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from arlib_amd import ops, engine
+    from arlib_amd.util import synthetic
+    from arlib_amd.util.sampler import MTState
+
+    # ---------------- workload: SYN-v1 graph, xavier tables, bit-exact batches
+    t_setup = time.perf_counter()
+    data = synthetic.syn_v1(args.users, args.items, args.mean_deg, args.seed)
+    U, I, nnz = data.training_size()
+    N, d, L, B = U + I, args.emb, args.layers, args.batch
+    rowptr, col = data.adjacency_pattern()
+    torch.manual_seed(args.seed)                      # recommender/LightGCN.py:222-228: xavier_uniform_, user table first
+    E0 = torch.cat([torch.nn.init.xavier_uniform_(torch.empty(U, d)), torch.nn.init.xavier_uniform_(torch.empty(I, d))], 0)
+    mt = MTState.from_seed(args.seed)
+    sampler = data.pair_sampler
+    n_batches = args.warmup + args.steps
+    t_s = time.perf_counter()
+    sampler.shuffle(mt)
+    host_batches = torch.empty(n_batches, 3, B, dtype=torch.int32).pin_memory()
+    hb = host_batches.numpy()
+    for k in range(n_batches):
+        sampler.batch(mt, k * B, B, out=hb[k])
+    t_sampler = time.perf_counter() - t_s
+    dev_batches = host_batches.to(dev, non_blocking=True)
+    assert int(dev_batches[:, 0].max()) < U and int(dev_batches[:, 1:].max()) < I and int(dev_batches.min()) >= 0
+
+    if world == 1:
+        w = torch.ones(2 * nnz, dtype=torch.float32, device=dev)
+        col_d = torch.from_numpy(col).to(dev)
+        val, _ = ops.norm_adj_values(torch.from_numpy(rowptr.astype(np.int32)).to(dev), col_d, w, N)
+        del w
+        A = ops.CSRGraph(rowptr, col_d, val, dev, chunk=args.chunk, validate=True)
+        eng = engine.PropagationEngine(A, U, I, d, L, 1e-4, 0.005, dev, table=E0.to(dev))
+        step = lambda k: eng.step(dev_batches[k, 0], dev_batches[k, 1], dev_batches[k, 2])
+        barrier = lambda: None
+        parallelism = 'single'
+    else:
+        from arlib_amd import dist_engine
+        eng = dist_engine.ShardedPropagationEngine.from_pairs(data.pairs0, U, I, d, L, 1e-4, 0.005, dev, rank, world, table=E0, chunk=args.chunk)
+        step = lambda k: eng.step(dev_batches[k, 0], dev_batches[k, 1], dev_batches[k, 2])
+        import torch.distributed as dist
+        barrier = dist.barrier
+        parallelism = 'user-sharded x%d, item partial sums all-reduced (RCCL) per hop' % world
+    setup_s = time.perf_counter() - t_setup
+
+    ev = SpmmEvents(torch)
+    if not args.no_kernel_events:
+        ops.EVENT_HOOK = ev
+
+    for k in range(args.warmup):
+        step(k)
+    barrier(); torch.cuda.synchronize()
+    ev.on = True
+    t0 = time.perf_counter()
+    for k in range(args.warmup, n_batches):
+        lo = step(k)
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    ev.on = False
+    ops.EVENT_HOOK = None
+    loss = float(lo[0] + lo[1])
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        E = 2 * nnz
+        step_bytes = L * (16 * E + 8 * N + 24 * N * d) + 28 * N * d + 24 * B * d
+        spmm_bytes = 8 * E + 4 * (N + 1) + 8 * N * d                                        # SURVEY 8d S_spmm
+        evs = ev.summary()
+        res = {
+            'metric': 'BPR-train interactions/sec (LightGCN d=%d L=%d + BPR + Adam, B=%d)' % (d, L, B),
+            'value': B * args.steps / dt, 'unit': 'interactions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'cfg2: LightGCN d=%d L=%d + BPR/L2 + dense Adam, SYN-v1 %d users x %d items, nnz=%d, B=%d, seed %d'
+                                   % (d, L, U, I, nnz, B, args.seed), 'parallelism': parallelism, 'chunk': args.chunk},
+            'final_loss': loss,
+            'step_roofline': {'bound': 'hbm', 'algorithmic_bytes_per_step': step_bytes, 'achieved': step_bytes / (ms * 1e-3) / 1e9 / world,
+                              'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': step_bytes / (ms * 1e-3) / 1e9 / world / HBM_PEAK_GBS,
+                              'note': 'whole step, per GPU'},
+            'sampler': {'host_seconds_for_%d_batches_incl_epoch_shuffle' % n_batches: t_sampler},
+            'setup_seconds': setup_s,
+        }
+        if evs:
+            # dominant kernel: spmm_rows_kernel<16,*> (+ its long-row combine), one event pair per C-ABI SpMM call
+            allv = [v for tag, s, e in ev.recs for v in [s.elapsed_time(e)]]
+            avg_ms = float(np.mean(allv))
+            # under sharding a launch covers this rank's rows only; report the single-GPU figure only for N=1
+            if world == 1:
+                res['roofline'] = {'bound': 'hbm', 'achieved': spmm_bytes / (avg_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                   'frac': spmm_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                                   'kernel': 'spmm_rows_kernel<LPR=%d> (+spmm_long_rows_kernel), avg over %d launches' % (max(4, d // 4), len(allv)),
+                                   'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': spmm_bytes,
+                                   'per_variant_ms': {k: v[0] for k, v in evs.items()},
+                                   'gather_model_bytes_per_launch': E * (8 + 4 * d) + 4 * N * d}
+            else:
+                res['spmm_events_ms'] = {k: v[0] for k, v in evs.items()}
+        if world == 1 and args.cpu_baseline:
+            val_np = eng.A.val.cpu().numpy()
+            batches = [(hb[k, 0].copy(), hb[k, 1].copy(), hb[k, 2].copy()) for k in range(min(n_batches, 8))]
+            res['cpu_baseline'] = cpu_baseline(data, rowptr, col, val_np, E0.numpy(), batches, args, args.cpu_seconds)
+        print(json.dumps(res))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

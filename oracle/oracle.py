@@ -156,14 +156,14 @@ def simgcl_perturb(E, noise, eps):
     return E
 
 
-def lightgcn_forward(csr, E0, L, skip0=False, noises=None, eps=0.1, return_layers=False):
+def lightgcn_forward(csr, E0, L, skip0=False, noises=None, eps=0.1, return_layers=False, f32acc=False):
     """recommender/LightGCN.py:230-240 (mean of E_0..E_L); skip0=True is SimGCL (recommender/SimGCL.py:198-210:
     mean of E_1..E_L, optional additive perturbation after each hop)."""
     E = _f32(E0)
     layers = [E]
     acc = np.zeros_like(E, dtype=np.float64) if skip0 else E.astype(np.float64)
     for k in range(L):
-        E = spmm(csr, E)
+        E = spmm(csr, E, f32acc=f32acc)
         if noises is not None:
             E = simgcl_perturb(E, noises[k], eps)
         layers.append(E)
@@ -172,19 +172,19 @@ def lightgcn_forward(csr, E0, L, skip0=False, noises=None, eps=0.1, return_layer
     return (out, layers) if return_layers else out
 
 
-def lightgcn_backward(csr, G, L, skip0=False):
+def lightgcn_backward(csr, G, L, skip0=False, f32acc=False):
     """Backward of the above w.r.t. E0 (adjacency symmetric): LightGCN dE0 = (1/(L+1)) sum_{k=0..L} A^k G,
     SimGCL dE0 = (1/L) sum_{k=1..L} A^k G (noise/sign carry no gradient).  Horner form."""
     G = _f32(G)
     acc = G
     if skip0:
         for _ in range(L - 1):
-            acc = spmm(csr, acc, 1.0, 1.0, G)
-        return spmm(csr, acc, 1.0 / L)
+            acc = spmm(csr, acc, 1.0, 1.0, G, f32acc=f32acc)
+        return spmm(csr, acc, 1.0 / L, f32acc=f32acc)
     for k in range(L):
         last = (k == L - 1)
         s = 1.0 / (L + 1) if last else 1.0
-        acc = spmm(csr, acc, s, s, G)
+        acc = spmm(csr, acc, s, s, G, f32acc=f32acc)
     if L == 0:
         return G
     return acc
@@ -269,18 +269,19 @@ class TrainState:
         self.m = np.zeros_like(self.E0); self.v = np.zeros_like(self.E0)
         self.csr, self.L, self.reg, self.lr, self.skip0, self.optimizer = csr, L, reg, lr, skip0, optimizer
         self.t = 0
+        self.f32acc = False          # True only for the timed CPU baseline (fp32 accumulators, like torch CPU)
 
     def forward(self):
         if self.L == 0 or self.csr is None:          # GMF: recommender/GMF.py:174-175
             return self.E0
-        return lightgcn_forward(self.csr, self.E0, self.L, self.skip0)
+        return lightgcn_forward(self.csr, self.E0, self.L, self.skip0, f32acc=self.f32acc)
 
     def grad(self, ui, pi, ni):
         out = self.forward()
         lb, lr_, G = bpr_l2(out, self.U, ui, pi, ni, self.reg)
         if self.L == 0 or self.csr is None:
             return lb + lr_, G
-        return lb + lr_, lightgcn_backward(self.csr, G, self.L, self.skip0)
+        return lb + lr_, lightgcn_backward(self.csr, G, self.L, self.skip0, f32acc=self.f32acc)
 
     def step(self, ui, pi, ni):
         loss, g = self.grad(ui, pi, ni)
