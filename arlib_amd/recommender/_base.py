@@ -1,0 +1,393 @@
+"""Shared machinery of the GMF / LightGCN / SimGCL mirrors (the reference repeats it per file:
+recommender/LightGCN.py:17-161,202-252, GMF.py:16-175, SimGCL.py:18-231).
+
+* `GraphEncoder` -- nn.Module with the reference encoder's surface: callable -> (user_emb, item_emb), differentiable;
+  `.embedding_dict['user_emb'|'item_emb']` real nn.Parameters (views of ONE packed [U+I,d] device buffer, so
+  torch.cat is never needed); `.sparse_norm_adj` (device CSR); `._init_uiAdj(scipy)`; `.attack_emb(du, di)`; `.cuda()`.
+* `Recommender` -- train()/save()/predict()/evaluate()/test() with the reference signatures.  train() runs the
+  fused device engine when it owns the optimizer (or is handed a plain torch Adam/SGD over exactly these parameters)
+  and otherwise drives the caller's optimizer through autograd with the same kernels.
+"""
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..engine import PropagationEngine
+from ..util.sampler import next_batch_pairwise
+from ..util.loss import bpr_l2_loss, InfoNCE
+from ..util.metrics import ranking_evaluation
+
+DEVICE = 'cuda'
+
+
+class SparseNormAdj:
+    """Device image of the normalised adjacency (the reference's `sparse_norm_adj` COO tensor, LightGCN.py:247-252),
+    kept as CSR with int32 indices.  `.requires_grad` / `.grad` mirror the tensor attributes attacks poke
+    (attack/White/PGA.py:98,117): the gradient lives on `.values` (one fp32 per stored edge, CSR order)."""
+
+    def __init__(self, mat):
+        m = sp.csr_matrix(mat, dtype=np.float32)
+        m.sort_indices()
+        self.shape = m.shape
+        self.indptr, self.indices = m.indptr.astype(np.int64), m.indices.astype(np.int32)
+        self.values = torch.from_numpy(m.data.astype(np.float32))
+        self._graph = None
+
+    @property
+    def requires_grad(self):
+        return self.values.requires_grad
+
+    @requires_grad.setter
+    def requires_grad(self, flag):
+        self.values.requires_grad_(bool(flag))
+
+    @property
+    def grad(self):
+        return self.values.grad
+
+    def cuda(self):
+        if not self.values.is_cuda:
+            rg = self.values.requires_grad
+            self.values = self.values.detach().to(DEVICE).requires_grad_(rg)
+            self._graph = None
+        return self
+
+    def graph(self):
+        self.cuda()
+        if self._graph is None or self._graph.val.data_ptr() != self.values.data_ptr():
+            if self._graph is None:
+                self._graph = ops.CSRGraph(self.indptr, self.indices, self.values.detach(), self.values.device)
+            else:
+                self._graph = self._graph.with_values(self.values.detach())
+        return self._graph
+
+    def to_scipy(self):
+        return sp.csr_matrix((self.values.detach().cpu().numpy(), self.indices, self.indptr), shape=self.shape)
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st['_graph'] = None
+        st['values'] = self.values.detach().cpu()
+        return st
+
+
+class TorchGraphInterface(object):
+    @staticmethod
+    def convert_sparse_mat_to_tensor(X):
+        return SparseNormAdj(X)
+
+
+class _Propagate(torch.autograd.Function):
+    """(user_emb, item_emb) -> propagated (user_emb, item_emb); forward and backward are SpMM kernel launches."""
+
+    @staticmethod
+    def forward(ctx, user_emb, item_emb, enc, noises):
+        eng = enc._engine()
+        out = torch.empty_like(eng.E0)
+        eng.forward(noises=noises, eps=enc.eps, out=out)
+        ctx.enc = enc
+        U = user_emb.shape[0]
+        return out[:U], out[U:]
+
+    @staticmethod
+    def backward(ctx, g_user, g_item):
+        eng = ctx.enc._engine()
+        G = torch.cat([g_user, g_item], 0).contiguous()
+        dE0 = eng.backward_to_table(G).clone()
+        U = g_user.shape[0]
+        return dE0[:U], dE0[U:], None, None
+
+
+class GraphEncoder(nn.Module):
+    n_prop_layers = 0          # 0 = plain matrix factorisation
+    skip_layer0 = False
+    eps = 0.1
+
+    def __init__(self, data, emb_size):
+        super().__init__()
+        self.data = data
+        self.latent_size = self.emb_size = emb_size
+        self.embedding_dict = self._init_model()
+        self._eng = None
+
+    # reference: recommender/LightGCN.py:222-228 (xavier_uniform_, user table first, on the CPU generator)
+    def _init_model(self):
+        init = nn.init.xavier_uniform_
+        packed = torch.cat([init(torch.empty(self.data.user_num, self.latent_size)), init(torch.empty(self.data.item_num, self.latent_size))], 0)
+        U = self.data.user_num
+        return nn.ParameterDict({'user_emb': nn.Parameter(packed[:U]), 'item_emb': nn.Parameter(packed[U:])})
+
+    def _init_uiAdj(self, ui_adj):
+        """recommender/LightGCN.py:212-215: D^-1/2 A D^-1/2 of an arbitrary weighted symmetric adjacency (no inf guard in the
+        reference; an isolated node simply has an empty row).  Row sums and scaling run on the GPU."""
+        m = sp.csr_matrix(ui_adj, dtype=np.float32)
+        m.sort_indices()
+        adj = SparseNormAdj.__new__(SparseNormAdj)
+        adj.shape = m.shape
+        adj.indptr, adj.indices = m.indptr.astype(np.int64), m.indices.astype(np.int32)
+        adj._graph = None
+        if torch.cuda.is_available():
+            w = torch.from_numpy(m.data.astype(np.float32)).to(DEVICE)
+            val, dinv = ops.norm_adj_values(torch.from_numpy(m.indptr.astype(np.int32)).to(DEVICE), torch.from_numpy(adj.indices).to(DEVICE), w, m.shape[0])
+            adj.values = val
+            adj.dinv = dinv
+        else:
+            raise ops._lib.ArlError('_init_uiAdj needs the GPU (no CPU fallback)')
+        self.sparse_norm_adj = adj
+        self._eng = None
+
+    def attack_emb(self, users_emb_grad, items_emb_grad):
+        with torch.no_grad():
+            self.embedding_dict['user_emb'] += users_emb_grad
+            self.embedding_dict['item_emb'] += items_emb_grad
+
+    def cuda(self, device=None):
+        self._pack()
+        return self
+
+    # ---- packed table: both Parameters must be adjacent views of one [U+I,d] device buffer
+    def _pack(self):
+        u, i = self.embedding_dict['user_emb'], self.embedding_dict['item_emb']
+        U, d = u.shape
+        es = u.element_size()
+        ok = (u.is_cuda and i.is_cuda and u.is_contiguous() and i.is_contiguous() and i.data_ptr() == u.data_ptr() + U * d * es
+              and u.untyped_storage().data_ptr() == i.untyped_storage().data_ptr())
+        if not ok:
+            packed = torch.cat([u.data.to(DEVICE), i.data.to(DEVICE)], 0).contiguous()
+            u.data, i.data = packed[:U], packed[U:]
+            self._eng = None
+        base = torch.as_strided(u.data, (U + i.shape[0], d), (d, 1))
+        return base
+
+    def _graph(self):
+        if self.n_prop_layers == 0:
+            return None
+        return self.sparse_norm_adj.graph()
+
+    def _engine(self, reg=0.0, lr=0.0, optimizer='adam'):
+        base = self._pack()
+        g = self._graph()
+        e = self._eng
+        if e is None or e.E0.data_ptr() != base.data_ptr() or e.A is not g or e.L != self.n_prop_layers:
+            e = PropagationEngine(g, self.data.user_num, self.data.item_num, self.latent_size, self.n_prop_layers, reg, lr, base.device,
+                                  skip_layer0=self.skip_layer0, optimizer=optimizer, table=base)
+            self._eng = e
+        return e
+
+    def forward(self, perturbed=False, noises=None):
+        u, i = self.embedding_dict['user_emb'], self.embedding_dict['item_emb']
+        if self.n_prop_layers == 0:
+            return u, i
+        self._pack()
+        if perturbed and noises is None:
+            N = u.shape[0] + i.shape[0]
+            noises = [torch.rand(N, self.latent_size, device=u.device) for _ in range(self.n_prop_layers)]      # SimGCL.py:204
+        return _Propagate.apply(u, i, self, noises)
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st['_eng'] = None
+        return st
+
+
+class Recommender:
+    """train()/save()/predict()/evaluate()/test() shared by the three models (reference: LightGCN.py:29-161)."""
+    print_every = 1000
+    has_extra_loss = False
+
+    def _common_init(self, args, data, name):
+        print('Recommender: ' + name)
+        self.data, self.args = data, args
+        self.bestPerformance, self.recOutput = [], []
+        self.topN = [int(n) for n in self.args.topK.split(',')]
+        self.max_N = max(self.topN)
+
+    # ---- optimizer handling -------------------------------------------------------------------------------------
+    def _params(self):
+        return [self.model.embedding_dict['user_emb'], self.model.embedding_dict['item_emb']]
+
+    def _fusable(self, optimizer):
+        """The fused engine may stand in for `optimizer` iff it is a stock Adam/SGD over exactly this model's two tables."""
+        if type(optimizer) not in (torch.optim.Adam, torch.optim.SGD) or len(optimizer.param_groups) != 1:
+            return None
+        g = optimizer.param_groups[0]
+        ps = g['params']
+        mine = self._params()
+        if len(ps) != 2 or ps[0] is not mine[0] or ps[1] is not mine[1] or g.get('weight_decay', 0) != 0 or g.get('maximize', False):
+            return None
+        if type(optimizer) is torch.optim.Adam:
+            if g.get('amsgrad', False) or g.get('capturable', False):
+                return None
+            return 'adam'
+        if g.get('momentum', 0) != 0 or g.get('nesterov', False) or g.get('dampening', 0) != 0:
+            return None
+        return 'sgd'
+
+    def _bind_optimizer_state(self, eng, optimizer, kind):
+        """Share Adam moments between the engine and a torch optimizer so either can continue the other's run."""
+        g = optimizer.param_groups[0]
+        eng.lr = float(g['lr'])
+        eng.optimizer = kind
+        if kind != 'adam':
+            return
+        eng.betas, eng.eps = tuple(g['betas']), float(g['eps'])
+        U = self.data.user_num
+        for p, sl in zip(self._params(), (slice(0, U), slice(U, None))):
+            st = optimizer.state[p]
+            if 'exp_avg' in st and st['exp_avg'].data_ptr() != eng.m[sl].data_ptr():
+                eng.m[sl].copy_(st['exp_avg']); eng.v[sl].copy_(st['exp_avg_sq'])
+                eng.t = int(st['step'])
+            st['exp_avg'], st['exp_avg_sq'] = eng.m[sl], eng.v[sl]
+            st.setdefault('step', torch.tensor(float(eng.t)))
+
+    def _sync_optimizer_step(self, eng, optimizer, kind):
+        if kind == 'adam':
+            for p in self._params():
+                optimizer.state[p]['step'] = torch.tensor(float(eng.t))
+
+    # ---- training ------------------------------------------------------------------------------------------------
+    def _extra_loss(self, model, user_idx, pos_idx):
+        return None
+
+    def _train_loop(self, Epoch, optimizer, evalNum, requires_embgrad=False, requires_adjgrad=False, gradIterationNum=10):
+        self.bestPerformance = []
+        model = self.model.cuda()
+        fused_kind = None
+        if optimizer is None:
+            optimizer = torch.optim.Adam(model.parameters(), lr=self.args.lRate)
+        if not requires_embgrad and not requires_adjgrad and not self.has_extra_loss:
+            fused_kind = self._fusable(optimizer)
+        self.optimizer = optimizer
+        if requires_adjgrad:
+            raise NotImplementedError('requires_adjgrad accumulates a dense N x N matrix in the reference (LightGCN.py:42-43, dead from the CLI); '
+                                      'use attack.White.PGA which computes the fake-user block directly')
+        if requires_embgrad:
+            model.requires_grad = True
+            self.usergrad = torch.zeros((self.data.user_num, self.args.emb_size), device=DEVICE)
+            self.itemgrad = torch.zeros((self.data.item_num, self.args.emb_size), device=DEVICE)
+        maxEpoch = Epoch if Epoch else self.args.maxEpoch
+        eng = None
+        if fused_kind:
+            eng = model._engine(self.args.reg, self.args.lRate, fused_kind)
+            eng.reg = float(self.args.reg)
+            self._bind_optimizer_state(eng, optimizer, fused_kind)
+        U, I = self.data.user_num, self.data.item_num
+        for epoch in range(maxEpoch):
+            for n, batch in enumerate(next_batch_pairwise(self.data, self.args.batch_size)):
+                user_idx, pos_idx, neg_idx = batch
+                if int(user_idx.max()) >= U or int(max(pos_idx.max(), neg_idx.max())) >= I:
+                    raise IndexError('sampler produced an index outside the embedding tables')
+                u = torch.from_numpy(user_idx).to(DEVICE, non_blocking=True)
+                p = torch.from_numpy(pos_idx).to(DEVICE, non_blocking=True)
+                ng = torch.from_numpy(neg_idx).to(DEVICE, non_blocking=True)
+                if eng is not None:
+                    lo = eng.step(u, p, ng)
+                    if n % self.print_every == 0:
+                        print('training:', epoch + 1, 'batch', n, 'batch_loss:', float(lo[0] + lo[1]))
+                    continue
+                model.train()
+                rec_user_emb, rec_item_emb = model()
+                ul, pl, nl = u.long(), p.long(), ng.long()
+                user_emb, pos_item_emb, neg_item_emb = rec_user_emb[ul], rec_item_emb[pl], rec_item_emb[nl]
+                batch_loss = bpr_l2_loss(user_emb, pos_item_emb, neg_item_emb, self.args.reg)
+                if self.has_extra_loss:
+                    batch_loss = batch_loss + self._extra_loss(model, ul, pl)
+                optimizer.zero_grad()
+                batch_loss.backward()
+                if requires_embgrad and maxEpoch - epoch < gradIterationNum:
+                    self.usergrad += model.embedding_dict['user_emb'].grad
+                    self.itemgrad += model.embedding_dict['item_emb'].grad
+                optimizer.step()
+                if n % self.print_every == 0:
+                    print('training:', epoch + 1, 'batch', n, 'batch_loss:', batch_loss.item())
+            if eng is not None:
+                self._sync_optimizer_step(eng, optimizer, fused_kind)
+            model.eval()
+            with torch.no_grad():
+                self.user_emb, self.item_emb = self._detached_forward()
+            if epoch % evalNum == 0:
+                self.evaluate(epoch)
+        self.user_emb, self.item_emb = self.best_user_emb, self.best_item_emb
+        if requires_embgrad:
+            return self.user_emb, self.item_emb, self.usergrad, self.itemgrad
+
+    def _detached_forward(self):
+        with torch.no_grad():
+            u, i = self.model()
+            if self.model.n_prop_layers == 0:
+                # reference quirk: Matrix_Factorization.forward returns the Parameters themselves (GMF.py:174-175), so
+                # user_emb / best_user_emb ALIAS the live tables and "best epoch" always tracks the latest values
+                return u.detach(), i.detach()
+            return u.detach().clone(), i.detach().clone()
+
+    def save(self):
+        self.best_user_emb, self.best_item_emb = self._detached_forward()
+
+    def predict(self, u):
+        with torch.no_grad():
+            u = self.data.get_user_id(u)
+            score = torch.matmul(self.user_emb[u], self.item_emb.transpose(0, 1))
+            return score.cpu().numpy()
+
+    # ---- evaluation (reference: LightGCN.py:92-161).  The per-user python loop + numba heap are replaced by one
+    # streaming score+mask+top-k kernel launch over all test users.
+    def evaluate(self, epoch):
+        print('Evaluating the model...')
+        rec_list, _ = self.test()
+        measure = ranking_evaluation(self.data.test_set, rec_list, [self.max_N])
+        performance = {}
+        for m in measure[1:]:
+            k, v = m.strip().split(':')
+            performance[k] = float(v)
+        if len(self.bestPerformance) > 0:
+            count = 0
+            for k in self.bestPerformance[1]:
+                count += 1 if self.bestPerformance[1][k] > performance[k] else -1
+            if count < 0:
+                self.bestPerformance[1] = performance
+                self.bestPerformance[0] = epoch + 1
+                self.save()
+        else:
+            self.bestPerformance.append(epoch + 1)
+            self.bestPerformance.append(performance)
+            self.save()
+        print('-' * 120)
+        print('Real-Time Ranking Performance ' + ' (Top-' + str(self.max_N) + ' Item Recommendation)')
+        measure = [m.strip() for m in measure[1:]]
+        print('*Current Performance*')
+        print('Epoch:', str(epoch + 1) + ',', '  |  '.join(measure))
+        bp = '  |  '.join(k + ':' + str(self.bestPerformance[1][k]) for k in ('Hit Ratio', 'Precision', 'Recall', 'NDCG'))
+        print('*Best Performance* ')
+        print('Epoch:', str(self.bestPerformance[0]) + ',', bp)
+        print('-' * 120)
+        return measure
+
+    def test(self):
+        users = list(self.data.test_set)
+        rec_list = {}
+        if users:
+            uid = torch.tensor([self.data.user[u] for u in users], dtype=torch.long, device=self.user_emb.device)
+            Pu = self.user_emb[uid].contiguous()
+            Pi = self.item_emb.contiguous()
+            # interacted-item mask (candidates[rated] = -10e8, LightGCN.py:153-154) as CSR over the selected users
+            cols = [np.fromiter((self.data.item[it] for it in self.data.training_set_u[u]), dtype=np.int32) for u in users]
+            rp = np.zeros(len(users) + 1, np.int32)
+            np.cumsum([len(c) for c in cols], out=rp[1:])
+            mc = np.concatenate([np.sort(c) for c in cols]) if rp[-1] else np.zeros(1, np.int32)
+            k = min(self.max_N, Pi.shape[0])
+            if Pu.shape[1] % 4 == 0 and k <= 128:
+                idx, val = ops.score_mask_topk(Pu, Pi, k, torch.from_numpy(rp).to(Pu.device), torch.from_numpy(mc.astype(np.int32)).to(Pu.device))
+            else:       # embedding sizes the kernel does not cover: torch plumbing
+                sc = Pu @ Pi.T
+                rows = torch.from_numpy(np.repeat(np.arange(len(users)), np.diff(rp))).to(Pu.device)
+                sc[rows, torch.from_numpy(mc[:rp[-1]].astype(np.int64)).to(Pu.device)] = -10e8
+                val, idx = torch.topk(sc, k)
+            idx, val = idx.cpu().numpy(), val.cpu().numpy()
+            for r, user in enumerate(users):
+                rec_list[user] = [(self.data.id2item[int(i)], float(s)) for i, s in zip(idx[r], val[r])]
+        sys.stdout.write('\rProgress: [' + '+' * 50 + ']100%\n')
+        return rec_list, ranking_evaluation(self.data.test_set, rec_list, self.topN)

@@ -1,0 +1,135 @@
+"""Host-side data object with the reference's DataLoader interface (util/DataLoader.py:7-177): first-seen id maps,
+dict-of-dict train/val/test sets, the (U+I)^2 bipartite adjacency, its D^-1/2 A D^-1/2 normalisation and the U x I
+interaction matrix.  Same attribute and method names, built with vectorised numpy/scipy instead of Python loops.
+This is glue around the hot path (text in, scipy out); the device-side graph is built from `norm_adj` by the models.
+"""
+from collections import defaultdict
+
+import numpy as np
+import scipy.sparse as sp
+
+from .FileIO import FileIO
+
+
+class DataLoader():
+    def __init__(self, args=None, training_data=None, val_data=None, test_data=None, dataName=None):
+        if args is not None:
+            base = args.data_path + args.dataset
+            training_data = FileIO.load_data_set(base + args.training_data)
+            val_data = FileIO.load_data_set(base + args.val_data)
+            test_data = FileIO.load_data_set(base + args.test_data)
+            dataName = args.dataset
+        self.training_data = training_data
+        self.val_data = val_data if val_data is not None else []
+        self.test_data = test_data if test_data is not None else []
+        self.dataName = dataName
+        self.user, self.item, self.id2user, self.id2item = {}, {}, {}, {}
+        self.training_set_u, self.training_set_i = defaultdict(dict), defaultdict(dict)
+        self.val_set, self.test_set = defaultdict(dict), defaultdict(dict)
+        self.val_set_item, self.test_set_item = set(), set()
+        for user, item, rating in self.training_data:           # util/DataLoader.py:33-43 first-seen ids
+            if user not in self.user:
+                self.user[user] = len(self.user)
+                self.id2user[self.user[user]] = user
+            if item not in self.item:
+                self.item[item] = len(self.item)
+                self.id2item[self.item[item]] = item
+            self.training_set_u[user][item] = rating
+            self.training_set_i[item][user] = rating
+        for src, dst, seen in ((self.val_data, self.val_set, self.val_set_item), (self.test_data, self.test_set, self.test_set_item)):
+            for user, item, rating in src:                      # util/DataLoader.py:44-55 (users unseen in training are skipped)
+                if user in self.user:
+                    dst[user][item] = rating
+                    seen.add(item)
+        self.user_num = len(self.training_set_u)
+        self.item_num = len(self.training_set_i)
+        self.ui_adj = self._bipartite_adjacency()
+        self.norm_adj = self.normalize_graph_mat(self.ui_adj)
+        self.interaction_mat = self._interaction_matrix()
+
+    # ---- matrices
+    def _ids(self):
+        u = np.fromiter((self.user[r[0]] for r in self.training_data), dtype=np.int64, count=len(self.training_data))
+        i = np.fromiter((self.item[r[1]] for r in self.training_data), dtype=np.int64, count=len(self.training_data))
+        return u, i
+
+    def _bipartite_adjacency(self, self_connection=False):
+        n = self.user_num + self.item_num
+        u, i = self._ids()
+        half = sp.csr_matrix((np.ones(len(u), np.float32), (u, i + self.user_num)), shape=(n, n), dtype=np.float32)
+        adj = half + half.T
+        if self_connection:
+            adj += sp.eye(n)
+        return adj
+
+    def normalize_graph_mat(self, adj_mat):
+        shape = adj_mat.get_shape()
+        rowsum = np.array(adj_mat.sum(1))
+        with np.errstate(divide='ignore'):
+            d_inv = np.power(rowsum, -0.5 if shape[0] == shape[1] else -1.0).flatten()
+        d_inv[np.isinf(d_inv)] = 0.
+        d_mat = sp.diags(d_inv)
+        out = d_mat.dot(adj_mat)
+        return out.dot(d_mat) if shape[0] == shape[1] else out
+
+    def convert_to_laplacian_mat(self, adj_mat):
+        r, c = adj_mat.get_shape()
+        rows, cols = adj_mat.nonzero()
+        half = sp.csr_matrix((adj_mat.data, (rows, cols + r)), shape=(r + c, r + c), dtype=np.float32)
+        return self.normalize_graph_mat(half + half.T)
+
+    def _interaction_matrix(self):
+        u, i = self._ids()
+        return sp.csr_matrix((np.ones(len(u), np.float64), (u, i)), shape=(self.user_num, self.item_num), dtype=np.float32)
+
+    def matrix(self):
+        return self._interaction_matrix()
+
+    # ---- accessors
+    def get_user_id(self, u):
+        return self.user.get(u)
+
+    def get_item_id(self, i):
+        return self.item.get(i)
+
+    def training_size(self):
+        return len(self.user), len(self.item), len(self.training_data)
+
+    def val_size(self):
+        return len(self.val_set), len(self.val_set_item), len(self.val_data)
+
+    def test_size(self):
+        return len(self.test_set), len(self.test_set_item), len(self.test_data)
+
+    def contain(self, u, i):
+        return u in self.user and i in self.training_set_u[u]
+
+    def contain_user(self, u):
+        return u in self.user
+
+    def contain_item(self, i):
+        return i in self.item
+
+    def user_rated(self, u):
+        return list(self.training_set_u[u].keys()), list(self.training_set_u[u].values())
+
+    def item_rated(self, i):
+        return list(self.training_set_i[i].keys()), list(self.training_set_i[i].values())
+
+    def row(self, u):
+        vec = np.zeros(len(self.item))
+        for it, r in self.training_set_u[self.id2user[u]].items():
+            vec[self.item[it]] = r
+        return vec
+
+    def col(self, i):
+        vec = np.zeros(len(self.user))
+        for us, r in self.training_set_i[self.id2item[i]].items():
+            vec[self.user[us]] = r
+        return vec
+
+    # pickling / deepcopy: drop the sampler's cached int image (rebuilt on demand)
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st.pop('_arl_sampler', None)
+        return st

@@ -337,6 +337,30 @@ def gen_simgcl(data):
     save('g5_simgcl.npz', **o)
 
 
+# --------------------------------------------------------------------------- G10: whole train() through the class API
+def gen_train_api():
+    """Reference `X(args,data).train(Epoch=2)` end to end (sampler + steps + per-epoch evaluation + best-epoch keep)."""
+    import io, contextlib
+    out = {}
+    for name, cls, kw in (('gmf', GMF, dict(emb_size=64, model_name='GMF')), ('lgn', LightGCN, dict(emb_size=64, n_layers=2))):
+        args = rec_args(**kw)
+        seedSet(2018)
+        data = DataLoader(args)
+        rec = cls(args, data)
+        with contextlib.redirect_stdout(io.StringIO()):
+            rec.train(Epoch=2, evalNum=1)
+            rec_list, measure = rec.test()
+        out[name + '_user'] = rec.model.embedding_dict['user_emb'].detach().numpy().copy()
+        out[name + '_item'] = rec.model.embedding_dict['item_emb'].detach().numpy().copy()
+        out[name + '_best_user'] = rec.best_user_emb.detach().numpy().copy()
+        out[name + '_best_epoch'] = np.array([rec.bestPerformance[0]], np.int64)
+        out[name + '_best_perf'] = np.array([rec.bestPerformance[1][k] for k in ('Hit Ratio', 'Precision', 'Recall', 'NDCG')], np.float64)
+        out[name + '_measure'] = np.array([float(m.strip().split(':')[1]) for m in measure[1:]], np.float64)
+        out[name + '_next_random'] = np.array([random.random()], np.float64)
+        out[name + '_predict0'] = rec.predict(data.id2user[0]).astype(np.float32)
+    save('g10_train_api.npz', **out)
+
+
 if __name__ == '__main__':
     gen_dataset()
     data = gen_sampler()
@@ -348,4 +372,5 @@ if __name__ == '__main__':
     gen_adj(data)
     gen_forward_and_steps(data)
     gen_simgcl(data)
+    gen_train_api()
     print('done; scratch dir', SCRATCH)

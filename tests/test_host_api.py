@@ -1,0 +1,117 @@
+"""CPU tests: host logic of the product (DataLoader mirror, drop-in sampler, metrics) and the C-ABI surface
+(the library loads and exports every symbol include/arlib_amd.h declares).  No GPU compute."""
+import ctypes
+import os
+import random
+import re
+import numpy as np
+import pytest
+from conftest import golden, ROOT
+
+
+def make_data():
+    from arlib_amd.util.DataLoader import DataLoader
+    g = golden('ml100k_data.npz')
+    rows = lambda u, i, r: [[str(a), str(b), float(c)] for a, b, c in zip(u, i, r)]
+    return DataLoader(training_data=rows(g['train_u'], g['train_i'], g['train_r']), val_data=rows(g['val_u'], g['val_i'], g['val_r']),
+                      test_data=rows(g['test_u'], g['test_i'], g['test_r']), dataName='ml-100k')
+
+
+def test_abi_exports_match_header():
+    from arlib_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'arlib_amd.h')).read()
+    declared = set(re.findall(r'\b(arl_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    l = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(l, name), name
+    assert _lib.lib().arl_abi_version() == _lib.ABI_VERSION
+    # argument validation happens before any device work: NULL pointers / bad sizes are rejected with ARL_E_* codes
+    assert _lib.lib().arl_sgd_dense_f32(None, None, 4, 0.1, None) == -1
+    assert _lib.lib().arl_bpr_l2_workspace_bytes(2048) == 4 * 4 * 2048
+    assert _lib.lib().arl_sampler_shuffle(None, None, 5) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from arlib_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libarlib_amd.so')
+    with pytest.raises(_lib.ArlError):
+        _lib.lib()
+
+
+def test_dataloader_matches_reference_ids_and_adjacency(ml100k):
+    data = make_data()
+    assert data.training_size() == (ml100k['U'], ml100k['I'], ml100k['nnz'])
+    ids = np.array([[data.user[r[0]], data.item[r[1]]] for r in data.training_data], np.int32)
+    assert np.array_equal(ids, ml100k['pairs0'])                       # first-seen id assignment
+    g = golden('g3_adj.npz')
+    na = data.norm_adj.tocsr(); na.sort_indices()
+    assert np.array_equal(na.indptr, g['norm_indptr']) and np.array_equal(na.indices, g['norm_indices'])
+    assert np.allclose(na.data, g['norm_data'], rtol=1e-6, atol=0)
+    assert data.matrix().shape == (ml100k['U'], ml100k['I']) and data.matrix().nnz == ml100k['nnz']
+    assert data.get_user_id('253') == 0 and data.get_item_id('465') == 0 and data.get_user_id('nope') is None
+
+
+def test_dropin_sampler_consumes_python_random_bit_exact(ml100k):
+    from arlib_amd.util.sampler import next_batch_pairwise
+    g = golden('g1_sampler.npz')
+    data = make_data()
+    random.seed(2018)
+    for ep in range(2):
+        bs = list(next_batch_pairwise(data, 2048))
+        assert [len(bs), len(bs[-1][0])] == list(g['ep%d_nb' % ep])
+        assert np.array_equal(np.concatenate([b[0] for b in bs]), g['ep%d_u' % ep])
+        assert np.array_equal(np.concatenate([b[1] for b in bs]), g['ep%d_p' % ep])
+        assert np.array_equal(np.concatenate([b[2] for b in bs]), g['ep%d_n' % ep])
+        # the Python list itself was shuffled in place, like the reference's (Q7 carry-over)
+        assert [data.user[r[0]] for r in data.training_data[:50]] == list(g['ep%d_u' % ep][:50])
+    assert random.random() == float(g['next_random'][0])
+    assert tuple(int(x) for x in g['mt_state_after'])[:5] != ()      # fixture sanity
+    # appended fake-user interactions (attack/White/CLeaR.py:190-191): empty training_set_u -> never rejected
+    data.user['fakeuser0'] = len(data.user); data.id2user[len(data.user) - 1] = 'fakeuser0'
+    for it in ('465', '222'):
+        data.training_data.append(('fakeuser0', it))
+    random.seed(3)
+    state = random.getstate()
+    bs = list(next_batch_pairwise(data, 4096))
+    assert sum(len(b[0]) for b in bs) == ml100k['nnz'] + 2
+    fu = data.user['fakeuser0']
+    assert sum(int((b[0] == fu).sum()) for b in bs) == 2
+
+
+def test_metrics_and_topk_helpers():
+    from arlib_amd.util.metrics import ranking_evaluation
+    from arlib_amd.util.algorithm import find_k_largest
+    origin = {'a': {'x': 1, 'y': 1}, 'b': {'z': 1}}
+    res = {'a': [('x', 0.9), ('q', 0.5)], 'b': [('q', 0.3), ('z', 0.2)]}
+    m = ranking_evaluation(origin, res, [2])
+    vals = {s.split(':')[0]: float(s.split(':')[1]) for s in m[1:]}
+    assert m[0] == 'Top 2\n' and abs(vals['Hit Ratio'] - 2 / 3) < 1e-12 and abs(vals['Precision'] - 0.5) < 1e-12
+    assert abs(vals['Recall'] - 0.75) < 1e-12
+    ids, sc = find_k_largest(3, np.array([0.1, 0.9, 0.5, 0.7, -1.0]))
+    assert ids == [1, 3, 2] and sc == [0.9, 0.7, 0.5]
+
+
+def test_synthetic_generator_is_deterministic_and_valid():
+    from arlib_amd.util import synthetic as S
+    p = S.syn_v1_pairs(2000, 300, mean_deg=16, seed=2018)
+    assert S.graph_digest(p) == S.graph_digest(S.syn_v1_pairs(2000, 300, mean_deg=16, seed=2018))
+    assert S.graph_digest(p) != S.graph_digest(S.syn_v1_pairs(2000, 300, mean_deg=16, seed=2019))
+    key = p[:, 0].astype(np.int64) * 300 + p[:, 1]
+    assert np.all(np.diff(key) > 0)                                     # user-major, strictly increasing, no duplicates
+    assert set(np.unique(p[:, 1])) == set(range(300))                   # every item covered
+    assert np.bincount(p[:, 0], minlength=2000).min() >= 1
+    rowptr, col = S.bipartite_csr_from_sorted_pairs(p, 2000, 300)
+    from oracle import oracle as O
+    rp2, col2, _ = O.bipartite_csr(p[:, 0], p[:, 1], 2000, 300)
+    assert np.array_equal(rowptr, rp2) and np.array_equal(col, col2)
+    d = S.InteractionData(p, 2000, 300)
+    from arlib_amd.util.sampler import MTState
+    mt = MTState.from_seed(5)
+    st = O.mt_seed(5)
+    pairs_o = p.copy()
+    memb = O.build_membership(p, 2000)
+    for (u, pp, n), (ou, op, on) in zip(d.pair_sampler.epoch(mt, 777), O.next_batch_pairwise(st, pairs_o, 777, 300, memb)):
+        assert np.array_equal(u, ou) and np.array_equal(pp, op) and np.array_equal(n, on)
+    assert np.array_equal(mt.words, st)
