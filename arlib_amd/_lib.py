@@ -43,7 +43,7 @@ _SIGS = {
     'arl_infonce_fwd_bwd_f32': (C.c_int, [_vp, _vp, _i64, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     'arl_simgcl_perturb_f32': (C.c_int, [_vp, _vp, _i64, _i64, _f, _vp]),
     'arl_sddmm_rows_dense_f32': (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp]),
-    'arl_pga_update_f32': (C.c_int, [_vp, _vp, _i64, _vp]),
+    'arl_pga_update_f32': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     'arl_score_mask_topk_f32': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
     'arl_topn_project_rows_f32': (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
 }

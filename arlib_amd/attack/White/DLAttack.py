@@ -1,0 +1,90 @@
+"""DLAttack -- mirror of the reference's attack/White/DLAttack.py (posionDataAttack :51-125, project :127-132,
+fakeUserInject :134-163) on the MI355X kernels: one fake user at a time, surrogate fine-tuning with BPR, filler items =
+top-n of (score * decaying popularity prior p).
+
+What changed mechanically: the U x I score matrix the reference materialises on the HOST every outer epoch
+(DLAttack.py:73-83) is replaced by the streaming score+mask+top-k kernel; the surrogate's BPR steps run on the fused
+training engine; the `Pu @ Pi.T` recomputed inside every mini-batch only to feed a constant into the printed loss
+(DLAttack.py:102-103; it carries no gradient) is not recomputed.
+"""
+from copy import deepcopy
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from ... import ops
+from ...util.sampler import next_batch_pairwise
+from .._common import AttackBase, DEVICE, symmetric_adjacency, rebuild_interaction_matrix, reinit_with_tables, cw_pairs
+
+
+def masked_topk(Pu, Pi, ui_mat, k):
+    """top-k of Pu @ Pi.T with interacted entries set to -10e8 (DLAttack.py:73-83 / CLeaR.py:75-82), streamed."""
+    m = sp.csr_matrix(ui_mat)
+    m.eliminate_zeros(); m.sort_indices()
+    rp = torch.from_numpy(m.indptr.astype(np.int32)).to(Pu.device)
+    mc = torch.from_numpy(m.indices.astype(np.int32) if m.nnz else np.zeros(1, np.int32)).to(Pu.device)
+    return ops.score_mask_topk(Pu.contiguous(), Pi.contiguous(), k, rp, mc)
+
+
+class DLAttack(AttackBase):
+    def __init__(self, arg, data):
+        super().__init__(arg, data)
+        self.batchSize = 256
+
+    def posionDataAttack(self, recommender):
+        self.fakeUser = list(range(self.userNum, self.userNum + self.fakeUserNum))
+        # bound to the model that fakeUserInject() is about to replace: the surrogate "retrain" below moves nothing (quirk Q4)
+        optimizer = torch.optim.Adam(recommender.model.parameters(), lr=recommender.args.lRate / 10)
+        topk = min(recommender.topN)
+        p = torch.ones(self.itemNum, device=DEVICE)
+        sigma = 0.8
+        uiAdj = None
+        for user in self.fakeUser:
+            self.fakeUserInject(recommender, user)
+            uiAdj = recommender.data.matrix()           # rebuilt from training_data: earlier fake users keep only their targets (quirk Q6)
+            tmpRecommender = deepcopy(recommender)
+            uiAdj2 = uiAdj.tolil(copy=True)
+            U_now = tmpRecommender.data.user_num
+            tmpRecommender.model._init_uiAdj(symmetric_adjacency(uiAdj2, U_now, self.itemNum))
+            tmpRecommender.train(Epoch=self.innerEpoch, optimizer=optimizer, evalNum=5)
+            optimizer_attack = torch.optim.Adam(tmpRecommender.model.parameters(), lr=recommender.args.lRate)
+            for _ in range(self.outerEpoch):
+                with torch.no_grad():
+                    Pu, Pi = tmpRecommender.model()
+                    top_idx, _ = masked_topk(Pu, Pi, uiAdj2, min(topk, self.itemNum))
+                    users, pos, neg = cw_pairs(top_idx, self.userNum, self.targetItem, pop=False)
+                    # CW term of DLAttack.py:92-101: computed on detached tensors there, i.e. a logged constant
+                    self.last_cw_loss = float(((Pu[users] * Pi[neg]).sum(1) - (Pu[users] * Pi[pos]).sum(1)).mean())
+                tmpRecommender.train_batches(next_batch_pairwise(self.data, tmpRecommender.args.batch_size), optimizer_attack)
+            with torch.no_grad():
+                Pu, Pi = tmpRecommender.model()
+                r = (Pu[user, :] @ Pi.T) * p
+            m, ind = self.project(r, self.maliciousFeedbackNum)
+            uiAdj2[user, :] = m.cpu().numpy()
+            p[ind] = p[ind] * sigma
+            if p.max() < 1:
+                p = torch.ones(self.itemNum, device=DEVICE)
+            recommender.model._init_uiAdj(symmetric_adjacency(uiAdj2, recommender.data.user_num, self.itemNum))
+            uiAdj = uiAdj2
+        self.interact = uiAdj
+        return self.interact
+
+    def project(self, mat, n):
+        """top-n of a score vector -> ({0,1} vector, indices) (DLAttack.py:127-132)."""
+        v = torch.as_tensor(mat, dtype=torch.float32, device=DEVICE).reshape(1, -1).contiguous()
+        out, idx = ops.topn_project_rows(v, int(n))
+        return out[0], idx[0].long()
+
+    def fakeUserInject(self, recommender, user):
+        """One more user whose only interactions are the targets; re-init the recommender and keep the old tables
+        (DLAttack.py:134-163)."""
+        Pu, Pi = recommender.model()
+        data = recommender.data
+        data.user_num += 1
+        data.user['fakeuser{}'.format(data.user_num)] = len(data.user)
+        data.id2user[len(data.user) - 1] = 'fakeuser{}'.format(data.user_num)
+        for i in self.targetItem:
+            data.training_data.append((data.id2user[user], data.id2item[i]))
+        _, _, data.interaction_mat = rebuild_interaction_matrix(data)
+        reinit_with_tables(recommender, Pu, Pi)

@@ -1,0 +1,190 @@
+"""PGA -- projected-gradient poisoning attack; mirror of the reference's attack/White/PGA.py on the MI355X kernels.
+
+Same protocol and numbers (posionDataAttack(recommender) -> scipy (U+F) x I matrix), different mechanics:
+  * the reference rebuilds the (U+F+I)^2 adjacency in scipy and re-uploads a COO tensor for every one of the
+    ceil(I/128) gradient steps (PGA.py:93-97).  Here the pattern (real edges + DENSE fake-user rows/columns) is
+    built once per outer epoch; a step only rewrites the 2*F*I fake-edge weights on the device and re-normalises
+    there (arl_norm_adj_values_f32).  Zero-weight fake edges contribute nothing, so results are identical.
+  * the reference takes autograd.grad w.r.t. ALL E adjacency values, densifies an N x N matrix and slices F rows
+    (PGA.py:117-134).  Here only the F x I block is ever computed: sum over layers of two row-restricted SDDMMs,
+      grad[f,j] = dinv[f] dinv[U'+j] ( sum_k <dE_{k+1}[f], E_k[U'+j]> + <dE_{k+1}[U'+j], E_k[f]> ),
+    with dE_k = G/(L+1) + A dE_{k+1} (adjacency symmetric) and G the gradient of the CW loss w.r.t. the output.
+"""
+from copy import deepcopy
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from ... import ops
+from .._common import AttackBase, DEVICE, symmetric_adjacency, rebuild_interaction_matrix, reinit_with_tables, cw_pairs
+
+
+class FakeBlockGraph:
+    """Device CSR of the (U'+I)^2 adjacency (U' = U + F) whose F fake-user rows (and the matching F columns of every item
+    row) are dense, so the fake block S [F, I] maps to two fixed index sets of the edge-weight array."""
+
+    def __init__(self, ui_real, n_real, n_fake, n_items, device=DEVICE):
+        U, F, I = int(n_real), int(n_fake), int(n_items)
+        Up = U + F
+        R = sp.csr_matrix(ui_real, dtype=np.float32)[:U]
+        R.eliminate_zeros(); R.sort_indices()
+        Rt = R.T.tocsr(); Rt.sort_indices()
+        deg_u = np.diff(R.indptr).astype(np.int64)
+        deg_i = np.diff(Rt.indptr).astype(np.int64)
+        rowptr = np.zeros(Up + I + 1, np.int64)
+        np.cumsum(np.concatenate([deg_u, np.full(F, I, np.int64), deg_i + F]), out=rowptr[1:])
+        nnz = int(rowptr[-1])
+        col = np.empty(nnz, np.int32); w = np.zeros(nnz, np.float32)
+        col[:R.nnz] = R.indices + Up; w[:R.nnz] = R.data
+        fb = int(rowptr[U])
+        col[fb:fb + F * I] = np.tile(np.arange(I, dtype=np.int32) + Up, F)
+        ib = int(rowptr[Up])
+        # item rows: real users ascending, then the F fake users
+        item_start = rowptr[Up:Up + I] - ib
+        real_pos = (np.arange(Rt.nnz, dtype=np.int64) + np.repeat(np.arange(I, dtype=np.int64) * F, deg_i)) + ib
+        col[real_pos] = Rt.indices; w[real_pos] = Rt.data
+        fake_pos = (rowptr[Up + 1:Up + I + 1] - F)[None, :] + np.arange(F, dtype=np.int64)[:, None]     # [F, I]
+        col[fake_pos] = (U + np.arange(F, dtype=np.int32))[:, None]
+        self.U, self.F, self.I, self.Up, self.N = U, F, I, Up, Up + I
+        self.device = torch.device(device)
+        self.rowptr_d = torch.from_numpy(rowptr.astype(np.int32)).to(self.device)
+        self.col_d = torch.from_numpy(col).to(self.device)
+        self.w = torch.from_numpy(w).to(self.device)
+        self.fwd_lo = fb
+        self.bwd_idx = torch.from_numpy(fake_pos.reshape(-1)).to(self.device)
+        self.graph = ops.CSRGraph(rowptr, self.col_d, torch.zeros(nnz, device=self.device), self.device)
+        self.fake_rows = torch.arange(U, Up, dtype=torch.int32, device=self.device)
+        self.dinv = None
+
+    def set_block(self, S):
+        """Write S [F, I] into both directions of the fake edges and re-normalise on device (LightGCN.py:212-215)."""
+        flat = S.reshape(-1)
+        self.w[self.fwd_lo:self.fwd_lo + flat.numel()] = flat
+        self.w[self.bwd_idx] = flat
+        val, self.dinv = ops.norm_adj_values(self.rowptr_d, self.col_d, self.w, self.N)
+        self.graph = self.graph.with_values(val)
+        return self.graph
+
+
+def cw_loss_and_grad(out, Up, users, pos, neg):
+    """CWloss = mean(<Pu_u, Pi_neg> - <Pu_u, Pi_pos>) (PGA.py:109-116) and its gradient w.r.t. the propagated table."""
+    u32, p32, n32 = users.to(torch.int32), (pos + Up).to(torch.int32), (neg + Up).to(torch.int32)
+    ue, pe, ne = ops.gather_rows(out, u32), ops.gather_rows(out, p32), ops.gather_rows(out, n32)
+    loss = ((ue * ne).sum(1) - (ue * pe).sum(1)).mean()
+    c = 1.0 / users.numel()
+    G = torch.zeros_like(out)
+    ops.scatter_add_rows(G, u32, ne - pe, c, check_range=False)
+    ops.scatter_add_rows(G, n32, ue, c, check_range=False)
+    ops.scatter_add_rows(G, p32, ue, -c, check_range=False)
+    return loss, G
+
+
+def pga_block_gradient(graph, fake_rows, Up, I, E0, L, G):
+    """Returns the un-normalised F x I block sum_k <dE_{k+1}[f], E_k[U'+j]> + <E_k[f], dE_{k+1}[U'+j]> for the LightGCN mean."""
+    E = [E0]
+    for k in range(L):
+        E.append(ops.spmm(graph, E[k]))
+    s = 1.0 / (L + 1)
+    Gs = G * s
+    dE = [None] * (L + 1)
+    dE[L] = Gs
+    for k in range(L - 1, 0, -1):
+        dE[k] = ops.spmm(graph, dE[k + 1], 1.0, 1.0, Gs)
+    block = torch.zeros(fake_rows.numel(), I, dtype=torch.float32, device=E0.device)
+    for k in range(L):
+        ops.sddmm_rows_dense(dE[k + 1], E[k], fake_rows, Up, I, out=block)
+        ops.sddmm_rows_dense(E[k], dE[k + 1], fake_rows, Up, I, out=block)
+    return block, E
+
+
+class PGA(AttackBase):
+    def __init__(self, arg, data):
+        super().__init__(arg, data)
+        self.batchSize = 128
+
+    def posionDataAttack(self, recommender):
+        Pu, Pi = recommender.model()
+        n_pop = int(Pi.shape[0] * 0.05)
+        maxRecNumItemInd = torch.topk(torch.as_tensor(np.asarray(self.interact.sum(0)).ravel()), n_pop)[1].numpy()
+        self.maxRecNumItemInd = maxRecNumItemInd
+        # optimizer bound to the OLD model's parameters; recommender.__init__ below replaces the model, so this
+        # train() never moves the new tables (reference quirk Q4, PGA.py:59-67) -- reproduced as is
+        optimizer = torch.optim.SGD(recommender.model.parameters(), lr=recommender.args.lRate / 10)
+        self.dataUpdate(recommender)
+        reinit_with_tables(recommender, Pu, Pi)
+        newAdj = recommender.data.matrix()
+        self.controlledUser = list(range(self.userNum, self.userNum + self.fakeUserNum))
+        recommender.train(Epoch=self.Epoch, optimizer=optimizer, evalNum=5)
+        originRecommender = deepcopy(recommender)
+        U, F, I = self.userNum, self.fakeUserNum, self.itemNum
+        # fake block S: targets 1, popular items one random weight per fake user (PGA.py:69-73)
+        S = torch.zeros(F, I, dtype=torch.float32)
+        for f in range(F):
+            S[f, self.targetItem] = 1
+            S[f, maxRecNumItemInd] = torch.rand([1]).item()
+        S = S.to(DEVICE)
+        recommender = deepcopy(originRecommender)
+        optimizer = torch.optim.Adam(recommender.model.parameters(), lr=recommender.args.lRate / 10)
+        real = sp.csr_matrix(newAdj[:U])
+        fg = FakeBlockGraph(real, U, F, I)
+        L = getattr(recommender.model, 'n_prop_layers', 0)
+        for epoch in range(self.outerEpoch):
+            # outer optimisation: victim retrain on the current poisoned graph
+            uiAdj = sp.vstack([real, sp.csr_matrix(S.cpu().numpy())]).tocsr()
+            recommender.model._init_uiAdj(symmetric_adjacency(uiAdj, U + F, I))
+            recommender.train(Epoch=self.Epoch, optimizer=optimizer, evalNum=3)
+            # inner optimisation on a frozen copy of the victim's tables
+            E0 = recommender.model._pack().detach().clone()
+            S2 = S.clone()
+            for _ in range(self.innerEpoch):
+                pairs = None
+                for batch in range(0, I, self.batchSize):
+                    graph = fg.set_block(S2)
+                    if L == 0:
+                        raise ValueError('PGA differentiates through the graph propagation; the victim has no propagation layers')
+                    if pairs is None:
+                        out = E0.clone()
+                        E = E0
+                        for k in range(L):
+                            E = ops.spmm(graph, E)
+                            out += E
+                        out /= (L + 1)
+                        top_idx, _ = ops.score_mask_topk(out[:U + F].contiguous(), out[U + F:].contiguous(), min(50, I))     # no interacted mask (PGA.py:101-102)
+                        pairs = cw_pairs(top_idx, U, self.targetItem, pop=True)
+                    out = E0.clone()
+                    E = E0
+                    for k in range(L):
+                        E = ops.spmm(graph, E)
+                        out += E
+                    out /= (L + 1)
+                    loss, G = cw_loss_and_grad(out, U + F, *pairs)
+                    block, _ = pga_block_gradient(graph, fg.fake_rows, U + F, I, E0, L, G)
+                    ops.pga_update_(S2, block, fg.dinv[U:U + F].contiguous(), fg.dinv[U + F:].contiguous())
+                    print('>> batchNum:{} Loss:{}'.format(int(batch / self.batchSize), loss.item()))
+            proj, _ = ops.topn_project_rows(S2, int(self.maliciousFeedbackSize * I))
+            proj[:, self.targetItem] = 1
+            S = proj
+            print('attack step {} is over\n'.format(epoch + 1))
+        self.interact = sp.vstack([real, sp.csr_matrix(S.cpu().numpy())]).tolil()
+        return self.interact
+
+    def project(self, mat, n):
+        """Per-row top-n -> {0,1} (PGA.py:153-167); accepts a scipy or dense matrix like the reference."""
+        M = torch.as_tensor(np.asarray(mat.todense() if hasattr(mat, 'todense') else mat), dtype=torch.float32, device=DEVICE).contiguous()
+        out, _ = ops.topn_project_rows(M, n)
+        return out.cpu()
+
+    def dataUpdate(self, recommender):
+        """Append F fake users to the id maps and rebuild ui_adj / norm_adj / interaction_mat (PGA.py:169-192)."""
+        data = recommender.data
+        data.user_num += self.fakeUserNum
+        for i in range(self.fakeUserNum):
+            data.user['fakeuser{}'.format(i)] = len(data.user)
+            data.id2user[len(data.user) - 1] = 'fakeuser{}'.format(i)
+        u, it, inter = rebuild_interaction_matrix(data)
+        n = data.user_num + data.item_num
+        half = sp.csr_matrix((np.ones(len(u), np.float32), (u, it + data.user_num)), shape=(n, n), dtype=np.float32)
+        data.ui_adj = half + half.T
+        data.norm_adj = data.normalize_graph_mat(data.ui_adj)
+        data.interaction_mat = inter

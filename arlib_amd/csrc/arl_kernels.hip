@@ -523,9 +523,19 @@ __global__ __launch_bounds__(kBlock) void sddmm_rows_dense_kernel(const float *_
     }
 }
 
-__global__ __launch_bounds__(kBlock) void pga_update_kernel(float *__restrict__ S, const float *__restrict__ grad, long long n) {
+// S = clamp(S - 0.2*tanh(g)), g = dinv_r[row] * dinv_c[col] * grad, and g = 0 where S has no stored entry (S == 0):
+// autograd.grad w.r.t. the sparse adjacency only yields pattern entries (attack/White/PGA.py:117-139).
+__global__ __launch_bounds__(kBlock) void pga_update_kernel(float *__restrict__ S, const float *__restrict__ grad, const float *__restrict__ dinv_r,
+                                                             const float *__restrict__ dinv_c, long long rows, long long cols) {
+    const long long n = rows * cols;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
-        float s = S[i] - 0.2f * tanhf(grad[i]);
+        const long long r = i / cols, c = i - r * cols;
+        const float s0 = S[i];
+        float g = grad[i];
+        if (dinv_r) g *= dinv_r[r];
+        if (dinv_c) g *= dinv_c[c];
+        if (s0 == 0.f) g = 0.f;
+        float s = s0 - 0.2f * tanhf(g);
         if (s > 1.f) s = 1.f;
         if (s <= 0.f) s = 10e-8f;
         S[i] = s;
@@ -870,11 +880,12 @@ int arl_sddmm_rows_dense_f32(const float *dY, const float *X, int64_t d, const i
     return ARL_OK;
 }
 
-int arl_pga_update_f32(float *S, const float *grad, int64_t n, arl_stream_t stream) {
+int arl_pga_update_f32(float *S, const float *grad, const float *dinv_rows, const float *dinv_cols, int64_t rows, int64_t cols, arl_stream_t stream) {
     if (!S || !grad) return ARL_E_NULL;
-    if (n < 0) return ARL_E_ARG;
-    if (n == 0) return ARL_OK;
-    hipLaunchKernelGGL(pga_update_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, S, grad, (long long)n);
+    if (rows < 0 || cols < 0) return ARL_E_ARG;
+    if (rows == 0 || cols == 0) return ARL_OK;
+    hipLaunchKernelGGL(pga_update_kernel, dim3(grid_for(rows * cols, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, S, grad, dinv_rows, dinv_cols,
+                       (long long)rows, (long long)cols);
     ARL_LAUNCH_CHECK();
     return ARL_OK;
 }

@@ -62,6 +62,8 @@ class CSRGraph:
             if np.any(np.diff(rp) < 0):
                 raise ValueError('CSRGraph: rowptr must be non-decreasing')
         self.device = torch.device(device)
+        if self.device.type == 'cuda' and self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self.n_rows, self.nnz, self.chunk = n, nnz, int(chunk)
         self.rowptr = torch.as_tensor(rp.astype(np.int32)).to(self.device)
         self.col = (col if isinstance(col, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(col, dtype=np.int32))).to(self.device, torch.int32).contiguous()
@@ -311,11 +313,20 @@ def sddmm_rows_dense(dY, X, rows, col_off, n_cols, out=None):
     return out
 
 
-def pga_update_(S, grad):
-    _dev(S, torch.float32, 'S'); _dev(grad, torch.float32, 'grad')
+def pga_update_(S, grad, dinv_rows=None, dinv_cols=None):
+    """In place: S = clamp(S - 0.2*tanh(dinv_rows[r]*grad*dinv_cols[c])), gradient ignored where S == 0 (not in the pattern)."""
+    _dev(S, torch.float32, 'S', 2); _dev(grad, torch.float32, 'grad', 2)
     if S.shape != grad.shape:
         raise ValueError('pga_update_: shape mismatch')
-    check(_lib.lib().arl_pga_update_f32(_ptr(S), _ptr(grad), S.numel(), _stream()), 'arl_pga_update_f32')
+    if dinv_rows is not None:
+        _dev(dinv_rows, torch.float32, 'dinv_rows', 1)
+        if dinv_rows.numel() != S.shape[0]:
+            raise ValueError('pga_update_: dinv_rows length')
+    if dinv_cols is not None:
+        _dev(dinv_cols, torch.float32, 'dinv_cols', 1)
+        if dinv_cols.numel() != S.shape[1]:
+            raise ValueError('pga_update_: dinv_cols length')
+    check(_lib.lib().arl_pga_update_f32(_ptr(S), _ptr(grad), _ptr(dinv_rows), _ptr(dinv_cols), S.shape[0], S.shape[1], _stream()), 'arl_pga_update_f32')
     return S
 
 

@@ -270,6 +270,12 @@ class Recommender:
             self.usergrad = torch.zeros((self.data.user_num, self.args.emb_size), device=DEVICE)
             self.itemgrad = torch.zeros((self.data.item_num, self.args.emb_size), device=DEVICE)
         maxEpoch = Epoch if Epoch else self.args.maxEpoch
+        # reference quirk Q4 (attack/White/PGA.py:59-67, DLAttack.py:53-68): an optimizer built on a model that
+        # recommender.__init__ has since replaced owns none of the live parameters, so the reference's loop moves
+        # nothing -- it only consumes the sampler's random stream and runs the per-epoch evaluation.  Same here,
+        # without spending the forward/backward.
+        mine = self._params()
+        inert = not requires_embgrad and not any(p is q for g in optimizer.param_groups for p in g['params'] for q in mine)
         eng = None
         if fused_kind:
             eng = model._engine(self.args.reg, self.args.lRate, fused_kind)
@@ -279,6 +285,8 @@ class Recommender:
         for epoch in range(maxEpoch):
             for n, batch in enumerate(next_batch_pairwise(self.data, self.args.batch_size)):
                 user_idx, pos_idx, neg_idx = batch
+                if inert:
+                    continue
                 if int(user_idx.max()) >= U or int(max(pos_idx.max(), neg_idx.max())) >= I:
                     raise IndexError('sampler produced an index outside the embedding tables')
                 u = torch.from_numpy(user_idx).to(DEVICE, non_blocking=True)
@@ -314,6 +322,37 @@ class Recommender:
         self.user_emb, self.item_emb = self.best_user_emb, self.best_item_emb
         if requires_embgrad:
             return self.user_emb, self.item_emb, self.usergrad, self.itemgrad
+
+    def train_batches(self, batches, optimizer):
+        """Run the BPR + L2 training step on an iterable of (u, p, n) batches with `optimizer` and no evaluation -- the
+        surrogate fine-tuning loop of attack/White/DLAttack.py:84-106 (fused engine when the optimizer allows it)."""
+        model = self.model.cuda()
+        kind = None if self.has_extra_loss else self._fusable(optimizer)
+        U, I = self.data.user_num, self.data.item_num
+        eng = None
+        if kind:
+            eng = model._engine(self.args.reg, self.args.lRate, kind)
+            eng.reg = float(self.args.reg)
+            self._bind_optimizer_state(eng, optimizer, kind)
+        last = None
+        for user_idx, pos_idx, neg_idx in batches:
+            if int(user_idx.max()) >= U or int(max(pos_idx.max(), neg_idx.max())) >= I:
+                raise IndexError('batch index outside the embedding tables')
+            u, p, ng = (torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32)).to(DEVICE) for x in (user_idx, pos_idx, neg_idx))
+            if eng is not None:
+                last = eng.step(u, p, ng)
+                continue
+            rec_user_emb, rec_item_emb = model()
+            loss = bpr_l2_loss(rec_user_emb[u.long()], rec_item_emb[p.long()], rec_item_emb[ng.long()], self.args.reg)
+            if self.has_extra_loss:
+                loss = loss + self._extra_loss(model, u.long(), p.long())
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+            last = loss
+        if eng is not None:
+            self._sync_optimizer_step(eng, optimizer, kind)
+        return last
 
     def _detached_forward(self):
         with torch.no_grad():

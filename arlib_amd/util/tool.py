@@ -32,7 +32,9 @@ def targetItemSelect(data, arg, popularThreshold=0.1):
         pool = order[-int(popularThreshold * itemNum):]
     else:
         pool = order[:int(0.2 * itemNum)]
-    targetItem = random.sample(sorted(set(pool)), targetNum)
+    # the reference samples from a *set* (util/tool.py:84-92); CPython 3.10 turns it into tuple(set) first, so the draw
+    # depends on the set's iteration order -- reproduced literally
+    targetItem = random.sample(tuple(set(pool)), targetNum)
     targetItem = [data.id2item[i] for i in targetItem]
     if os.path.isdir(os.path.dirname(path)):
         with open(path, 'w') as f:

@@ -156,8 +156,12 @@ int arl_simgcl_perturb_f32(float *E, const float *noise, int64_t n, int64_t d, f
  *   out[t, j] += <dY[rows[t]], X[col_off + j]> ,  0 <= j < n_cols.   out: [n_rows_sel, n_cols]. */
 int arl_sddmm_rows_dense_f32(const float *dY, const float *X, int64_t d, const int32_t *rows, int64_t n_rows_sel,
                              int64_t col_off, int64_t n_cols, float *out, arl_stream_t stream);
-/* S = S - 0.2*tanh(grad); S>1 -> 1; S<=0 -> 10e-8   (attack/White/PGA.py:135-139) */
-int arl_pga_update_f32(float *S, const float *grad, int64_t n, arl_stream_t stream);
+/* Projected-gradient step on the fake-user block S [rows, cols] (attack/White/PGA.py:118-139):
+ *   g = dinv_rows[r] * grad[r,c] * dinv_cols[c]   (D^-1/2 grad D^-1/2; either scale vector may be NULL = 1)
+ *   g = 0 where S[r,c] == 0                       (autograd.grad on a sparse tensor only yields pattern entries)
+ *   S = S - 0.2*tanh(g);  S > 1 -> 1;  S <= 0 -> 10e-8 */
+int arl_pga_update_f32(float *S, const float *grad, const float *dinv_rows, const float *dinv_cols, int64_t rows,
+                       int64_t cols, arl_stream_t stream);
 /* Streaming scores + interacted mask + top-k, never materialising U x I.  Replaces the chunked Pu@Pi.T into a
  * host buffer, scores[nonzero] = -10e8 and torch.topk (attack/White/DLAttack.py:73-83, CLeaR.py:75-82,
  * PGA.py:100-102 with mask_rowptr == NULL).  Output sorted by descending score, ties by ascending item id.

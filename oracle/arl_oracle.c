@@ -416,15 +416,23 @@ void orc_topn_project_rows(const float *M, int64_t rows, int64_t cols, int64_t n
     free(tmp);
 }
 
-/* attack/White/PGA.py:135-139:  S -= 0.2*tanh(grad); S[S>1]=1; S[S<=0]=10e-8 */
-void orc_pga_update(float *S, const float *grad, int64_t n)
+/* attack/White/PGA.py:117-139.  doubleGrad = autograd.grad(Loss, sparse_norm_adj) exists only on the stored pattern,
+ * is scaled D^-1/2 . D^-1/2 (:118-126), densified and sliced to the fake rows (:128-134); then
+ * S -= 0.2*tanh(grad); S[S>1]=1; S[S<=0]=10e-8 (:135-139).  Entries with S == 0 are not in the pattern -> grad 0. */
+void orc_pga_update(float *S, const float *grad, const float *dinv_rows, const float *dinv_cols, int64_t rows, int64_t cols)
 {
-    for (int64_t i = 0; i < n; i++) {
-        float s = S[i] - 0.2f * tanhf(grad[i]);
-        if (s > 1.f) s = 1.f;
-        if (s <= 0.f) s = 10e-8f;
-        S[i] = s;
-    }
+    for (int64_t r = 0; r < rows; r++)
+        for (int64_t c = 0; c < cols; c++) {
+            int64_t i = r * cols + c;
+            float g = grad[i];
+            if (dinv_rows) g *= dinv_rows[r];
+            if (dinv_cols) g *= dinv_cols[c];
+            if (S[i] == 0.f) g = 0.f;
+            float s = S[i] - 0.2f * tanhf(g);
+            if (s > 1.f) s = 1.f;
+            if (s <= 0.f) s = 10e-8f;
+            S[i] = s;
+        }
 }
 
 int orc_num_threads(void)

@@ -248,9 +248,10 @@ def topn_project_rows(M, n):
     return out, idx
 
 
-def pga_update(S, grad):
+def pga_update(S, grad, dinv_rows=None, dinv_cols=None):
     S = _f32(S).copy()
-    lib().orc_pga_update(_p(S), _p(_f32(grad)), C.c_int64(S.size))
+    lib().orc_pga_update(_p(S), _p(_f32(grad)), _p(_f32(dinv_rows)) if dinv_rows is not None else None,
+                         _p(_f32(dinv_cols)) if dinv_cols is not None else None, C.c_int64(S.shape[0]), C.c_int64(S.shape[1]))
     return S
 
 
@@ -291,3 +292,64 @@ class TrainState:
         else:
             sgd_step(self.E0, g, self.lr)
         return loss
+
+
+# ------------------------------------------------------------------ white-box attack compositions (numpy over the C pieces)
+def cw_pairs(top_idx, n_real_users, targets, pop=True):
+    """attack/White/PGA.py:104-108 / CLeaR.py:84-88 (`top_items[u].pop()` per target: ranks k, k-1, ...) and
+    DLAttack.py:92-96 (`top_items[u][-1]`: always rank k)."""
+    T, k = len(targets), top_idx.shape[1]
+    users = np.repeat(np.arange(n_real_users), T)
+    pos = np.tile(np.asarray(targets), n_real_users)
+    ranks = np.tile(k - 1 - np.arange(T), n_real_users) if pop else np.full(n_real_users * T, k - 1)
+    return users, pos, top_idx[users, ranks].astype(np.int64)
+
+
+def cw_loss_grad(out, Up, users, pos, neg):
+    """CWloss = mean(neg_score - pos_score) (PGA.py:109-116) and dL/d(out)."""
+    ue, pe, ne = out[users], out[Up + pos], out[Up + neg]
+    loss = float(np.mean((ue.astype(np.float64) * ne).sum(1) - (ue.astype(np.float64) * pe).sum(1)))
+    c = 1.0 / len(users)
+    G = np.zeros(out.shape, np.float64)
+    np.add.at(G, users, c * (ne.astype(np.float64) - pe))
+    np.add.at(G, Up + neg, c * ue.astype(np.float64))
+    np.add.at(G, Up + pos, -c * ue.astype(np.float64))
+    return loss, G.astype(np.float32)
+
+
+def pga_weighted_graph(real_indptr, real_indices, U, F, I, S):
+    """(U+F+I)^2 normalised adjacency of the real interactions plus the weighted fake block S (entries with S != 0 only:
+    scipy's `ui_adj + ui_adj.T` drops explicit zeros) -- what PGA.py:93-97 hands to _init_uiAdj.  Returns (csr, dinv)."""
+    ru = np.repeat(np.arange(U), np.diff(real_indptr[:U + 1]))
+    fu, fi = np.nonzero(S)
+    u = np.concatenate([ru, fu + U]); i = np.concatenate([real_indices[:len(ru)], fi])
+    w = np.concatenate([np.ones(len(ru), np.float32), S[fu, fi].astype(np.float32)])
+    rowptr, col, ww = bipartite_csr(u, i, U + F, I, w)
+    val = norm_adj_values(rowptr, col, ww)
+    rows = np.repeat(np.arange(len(rowptr) - 1), np.diff(rowptr))
+    deg = np.zeros(len(rowptr) - 1, np.float32)
+    np.add.at(deg, rows, ww)
+    with np.errstate(divide='ignore'):
+        dinv = np.where(deg > 0, 1.0 / np.sqrt(deg), 0.0).astype(np.float32)
+    return (rowptr, col, val), dinv
+
+
+def pga_step(real_indptr, real_indices, U, F, I, S, E0, L, users, pos, neg):
+    """One projected-gradient step on the fake block (PGA.py:92-142).  Returns (scaled gradient block, new S, CW loss)."""
+    csr, dinv = pga_weighted_graph(real_indptr, real_indices, U, F, I, S)
+    Up = U + F
+    out, E = lightgcn_forward(csr, E0, L, return_layers=True)
+    loss, G = cw_loss_grad(out, Up, users, pos, neg)
+    s = 1.0 / (L + 1)
+    Gs = (G * s).astype(np.float32)
+    dE = [None] * (L + 1)
+    dE[L] = Gs
+    for k in range(L - 1, 0, -1):
+        dE[k] = spmm(csr, dE[k + 1], 1.0, 1.0, Gs)
+    rows = np.arange(U, Up, dtype=np.int32)
+    block = np.zeros((F, I), np.float32)
+    for k in range(L):
+        sddmm_rows_dense(dE[k + 1], E[k], rows, Up, I, out=block)
+        sddmm_rows_dense(E[k], dE[k + 1], rows, Up, I, out=block)
+    grad = block * dinv[U:Up, None] * dinv[None, Up:] * (S != 0)
+    return grad, pga_update(S, block, dinv[U:Up], dinv[Up:]), loss

@@ -361,6 +361,181 @@ def gen_train_api():
     save('g10_train_api.npz', **out)
 
 
+# --------------------------------------------------------------------------- G7-G9: white-box attacks, traced
+# The attacks are run UNMODIFIED; intermediates are captured by wrapping functions they call (no attack line is re-typed):
+#   LGCN_Encoder._init_uiAdj -> the weighted adjacency handed over + the model's tables at that moment
+#   LGCN_Encoder.forward     -> last propagated tables
+#   torch.topk / torch.tanh / torch.randn / Tensor.backward / Adam.step -> inputs / outputs of interest
+def _attack_args(**kw):
+    a = dict(attackCategory='White', attackModelName='PGA', times=1, poisonDatasetOutPath='data/poison/', poisondataSaveFlag=False,
+             maliciousUserSize=3, maliciousFeedbackSize=0, Epoch=1, innerEpoch=1, outerEpoch=1, gradMaxLimitation=1,
+             gradNumLimitation=60, gradIterationNum=10, attackTargetChooseWay='unpopular', targetSize=5)
+    a.update(kw)
+    return SimpleNamespace(**a)
+
+
+def _scipy_torch_index_shim():
+    """Quirk Q13: under scipy >= 1.8 a torch tensor used as a scipy index fails (PGA.py:56,73); convert in the harness."""
+    import scipy.sparse._index as spi
+    orig = spi.IndexMixin._validate_indices
+
+    def patched(self, key, *a, **k):
+        conv = lambda x: x.numpy().copy() if isinstance(x, torch.Tensor) else x
+        if isinstance(key, tuple):
+            key = tuple(conv(x) for x in key)
+        else:
+            key = conv(key)
+        return orig(self, key, *a, **k)
+    spi.IndexMixin._validate_indices = patched
+    return lambda: setattr(spi.IndexMixin, '_validate_indices', orig)
+
+
+def gen_attacks():
+    import io, contextlib
+    from copy import deepcopy
+    import recommender.LightGCN as RL
+    from attack.White.PGA import PGA
+    from attack.White.DLAttack import DLAttack
+    from attack.White.CLeaR import CLeaR
+    os.makedirs('data/clean/ml-100k', exist_ok=True)
+    undo_shim = _scipy_torch_index_shim()
+    rargs = rec_args(emb_size=16, n_layers=2, maxEpoch=1)
+
+    def fresh():
+        seedSet(2018)
+        data = DataLoader(rargs)
+        rec = LightGCN(rargs, data)
+        with contextlib.redirect_stdout(io.StringIO()):
+            rec.train(Epoch=1, evalNum=5)
+        return data, rec
+
+    trace = {}
+    orig_init, orig_fwd = RL.LGCN_Encoder._init_uiAdj, RL.LGCN_Encoder.forward
+    orig_topk, orig_tanh, orig_randn = torch.topk, torch.tanh, torch.randn
+    orig_backward, orig_adam_step = torch.Tensor.backward, torch.optim.Adam.step
+
+    def init_wrap(self, ui_adj):
+        trace.setdefault('init', []).append((sp.csr_matrix(ui_adj).copy(), self.embedding_dict['user_emb'].detach().numpy().copy(),
+                                             self.embedding_dict['item_emb'].detach().numpy().copy()))
+        return orig_init(self, ui_adj)
+
+    def fwd_wrap(self, *a, **k):
+        out = orig_fwd(self, *a, **k)
+        trace['last_fwd'] = (out[0].detach().numpy().copy(), out[1].detach().numpy().copy())
+        return out
+
+    def topk_wrap(inp, k, *a, **kw):
+        out = orig_topk(inp, k, *a, **kw)
+        if inp.dim() == 2 and inp.shape[0] > 100:
+            trace.setdefault('topk', []).append((k, out[1].numpy().copy(), trace.get('last_fwd'), len(trace.get('init', []))))
+        return out
+
+    def tanh_wrap(x):
+        trace.setdefault('tanh', []).append(x.detach().numpy().copy())
+        return orig_tanh(x)
+
+    RL.LGCN_Encoder._init_uiAdj, RL.LGCN_Encoder.forward = init_wrap, fwd_wrap
+    torch.topk, torch.tanh = topk_wrap, tanh_wrap
+    out = {}
+    try:
+        # ------------------------------------------------------------------ PGA (a16)
+        data, rec = fresh()
+        aargs = _attack_args(attackModelName='PGA')
+        atk = PGA(aargs, data)
+        trace.clear()
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = atk.posionDataAttack(deepcopy(rec))
+        U, I, F = atk.userNum, atk.itemNum, atk.fakeUserNum
+        out['pga_sizes'] = np.array([U, I, F, rargs.n_layers, rargs.emb_size], np.int64)
+        out['pga_targets'] = np.array(atk.targetItem, np.int32)
+        # init[0] = outer-loop _init_uiAdj; init[1..] = per-gradient-step adjacency (PGA.py:93-97)
+        steps = trace['init'][1:]
+        assert len(steps) == len(trace['tanh'])
+        real = steps[0][0][:U, U + F:]
+        out['pga_real_indptr'], out['pga_real_indices'] = real.indptr.astype(np.int64), real.indices.astype(np.int32)
+        out['pga_user_tab'], out['pga_item_tab'] = steps[0][1], steps[0][2]
+        K = 4
+        out['pga_S'] = np.stack([np.asarray(steps[s][0][U:U + F, U + F:].todense(), np.float32) for s in range(K + 1)])   # fake block before step s
+        out['pga_grad'] = np.stack(trace['tanh'][:K]).astype(np.float32)                                                 # D^-1/2 g D^-1/2 block of step s
+        k50 = [t for t in trace['topk'] if t[0] == 50][0]
+        out['pga_top50'] = k50[1][:U].astype(np.int32)
+        out['pga_result_fake_rows'] = np.asarray(res[U:U + F, :].todense(), np.float32)
+
+        # ------------------------------------------------------------------ DLAttack (a18 scoring+mask+top-k, a17 project)
+        data, rec = fresh()
+        atk = DLAttack(_attack_args(attackModelName='DLAttack', maliciousUserSize=2), data)
+        proj = []
+        orig_project = DLAttack.project
+
+        def project_wrap(self, mat, n):
+            m, ind = orig_project(self, mat, n)
+            proj.append((np.asarray(mat.detach().numpy(), np.float32).copy(), int(n), m.numpy().copy(), ind.numpy().copy()))
+            return m, ind
+        DLAttack.project = project_wrap
+        trace.clear()
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = atk.posionDataAttack(deepcopy(rec))
+        DLAttack.project = orig_project
+        tk = trace['topk'][0]
+        adj = trace['init'][tk[3] - 1][0]
+        Un = tk[2][0].shape[0]
+        mask = adj[:Un, Un:]
+        out['dl_Pu'], out['dl_Pi'] = tk[2]
+        out['dl_mask_indptr'], out['dl_mask_indices'] = mask.indptr.astype(np.int64), mask.indices.astype(np.int32)
+        out['dl_topk'] = tk[1].astype(np.int32)
+        out['dl_k'] = np.array([tk[0]], np.int64)
+        out['dl_proj_in'] = np.stack([p[0] for p in proj]); out['dl_proj_n'] = np.array([p[1] for p in proj], np.int64)
+        out['dl_proj_out'] = np.stack([p[2] for p in proj]); out['dl_proj_idx'] = np.stack([p[3] for p in proj]).astype(np.int32)
+        out['dl_result_fake_rowsums'] = np.asarray(res[atk.userNum:, :].sum(1)).ravel().astype(np.float32)
+
+        # ------------------------------------------------------------------ CLeaR (a19: CW + SFA loss and parameter gradients)
+        data, rec = fresh()
+        atk = CLeaR(_attack_args(attackModelName='CLeaR', maliciousUserSize=3), data)
+        r_fixed = torch.Generator().manual_seed(99)
+        r0 = torch.randn(rargs.emb_size, generator=r_fixed)
+        cap = {}
+
+        def randn_wrap(*a, **k):
+            if len(a) == 1 and a[0] == rargs.emb_size:
+                return r0.clone()
+            return orig_randn(*a, **k)
+
+        def backward_wrap(self, *a, **k):
+            if 'loss' not in cap:
+                cap['loss'] = float(self.item())
+            return orig_backward(self, *a, **k)
+
+        def adam_step_wrap(self, *a, **k):
+            if 'grads' not in cap and 'loss' in cap:
+                ps = self.param_groups[0]['params']
+                cap['grads'] = [p.grad.detach().numpy().copy() for p in ps]
+                cap['n_init'] = len(trace.get('init', []))
+            return orig_adam_step(self, *a, **k)
+        torch.randn, torch.Tensor.backward, torch.optim.Adam.step = randn_wrap, backward_wrap, adam_step_wrap
+        trace.clear()
+        random.seed(4242)
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = atk.posionDataAttack(deepcopy(rec))
+        torch.randn, torch.Tensor.backward, torch.optim.Adam.step = orig_randn, orig_backward, orig_adam_step
+        adj, utab, itab = trace['init'][cap['n_init'] - 1]
+        Un = utab.shape[0]
+        blk = adj[:Un, Un:]
+        out['cl_user_tab'], out['cl_item_tab'] = utab, itab
+        out['cl_ui_indptr'], out['cl_ui_indices'], out['cl_ui_data'] = blk.indptr.astype(np.int64), blk.indices.astype(np.int32), blk.data.astype(np.float32)
+        out['cl_r0'] = r0.numpy()
+        out['cl_loss'] = np.array([cap['loss']], np.float32)
+        out['cl_grad_user'], out['cl_grad_item'] = cap['grads']
+        out['cl_targets'] = np.array(atk.targetItem, np.int32)
+        out['cl_sizes'] = np.array([atk.userNum, atk.itemNum, atk.fakeUserNum, min(rec.topN)], np.int64)
+        out['cl_result_fake_rowsums'] = np.asarray(res[atk.userNum:, :].sum(1)).ravel().astype(np.float32)
+    finally:
+        RL.LGCN_Encoder._init_uiAdj, RL.LGCN_Encoder.forward = orig_init, orig_fwd
+        torch.topk, torch.tanh, torch.randn = orig_topk, orig_tanh, orig_randn
+        torch.Tensor.backward, torch.optim.Adam.step = orig_backward, orig_adam_step
+        undo_shim()
+    save('g7_attacks.npz', **out)
+
+
 if __name__ == '__main__':
     gen_dataset()
     data = gen_sampler()
@@ -373,4 +548,5 @@ if __name__ == '__main__':
     gen_forward_and_steps(data)
     gen_simgcl(data)
     gen_train_api()
+    gen_attacks()
     print('done; scratch dir', SCRATCH)

@@ -1,0 +1,140 @@
+"""GPU parity of the white-box attack inner loops against intermediates traced from the UNMODIFIED reference attacks
+(tests/golden/g7_attacks.npz): PGA's gradient w.r.t. the fake interactions (a16), DLAttack's masked top-k and top-n
+projection (a17/a18), CLeaR's CW + SFA loss and parameter gradients (a19); plus end-to-end posionDataAttack() runs."""
+import contextlib
+import io
+import random
+from types import SimpleNamespace
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+from conftest import golden, rel_err, RTOL
+from test_host_api import make_data
+from test_gpu_api import rec_args
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module', autouse=True)
+def need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail('GPU tests need a GPU')
+
+
+def T(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+
+
+def attack_args(**kw):
+    a = dict(maliciousUserSize=3, maliciousFeedbackSize=0, Epoch=1, innerEpoch=1, outerEpoch=1, attackTargetChooseWay='unpopular', targetSize=5)
+    a.update(kw)
+    return SimpleNamespace(**a)
+
+
+def test_pga_gradient_steps_match_reference_trace():
+    from arlib_amd import ops
+    from arlib_amd.attack.White.PGA import FakeBlockGraph, cw_loss_and_grad, pga_block_gradient
+    from arlib_amd.attack._common import cw_pairs
+    g = golden('g7_attacks.npz')
+    U, I, F, L, d = (int(x) for x in g['pga_sizes'])
+    real = sp.csr_matrix((np.ones(len(g['pga_real_indices']), np.float32), g['pga_real_indices'], g['pga_real_indptr']), shape=(U, I))
+    fg = FakeBlockGraph(real, U, F, I)
+    E0 = T(np.concatenate([g['pga_user_tab'], g['pga_item_tab']]))
+    # top-50 without mask from the propagated tables of the first step's graph (PGA.py:100-102)
+    graph = fg.set_block(T(g['pga_S'][0]))
+    out = E0.clone(); E = E0
+    for k in range(L):
+        E = ops.spmm(graph, E); out += E
+    out /= (L + 1)
+    top_idx, _ = ops.score_mask_topk(out[:U].contiguous(), out[U + F:].contiguous(), 50)
+    assert (top_idx.cpu().numpy() == g['pga_top50']).mean() > 0.999
+    pairs = cw_pairs(T(g['pga_top50']).long(), U, [int(t) for t in g['pga_targets']], pop=True)      # reference's own list: isolates the gradient check
+    S = T(g['pga_S'][0]).clone()
+    for s in range(g['pga_grad'].shape[0]):
+        graph = fg.set_block(S)
+        out = E0.clone(); E = E0
+        for k in range(L):
+            E = ops.spmm(graph, E); out += E
+        out /= (L + 1)
+        loss, G = cw_loss_and_grad(out, U + F, *pairs)
+        block, _ = pga_block_gradient(graph, fg.fake_rows, U + F, I, E0, L, G)
+        scaled = block * fg.dinv[U:U + F, None] * fg.dinv[None, U + F:] * (S != 0)
+        assert rel_err(scaled.cpu().numpy(), g['pga_grad'][s]) < RTOL, s
+        ops.pga_update_(S, block, fg.dinv[U:U + F].contiguous(), fg.dinv[U + F:].contiguous())
+        assert rel_err(S.cpu().numpy(), g['pga_S'][s + 1]) < 1e-6, s
+
+
+def test_dlattack_masked_topk_and_project_match_reference_trace():
+    from arlib_amd.attack.White.DLAttack import masked_topk, DLAttack
+    g = golden('g7_attacks.npz')
+    k = int(g['dl_k'][0])
+    Un, I = g['dl_Pu'].shape[0], g['dl_Pi'].shape[0]
+    mask = sp.csr_matrix((np.ones(len(g['dl_mask_indices']), np.float32), g['dl_mask_indices'], g['dl_mask_indptr']), shape=(Un, I))
+    idx, _ = masked_topk(T(g['dl_Pu']), T(g['dl_Pi']), mask, k)
+    idx = idx.cpu().numpy()
+    assert (idx == g['dl_topk']).mean() > 0.999 and (np.sort(idx, 1) == np.sort(g['dl_topk'], 1)).mean() > 0.9999
+    atk = object.__new__(DLAttack)
+    for r in range(len(g['dl_proj_n'])):
+        m, ind = atk.project(g['dl_proj_in'][r], int(g['dl_proj_n'][r]))
+        assert np.array_equal(m.cpu().numpy(), g['dl_proj_out'][r]) and np.array_equal(ind.cpu().numpy(), g['dl_proj_idx'][r])
+
+
+def test_clear_surrogate_loss_and_gradients_match_reference_trace():
+    from arlib_amd.recommender.LightGCN import LGCN_Encoder
+    from arlib_amd.attack.White.CLeaR import CLeaR
+    from arlib_amd.attack._common import symmetric_adjacency
+    g = golden('g7_attacks.npz')
+    U, I, F, topk = (int(x) for x in g['cl_sizes'])
+    Up = U + F
+    data = SimpleNamespace(user_num=Up, item_num=I, norm_adj=sp.identity(Up + I, dtype=np.float32, format='csr'))
+    model = LGCN_Encoder(data, 16, 2).cuda()
+    with torch.no_grad():
+        model.embedding_dict['user_emb'][:] = T(g['cl_user_tab']); model.embedding_dict['item_emb'][:] = T(g['cl_item_tab'])
+    ui = sp.csr_matrix((g['cl_ui_data'], g['cl_ui_indices'], g['cl_ui_indptr']), shape=(Up, I))
+    model._init_uiAdj(symmetric_adjacency(ui, Up, I))
+    atk = object.__new__(CLeaR)
+    atk.userNum, atk.itemNum, atk.fakeUserNum, atk.targetItem = U, I, F, [int(t) for t in g['cl_targets']]
+    lossall, Pu, Pi, cw, sfa = atk.surrogate_loss(model, ui, topk, r0=T(g['cl_r0']))
+    assert abs(lossall.item() - g['cl_loss'][0]) <= RTOL * abs(g['cl_loss'][0])
+    lossall.backward()
+    grads = {a.shape[0]: a for a in (g['cl_grad_user'], g['cl_grad_item'])}           # keyed by row count (945 users / 1412 items)
+    assert rel_err(model.embedding_dict['user_emb'].grad.cpu().numpy(), grads[Up]) < RTOL
+    assert rel_err(model.embedding_dict['item_emb'].grad.cpu().numpy(), grads[I]) < RTOL
+
+
+@pytest.mark.parametrize('name', ['PGA', 'DLAttack', 'CLeaR'])
+def test_posion_data_attack_end_to_end(name, tmp_path, monkeypatch):
+    """Whole posionDataAttack() on ml-100k with the reference's protocol; structural checks the reference run also satisfies
+    (g7: DLAttack row sums [5, 46] (quirk Q6), CLeaR 51 = 46 fillers + 5 targets, PGA targets only at the default n = 0 (Q5))."""
+    import importlib
+    from copy import deepcopy
+    from arlib_amd.util.tool import seedSet
+    from arlib_amd.recommender.LightGCN import LightGCN
+    monkeypatch.chdir(tmp_path)
+    g = golden('g7_attacks.npz')
+    seedSet(2018)
+    data = make_data()
+    rec = LightGCN(rec_args(emb_size=16, n_layers=2, maxEpoch=1), data)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rec.train(Epoch=1, evalNum=5)
+    cls = getattr(importlib.import_module('arlib_amd.attack.White.' + name), name)
+    F = 2 if name == 'DLAttack' else 3
+    atk = cls(attack_args(maliciousUserSize=F), data)
+    assert sorted(atk.targetItem) == sorted(int(t) for t in g['pga_targets'])       # same python-random target draw as the reference run
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = atk.posionDataAttack(deepcopy(rec))
+    res = sp.csr_matrix(res)
+    U, I = 942, 1412
+    assert res.shape == (U + F, I)
+    assert (res[:U] != data.matrix()).nnz == 0                                       # real users untouched
+    fake = np.asarray(res[U:].todense())
+    assert np.all(fake[:, atk.targetItem] == 1) and set(np.unique(fake)) <= {0.0, 1.0}
+    sums = fake.sum(1).tolist()
+    if name == 'PGA':
+        assert sums == [5.0] * F and np.array_equal(fake, g['pga_result_fake_rows'])
+    elif name == 'DLAttack':
+        assert sums == [float(x) for x in g['dl_result_fake_rowsums']]
+    else:
+        assert sums == [float(x) for x in g['cl_result_fake_rowsums']]
