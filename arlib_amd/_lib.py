@@ -35,6 +35,8 @@ _SIGS = {
     'arl_spmm_csr_adam_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),
     'arl_bpr_l2_workspace_bytes': (_i64, [_i64]),
     'arl_bpr_l2_fwd_bwd_f32': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _f, _f, _vp, _vp, _vp, _vp]),
+    'arl_bpr_l2_partial_f32': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    'arl_bpr_l2_backward_f32': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _f, _f, _vp, _vp, _vp, _vp]),
     'arl_adam_dense_f32': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i64, _vp]),
     'arl_sgd_dense_f32': (C.c_int, [_vp, _vp, _i64, _f, _vp]),
     'arl_gather_rows_f32': (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),

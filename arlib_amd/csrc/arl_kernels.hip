@@ -261,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void norm_vals_kernel(int n_rows, const int
 // ================================================================================================
 __global__ __launch_bounds__(kBlock) void bpr_fwd_kernel(const float *__restrict__ emb, int d, long long item_off,
                                                           const int32_t *__restrict__ ui, const int32_t *__restrict__ pi,
-                                                          const int32_t *__restrict__ ni, int B, float *__restrict__ ws) {
+                                                          const int32_t *__restrict__ ni, int B, float b_norm, float *__restrict__ ws) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_kernel(const float *__restrict
     if (lane == 0) {
         const float x = ps - ns;
         const float s = 1.0f / (1.0f + expf(-x));
-        ws[b] = -(s * (1.0f - s)) / ((1e-7f + s) * (float)B);      // d(mean loss)/dx_b
+        ws[b] = -(s * (1.0f - s)) / ((1e-7f + s) * b_norm);        // d(mean loss)/dx_b; b_norm = global batch size
         ws[B + b] = -logf(1e-7f + s);
         ws[2 * B + b] = uu;
         ws[3 * B + b] = pp;
@@ -283,7 +283,9 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_kernel(const float *__restrict
 }
 
 // single block: fixed-order tree reduction -> bitwise reproducible loss and norms
-__global__ __launch_bounds__(kBlock) void bpr_finalize_kernel(int B, float reg, const float *__restrict__ ws, float *__restrict__ out) {
+// raw_sums != 0 (user-sharded batch): out[0..2] = sum of loss terms, sum |u|^2, sum |p|^2 over the LOCAL samples, to be
+// all-reduced by the caller before the backward kernel.
+__global__ __launch_bounds__(kBlock) void bpr_finalize_kernel(int B, float reg, const float *__restrict__ ws, float *__restrict__ out, int raw_sums) {
     __shared__ float sh[3][kBlock];
     float a = 0.f, b = 0.f, c = 0.f;
     for (int i = threadIdx.x; i < B; i += kBlock) { a += ws[B + i]; b += ws[2 * B + i]; c += ws[3 * B + i]; }
@@ -295,7 +297,9 @@ __global__ __launch_bounds__(kBlock) void bpr_finalize_kernel(int B, float reg, 
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && raw_sums) {
+        out[0] = sh[0][0]; out[1] = sh[1][0]; out[2] = sh[2][0];
+    } else if (threadIdx.x == 0) {
         const float nu = sqrtf(sh[1][0]), np_ = sqrtf(sh[2][0]);
         out[0] = sh[0][0] / (float)B;
         out[1] = reg * (nu + np_);
@@ -759,15 +763,47 @@ int arl_bpr_l2_fwd_bwd_f32(const float *emb, int64_t d, int64_t item_off, const 
     hipStream_t st = (hipStream_t)stream;
     float *ws = (float *)workspace;
     const unsigned grid = (unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL(bpr_fwd_kernel, dim3(grid), dim3(kBlock), 0, st, emb, (int)d, (long long)item_off, u, p, n, (int)B, ws);
+    hipLaunchKernelGGL(bpr_fwd_kernel, dim3(grid), dim3(kBlock), 0, st, emb, (int)d, (long long)item_off, u, p, n, (int)B, (float)B, ws);
     ARL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bpr_finalize_kernel, dim3(1), dim3(kBlock), 0, st, (int)B, reg, ws, loss_out);
+    hipLaunchKernelGGL(bpr_finalize_kernel, dim3(1), dim3(kBlock), 0, st, (int)B, reg, ws, loss_out, 0);
     ARL_LAUNCH_CHECK();
     if (G) {
         hipLaunchKernelGGL(bpr_bwd_kernel, dim3(grid), dim3(kBlock), 0, st, emb, (int)d, (long long)item_off, u, p, n, (int)B, reg, upstream, ws,
                            loss_out, G);
         ARL_LAUNCH_CHECK();
     }
+    return ARL_OK;
+}
+
+int arl_bpr_l2_partial_f32(const float *emb, int64_t d, int64_t item_off, const int32_t *u, const int32_t *p, const int32_t *n, int64_t B_local,
+                           int64_t B_global, float *sums_out, void *workspace, arl_stream_t stream) {
+    if (!emb || !sums_out || !workspace) return ARL_E_NULL;
+    if (B_local > 0 && (!u || !p || !n)) return ARL_E_NULL;
+    if (d <= 0 || B_local < 0 || B_global < B_local || B_global <= 0 || item_off < 0) return ARL_E_ARG;
+    if (B_local > 0x7fffffffll / 4 || d > 0x7fffffffll) return ARL_E_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+    float *ws = (float *)workspace;
+    if (B_local > 0) {
+        const unsigned grid = (unsigned)((B_local + kWavesPerBlock - 1) / kWavesPerBlock);
+        hipLaunchKernelGGL(bpr_fwd_kernel, dim3(grid), dim3(kBlock), 0, st, emb, (int)d, (long long)item_off, u, p, n, (int)B_local, (float)B_global, ws);
+        ARL_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(bpr_finalize_kernel, dim3(1), dim3(kBlock), 0, st, (int)B_local, 0.f, ws, sums_out, 1);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_bpr_l2_backward_f32(const float *emb, int64_t d, int64_t item_off, const int32_t *u, const int32_t *p, const int32_t *n, int64_t B_local,
+                            float reg, float upstream, const float *norms4, float *G, const void *workspace, arl_stream_t stream) {
+    if (!emb || !norms4 || !G || !workspace) return ARL_E_NULL;
+    if (B_local > 0 && (!u || !p || !n)) return ARL_E_NULL;
+    if (d <= 0 || B_local < 0 || item_off < 0) return ARL_E_ARG;
+    if (B_local > 0x7fffffffll / 4 || d > 0x7fffffffll) return ARL_E_RANGE;
+    if (B_local == 0) return ARL_OK;
+    const unsigned grid = (unsigned)((B_local + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(bpr_bwd_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, emb, (int)d, (long long)item_off, u, p, n, (int)B_local, reg,
+                       upstream, (const float *)workspace, norms4, G);
+    ARL_LAUNCH_CHECK();
     return ARL_OK;
 }
 

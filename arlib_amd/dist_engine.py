@@ -1,0 +1,194 @@
+"""User-sharded LightGCN training step for the 8 GPUs of one node.  One process per GPU; `torch.distributed`
+(backend "nccl" = RCCL over xGMI) provides the collective.  The reference has no multi-GPU path at all; this is new design.
+
+Partition
+  * users are split into `world` contiguous blocks; rank r owns user rows [u0, u1): their embedding rows, Adam moments and
+    CSR rows.  The item table (I x d; 25.6 MB at cfg2) and its Adam moments are REPLICATED.
+  * per-rank buffers are [Ul + I, d]: local users first, then all items -- the same packed layout as the single-GPU
+    engine, so every kernel is reused unchanged.
+  * the local graph is two rectangular CSR blocks over that packed index space:
+      A_u : Ul rows, gathers item rows      (exact: a user's neighbours are all items, all replicated)
+      A_i : I  rows, gathers LOCAL user rows (partial sums over this rank's users)
+    with the GLOBAL degree normalisation 1/sqrt(deg_u deg_i).
+Per propagation hop (forward and backward alike; the adjacency is symmetric):
+      launch A_i  ->  async sum-all-reduce of the I x d partial (25.6 MB)  ||  launch A_u on the compute stream  ->  wait.
+  That is the one real exchange step of the path: 2L + 1 all-reduces of I*d fp32 per training step (L forward hops, the
+  batch gradient's item rows, L backward hops), plus one 3-float all-reduce for the batch-wide loss sums.  The item-side gradient therefore arrives already reduced and every rank applies
+  the identical Adam update to its replica ("RCCL all-reduce of item-embedding grads", north_star).
+The BPR batch is global (same bit-exact sampler stream on every rank); a rank takes the samples whose user it owns.
+
+The collective and the kernel set are injected (`comm`, `kernels`) so the shard arithmetic can be exercised with
+world_size-2 gloo processes on CPU in the test-suite; the defaults are RCCL and the HIP kernels, nothing else.
+"""
+import numpy as np
+import torch
+
+
+class TorchDistComm:
+    """torch.distributed sum-all-reduce (NCCL backend = RCCL on ROCm)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+
+    def all_reduce_async(self, t):
+        return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def all_reduce(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+def shard_bounds(n_users, world):
+    """Contiguous user blocks, sizes differing by at most one."""
+    base, rem = divmod(int(n_users), int(world))
+    starts = [r * base + min(r, rem) for r in range(world + 1)]
+    return starts
+
+
+def build_local_blocks(pairs, n_users, n_items, rank, world):
+    """Host-side (numpy) construction of the rank's two CSR blocks from the user-major sorted pair list.
+    Returns dict(u0, u1, Au=(rowptr,col,val), Ai=(rowptr,col,val)) with columns in the packed [Ul + I] index space."""
+    pairs = np.asarray(pairs)
+    U, I = int(n_users), int(n_items)
+    u_all = pairs[:, 0].astype(np.int64); i_all = pairs[:, 1].astype(np.int64)
+    deg_u = np.bincount(u_all, minlength=U).astype(np.float32)
+    deg_i = np.bincount(i_all, minlength=I).astype(np.float32)
+    with np.errstate(divide='ignore'):
+        du = np.where(deg_u > 0, 1.0 / np.sqrt(deg_u), 0.0).astype(np.float32)       # util/DataLoader.py:77-78 (isinf -> 0)
+        di = np.where(deg_i > 0, 1.0 / np.sqrt(deg_i), 0.0).astype(np.float32)
+    b = shard_bounds(U, world)
+    u0, u1 = b[rank], b[rank + 1]
+    Ul = u1 - u0
+    lo, hi = np.searchsorted(u_all, u0, 'left'), np.searchsorted(u_all, u1, 'left')      # pairs are user-major sorted
+    lu = u_all[lo:hi] - u0
+    li = i_all[lo:hi]
+    val = ((du[u_all[lo:hi]] * np.float32(1.0)) * di[li]).astype(np.float32)             # (dinv[r]*w)*dinv[c], w = 1
+    rp_u = np.zeros(Ul + 1, np.int64)
+    np.cumsum(np.bincount(lu, minlength=Ul), out=rp_u[1:])
+    col_u = (li + Ul).astype(np.int32)
+    order = np.argsort(li, kind='stable')
+    rp_i = np.zeros(I + 1, np.int64)
+    np.cumsum(np.bincount(li, minlength=I), out=rp_i[1:])
+    col_i = lu[order].astype(np.int32)
+    val_i = ((di[li[order]] * np.float32(1.0)) * du[u_all[lo:hi][order]]).astype(np.float32)
+    return dict(u0=u0, u1=u1, Au=(rp_u, col_u, val), Ai=(rp_i, col_i, val_i))
+
+
+class ShardedPropagationEngine:
+    """Rank-local state + step() of the user-sharded LightGCN (mean of L+1 layers) + BPR/L2 + dense Adam."""
+
+    def __init__(self, blocks, n_users, n_items, emb_size, n_layers, reg, lr, device, rank, world, table, chunk=512,
+                 comm=None, kernels=None, betas=(0.9, 0.999), eps=1e-8):
+        if kernels is None:
+            from . import ops as kernels         # the HIP kernels; fails loudly if libarlib_amd.so is missing
+        self.k = kernels
+        self.comm = comm if comm is not None else TorchDistComm()
+        self.rank, self.world = rank, world
+        self.U, self.I, self.d, self.L = int(n_users), int(n_items), int(emb_size), int(n_layers)
+        if self.L < 1:
+            raise ValueError('the sharded engine is for graph models (n_layers >= 1)')
+        self.u0, self.u1 = blocks['u0'], blocks['u1']
+        self.Ul = self.u1 - self.u0
+        self.Nl = self.Ul + self.I
+        self.reg, self.lr, self.betas, self.eps = float(reg), float(lr), betas, eps
+        self.device = torch.device(device)
+        rp, col, val = blocks['Au']
+        self.Au = kernels.CSRGraph(rp, col, val, self.device, chunk=chunk, n_cols=self.Nl)
+        rp, col, val = blocks['Ai']
+        self.Ai = kernels.CSRGraph(rp, col, val, self.device, chunk=chunk, n_cols=self.Nl)
+        table = torch.as_tensor(table, dtype=torch.float32)
+        if table.shape != (self.U + self.I, self.d):
+            raise ValueError('table must be the full [U+I, d] initial table (every rank slices its own rows)')
+        z = lambda: torch.zeros(self.Nl, self.d, dtype=torch.float32, device=self.device)
+        self.E0 = torch.cat([table[self.u0:self.u1], table[self.U:]], 0).to(self.device).contiguous()
+        self.m, self.v, self.G, self.S, self.Ea, self.Eb = z(), z(), z(), z(), z(), z()
+        self.t = 0
+        self.ws = None
+        self.sums = torch.zeros(3, dtype=torch.float32, device=self.device)
+        self.loss_out = torch.zeros(4, dtype=torch.float32, device=self.device)
+
+    @classmethod
+    def from_pairs(cls, pairs, n_users, n_items, emb_size, n_layers, reg, lr, device, rank, world, table, **kw):
+        return cls(build_local_blocks(pairs, n_users, n_items, rank, world), n_users, n_items, emb_size, n_layers, reg, lr, device, rank, world, table, **kw)
+
+    # one hop: dst = alpha * (A src) + beta * Z for user rows (exact) and item rows (all-reduced over ranks).
+    # Z is added on the item side BEFORE the reduction when `z_partial` (Z holds a per-rank partial, e.g. batch gradients),
+    # AFTER it otherwise (Z is replicated, e.g. the running layer sum).
+    def _hop(self, src, dst, alpha=1.0, beta=0.0, Z=None, z_partial=False):
+        k, Ul = self.k, self.Ul
+        di, du = dst[Ul:], dst[:Ul]
+        if beta != 0.0 and z_partial:
+            k.spmm(self.Ai, src, alpha, beta, Z[Ul:], out=di)
+        else:
+            k.spmm(self.Ai, src, alpha, out=di)
+        work = self.comm.all_reduce_async(di)
+        if beta != 0.0:
+            k.spmm(self.Au, src, alpha, beta, Z[:Ul], out=du)
+        else:
+            k.spmm(self.Au, src, alpha, out=du)
+        work.wait()
+        if beta != 0.0 and not z_partial:
+            di.add_(Z[Ul:], alpha=beta)
+        return dst
+
+    def forward(self):
+        """Propagated tables for the local users and all items: mean(E_0..E_L) (recommender/LightGCN.py:230-240)."""
+        L = self.L
+        cur, nxt = self.Ea, self.Eb
+        self._hop(self.E0, cur)
+        torch.add(self.E0, cur, out=self.S)
+        for _ in range(L - 1):
+            self._hop(cur, nxt)
+            self.S.add_(nxt)
+            cur, nxt = nxt, cur
+        self.S.mul_(1.0 / (L + 1))
+        return self.S
+
+    def _local_batch(self, u, p, n):
+        sel = (u >= self.u0) & (u < self.u1)
+        return (u[sel] - self.u0).to(torch.int32).contiguous(), p[sel].contiguous(), n[sel].contiguous()
+
+    def step(self, u, p, n):
+        """One training iteration on the GLOBAL batch (device int32 tensors, identical on every rank)."""
+        k, L, Ul = self.k, self.L, self.Ul
+        B = u.numel()
+        out = self.forward()
+        lu, lp, ln = self._local_batch(u, p, n)
+        if self.ws is None or self.ws.numel() < 4 * max(B, 1):
+            self.ws = torch.empty(4 * max(B, 1), dtype=torch.float32, device=self.device)
+        k.bpr_l2_partial(out, Ul, lu, lp, ln, B, self.ws, self.sums)
+        self.comm.all_reduce(self.sums)
+        nu, np_ = torch.sqrt(self.sums[1]), torch.sqrt(self.sums[2])
+        self.loss_out[0] = self.sums[0] / B
+        self.loss_out[1] = self.reg * (nu + np_)
+        self.loss_out[2] = nu
+        self.loss_out[3] = np_
+        self.G.zero_()
+        if lu.numel():
+            k.bpr_l2_backward(out, Ul, lu, lp, ln, self.reg, self.loss_out, self.G, self.ws)
+        # backward, Horner form.  The user-side hop gathers ITEM rows of its operand, so G's item rows (per-rank partials:
+        # each rank saw only its own samples) must be complete first: one more I x d all-reduce, after which G is
+        # replicated on the item side and is added after each hop's reduction.
+        self.comm.all_reduce(self.G[Ul:])
+        self.t += 1
+        acc = self.G
+        bufs = [self.Ea, self.Eb]
+        s = 1.0 / (L + 1)
+        for h in range(L):
+            last = h == L - 1
+            dst = bufs[h % 2]
+            a = s if last else 1.0
+            self._hop(acc, dst, a, a, self.G, z_partial=False)
+            acc = dst
+        if hasattr(k, 'adam_dense'):
+            k.adam_dense(self.E0, acc, self.m, self.v, self.lr, self.t, self.betas, self.eps)
+        return self.loss_out
+
+    def gather_full_table(self):
+        """[U+I, d] table assembled on every rank (tests / checkpoints): all-gather of the user blocks + the replica."""
+        full = torch.zeros(self.U + self.I, self.d, dtype=torch.float32, device=self.device)
+        full[self.u0:self.u1] = self.E0[:self.Ul]
+        self.comm.all_reduce(full[:self.U])
+        full[self.U:] = self.E0[self.Ul:]
+        return full

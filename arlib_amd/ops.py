@@ -52,7 +52,7 @@ class CSRGraph:
     (monotone rowptr, col in range) because the kernels trust them.
     """
 
-    def __init__(self, rowptr, col, val, device, chunk=DEFAULT_CHUNK, validate=True):
+    def __init__(self, rowptr, col, val, device, chunk=DEFAULT_CHUNK, validate=True, n_cols=None):
         rp = np.ascontiguousarray(rowptr.cpu().numpy() if isinstance(rowptr, torch.Tensor) else rowptr).astype(np.int64)
         n = len(rp) - 1
         nnz = int(rp[-1])
@@ -65,6 +65,7 @@ class CSRGraph:
         if self.device.type == 'cuda' and self.device.index is None:
             self.device = torch.device('cuda', torch.cuda.current_device())
         self.n_rows, self.nnz, self.chunk = n, nnz, int(chunk)
+        self.n_cols = n if n_cols is None else int(n_cols)      # rectangular blocks (user-sharded graph) gather from an [n_cols, d] operand
         self.rowptr = torch.as_tensor(rp.astype(np.int32)).to(self.device)
         self.col = (col if isinstance(col, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(col, dtype=np.int32))).to(self.device, torch.int32).contiguous()
         self.val = (val if isinstance(val, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(val, dtype=np.float32))).to(self.device, torch.float32).contiguous()
@@ -72,8 +73,8 @@ class CSRGraph:
             raise ValueError('CSRGraph: col/val length != rowptr[-1]')
         if validate and nnz:
             lo, hi = int(self.col.min()), int(self.col.max())
-            if lo < 0 or hi >= n:
-                raise ValueError('CSRGraph: column index out of range [0,%d): %d..%d' % (n, lo, hi))
+            if lo < 0 or hi >= self.n_cols:
+                raise ValueError('CSRGraph: column index out of range [0,%d): %d..%d' % (self.n_cols, lo, hi))
         # long-row plan (host, once per graph)
         deg = np.diff(rp)
         long_rows = np.nonzero(deg > self.chunk)[0] if self.chunk > 0 else np.zeros(0, np.int64)
@@ -132,10 +133,11 @@ def norm_adj_values(rowptr, col, w, n_rows):
     return val, dinv
 
 
-def _check_xy(A, X, name='X'):
+def _check_xy(A, X, name='X', rows=None):
     _dev(X, torch.float32, name, 2)
-    if X.shape[0] != A.n_rows:
-        raise ValueError('%s: %d rows, adjacency has %d' % (name, X.shape[0], A.n_rows))
+    want = A.n_rows if rows is None else rows
+    if X.shape[0] != want:
+        raise ValueError('%s: %d rows, expected %d' % (name, X.shape[0], want))
     d = X.shape[1]
     if d % 4 or d > 256:
         raise ValueError('embedding size %d unsupported (multiple of 4, <= 256)' % d)
@@ -145,16 +147,14 @@ def _check_xy(A, X, name='X'):
 
 
 def spmm(A, X, alpha=1.0, beta=0.0, Z=None, out=None):
-    """out = alpha * (A @ X) + beta * Z."""
-    d = _check_xy(A, X)
-    Y = torch.empty_like(X) if out is None else out
-    _check_xy(A, Y, 'out')
-    if Y.shape != X.shape or Y.data_ptr() == X.data_ptr():
-        raise ValueError('spmm: out must have X\'s shape and must not alias X')
+    """out = alpha * (A @ X) + beta * Z.   X: [A.n_cols, d]; out, Z: [A.n_rows, d]."""
+    d = _check_xy(A, X, 'X', A.n_cols)
+    Y = torch.empty(A.n_rows, d, dtype=torch.float32, device=X.device) if out is None else out
+    if _check_xy(A, Y, 'out') != d or Y.data_ptr() == X.data_ptr():
+        raise ValueError('spmm: out must be [n_rows, d] and must not alias X')
     if beta != 0.0:
-        if Z is None or Z.shape != X.shape:
-            raise ValueError('spmm: Z required with X\'s shape when beta != 0')
-        _check_xy(A, Z, 'Z')
+        if Z is None or _check_xy(A, Z, 'Z') != d:
+            raise ValueError('spmm: Z [n_rows, d] required when beta != 0')
     s = A._struct(d)
     tok = EVENT_HOOK.begin('axpby') if EVENT_HOOK is not None else None
     check(_lib.lib().arl_spmm_csr_f32(C.byref(s), _ptr(X), d, alpha, beta, _ptr(Z) if beta != 0.0 else None, _ptr(Y), _stream()), 'arl_spmm_csr_f32')
@@ -185,15 +185,13 @@ def spmm_layersum(A, X, S_in, S, Y=None):
 
 
 def spmm_adam(A, X, alpha, beta, Z, P, M, V, lr, step, betas=(0.9, 0.999), eps=1e-8):
-    """g = alpha*(A@X) + beta*Z ; Adam update of (P, M, V) with g, fused in the SpMM epilogue."""
-    d = _check_xy(A, X)
+    """g = alpha*(A@X) + beta*Z ; Adam update of (P, M, V) with g, fused in the SpMM epilogue.  X: [A.n_cols, d]; rest [A.n_rows, d]."""
+    d = _check_xy(A, X, 'X', A.n_cols)
     for t, nm in ((P, 'P'), (M, 'M'), (V, 'V')):
-        _check_xy(A, t, nm)
-        if t.shape != X.shape or t.data_ptr() == X.data_ptr():
+        if _check_xy(A, t, nm) != d or t.data_ptr() == X.data_ptr():
             raise ValueError('spmm_adam: %s shape/alias error' % nm)
     if beta != 0.0:
-        _check_xy(A, Z, 'Z')
-        if Z.shape != X.shape:
+        if Z is None or _check_xy(A, Z, 'Z') != d:
             raise ValueError('spmm_adam: Z shape mismatch')
     s = A._struct(d)
     tok = EVENT_HOOK.begin('adam') if EVENT_HOOK is not None else None
@@ -358,3 +356,30 @@ def topn_project_rows(M, n):
     scratch = torch.empty_like(M)
     check(_lib.lib().arl_topn_project_rows_f32(_ptr(M), rows, cols, n, _ptr(out), _ptr(idx), _ptr(scratch), _stream()), 'arl_topn_project_rows_f32')
     return out, idx[:, :n]
+
+
+# ------------------------------------------------------------------------------------------------ user-sharded loss
+def bpr_l2_partial(emb, item_off, u, p, n, B_global, workspace, sums_out):
+    """Per-sample BPR coefficients (into `workspace`) + local sums [sum loss terms, sum|u|^2, sum|p|^2] (into sums_out)."""
+    _dev(emb, torch.float32, 'emb', 2); _dev(sums_out, torch.float32, 'sums_out', 1); _dev(workspace, torch.float32, 'workspace', 1)
+    B = u.numel()
+    for t, nm in ((u, 'u'), (p, 'p'), (n, 'n')):
+        _check_idx(t, nm, emb.shape[0], B)
+    if sums_out.numel() < 3 or workspace.numel() < 4 * max(B, 1) or B_global < B:
+        raise ValueError('bpr_l2_partial: workspace / sums_out too small or B_global < B_local')
+    check(_lib.lib().arl_bpr_l2_partial_f32(_ptr(emb), emb.shape[1], item_off, _ptr(u), _ptr(p), _ptr(n), B, B_global, _ptr(sums_out), _ptr(workspace),
+                                            _stream()), 'arl_bpr_l2_partial_f32')
+    return sums_out
+
+
+def bpr_l2_backward(emb, item_off, u, p, n, reg, norms4, G, workspace, upstream=1.0):
+    """Scatter-add the gradient of the local samples into G given the whole batch's norms (norms4[2], norms4[3])."""
+    _dev(emb, torch.float32, 'emb', 2); _dev(G, torch.float32, 'G', 2); _dev(norms4, torch.float32, 'norms4', 1); _dev(workspace, torch.float32, 'workspace', 1)
+    B = u.numel()
+    for t, nm in ((u, 'u'), (p, 'p'), (n, 'n')):
+        _check_idx(t, nm, emb.shape[0], B)
+    if G.shape != emb.shape or norms4.numel() < 4 or workspace.numel() < 4 * max(B, 1):
+        raise ValueError('bpr_l2_backward: shape mismatch')
+    check(_lib.lib().arl_bpr_l2_backward_f32(_ptr(emb), emb.shape[1], item_off, _ptr(u), _ptr(p), _ptr(n), B, reg, upstream, _ptr(norms4), _ptr(G),
+                                             _ptr(workspace), _stream()), 'arl_bpr_l2_backward_f32')
+    return G

@@ -118,6 +118,19 @@ int arl_bpr_l2_fwd_bwd_f32(const float *emb, int64_t d, int64_t item_off, const 
                            const int32_t *n, int64_t B, float reg, float upstream, float *loss_out, float *G,
                            void *workspace, arl_stream_t stream);
 
+/* User-sharded form of the same loss (one process per GPU holds a block of users): the batch is split by
+ * user shard, so the mean (1/B_global) and the two Frobenius norms need the whole batch.
+ *   arl_bpr_l2_partial_f32  : per-sample coefficients into `workspace`, and sums_out[0..2] = sum of -log(...) terms,
+ *                             sum |u|^2, sum |p|^2 over the B_local samples -> caller all-reduces (RCCL) the 3 floats.
+ *   arl_bpr_l2_backward_f32 : scatter-adds the gradient of the B_local samples into G using norms4[2] = ||U_b||_F and
+ *                             norms4[3] = ||P_b||_F of the WHOLE batch (same layout as loss_out above). */
+int arl_bpr_l2_partial_f32(const float *emb, int64_t d, int64_t item_off, const int32_t *u, const int32_t *p,
+                           const int32_t *n, int64_t B_local, int64_t B_global, float *sums_out, void *workspace,
+                           arl_stream_t stream);
+int arl_bpr_l2_backward_f32(const float *emb, int64_t d, int64_t item_off, const int32_t *u, const int32_t *p,
+                            const int32_t *n, int64_t B_local, float reg, float upstream, const float *norms4, float *G,
+                            const void *workspace, arl_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Dense optimisers -- torch.optim.Adam (betas, eps, no weight decay; recommender/LightGCN.py:33,64) and
  * torch.optim.SGD (attack/White/PGA.py:59) over a whole table.  `step` is the 1-based step count.

@@ -1,0 +1,80 @@
+"""CPU tests of the N>1 path: block construction ("virtual ranks" in one process) and the user-sharded engine under
+world_size-2 gloo with the oracle-backed kernel shim.  The result must equal the single-process oracle run."""
+import os
+import sys
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+from conftest import rel_err, RTOL, ROOT
+from oracle import oracle as O
+
+
+def small_problem():
+    from arlib_amd.util import synthetic as S
+    U, I, d, L, B = 600, 90, 16, 3, 256
+    pairs = S.syn_v1_pairs(U, I, mean_deg=10, seed=7)
+    rng = np.random.default_rng(1)
+    E0 = ((rng.random((U + I, d)) * 2 - 1) * 0.1).astype(np.float32)
+    batches = []
+    for k in range(3):
+        sel = rng.integers(0, len(pairs), B)
+        batches.append((pairs[sel, 0].copy(), pairs[sel, 1].copy(), rng.integers(0, I, B).astype(np.int32)))
+    return U, I, d, L, pairs, E0, batches
+
+
+def oracle_run(U, I, d, L, pairs, E0, batches):
+    rowptr, col, w = O.bipartite_csr(pairs[:, 0], pairs[:, 1], U, I)
+    st = O.TrainState(E0[:U], E0[U:], (rowptr, col, O.norm_adj_values(rowptr, col, w)), L, 1e-4, 0.005)
+    losses = [st.step(*b) for b in batches]
+    return st.E0, losses
+
+
+@pytest.mark.parametrize('world', [2, 3, 8])
+def test_virtual_ranks_partial_item_sums_add_up(world):
+    from arlib_amd.dist_engine import build_local_blocks, shard_bounds
+    U, I, d, L, pairs, E0, _ = small_problem()
+    rowptr, col, w = O.bipartite_csr(pairs[:, 0], pairs[:, 1], U, I)
+    full = O.spmm((rowptr, col, O.norm_adj_values(rowptr, col, w)), E0)
+    assert shard_bounds(U, world)[-1] == U
+    item_sum = np.zeros((I, d), np.float64)
+    for r in range(world):
+        b = build_local_blocks(pairs, U, I, r, world)
+        Ul = b['u1'] - b['u0']
+        X = np.concatenate([E0[b['u0']:b['u1']], E0[U:]])
+        yu = O.spmm(b['Au'], X)
+        assert rel_err(yu, full[b['u0']:b['u1']]) < 1e-6                 # user rows are exact on their owner
+        item_sum += O.spmm(b['Ai'], X)
+    assert rel_err(item_sum, full[U:]) < 1e-6                             # item rows = sum of per-rank partials
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import torch.distributed as dist
+    import cpu_kernels_shim as shim
+    from arlib_amd.dist_engine import ShardedPropagationEngine
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    U, I, d, L, pairs, E0, batches = small_problem()
+    eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cpu', rank, world, torch.from_numpy(E0), kernels=shim)
+    losses = []
+    for u, p, n in batches:
+        lo = eng.step(torch.from_numpy(u), torch.from_numpy(p), torch.from_numpy(n))
+        losses.append(float(lo[0] + lo[1]))
+    full = eng.gather_full_table().numpy()
+    if rank == 0:
+        ret['table'], ret['losses'] = full, losses
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2])
+def test_sharded_engine_gloo_matches_single_process_oracle(world):
+    U, I, d, L, pairs, E0, batches = small_problem()
+    ref_table, ref_losses = oracle_run(U, I, d, L, pairs, E0, batches)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert np.allclose(ret['losses'], ref_losses, rtol=RTOL, atol=0)
+    assert rel_err(ret['table'], ref_table) < RTOL
