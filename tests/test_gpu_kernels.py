@@ -144,7 +144,7 @@ def test_bpr_l2_duplicates_and_ragged(ops):
         assert abs(out[0] - lb) <= RTOL * abs(lb) and abs(out[1] - lr_) <= RTOL * abs(lr_)
         assert rel_err(G.cpu().numpy(), Gr) < RTOL
     with pytest.raises(IndexError):
-        ops.bpr_l2_fwd_bwd(T(e), 20, T(np.array([25], np.int32)), T(np.array([0], np.int32)), T(np.array([0], np.int32)), 1e-3)
+        ops.bpr_l2_fwd_bwd(T(e), 20, T(np.array([3], np.int32)), T(np.array([30], np.int32)), T(np.array([0], np.int32)), 1e-3)   # item 30 + offset 20 = row 50: out of range
 
 
 def test_adam_sgd_dense(ops):
