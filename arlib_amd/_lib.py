@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libarlib_amd.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 
@@ -32,7 +32,12 @@ _SIGS = {
     'arl_norm_adj_values_f32': (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     'arl_spmm_csr_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _f, _f, _vp, _vp, _vp]),
     'arl_spmm_csr_layersum_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _vp, _vp, _vp, _vp]),
-    'arl_spmm_csr_adam_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),
+    'arl_spmm_csr_adam_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),
+    'arl_spmm_csr_flagged_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _vp, _f, _f, _vp, _vp, _vp, _vp]),
+    'arl_spmm_csr_rows_workspace_bytes': (_i64, [_i64, _i64, _i64]),
+    'arl_spmm_csr_rows_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _vp, _i64, _i64, _vp, _i64, _f, _vp, _vp, _vp]),
+    'arl_mark_rows_u8': (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    'arl_zero_rows_f32': (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     'arl_bpr_l2_workspace_bytes': (_i64, [_i64]),
     'arl_bpr_l2_fwd_bwd_f32': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _f, _f, _vp, _vp, _vp, _vp]),
     'arl_bpr_l2_partial_f32': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),

@@ -58,6 +58,7 @@ enum { EPI_AXPBY = 0, EPI_LAYERSUM = 1, EPI_ADAM = 2 };
 struct Epi {
     float alpha, beta;
     const float *Z;          // AXPBY / ADAM
+    const uint8_t *zflags;   // optional: Z[row] is read only where zflags[row] != 0 (Z is zero elsewhere: sparse batch gradient)
     float *Y;                // AXPBY / LAYERSUM
     const float *S_in;       // LAYERSUM
     float *S;
@@ -124,7 +125,7 @@ __device__ __forceinline__ void spmm_epilogue(const Epi &ep, int row, int d, int
     const size_t o = (size_t)row * d + q * 4;
     if (MODE == EPI_AXPBY) {
         float4 y = make_float4(ep.alpha * a.x, ep.alpha * a.y, ep.alpha * a.z, ep.alpha * a.w);
-        if (ep.Z) {
+        if (ep.Z && (!ep.zflags || ep.zflags[row])) {
             const float4 z = *reinterpret_cast<const float4 *>(ep.Z + o);
             y.x = fmaf(ep.beta, z.x, y.x); y.y = fmaf(ep.beta, z.y, y.y); y.z = fmaf(ep.beta, z.z, y.z); y.w = fmaf(ep.beta, z.w, y.w);
         }
@@ -135,7 +136,7 @@ __device__ __forceinline__ void spmm_epilogue(const Epi &ep, int row, int d, int
         *reinterpret_cast<float4 *>(ep.S + o) = add4(s, a);
     } else {  // EPI_ADAM: torch/optim/adam.py _single_tensor_adam
         float g[4] = {ep.alpha * a.x, ep.alpha * a.y, ep.alpha * a.z, ep.alpha * a.w};
-        if (ep.Z) {
+        if (ep.Z && (!ep.zflags || ep.zflags[row])) {
             const float4 z = *reinterpret_cast<const float4 *>(ep.Z + o);
             g[0] = fmaf(ep.beta, z.x, g[0]); g[1] = fmaf(ep.beta, z.y, g[1]); g[2] = fmaf(ep.beta, z.z, g[2]); g[3] = fmaf(ep.beta, z.w, g[3]);
         }
@@ -195,8 +196,128 @@ __global__ __launch_bounds__(kBlock) void spmm_long_rows_kernel(CsrDev A, int d,
     if (lane < LPR && q * 4 < d) spmm_epilogue<MODE>(ep, A.long_row[t], d, q, a);
 }
 
+// ---- masked gather: the operand X is zero except on rows with xflags != 0 (the batch gradient G: <= 3B non-zero rows).
+// Per 64-edge window the flagged edges are compacted through a per-wave LDS slot array, so the work is proportional to
+// the flagged edges; `val` is only loaded for those.  Unflagged windows cost one coalesced col load + one byte gather.
+template <int LPR, int UNROLL>
+__device__ __forceinline__ float4 spmm_gather_masked(const int32_t *__restrict__ col, const float *__restrict__ val, int begin, int end,
+                                                     const float *__restrict__ X, int d, int lane, const uint8_t *__restrict__ xflags,
+                                                     int2 *__restrict__ slots) {
+    constexpr int G = kWave / LPR;
+    const int g = lane / LPR, q = lane % LPR;
+    const bool qact = (q * 4 < d);
+    const float *xq = X + q * 4;
+    float4 acc[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = begin; base < end; base += kWave) {
+        const int e = base + lane;
+        int c = 0;
+        bool f = false;
+        if (e < end) { c = col[e]; f = xflags[c] != 0; }
+        const unsigned long long mask = __ballot(f);
+        if (mask == 0ull) continue;
+        const int cnt = __popcll(mask);
+        if (f) {
+            const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+            slots[rank] = make_int2(c, __float_as_int(val[e]));
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        for (int j = 0; j < cnt; j += G * UNROLL) {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int s = j + u * G + g;
+                if (qact && s < cnt) {
+                    const int2 cv = slots[s];
+                    const float4 x = *reinterpret_cast<const float4 *>(xq + (size_t)cv.x * d);
+                    fma4(acc[u], __int_as_float(cv.y), x);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    }
+#pragma unroll
+    for (int u = 1; u < UNROLL; ++u) acc[0] = add4(acc[0], acc[u]);
+    return acc[0];
+}
+
+template <int LPR, int MODE>
+__global__ __launch_bounds__(kBlock) void spmm_rows_masked_kernel(CsrDev A, const float *__restrict__ X, int d, Epi ep, const uint8_t *__restrict__ xflags) {
+    __shared__ int2 slot_mem[kWavesPerBlock][kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    int2 *slots = slot_mem[threadIdx.x >> 6];
+    const long long task = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int q = lane % LPR;
+    if (task < A.n_chunks) {
+        const int t = (int)task;
+        float4 a = spmm_gather_masked<LPR, 2>(A.col, A.val, A.chunk_begin[t], A.chunk_end[t], X, d, lane, xflags, slots);
+        a = group_reduce<LPR>(a);
+        if (lane < LPR && q * 4 < d) *reinterpret_cast<float4 *>(A.partial + (size_t)t * d + q * 4) = a;
+        return;
+    }
+    const long long r = task - A.n_chunks;
+    if (r >= A.n_rows) return;
+    const int begin = A.rowptr[r], end = A.rowptr[r + 1];
+    if (A.n_chunks > 0 && end - begin > A.chunk) return;
+    float4 a = spmm_gather_masked<LPR, 2>(A.col, A.val, begin, end, X, d, lane, xflags, slots);
+    a = group_reduce<LPR>(a);
+    if (lane < LPR && q * 4 < d) spmm_epilogue<MODE>(ep, (int)r, d, q, a);
+}
+
+// ---- row-subset SpMM: only the listed rows are produced (the last forward hop is consumed on the <= 3B batch rows only).
+// Each listed row is cut into `nsplit` equal edge ranges (a 100k-edge popular item must not serialise one wave); partials are
+// combined in split order by subset_finish_kernel, which also adds the earlier layers' rows: out_c[t] = alpha * (sum_k layer_k[r] + (A X)[r]).
+struct LayerPtrs { const float *p[8]; int n; };
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void spmm_subset_kernel(CsrDev A, const float *__restrict__ X, int d, const int32_t *__restrict__ rows, int n,
+                                                              int nsplit, float *__restrict__ partial) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const long long task = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (task >= (long long)n * nsplit) return;
+    const int t = (int)(task / nsplit), sp = (int)(task % nsplit);
+    const int r = rows[t];
+    const int begin = A.rowptr[r], end = A.rowptr[r + 1];
+    const int per = (end - begin + nsplit - 1) / nsplit;
+    const int b = begin + sp * per, e = min(end, b + per);
+    const int q = lane % LPR;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b < e) a = spmm_gather<LPR, 4>(A.col, A.val, b, e, X, d, lane);
+    a = group_reduce<LPR>(a);
+    if (lane < LPR && q * 4 < d) *reinterpret_cast<float4 *>(partial + (size_t)task * d + q * 4) = a;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void subset_finish_kernel(const float *__restrict__ partial, int n, int nsplit, int d, const int32_t *__restrict__ rows,
+                                                                LayerPtrs L, float alpha, float *__restrict__ out_c) {
+    constexpr int G = kWave / LPR;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int g = lane / LPR, q = lane % LPR;
+    const int t = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * G + g;
+    if (t >= n || q * 4 >= d) return;
+    const int r = rows[t];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < L.n; ++k) a = add4(a, *reinterpret_cast<const float4 *>(L.p[k] + (size_t)r * d + q * 4));
+    for (int s = 0; s < nsplit; ++s) a = add4(a, *reinterpret_cast<const float4 *>(partial + ((size_t)t * nsplit + s) * d + q * 4));
+    *reinterpret_cast<float4 *>(out_c + (size_t)t * d + q * 4) = make_float4(alpha * a.x, alpha * a.y, alpha * a.z, alpha * a.w);
+}
+
+__global__ __launch_bounds__(kBlock) void mark_rows_kernel(uint8_t *__restrict__ flags, const int32_t *__restrict__ idx, int n, int value) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t < n) flags[idx[t]] = (uint8_t)value;
+}
+__global__ __launch_bounds__(kBlock) void zero_rows_kernel(float *__restrict__ dst, const int32_t *__restrict__ idx, int n, int d) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (t >= n) return;
+    float *o = dst + (size_t)idx[t] * d;
+    for (int k = lane; k < d; k += kWave) o[k] = 0.f;
+}
+
 template <int MODE>
-int launch_spmm(const arl_csr *A, const float *X, int64_t d, const Epi &ep, hipStream_t st) {
+int launch_spmm(const arl_csr *A, const float *X, int64_t d, const Epi &ep, hipStream_t st, const uint8_t *xflags = nullptr) {
     if (!A || !X || !A->rowptr || (A->nnz > 0 && (!A->col || !A->val))) return ARL_E_NULL;
     if (d <= 0 || d > 256 || (d & 3)) return ARL_E_DIM;
     if (A->n_rows < 0 || A->n_rows > 0x7fffffffll || A->nnz > 0x7fffffffll || A->n_chunks > 0x7fffffffll) return ARL_E_RANGE;
@@ -215,7 +336,8 @@ int launch_spmm(const arl_csr *A, const float *X, int64_t d, const Epi &ep, hipS
     const int di = (int)d;
 #define ARL_SPMM_CASE(LPRV)                                                                              \
     do {                                                                                                 \
-        hipLaunchKernelGGL((spmm_rows_kernel<LPRV, MODE>), dim3(grid), dim3(kBlock), 0, st, D, X, di, ep); \
+        if (xflags) hipLaunchKernelGGL((spmm_rows_masked_kernel<LPRV, MODE>), dim3(grid), dim3(kBlock), 0, st, D, X, di, ep, xflags); \
+        else hipLaunchKernelGGL((spmm_rows_kernel<LPRV, MODE>), dim3(grid), dim3(kBlock), 0, st, D, X, di, ep); \
         ARL_LAUNCH_CHECK();                                                                              \
         if (D.n_long > 0) {                                                                              \
             hipLaunchKernelGGL((spmm_long_rows_kernel<LPRV, MODE>), dim3(grid_long), dim3(kBlock), 0, st, D, di, ep); \
@@ -740,17 +862,84 @@ int arl_spmm_csr_layersum_f32(const arl_csr *A, const float *X, int64_t d, const
     return launch_spmm<EPI_LAYERSUM>(A, X, d, ep, (hipStream_t)stream);
 }
 
-int arl_spmm_csr_adam_f32(const arl_csr *A, const float *X, int64_t d, float alpha, float beta, const float *Z, float *P, float *M, float *V,
-                          float lr, float beta1, float beta2, float eps, int64_t step, arl_stream_t stream) {
+int arl_spmm_csr_flagged_f32(const arl_csr *A, const float *X, int64_t d, const uint8_t *xflags, float alpha, float beta, const float *Z,
+                             const uint8_t *zflags, float *Y, arl_stream_t stream) {
+    if (!Y) return ARL_E_NULL;
+    if (beta != 0.f && !Z) return ARL_E_NULL;
+    if (Y == X) return ARL_E_ARG;
+    Epi ep = {};
+    ep.alpha = alpha; ep.beta = beta; ep.Z = (beta != 0.f) ? Z : nullptr; ep.zflags = zflags; ep.Y = Y;
+    return launch_spmm<EPI_AXPBY>(A, X, d, ep, (hipStream_t)stream, xflags);
+}
+
+int arl_spmm_csr_adam_f32(const arl_csr *A, const float *X, int64_t d, float alpha, float beta, const float *Z, const uint8_t *zflags, float *P,
+                          float *M, float *V, float lr, float beta1, float beta2, float eps, int64_t step, arl_stream_t stream) {
     if (!P || !M || !V) return ARL_E_NULL;
     if (beta != 0.f && !Z) return ARL_E_NULL;
     if (step < 1) return ARL_E_ARG;
     if (P == X) return ARL_E_ARG;
     Epi ep = {};
-    ep.alpha = alpha; ep.beta = beta; ep.Z = (beta != 0.f) ? Z : nullptr; ep.P = P; ep.M = M; ep.V = V;
+    ep.alpha = alpha; ep.beta = beta; ep.Z = (beta != 0.f) ? Z : nullptr; ep.zflags = zflags; ep.P = P; ep.M = M; ep.V = V;
     ep.b1 = beta1; ep.b2 = beta2; ep.eps = eps;
     adam_scalars(lr, beta1, beta2, step, &ep.step_size, &ep.inv_bc2_sqrt);
     return launch_spmm<EPI_ADAM>(A, X, d, ep, (hipStream_t)stream);
+}
+
+int64_t arl_spmm_csr_rows_workspace_bytes(int64_t n_rows_sel, int64_t nsplit, int64_t d) {
+    return (n_rows_sel < 0 || nsplit < 1 || d < 0) ? 0 : (int64_t)sizeof(float) * n_rows_sel * nsplit * d;
+}
+
+int arl_spmm_csr_rows_f32(const arl_csr *A, const float *X, int64_t d, const int32_t *rows, int64_t n_rows_sel, int64_t nsplit,
+                          const float *const *layers, int64_t n_layers, float alpha, float *out_c, void *workspace, arl_stream_t stream) {
+    if (!A || !X || !rows || !out_c || !workspace || !A->rowptr) return ARL_E_NULL;
+    if (A->nnz > 0 && (!A->col || !A->val)) return ARL_E_NULL;
+    if (n_layers < 0 || n_layers > 8 || (n_layers > 0 && !layers)) return ARL_E_ARG;
+    if (d <= 0 || d > 256 || (d & 3)) return ARL_E_DIM;
+    if (n_rows_sel < 0 || nsplit < 1 || nsplit > 1024 || n_rows_sel * nsplit > 0x7fffffffll) return ARL_E_RANGE;
+    if (n_rows_sel == 0) return ARL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    CsrDev D = {};
+    D.n_rows = (int)A->n_rows; D.rowptr = A->rowptr; D.col = A->col; D.val = A->val;
+    LayerPtrs LP = {};
+    LP.n = (int)n_layers;
+    for (int k = 0; k < LP.n; ++k) { if (!layers[k]) return ARL_E_NULL; LP.p[k] = layers[k]; }
+    const long long tasks = n_rows_sel * nsplit;
+    const unsigned grid = (unsigned)((tasks + kWavesPerBlock - 1) / kWavesPerBlock);
+    const int di = (int)d, n = (int)n_rows_sel, ns = (int)nsplit;
+    float *part = (float *)workspace;
+#define ARL_SUBSET_CASE(LPRV)                                                                                                  \
+    do {                                                                                                                       \
+        hipLaunchKernelGGL((spmm_subset_kernel<LPRV>), dim3(grid), dim3(kBlock), 0, st, D, X, di, rows, n, ns, part);          \
+        ARL_LAUNCH_CHECK();                                                                                                    \
+        const unsigned g2 = (unsigned)((n + kWavesPerBlock * (kWave / LPRV) - 1) / (kWavesPerBlock * (kWave / LPRV)));         \
+        hipLaunchKernelGGL((subset_finish_kernel<LPRV>), dim3(g2), dim3(kBlock), 0, st, part, n, ns, di, rows, LP, alpha, out_c); \
+        ARL_LAUNCH_CHECK();                                                                                                    \
+    } while (0)
+    if (d <= 16) ARL_SUBSET_CASE(4);
+    else if (d <= 32) ARL_SUBSET_CASE(8);
+    else if (d <= 64) ARL_SUBSET_CASE(16);
+    else if (d <= 128) ARL_SUBSET_CASE(32);
+    else ARL_SUBSET_CASE(64);
+#undef ARL_SUBSET_CASE
+    return ARL_OK;
+}
+
+int arl_mark_rows_u8(uint8_t *flags, const int32_t *idx, int64_t n, int32_t value, arl_stream_t stream) {
+    if (!flags || !idx) return ARL_E_NULL;
+    if (n < 0 || n > 0x7fffffffll) return ARL_E_ARG;
+    if (n == 0) return ARL_OK;
+    hipLaunchKernelGGL(mark_rows_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, flags, idx, (int)n, (int)value);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_zero_rows_f32(float *dst, const int32_t *idx, int64_t n, int64_t d, arl_stream_t stream) {
+    if (!dst || !idx) return ARL_E_NULL;
+    if (n < 0 || d <= 0 || n > 0x7fffffffll || d > 0x7fffffffll) return ARL_E_ARG;
+    if (n == 0) return ARL_OK;
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, dst, idx, (int)n, (int)d);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
 }
 
 int64_t arl_bpr_l2_workspace_bytes(int64_t B) { return B < 0 ? 0 : (int64_t)sizeof(float) * 4 * B; }

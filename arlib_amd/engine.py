@@ -120,6 +120,7 @@ class PropagationEngine:
 
     def loss_and_grad_out(self, out, u, p, n):
         self.G.zero_()
+        self._G_dirty = True          # the sparse step keeps G all-zero between calls; dense users leave it dirty
         if self._ws is None or self._ws.numel() < 4 * u.numel():
             self._ws = torch.empty(4 * u.numel(), dtype=torch.float32, device=self.device)
         ops.bpr_l2_fwd_bwd(out, self.U, u, p, n, self.reg, self.G, workspace=self._ws, loss_out=self.loss_out, check_range=False)
@@ -131,9 +132,72 @@ class PropagationEngine:
         lo = self.loss_and_grad_out(out, u, p, n)
         return lo, self.backward_to_table(self.G)
 
-    def step(self, u, p, n):
+    def step(self, u, p, n, rows=None):
         """One training iteration on a device batch (int32 tensors, already range-checked by the caller).
-        Returns the device tensor [bpr, reg_term, ||U_b||, ||P_b||]; loss = [0]+[1] (no host sync here)."""
+        Returns the device tensor [bpr, reg_term, ||U_b||, ||P_b||]; loss = [0]+[1] (no host sync here).
+
+        Sparse-batch form (LightGCN + Adam): the loss reads the propagated table on <= 3B rows only and its gradient G is
+        non-zero on those rows only, so
+          * the last forward hop is evaluated on the batch rows alone (arl_spmm_csr_rows_f32), and the running layer sum
+            is never materialised for the other N - 3B rows;
+          * the first backward hop A.G gathers only edges whose source row is flagged (arl_spmm_csr_flagged_f32);
+          * G is kept all-zero between steps (batch rows are cleared afterwards) instead of memset per step.
+        Same numbers as `step_dense` (which evaluates all 2L hops on the full graph), 2 of the 2L full hops cheaper.
+        `rows` = cat(u, U+p, U+n) may be passed in when the caller has it precomputed."""
+        L, A = self.L, self.A
+        if self.optimizer != 'adam' or L == 0 or self.skip0 or L > 8:
+            return self.step_dense(u, p, n)
+        B = u.numel()
+        if rows is None:
+            rows = torch.cat([u, p + self.U, n + self.U])
+        self._sparse_buffers(B)
+        if getattr(self, '_G_dirty', True):
+            self.G.zero_()
+            self._G_dirty = False
+        s = 1.0 / (L + 1)
+        # forward: L-1 full hops, last hop on the batch rows
+        layers = [self.E0]
+        for k in range(L - 1):
+            ops.spmm(A, layers[-1], out=self.hops[k])
+            layers.append(self.hops[k])
+        ops.spmm_rows(A, layers[-1], rows, layers, s, nsplit=self.nsplit, out=self.out_c, workspace=self.rows_ws, check_range=False)
+        # loss + compact per-sample gradients (rows [0,B) users, [B,2B) positives, [2B,3B) negatives of out_c)
+        self.Gc.zero_()
+        ops.bpr_l2_fwd_bwd(self.out_c, B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self._ws, loss_out=self.loss_out, check_range=False)
+        ops.scatter_add_rows(self.G, rows, self.Gc, 1.0, check_range=False)          # duplicates accumulate
+        ops.mark_rows_(self.flags, rows, 1, check_range=False)
+        # backward (Horner): first hop gathers flagged rows only; G is read through the flags everywhere
+        self.t += 1
+        if L == 1:
+            ops.spmm_flagged(A, self.G, self.flags, s, s, self.G, self.flags, out=self.hops[0])
+            ops.adam_dense(self.E0, self.hops[0], self.m, self.v, self.lr, self.t, self.betas, self.eps)
+        else:
+            acc = ops.spmm_flagged(A, self.G, self.flags, 1.0, 1.0, self.G, self.flags, out=self.hops[0])
+            for k in range(1, L - 1):
+                acc = ops.spmm_flagged(A, acc, None, 1.0, 1.0, self.G, self.flags, out=self.hops[k % 2 if len(self.hops) == 2 else k])
+            ops.spmm_adam(A, acc, s, s, self.G, self.E0, self.m, self.v, self.lr, self.t, self.betas, self.eps, zflags=self.flags)
+        ops.zero_rows_(self.G, rows, check_range=False)
+        ops.mark_rows_(self.flags, rows, 0, check_range=False)
+        return self.loss_out
+
+    def _sparse_buffers(self, B):
+        if getattr(self, '_sparse_B', None) == B:
+            return
+        dev, d = self.device, self.d
+        self.flags = torch.zeros(self.N, dtype=torch.uint8, device=dev)
+        self.Gc = torch.zeros(3 * B, d, dtype=torch.float32, device=dev)
+        self.out_c = torch.empty(3 * B, d, dtype=torch.float32, device=dev)
+        self.nsplit = 16
+        self.rows_ws = torch.empty(3 * B * self.nsplit * d, dtype=torch.float32, device=dev)
+        self.ar = torch.arange(B, dtype=torch.int32, device=dev)
+        self.arB = self.ar + B
+        self._ws = torch.empty(4 * B, dtype=torch.float32, device=dev)
+        # forward needs E_1..E_{L-1} alive at the same time; Ea/Eb cover L <= 3
+        self.hops = [self.Ea, self.Eb] + [torch.empty_like(self.Ea) for _ in range(max(0, self.L - 3))]
+        self._sparse_B = B
+
+    def step_dense(self, u, p, n):
+        """Reference-shaped step: all 2L hops over the full graph (kept for A/B comparison and for SGD / SimGCL / GMF)."""
         L, A = self.L, self.A
         out = self.forward()
         lo = self.loss_and_grad_out(out, u, p, n)

@@ -184,8 +184,16 @@ def spmm_layersum(A, X, S_in, S, Y=None):
     return S
 
 
-def spmm_adam(A, X, alpha, beta, Z, P, M, V, lr, step, betas=(0.9, 0.999), eps=1e-8):
-    """g = alpha*(A@X) + beta*Z ; Adam update of (P, M, V) with g, fused in the SpMM epilogue.  X: [A.n_cols, d]; rest [A.n_rows, d]."""
+def _check_flags(t, n, name):
+    _dev(t, torch.uint8, name, 1)
+    if t.numel() != n:
+        raise ValueError('%s: %d flags, expected %d' % (name, t.numel(), n))
+    return t
+
+
+def spmm_adam(A, X, alpha, beta, Z, P, M, V, lr, step, betas=(0.9, 0.999), eps=1e-8, zflags=None):
+    """g = alpha*(A@X) + beta*Z ; Adam update of (P, M, V) with g, fused in the SpMM epilogue.  X: [A.n_cols, d]; rest [A.n_rows, d].
+    zflags (uint8 [n_rows], optional): Z is read only on flagged rows (it is zero elsewhere)."""
     d = _check_xy(A, X, 'X', A.n_cols)
     for t, nm in ((P, 'P'), (M, 'M'), (V, 'V')):
         if _check_xy(A, t, nm) != d or t.data_ptr() == X.data_ptr():
@@ -193,12 +201,82 @@ def spmm_adam(A, X, alpha, beta, Z, P, M, V, lr, step, betas=(0.9, 0.999), eps=1
     if beta != 0.0:
         if Z is None or _check_xy(A, Z, 'Z') != d:
             raise ValueError('spmm_adam: Z shape mismatch')
+    if zflags is not None:
+        _check_flags(zflags, A.n_rows, 'zflags')
     s = A._struct(d)
     tok = EVENT_HOOK.begin('adam') if EVENT_HOOK is not None else None
-    check(_lib.lib().arl_spmm_csr_adam_f32(C.byref(s), _ptr(X), d, alpha, beta, _ptr(Z) if beta != 0.0 else None, _ptr(P), _ptr(M), _ptr(V),
+    check(_lib.lib().arl_spmm_csr_adam_f32(C.byref(s), _ptr(X), d, alpha, beta, _ptr(Z) if beta != 0.0 else None, _ptr(zflags), _ptr(P), _ptr(M), _ptr(V),
                                            lr, betas[0], betas[1], eps, int(step), _stream()), 'arl_spmm_csr_adam_f32')
     if tok is not None:
         EVENT_HOOK.end(tok)
+
+
+def spmm_flagged(A, X, xflags=None, alpha=1.0, beta=0.0, Z=None, zflags=None, out=None):
+    """out = alpha*(A@X) + beta*Z where X is zero except on rows with xflags != 0 (masked gather) and Z is read only where
+    zflags != 0.  Either flag vector may be None (= dense)."""
+    d = _check_xy(A, X, 'X', A.n_cols)
+    Y = torch.empty(A.n_rows, d, dtype=torch.float32, device=X.device) if out is None else out
+    if _check_xy(A, Y, 'out') != d or Y.data_ptr() == X.data_ptr():
+        raise ValueError('spmm_flagged: out must be [n_rows, d] and must not alias X')
+    if beta != 0.0 and (Z is None or _check_xy(A, Z, 'Z') != d):
+        raise ValueError('spmm_flagged: Z [n_rows, d] required when beta != 0')
+    if xflags is not None:
+        _check_flags(xflags, A.n_cols, 'xflags')
+    if zflags is not None:
+        _check_flags(zflags, A.n_rows, 'zflags')
+    s = A._struct(d)
+    tok = EVENT_HOOK.begin('masked' if xflags is not None else 'axpby') if EVENT_HOOK is not None else None
+    check(_lib.lib().arl_spmm_csr_flagged_f32(C.byref(s), _ptr(X), d, _ptr(xflags), alpha, beta, _ptr(Z) if beta != 0.0 else None, _ptr(zflags), _ptr(Y),
+                                              _stream()), 'arl_spmm_csr_flagged_f32')
+    if tok is not None:
+        EVENT_HOOK.end(tok)
+    return Y
+
+
+def spmm_rows(A, X, rows, layers=(), alpha=1.0, nsplit=16, out=None, workspace=None, check_range=True):
+    """out[t] = alpha * ( sum_k layers[k][rows[t]] + (A @ X)[rows[t]] ) for the listed rows only (duplicates allowed)."""
+    d = _check_xy(A, X, 'X', A.n_cols)
+    _dev(rows, torch.int32, 'rows', 1)
+    n = rows.numel()
+    if check_range and n and (int(rows.min()) < 0 or int(rows.max()) >= A.n_rows):
+        raise IndexError('spmm_rows: row index out of range')
+    if len(layers) > 8:
+        raise ValueError('spmm_rows: at most 8 layer tables')
+    for t in layers:
+        if _check_xy(A, t, 'layer') != d:
+            raise ValueError('spmm_rows: layer table shape mismatch')
+    if out is None:
+        out = torch.empty(n, d, dtype=torch.float32, device=X.device)
+    _dev(out, torch.float32, 'out', 2)
+    if out.shape != (n, d):
+        raise ValueError('spmm_rows: out must be [len(rows), d]')
+    need = _lib.lib().arl_spmm_csr_rows_workspace_bytes(n, nsplit, d) // 4
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 1), dtype=torch.float32, device=X.device)
+    arr = (C.c_void_p * max(len(layers), 1))(*[t.data_ptr() for t in layers])
+    s = A._struct(d)
+    tok = EVENT_HOOK.begin('rows') if EVENT_HOOK is not None else None
+    check(_lib.lib().arl_spmm_csr_rows_f32(C.byref(s), _ptr(X), d, _ptr(rows), n, nsplit, C.cast(arr, C.c_void_p), len(layers), alpha, _ptr(out),
+                                           _ptr(workspace), _stream()), 'arl_spmm_csr_rows_f32')
+    if tok is not None:
+        EVENT_HOOK.end(tok)
+    return out
+
+
+def mark_rows_(flags, idx, value, check_range=True):
+    _dev(flags, torch.uint8, 'flags', 1); _dev(idx, torch.int32, 'idx', 1)
+    if check_range and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= flags.numel()):
+        raise IndexError('mark_rows_: index out of range')
+    check(_lib.lib().arl_mark_rows_u8(_ptr(flags), _ptr(idx), idx.numel(), int(value), _stream()), 'arl_mark_rows_u8')
+    return flags
+
+
+def zero_rows_(dst, idx, check_range=True):
+    _dev(dst, torch.float32, 'dst', 2); _dev(idx, torch.int32, 'idx', 1)
+    if check_range and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= dst.shape[0]):
+        raise IndexError('zero_rows_: index out of range')
+    check(_lib.lib().arl_zero_rows_f32(_ptr(dst), _ptr(idx), idx.numel(), dst.shape[1], _stream()), 'arl_zero_rows_f32')
+    return dst
 
 
 # ------------------------------------------------------------------------------------------------ losses

@@ -128,3 +128,68 @@ def test_engine_vs_oracle_synthetic_long_rows(mods):
         assert abs(lo[0] + lo[1] - loss) <= RTOL * abs(loss)
     assert rel_err(eng.E0.cpu().numpy(), st.E0) < RTOL
     assert rel_err(eng.m.cpu().numpy(), st.m) < RTOL and rel_err(eng.v.cpu().numpy(), st.v) < RTOL
+
+
+def test_sparse_step_equals_dense_step(mods):
+    """The sparse-batch step (row-subset last hop, flag-masked first backward hop) must reproduce the dense 2L-hop step."""
+    ops, engine = mods
+    rng = np.random.default_rng(9)
+    U, I, d, B = 6000, 800, 64, 512
+    us = np.repeat(np.arange(U), 10)
+    its = np.floor(I * rng.random(len(us)) ** 2).astype(np.int64)
+    key = np.unique(us * I + its)
+    us, its = (key // I).astype(np.int32), (key % I).astype(np.int32)
+    rowptr, col, w = O.bipartite_csr(us, its, U, I)
+    val = O.norm_adj_values(rowptr, col, w)
+    assert np.diff(rowptr).max() > 1500                                   # hot items: long rows in the subset hop too
+    E0 = ((rng.random((U + I, d)) * 2 - 1) * 0.05).astype(np.float32)
+    for L in (1, 2, 3, 4):
+        A = ops.CSRGraph(rowptr, col, val, DEV)
+        ea = engine.PropagationEngine(A, U, I, d, L, 1e-4, 0.005, DEV, table=T(E0))
+        eb = engine.PropagationEngine(A, U, I, d, L, 1e-4, 0.005, DEV, table=T(E0))
+        for k in range(4):
+            sel = rng.integers(0, len(us), B)
+            bu, bp, bn = T(us[sel].copy()), T(its[sel].copy()), T(rng.integers(0, I, B).astype(np.int32))
+            if k == 2:
+                bu[:50] = bu[0]; bp[:80] = bp[1]; bn[:30] = bp[1]            # heavy duplicates, item both positive and negative
+            la = ea.step(bu, bp, bn).cpu().numpy()
+            lb = eb.step_dense(bu, bp, bn).cpu().numpy()
+            assert np.allclose(la, lb, rtol=RTOL, atol=0), (L, k)
+        assert rel_err(ea.E0.cpu().numpy(), eb.E0.cpu().numpy()) < RTOL, L
+        assert rel_err(ea.m.cpu().numpy(), eb.m.cpu().numpy()) < RTOL and rel_err(ea.v.cpu().numpy(), eb.v.cpu().numpy()) < RTOL
+        assert float(ea.G.abs().max()) == 0.0 and int(ea.flags.max()) == 0       # sparse state is cleared after every step
+
+
+def test_spmm_rows_and_flagged_primitives(mods):
+    ops, engine = mods
+    rng = np.random.default_rng(10)
+    U, I, d = 3000, 500, 32
+    us = np.repeat(np.arange(U), 8)
+    its = np.floor(I * rng.random(len(us)) ** 2).astype(np.int64)
+    key = np.unique(us * I + its)
+    us, its = (key // I).astype(np.int32), (key % I).astype(np.int32)
+    rowptr, col, w = O.bipartite_csr(us, its, U, I)
+    val = O.norm_adj_values(rowptr, col, w)
+    csr = (rowptr, col, val)
+    A = ops.CSRGraph(rowptr, col, val, DEV)
+    N = U + I
+    X = rng.standard_normal((N, d)).astype(np.float32); L1 = rng.standard_normal((N, d)).astype(np.float32)
+    rows = np.concatenate([rng.integers(0, N, 700), [U, U, U + 1, 0]]).astype(np.int32)     # hottest items, duplicates
+    ref = 0.25 * (X[rows] + L1[rows] + O.spmm(csr, X)[rows])
+    for ns in (1, 16, 33):
+        got = ops.spmm_rows(A, T(X), T(rows), [T(X), T(L1)], 0.25, nsplit=ns).cpu().numpy()
+        assert rel_err(got, ref) < RTOL
+    Gs = np.zeros((N, d), np.float32)
+    nz = rng.choice(N, 300, replace=False); nz[:3] = [U, U + 1, 5]
+    Gs[nz] = rng.standard_normal((300, d)).astype(np.float32)
+    flags = np.zeros(N, np.uint8); flags[nz] = 1
+    ref = O.spmm(csr, Gs, 1.0, 1.0, Gs)
+    got = ops.spmm_flagged(A, T(Gs), T(flags), 1.0, 1.0, T(Gs), T(flags)).cpu().numpy()
+    assert rel_err(got, ref) < RTOL
+    got2 = ops.spmm_flagged(A, T(X), None, 0.5, 0.5, T(Gs), T(flags)).cpu().numpy()
+    assert rel_err(got2, O.spmm(csr, X, 0.5, 0.5, Gs)) < RTOL
+    f = torch.zeros(N, dtype=torch.uint8, device=DEV)
+    ops.mark_rows_(f, T(nz.astype(np.int32)), 1)
+    assert np.array_equal(f.cpu().numpy(), flags)
+    Z = T(Gs.copy()); ops.zero_rows_(Z, T(nz.astype(np.int32)))
+    assert float(Z.abs().max()) == 0.0
