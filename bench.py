@@ -41,6 +41,7 @@ def parse():
     ap.add_argument('--cpu-baseline', type=int, default=1, help='0 disables the CPU baseline leg')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target seconds of CPU work for the baseline sample')
     ap.add_argument('--no-kernel-events', action='store_true', help='do not bracket SpMM launches with HIP events')
+    ap.add_argument('--dense-step', action='store_true', help='time the reference-shaped step (all 2L hops on the full graph) as the main number')
     return ap.parse_args()
 
 
@@ -142,7 +143,11 @@ def main():
         del w
         A = ops.CSRGraph(rowptr, col_d, val, dev, chunk=args.chunk, validate=True)
         eng = engine.PropagationEngine(A, U, I, d, L, 1e-4, 0.005, dev, table=E0.to(dev))
-        step = lambda k: eng.step(dev_batches[k, 0], dev_batches[k, 1], dev_batches[k, 2])
+        dev_rows = torch.cat([dev_batches[:, 0], dev_batches[:, 1] + U, dev_batches[:, 2] + U], 1).contiguous()     # packed row ids [u, U+p, U+n]
+        if args.dense_step:
+            step = lambda k: eng.step_dense(dev_batches[k, 0], dev_batches[k, 1], dev_batches[k, 2])
+        else:
+            step = lambda k: eng.step(dev_batches[k, 0], dev_batches[k, 1], dev_batches[k, 2], rows=dev_rows[k])
         barrier = lambda: None
         parallelism = 'single'
     else:
@@ -197,7 +202,8 @@ def main():
         }
         if evs:
             # dominant kernel: spmm_rows_kernel<16,*> (+ its long-row combine), one event pair per C-ABI SpMM call
-            allv = [v for tag, s, e in ev.recs for v in [s.elapsed_time(e)]]
+            # full-graph launches only (the row-subset and flag-masked hops are separate, much shorter kernels)
+            allv = [s.elapsed_time(e) for tag, s, e in ev.recs if tag in ('axpby', 'layersum', 'adam')]
             avg_ms = float(np.mean(allv))
             # under sharding a launch covers this rank's rows only; report the single-GPU figure only for N=1
             if world == 1:
@@ -209,6 +215,18 @@ def main():
                                    'gather_model_bytes_per_launch': E * (8 + 4 * d) + 4 * N * d}
             else:
                 res['spmm_events_ms'] = {k: v[0] for k, v in evs.items()}
+        if world == 1:
+            # A/B: the reference-shaped step (all 2L hops over the full graph), same engine state, few steps
+            other = (lambda k: eng.step(dev_batches[k, 0], dev_batches[k, 1], dev_batches[k, 2], rows=dev_rows[k])) if args.dense_step else \
+                    (lambda k: eng.step_dense(dev_batches[k, 0], dev_batches[k, 1], dev_batches[k, 2]))
+            other(0); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            nn = min(8, n_batches)
+            for k in range(nn):
+                other(k)
+            torch.cuda.synchronize()
+            res['ab_compare'] = {'main_step': 'dense (2L full hops)' if args.dense_step else 'sparse-batch (2L-2 full hops + row-subset + flag-masked hop)',
+                                 'other_step_ms': 1e3 * (time.perf_counter() - t1) / nn}
         if world == 1 and args.cpu_baseline:
             val_np = eng.A.val.cpu().numpy()
             batches = [(hb[k, 0].copy(), hb[k, 1].copy(), hb[k, 2].copy()) for k in range(min(n_batches, 8))]
