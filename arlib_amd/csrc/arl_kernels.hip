@@ -69,7 +69,7 @@ struct Epi {
 // Accumulate sum_e val[e] * X[col[e], 4q..4q+3] over edges [begin,end) for this lane's column quad.
 // Lanes are split in G = 64/LPR groups; group g takes edges g, g+G, ... of each 64-edge window.
 // Returns the per-lane partial (still split over the G groups).
-template <int LPR, int UNROLL>
+template <int LPR, int UNROLL, bool NT = false>
 __device__ __forceinline__ float4 spmm_gather(const int32_t *__restrict__ col, const float *__restrict__ val, int begin,
                                               int end, const float *__restrict__ X, int d, int lane) {
     constexpr int G = kWave / LPR;
@@ -83,7 +83,10 @@ __device__ __forceinline__ float4 spmm_gather(const int32_t *__restrict__ col, c
         const int e = base + lane;
         int c = 0;
         float v = 0.f;
-        if (e < end) { c = col[e]; v = val[e]; }
+        if (e < end) {
+            if (NT) { c = __builtin_nontemporal_load(col + e); v = __builtin_nontemporal_load(val + e); }
+            else { c = col[e]; v = val[e]; }
+        }
         const int cnt = min(kWave, end - base);
         for (int j = 0; j < cnt; j += G * UNROLL) {
             int cj[UNROLL];
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(kBlock) void spmm_long_rows_kernel(CsrDev A, int d,
     a = group_reduce<LPR>(a);
     if (lane < LPR && q * 4 < d) spmm_epilogue<MODE>(ep, A.long_row[t], d, q, a);
 }
+
 
 // ---- masked gather: the operand X is zero except on rows with xflags != 0 (the batch gradient G: <= 3B non-zero rows).
 // Per 64-edge window the flagged edges are compacted through a per-wave LDS slot array, so the work is proportional to
