@@ -80,6 +80,26 @@ def cw_loss_and_grad(out, Up, users, pos, neg):
     return loss, G
 
 
+def cw_operator(n_nodes, Up, users, pos, neg, device):
+    """The CW loss is bilinear in the propagated table: L = 1/2 out^T M out with the fixed sparse symmetric M built from the
+    (user, target, negative) triples of one inner epoch (PGA.py:104-116).  Then dL/d(out) = M out is ONE SpMM -- no atomics
+    on the five target rows that every user pair hits -- and L = 1/2 <out, M out>."""
+    c = 1.0 / users.numel()
+    u, p, n = users.long(), pos.long() + Up, neg.long() + Up
+    rows = torch.cat([u, u, n, p])
+    cols = torch.cat([n, p, u, u]).to(torch.int32)
+    vals = torch.cat([torch.full_like(u, c, dtype=torch.float32), torch.full_like(u, -c, dtype=torch.float32)] * 2)
+    order = torch.sort(rows, stable=True)[1]
+    rowptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=rows.device)
+    rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n_nodes), 0)
+    return ops.CSRGraph(rowptr.cpu().numpy(), cols[order].contiguous(), vals[order].contiguous(), device)
+
+
+def cw_loss_and_grad_op(M, out):
+    G = ops.spmm(M, out)
+    return 0.5 * (out * G).sum(), G
+
+
 def pga_block_gradient(graph, fake_rows, Up, I, E0, L, G):
     """Returns the un-normalised F x I block sum_k <dE_{k+1}[f], E_k[U'+j]> + <E_k[f], dE_{k+1}[U'+j]> for the LightGCN mean."""
     E = [E0]
@@ -96,6 +116,29 @@ def pga_block_gradient(graph, fake_rows, Up, I, E0, L, G):
         ops.sddmm_rows_dense(dE[k + 1], E[k], fake_rows, Up, I, out=block)
         ops.sddmm_rows_dense(E[k], dE[k + 1], fake_rows, Up, I, out=block)
     return block, E
+
+
+def pga_step_block(graph, fake_rows, Up, I, E0, L, M):
+    """Forward (layers kept), CW gradient through the operator M, backward, and the F x I block -- one PGA gradient step
+    minus the update (PGA.py:99-134)."""
+    E = [E0]
+    out = E0.clone()
+    for k in range(L):
+        E.append(ops.spmm(graph, E[k]))
+        out += E[-1]
+    out /= (L + 1)
+    loss, G = cw_loss_and_grad_op(M, out)
+    s = 1.0 / (L + 1)
+    Gs = G * s
+    dE = [None] * (L + 1)
+    dE[L] = Gs
+    for k in range(L - 1, 0, -1):
+        dE[k] = ops.spmm(graph, dE[k + 1], 1.0, 1.0, Gs)
+    block = torch.zeros(fake_rows.numel(), I, dtype=torch.float32, device=E0.device)
+    for k in range(L):
+        ops.sddmm_rows_dense(dE[k + 1], E[k], fake_rows, Up, I, out=block)
+        ops.sddmm_rows_dense(E[k], dE[k + 1], fake_rows, Up, I, out=block)
+    return block, loss
 
 
 class PGA(AttackBase):
@@ -151,15 +194,8 @@ class PGA(AttackBase):
                             out += E
                         out /= (L + 1)
                         top_idx, _ = ops.score_mask_topk(out[:U + F].contiguous(), out[U + F:].contiguous(), min(50, I))     # no interacted mask (PGA.py:101-102)
-                        pairs = cw_pairs(top_idx, U, self.targetItem, pop=True)
-                    out = E0.clone()
-                    E = E0
-                    for k in range(L):
-                        E = ops.spmm(graph, E)
-                        out += E
-                    out /= (L + 1)
-                    loss, G = cw_loss_and_grad(out, U + F, *pairs)
-                    block, _ = pga_block_gradient(graph, fg.fake_rows, U + F, I, E0, L, G)
+                        pairs = cw_operator(U + F + I, U + F, *cw_pairs(top_idx, U, self.targetItem, pop=True), device=E0.device)
+                    block, loss = pga_step_block(graph, fg.fake_rows, U + F, I, E0, L, pairs)
                     ops.pga_update_(S2, block, fg.dinv[U:U + F].contiguous(), fg.dinv[U + F:].contiguous())
                     print('>> batchNum:{} Loss:{}'.format(int(batch / self.batchSize), loss.item()))
             proj, _ = ops.topn_project_rows(S2, int(self.maliciousFeedbackSize * I))

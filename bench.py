@@ -41,6 +41,8 @@ def parse():
     ap.add_argument('--cpu-baseline', type=int, default=1, help='0 disables the CPU baseline leg')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target seconds of CPU work for the baseline sample')
     ap.add_argument('--no-kernel-events', action='store_true', help='do not bracket SpMM launches with HIP events')
+    ap.add_argument('--attack-steps', type=int, default=5, help='PGA gradient steps to time at N=1 (0 disables the attack leg)')
+    ap.add_argument('--fake-users', type=int, default=64)
     ap.add_argument('--dense-step', action='store_true', help='time the reference-shaped step (all 2L hops on the full graph) as the main number')
     return ap.parse_args()
 
@@ -93,6 +95,59 @@ def cpu_baseline(data, rowptr, col, val_np, E0, batches, args, target_s):
             'sample': '%d full training steps of the same workload (same graph, tables and batches), %.1f s of CPU work, '
                       'oracle/arl_oracle.c with OpenMP over rows' % (done, t_used),
             'ms_per_step': 1e3 * t_used / done}
+
+
+def attack_leg(torch, ops, data, E0_dev, args):
+    """attack-grad steps/sec (BASELINE metric, configs[2]): one step = one PGA iteration on the fake-interaction block
+    (attack/White/PGA.py:92-142): device re-normalisation of the poisoned graph, L-hop forward, CW gradient (one SpMM with the
+    bilinear operator), L-1 hop backward, 2L row-restricted SDDMMs, tanh/clamp update.  F fake users, T=5 unpopular targets."""
+    import scipy.sparse as sp
+    from arlib_amd.attack.White.PGA import FakeBlockGraph, cw_operator, pga_step_block
+    from arlib_amd.attack._common import cw_pairs
+    U, I, nnz = data.training_size()
+    F, L, d = args.fake_users, args.layers, args.emb
+    t0 = time.perf_counter()
+    real = sp.csr_matrix((np.ones(nnz, np.float32), (data.pairs0[:, 0], data.pairs0[:, 1])), shape=(U, I))
+    deg_i = np.bincount(data.pairs0[:, 1], minlength=I)
+    targets = [int(t) for t in np.argsort(deg_i, kind='stable')[:5]]
+    popular = np.argsort(-deg_i, kind='stable')[:int(0.05 * I)]
+    fg = FakeBlockGraph(real, U, F, I, device=E0_dev.device)
+    del real
+    S = torch.zeros(F, I, device=E0_dev.device)
+    S[:, targets] = 1.0
+    S[:, torch.from_numpy(popular).to(S.device)] = 0.5
+    g = torch.Generator().manual_seed(args.seed)
+    fake_tab = torch.nn.init.xavier_uniform_(torch.empty(F, d), generator=g).to(E0_dev.device)
+    E0 = torch.cat([E0_dev[:U], fake_tab, E0_dev[U:]], 0).contiguous()
+    setup_s = time.perf_counter() - t0
+    graph = fg.set_block(S)
+    out = E0.clone(); E = E0
+    for k in range(L):
+        E = ops.spmm(graph, E); out += E
+    out /= (L + 1)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    top_idx, _ = ops.score_mask_topk(out[:U + F].contiguous(), out[U + F:].contiguous(), 50)
+    torch.cuda.synchronize(); topk_s = time.perf_counter() - t1
+    M = cw_operator(U + F + I, U + F, *cw_pairs(top_idx, U, targets, pop=True), device=E0.device)
+
+    def step():
+        gr = fg.set_block(S)
+        block, loss = pga_step_block(gr, fg.fake_rows, U + F, I, E0, L, M)
+        ops.pga_update_(S, block, fg.dinv[U:U + F].contiguous(), fg.dinv[U + F:].contiguous())
+        return loss
+    step(); torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(args.attack_steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t2) / args.attack_steps
+    Ep, Np = 2 * nnz + 2 * F * I, U + F + I
+    step_bytes = L * (8 * Ep + 4 * Np + 16 * Np * d) + (L - 1) * (8 * Ep + 4 * Np + 8 * Np * d) + L * (2 * F * I * 4 + 2 * I * d * 4 + 2 * F * d * 4) + 3 * F * I * 4
+    return {'metric': 'attack-grad steps/sec (PGA gradient w.r.t. fake interactions, LightGCN d=%d L=%d surrogate)' % (d, L),
+            'value': 1.0 / dt, 'unit': 'steps/s', 'ms_per_step': 1e3 * dt, 'fake_users': F, 'targets': 5, 'cw_loss': float(loss),
+            'algorithmic_bytes_per_step': step_bytes, 'hbm_frac': step_bytes / dt / 1e9 / HBM_PEAK_GBS,
+            'score_topk_pass': {'seconds': topk_s, 'tflops': 2.0 * (U + F) * I * d / topk_s / 1e12, 'note': 'once per inner epoch, not per step'},
+            'setup_seconds': setup_s}
 
 
 def main():
@@ -227,6 +282,10 @@ def main():
             torch.cuda.synchronize()
             res['ab_compare'] = {'main_step': 'dense (2L full hops)' if args.dense_step else 'sparse-batch (2L-2 full hops + row-subset + flag-masked hop)',
                                  'other_step_ms': 1e3 * (time.perf_counter() - t1) / nn}
+        if world == 1 and args.attack_steps > 0:
+            E0_snapshot = eng.E0.clone()
+            del eng.Ea, eng.Eb, eng.S
+            res['attack'] = attack_leg(torch, ops, data, E0_snapshot, args)
         if world == 1 and args.cpu_baseline:
             val_np = eng.A.val.cpu().numpy()
             batches = [(hb[k, 0].copy(), hb[k, 1].copy(), hb[k, 2].copy()) for k in range(min(n_batches, 8))]

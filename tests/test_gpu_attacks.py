@@ -35,7 +35,7 @@ def attack_args(**kw):
 
 def test_pga_gradient_steps_match_reference_trace():
     from arlib_amd import ops
-    from arlib_amd.attack.White.PGA import FakeBlockGraph, cw_loss_and_grad, pga_block_gradient
+    from arlib_amd.attack.White.PGA import FakeBlockGraph, cw_loss_and_grad, pga_block_gradient, cw_operator, pga_step_block
     from arlib_amd.attack._common import cw_pairs
     g = golden('g7_attacks.npz')
     U, I, F, L, d = (int(x) for x in g['pga_sizes'])
@@ -62,6 +62,10 @@ def test_pga_gradient_steps_match_reference_trace():
         block, _ = pga_block_gradient(graph, fg.fake_rows, U + F, I, E0, L, G)
         scaled = block * fg.dinv[U:U + F, None] * fg.dinv[None, U + F:] * (S != 0)
         assert rel_err(scaled.cpu().numpy(), g['pga_grad'][s]) < RTOL, s
+        # production form: CW gradient as one SpMM with the bilinear operator M (no atomics), same block and loss
+        M = cw_operator(U + F + I, U + F, *pairs, device=E0.device)
+        block2, loss2 = pga_step_block(graph, fg.fake_rows, U + F, I, E0, L, M)
+        assert rel_err(block2.cpu().numpy(), block.cpu().numpy()) < RTOL and abs(loss2.item() - loss.item()) <= RTOL * abs(loss.item())
         ops.pga_update_(S, block, fg.dinv[U:U + F].contiguous(), fg.dinv[U + F:].contiguous())
         assert rel_err(S.cpu().numpy(), g['pga_S'][s + 1]) < 1e-6, s
 
