@@ -261,9 +261,16 @@ def main():
             allv = [s.elapsed_time(e) for tag, s, e in ev.recs if tag in ('axpby', 'layersum', 'adam')]
             avg_ms = float(np.mean(allv))
             # under sharding a launch covers this rank's rows only; report the single-GPU figure only for N=1
+            traffic = None
+            try:        # HBM-side traffic per launch from the committed PMC passes (profiles/), only for the workload they were taken on
+                pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+                if (U, I, d, args.mean_deg, args.seed, args.chunk) == (1_000_000, 100_000, 64, 32.0, 2018, 512):
+                    traffic = pm['traffic_corrected_bytes']
+            except Exception:
+                traffic = None
             if world == 1:
                 res['roofline'] = {'bound': 'hbm', 'achieved': spmm_bytes / (avg_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                   'frac': spmm_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                                   'frac': spmm_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': traffic,
                                    'kernel': 'spmm_rows_kernel<LPR=%d> (+spmm_long_rows_kernel), avg over %d launches' % (max(4, d // 4), len(allv)),
                                    'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': spmm_bytes,
                                    'per_variant_ms': {k: v[0] for k, v in evs.items()},
