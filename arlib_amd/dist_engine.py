@@ -185,6 +185,83 @@ class ShardedPropagationEngine:
             k.adam_dense(self.E0, acc, self.m, self.v, self.lr, self.t, self.betas, self.eps)
         return self.loss_out
 
+    # ---- sparse-batch step (same idea as PropagationEngine.step): L-1 full hops + a row-subset hop forward, a flag-masked
+    # first hop backward.  The compact batch rows [3B, d] are completed with ONE small all-reduce (users: the owner
+    # contributes the row, everybody else zeros; items: partial sums), after which every rank evaluates the loss on the
+    # whole batch redundantly (a few microseconds) -- so the batch-wide mean/norms and the item-side gradient need no
+    # further collective.  Full-size all-reduces per step: 2(L-1) + 1 instead of 2L + 1.
+    def step_sparse(self, u, p, n):
+        k, L, Ul, d = self.k, self.L, self.Ul, self.d
+        B = u.numel()
+        dev = self.device
+        s = 1.0 / (L + 1)
+        if getattr(self, '_sp_B', None) != B:
+            self.flags = torch.zeros(self.Nl, dtype=torch.uint8, device=dev)
+            self.C = torch.zeros(3 * B, d, dtype=torch.float32, device=dev)
+            self.Gc = torch.zeros(3 * B, d, dtype=torch.float32, device=dev)
+            self.ar = torch.arange(B, dtype=torch.int32, device=dev)
+            self.arB = self.ar + B
+            self.ws = torch.empty(4 * B, dtype=torch.float32, device=dev)
+            self.hops = [self.Ea, self.Eb] + [torch.empty_like(self.Ea) for _ in range(max(0, L - 3))]
+            self.G.zero_()
+            self._sp_B = B
+        loc = ((u >= self.u0) & (u < self.u1)).nonzero().squeeze(1)            # positions of this rank's samples
+        lu = (u[loc] - self.u0).to(torch.int32).contiguous()
+        item_rows = torch.cat([p, n]).to(torch.int32).contiguous()              # item ids of ALL samples, [2B]
+        item_rows_packed = item_rows + Ul
+        # forward
+        layers = [self.E0]
+        for h in range(L - 1):
+            self._hop(layers[-1], self.hops[h])
+            layers.append(self.hops[h])
+        X = layers[-1]
+        self.C.zero_()
+        if lu.numel():
+            cu = k.spmm_rows(self.Au, X, lu, [t[:Ul] for t in layers], 1.0)
+            self.C[loc] = cu
+        self.C[B:] = k.spmm_rows(self.Ai, X, item_rows, (), 1.0)
+        self.comm.all_reduce(self.C)
+        for t in layers:
+            self.C[B:] += k.gather_rows(t, item_rows_packed)
+        self.C.mul_(s)
+        # loss on the whole batch (identical on every rank), compact per-sample gradients
+        self.Gc.zero_()
+        k.bpr_l2_fwd_bwd(self.C, B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self.ws, loss_out=self.loss_out, check_range=False)
+        if lu.numel():
+            k.scatter_add_rows(self.G, lu, self.Gc[loc].contiguous(), 1.0)
+            k.mark_rows_(self.flags, lu, 1)
+        k.scatter_add_rows(self.G, item_rows_packed, self.Gc[B:].contiguous(), 1.0)
+        k.mark_rows_(self.flags, item_rows_packed, 1)
+        # backward (Horner).  hop 1: flag-masked gathers; later hops dense; G (complete on the item side) added through flags
+        self.t += 1
+        zu, zi = self.flags[:Ul], self.flags[Ul:]
+        acc = self.G
+        for h in range(L):
+            last = h == L - 1
+            a = s if last else 1.0
+            dst = self.hops[h % 2] if L <= 3 else self.hops[h % len(self.hops)]
+            if dst is acc:
+                dst = self.hops[(h + 1) % len(self.hops)]
+            xf = self.flags if h == 0 else None
+            di, du = dst[Ul:], dst[:Ul]
+            k.spmm_flagged(self.Ai, acc, xf, a, 0.0, None, None, out=di)
+            work = self.comm.all_reduce_async(di)
+            if last:
+                k.spmm_adam(self.Au, acc, a, a, self.G[:Ul], self.E0[:Ul], self.m[:Ul], self.v[:Ul], self.lr, self.t, self.betas, self.eps, zflags=zu)
+            else:
+                k.spmm_flagged(self.Au, acc, xf, a, a, self.G[:Ul], zu, out=du)
+            work.wait()
+            di.add_(self.G[Ul:], alpha=a)
+            acc = dst
+        k.adam_dense(self.E0[Ul:], acc[Ul:], self.m[Ul:], self.v[Ul:], self.lr, self.t, self.betas, self.eps)
+        # clear the sparse state
+        if lu.numel():
+            k.zero_rows_(self.G, lu)
+            k.mark_rows_(self.flags, lu, 0)
+        k.zero_rows_(self.G, item_rows_packed)
+        k.mark_rows_(self.flags, item_rows_packed, 0)
+        return self.loss_out
+
     def gather_full_table(self):
         """[U+I, d] table assembled on every rank (tests / checkpoints): all-gather of the user blocks + the replica."""
         full = torch.zeros(self.U + self.I, self.d, dtype=torch.float32, device=self.device)

@@ -51,3 +51,68 @@ def bpr_l2_backward(emb, item_off, u, p, n, reg, norms4, G, workspace, upstream=
 def adam_dense(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8):
     pn, mn, vn = p.numpy(), m.numpy(), v.numpy()           # share memory with the tensors
     O.adam_step(pn, np.ascontiguousarray(g.numpy()), mn, vn, lr, step, betas[0], betas[1], eps)
+
+
+# ---- sparse-batch primitives (same contracts as arlib_amd.ops)
+def spmm_rows(A, X, rows, layers=(), alpha=1.0, nsplit=16, out=None, workspace=None, check_range=True):
+    r = rows.numpy().astype(np.int64)
+    y = O.spmm((A.rowptr, A.col, A.val), X.numpy())[r].astype(np.float64)
+    for t in layers:
+        y += t.numpy()[r]
+    res = torch.from_numpy((alpha * y).astype(np.float32))
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
+def spmm_flagged(A, X, xflags=None, alpha=1.0, beta=0.0, Z=None, zflags=None, out=None):
+    Xn = X.numpy()
+    if xflags is not None:
+        assert np.all(Xn[xflags.numpy() == 0] == 0), 'operand must be zero on unflagged rows'
+    Zn = None
+    if beta != 0.0:
+        Zn = Z.numpy().copy()
+        if zflags is not None:
+            assert np.all(Zn[zflags.numpy() == 0] == 0), 'Z must be zero on unflagged rows'
+    y = torch.from_numpy(O.spmm((A.rowptr, A.col, A.val), Xn, alpha, beta, Zn))
+    if out is None:
+        return y
+    out.copy_(y)
+    return out
+
+
+def spmm_adam(A, X, alpha, beta, Z, P, M, V, lr, step, betas=(0.9, 0.999), eps=1e-8, zflags=None):
+    g = O.spmm((A.rowptr, A.col, A.val), X.numpy(), alpha, beta, Z.numpy() if beta != 0.0 else None)
+    p, m, v = (np.ascontiguousarray(t.numpy()) for t in (P, M, V))
+    O.adam_step(p, g, m, v, lr, step, betas[0], betas[1], eps)
+    P.copy_(torch.from_numpy(p)); M.copy_(torch.from_numpy(m)); V.copy_(torch.from_numpy(v))
+
+
+def bpr_l2_fwd_bwd(emb, item_off, u, p, n, reg, G=None, upstream=1.0, workspace=None, loss_out=None, check_range=True):
+    lb, lr_, Gn = O.bpr_l2(emb.numpy(), item_off, u.numpy(), p.numpy(), n.numpy(), reg)
+    if G is not None:
+        G.add_(torch.from_numpy(Gn))
+    e = emb.numpy().astype(np.float64)
+    loss_out[0], loss_out[1] = lb, lr_
+    loss_out[2] = float(np.sqrt((e[u.numpy()] ** 2).sum())); loss_out[3] = float(np.sqrt((e[p.numpy() + item_off] ** 2).sum()))
+    return loss_out
+
+
+def gather_rows(src, idx, check_range=True):
+    return src[idx.long()].clone()
+
+
+def scatter_add_rows(dst, idx, src, scale=1.0, check_range=True):
+    dst.index_add_(0, idx.long(), src * scale)
+    return dst
+
+
+def mark_rows_(flags, idx, value, check_range=True):
+    flags[idx.long()] = value
+    return flags
+
+
+def zero_rows_(dst, idx, check_range=True):
+    dst[idx.long()] = 0
+    return dst

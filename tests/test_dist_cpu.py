@@ -48,7 +48,7 @@ def test_virtual_ranks_partial_item_sums_add_up(world):
     assert rel_err(item_sum, full[U:]) < 1e-6                             # item rows = sum of per-rank partials
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, sparse):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import torch.distributed as dist
     import cpu_kernels_shim as shim
@@ -60,7 +60,7 @@ def _worker(rank, world, port, ret):
     eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cpu', rank, world, torch.from_numpy(E0), kernels=shim)
     losses = []
     for u, p, n in batches:
-        lo = eng.step(torch.from_numpy(u), torch.from_numpy(p), torch.from_numpy(n))
+        lo = (eng.step_sparse if sparse else eng.step)(torch.from_numpy(u), torch.from_numpy(p), torch.from_numpy(n))
         losses.append(float(lo[0] + lo[1]))
     full = eng.gather_full_table().numpy()
     if rank == 0:
@@ -68,13 +68,13 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2])
-def test_sharded_engine_gloo_matches_single_process_oracle(world):
+@pytest.mark.parametrize('world,sparse', [(2, False), (2, True), (3, True)])
+def test_sharded_engine_gloo_matches_single_process_oracle(world, sparse):
     U, I, d, L, pairs, E0, batches = small_problem()
     ref_table, ref_losses = oracle_run(U, I, d, L, pairs, E0, batches)
     mgr = mp.Manager()
     ret = mgr.dict()
     port = 29500 + os.getpid() % 2000
-    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, ret, sparse), nprocs=world, join=True)
     assert np.allclose(ret['losses'], ref_losses, rtol=RTOL, atol=0)
     assert rel_err(ret['table'], ref_table) < RTOL

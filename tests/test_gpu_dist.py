@@ -33,7 +33,7 @@ class HostStagedComm:
         return self._Done()
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, sparse):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import torch.distributed as dist
     from arlib_amd.dist_engine import ShardedPropagationEngine
@@ -44,7 +44,7 @@ def _worker(rank, world, port, ret):
     eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cuda:0', rank, world, torch.from_numpy(E0), comm=HostStagedComm())
     losses = []
     for u, p, n in batches:
-        lo = eng.step(torch.from_numpy(u).cuda(), torch.from_numpy(p).cuda(), torch.from_numpy(n).cuda())
+        lo = (eng.step_sparse if sparse else eng.step)(torch.from_numpy(u).cuda(), torch.from_numpy(p).cuda(), torch.from_numpy(n).cuda())
         losses.append(float(lo[0] + lo[1]))
     full = eng.gather_full_table().cpu().numpy()
     if rank == 0:
@@ -52,7 +52,8 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_sharded_engine_two_ranks_hip_kernels():
+@pytest.mark.parametrize('sparse', [False, True])
+def test_sharded_engine_two_ranks_hip_kernels(sparse):
     if not torch.cuda.is_available():
         pytest.fail('GPU tests need a GPU')
     U, I, d, L, pairs, E0, batches = small_problem()
@@ -61,6 +62,6 @@ def test_sharded_engine_two_ranks_hip_kernels():
     mgr = ctx.Manager()
     ret = mgr.dict()
     port = 29500 + os.getpid() % 2000
-    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, ret, sparse), nprocs=2, join=True)
     assert np.allclose(ret['losses'], ref_losses, rtol=RTOL, atol=0)
     assert rel_err(ret['table'], ref_table) < RTOL
