@@ -160,11 +160,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
         raise SystemExit('WORLD_SIZE %d != --gpus %d' % (world, args.gpus))
+    # test hook (1-GPU boxes): ARL_BENCH_BACKEND=gloo + ARL_BENCH_SINGLE_DEVICE=1 runs the N>1 code path with every rank on cuda:0
+    backend = os.environ.get('ARL_BENCH_BACKEND', 'nccl')
+    if os.environ.get('ARL_BENCH_SINGLE_DEVICE') == '1':
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)       # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     from arlib_amd import ops, engine
     from arlib_amd.util import synthetic

@@ -353,3 +353,17 @@ def pga_step(real_indptr, real_indices, U, F, I, S, E0, L, users, pos, neg):
         sddmm_rows_dense(E[k], dE[k + 1], rows, Up, I, out=block)
     grad = block * dinv[U:Up, None] * dinv[None, Up:] * (S != 0)
     return grad, pga_update(S, block, dinv[U:Up], dinv[Up:]), loss
+
+
+# ------------------------------------------------------------------ NGCF forward (recommender/NGCF.py:197-212)
+def ngcf_forward(csr, E0, W1s, W2s, slope=0.01):
+    """per layer: t = E W1; E' = leaky_relu(A t + t + ((A E) * E) W2); mean of L+1 layers -- written with BOTH sparse hops,
+    exactly as the reference does (the product uses A(E W1) = (A E) W1 to save one)."""
+    E = _f32(E0)
+    acc = E.astype(np.float64)
+    for W1, W2 in zip(W1s, W2s):
+        t = (E.astype(np.float64) @ W1.astype(np.float64)).astype(np.float32)
+        z = spmm(csr, t).astype(np.float64) + t + ((spmm(csr, E).astype(np.float64) * E) @ W2.astype(np.float64))
+        E = np.where(z > 0, z, slope * z).astype(np.float32)
+        acc += E
+    return (acc / (len(W1s) + 1)).astype(np.float32)

@@ -535,6 +535,41 @@ def gen_attacks():
         undo_shim()
     save('g7_attacks.npz', **out)
 
+# --------------------------------------------------------------------------- NGCF (a9): forward + 3 Adam steps
+def gen_ngcf():
+    from recommender.NGCF import NGCF
+    args = rec_args(emb_size=32, n_layers=2, model_name='NGCF')
+    seedSet(2018)
+    data = DataLoader(args)
+    rec = NGCF(args, data)
+    model = rec.model
+    o = {'user0': model.embedding_dict['user_emb'].detach().numpy().copy(), 'item0': model.embedding_dict['item_emb'].detach().numpy().copy()}
+    for k in range(2):
+        o['w1_%d' % k] = model.W['w1_%d' % k].detach().numpy().copy(); o['w2_%d' % k] = model.W['w2_%d' % k].detach().numpy().copy()
+    with torch.no_grad():
+        u, i = model()
+    o['fwd_user'], o['fwd_item'] = u.numpy().copy(), i.numpy().copy()
+    optim = torch.optim.Adam(model.parameters(), lr=args.lRate)
+    random.seed(2018)
+    losses, bu, bp, bn = [], [], [], []
+    for step, batch in enumerate(ref_sampler.next_batch_pairwise(data, args.batch_size)):
+        if step == 3:
+            break
+        user_idx, pos_idx, neg_idx = batch
+        ue, ie = model()
+        loss = ref_loss.bpr_loss(ue[user_idx], ie[pos_idx], ie[neg_idx]) + ref_loss.l2_reg_loss(args.reg, ue[user_idx], ie[pos_idx])
+        optim.zero_grad(); loss.backward()
+        if step == 0:
+            o['grad_user'] = model.embedding_dict['user_emb'].grad.numpy().copy()
+            o['grad_w1_0'] = model.W['w1_0'].grad.numpy().copy(); o['grad_w2_1'] = model.W['w2_1'].grad.numpy().copy()
+        optim.step()
+        losses.append(loss.item()); bu.append(np.asarray(user_idx, np.int32)); bp.append(np.asarray(pos_idx, np.int32)); bn.append(np.asarray(neg_idx, np.int32))
+    o['losses'] = np.array(losses, np.float32)
+    o['batch_u'], o['batch_p'], o['batch_n'] = np.stack(bu), np.stack(bp), np.stack(bn)
+    o['user_k3'] = model.embedding_dict['user_emb'].detach().numpy().copy(); o['item_k3'] = model.embedding_dict['item_emb'].detach().numpy().copy()
+    o['w1_0_k3'] = model.W['w1_0'].detach().numpy().copy()
+    save('g9_ngcf.npz', **o)
+
 
 if __name__ == '__main__':
     gen_dataset()
@@ -549,4 +584,5 @@ if __name__ == '__main__':
     gen_simgcl(data)
     gen_train_api()
     gen_attacks()
+    gen_ngcf()
     print('done; scratch dir', SCRATCH)

@@ -195,3 +195,11 @@ def test_simgcl_forward_and_step(ml100k):
     m = np.zeros_like(E0); v = np.zeros_like(E0); E = E0.copy()
     O.adam_step(E, grad, m, v, 0.005, 1)
     assert rel_err(E[:U], g['user_k1']) < RTOL and rel_err(E[U:], g['item_k1']) < RTOL
+
+
+def test_ngcf_forward(ml100k):
+    g = golden('g9_ngcf.npz')
+    csr = _ml100k_csr(ml100k)
+    out = O.ngcf_forward(csr, np.concatenate([g['user0'], g['item0']]), [g['w1_0'], g['w1_1']], [g['w2_0'], g['w2_1']])
+    U = ml100k['U']
+    assert rel_err(out[:U], g['fwd_user']) < RTOL and rel_err(out[U:], g['fwd_item']) < RTOL
