@@ -787,6 +787,157 @@ __global__ __launch_bounds__(kBlock) void score_mask_topk_kernel(const float *__
     }
 }
 
+// ---- MFMA form of the streaming score + mask + top-k (d in {16,32,64,128}, k <= 64) ---------------------------------------
+// scores = Pu . Pi^T is the one dense contraction of the path (2*U*I*d flop; 1.3e13 at cfg2), so it goes on the matrix cores:
+// v_mfma_f32_32x32x2_f32 (exact f32, bitwise an fmaf chain).  One wave owns 32 users for the whole kernel: its A fragment
+// (32 users x d) stays in d/2 VGPRs; the block (4 waves = 128 users) streams 32-item tiles of Pi through a double-buffered LDS
+// image (one __syncthreads per tile, next tile's global loads in flight during the MFMAs).  Lane l supplies A[user l&31][k] and
+// B[k][item l&31] for k = (d/2)*(l>>5) + t at MFMA step t -- the k order is a permutation of 0..d-1, irrelevant to the sum, and
+// it makes every lane's fragment d/2 CONTIGUOUS floats (ds_read_b128).  C: item = lane&31, user = (reg&3)+8*(reg>>2)+4*(lane>>5).
+// Top-k per user: candidate keys above the user's running k-th best are appended to a 128-slot LDS buffer owned by the user's
+// wave (so compaction needs no block barrier); a 32-item tile can add at most 32, compaction (bitonic sort, keep k) runs when
+// more than 96 are held.  The interacted-item mask is only evaluated for the rare candidates that pass the threshold.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kMU = 128;         // users per block (32 per wave)
+constexpr int kMI = 32;          // items per tile
+constexpr int kMCap = 128;       // candidate slots per user
+
+__device__ void wave_sort_desc_128(unsigned long long *c, int lane) {
+    for (int k = 2; k <= kMCap; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < kMCap; t += kWave) {
+                const int ixj = t ^ j;
+                if (ixj > t) {
+                    const unsigned long long a = c[t], b = c[ixj];
+                    const bool desc = ((t & k) == 0);
+                    if (desc ? (a < b) : (a > b)) { c[t] = b; c[ixj] = a; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void score_mask_topk_mfma_kernel(const float *__restrict__ Pu, const float *__restrict__ Pi, int U, int I,
+                                                                       const int32_t *__restrict__ mrp, const int32_t *__restrict__ mcol, int k,
+                                                                       int32_t *__restrict__ top_idx, float *__restrict__ top_val) {
+    constexpr int H = D / 2;                  // k-steps = floats per lane fragment
+    constexpr int LD = D + 4;                 // LDS row stride (floats): 16-B aligned rows, rows shifted by 4 banks
+    extern __shared__ unsigned char smem_raw[];
+    unsigned long long *cand = reinterpret_cast<unsigned long long *>(smem_raw);                 // [kMU][kMCap]
+    unsigned long long *thr = cand + kMU * kMCap;                                                // [kMU]
+    int *cnt = reinterpret_cast<int *>(thr + kMU);                                               // [kMU]
+    float *bt = reinterpret_cast<float *>(cnt + kMU);                                            // [2][kMI][LD]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int u_base = blockIdx.x * kMU + wv * 32;             // this wave's 32 users
+    // A fragment: user (u_base + r), columns [H*h, H*h + H)
+    float a[H];
+    {
+        const int u = u_base + r;
+#pragma unroll
+        for (int t = 0; t < H; t += 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < U) v = *reinterpret_cast<const float4 *>(Pu + (size_t)u * D + H * h + t);
+            a[t] = v.x; a[t + 1] = v.y; a[t + 2] = v.z; a[t + 3] = v.w;
+        }
+    }
+    for (int t = lane; t < 32 * kMCap; t += kWave) cand[(size_t)wv * 32 * kMCap + t] = 0ull;
+    if (lane < 32) { thr[wv * 32 + lane] = 0ull; cnt[wv * 32 + lane] = 0; }
+    // B staging: 32 items x D floats per tile = 8*D float4; thread tid moves float4 number tid, tid+256, ...
+    constexpr int F4 = kMI * D / 4;                         // float4 per tile
+    constexpr int PER = (F4 + kBlock - 1) / kBlock;
+    float4 nb[PER];
+    const int ntiles = (I + kMI - 1) / kMI;
+    auto fetch = [&](int it) {
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            const int f = tid + p * kBlock;
+            nb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < F4) {
+                const int row = f / (D / 4), c4 = f % (D / 4);
+                const int item = it * kMI + row;
+                if (item < I) nb[p] = *reinterpret_cast<const float4 *>(Pi + (size_t)item * D + c4 * 4);
+            }
+        }
+    };
+    fetch(0);
+    for (int it = 0; it < ntiles; ++it) {
+        float *buf = bt + (it & 1) * kMI * LD;
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            const int f = tid + p * kBlock;
+            if (f < F4) { const int row = f / (D / 4), c4 = f % (D / 4); *reinterpret_cast<float4 *>(buf + row * LD + c4 * 4) = nb[p]; }
+        }
+        __syncthreads();
+        if (it + 1 < ntiles) fetch(it + 1);
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float *brow = buf + r * LD + H * h;
+#pragma unroll
+        for (int t = 0; t < H; t += 4) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(brow + t);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 1], b4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 2], b4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 3], b4.w, acc, 0, 0, 0);
+        }
+        const int item = it * kMI + r;
+        if (item < I) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int ul = wv * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;       // user slot in the block
+                const int u = blockIdx.x * kMU + ul;
+                if (u >= U) continue;
+                unsigned long long key = pack_cand(acc[reg], item);
+                if (key > thr[ul]) {
+                    if (mrp) {
+                        int lo = mrp[u], hi = mrp[u + 1];
+                        const int end = hi;
+                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (mcol[mid] < item) lo = mid + 1; else hi = mid; }
+                        if (lo < end && mcol[lo] == item) key = pack_cand(-10e8f, item);
+                    }
+                    if (key > thr[ul]) {
+                        const int slot = atomicAdd(&cnt[ul], 1);
+                        cand[(size_t)ul * kMCap + slot] = key;          // slot < 128: at most 96 held + 32 new per tile
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        for (int q = 0; q < 32; ++q) {                                     // this wave's users only: no block barrier needed
+            const int ul = wv * 32 + q;
+            const int c = cnt[ul];
+            if (c > kMCap - kMI) {
+                unsigned long long *cc = cand + (size_t)ul * kMCap;
+                for (int t = c + lane; t < kMCap; t += kWave) cc[t] = 0ull;
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+                wave_sort_desc_128(cc, lane);
+                if (lane == 0) { thr[ul] = cc[k - 1]; cnt[ul] = k; }
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+            }
+        }
+    }
+    for (int q = 0; q < 32; ++q) {
+        const int ul = wv * 32 + q;
+        const int u = blockIdx.x * kMU + ul;
+        if (u >= U) continue;
+        unsigned long long *cc = cand + (size_t)ul * kMCap;
+        for (int t = cnt[ul] + lane; t < kMCap; t += kWave) cc[t] = 0ull;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        wave_sort_desc_128(cc, lane);
+        for (int t = lane; t < k; t += kWave) {
+            top_idx[(size_t)u * k + t] = cand_item(cc[t]);
+            top_val[(size_t)u * k + t] = cand_score(cc[t]);
+        }
+    }
+}
+
 // per-row top-n by n rounds of block arg-max over a scratch copy (n ~ average user degree, small)
 __global__ __launch_bounds__(kBlock) void topn_project_kernel(const float *__restrict__ M, int cols, int n, float *__restrict__ out,
                                                                int32_t *__restrict__ idx, float *__restrict__ scratch) {
@@ -1127,6 +1278,25 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
     if (k <= 0 || k > 128 || k > I) return ARL_E_ARG;
     if (U < 0 || I <= 0 || U > 0x7fffffffll || I > 0x7fffffffll) return ARL_E_RANGE;
     if (U == 0) return ARL_OK;
+    if (k <= 64 && (d == 16 || d == 32 || d == 64 || d == 128)) {        // matrix-core path
+        const size_t shm_m = sizeof(unsigned long long) * kMU * kMCap + sizeof(unsigned long long) * kMU + sizeof(int) * kMU +
+                             sizeof(float) * 2 * kMI * (size_t)(d + 4);
+        const unsigned grid_m = (unsigned)((U + kMU - 1) / kMU);
+#define ARL_TOPK_CASE(DV)                                                                                                              \
+        do {                                                                                                                           \
+            hipError_t em = hipFuncSetAttribute((const void *)score_mask_topk_mfma_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m); \
+            if (em != hipSuccess) return (int)em;                                                                                      \
+            hipLaunchKernelGGL((score_mask_topk_mfma_kernel<DV>), dim3(grid_m), dim3(kBlock), shm_m, (hipStream_t)stream, Pu, Pi, (int)U, (int)I, \
+                               mask_rowptr, mask_col, (int)k, top_idx, top_val);                                                       \
+        } while (0)
+        if (d == 16) ARL_TOPK_CASE(16);
+        else if (d == 32) ARL_TOPK_CASE(32);
+        else if (d == 64) ARL_TOPK_CASE(64);
+        else ARL_TOPK_CASE(128);
+#undef ARL_TOPK_CASE
+        ARL_LAUNCH_CHECK();
+        return ARL_OK;
+    }
     const size_t shm = sizeof(unsigned long long) * kTU * kCap + sizeof(float) * kTU * 256 + sizeof(unsigned long long) * kTU + sizeof(int) * kTU;
     hipError_t e = hipFuncSetAttribute((const void *)score_mask_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return (int)e;
