@@ -800,12 +800,12 @@ __global__ __launch_bounds__(kBlock) void score_mask_topk_kernel(const float *__
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kMU = 128;         // users per block (32 per wave)
 constexpr int kMI = 32;          // items per tile
-constexpr int kMCap = 128;       // candidate slots per user
+constexpr int kMCap = 112;       // candidate slots per user (>= k_max 64 + 32 + slack; 128 x 112 x 8 B = 112 KiB of the 160 KiB LDS)
 
 __device__ void wave_sort_desc_128(unsigned long long *c, int lane) {
-    for (int k = 2; k <= kMCap; k <<= 1) {
+    for (int k = 2; k <= 128; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = lane; t < kMCap; t += kWave) {
+            for (int t = lane; t < 128; t += kWave) {
                 const int ixj = t ^ j;
                 if (ixj > t) {
                     const unsigned long long a = c[t], b = c[ixj];
@@ -819,22 +819,41 @@ __device__ void wave_sort_desc_128(unsigned long long *c, int lane) {
     }
 }
 
+// Cut a user's <= 128 candidate keys down to the k largest without sorting: radix-select the k-th largest 64-bit key bit by
+// bit with wave ballots (keys are distinct: the item id is part of the key), then compact the survivors with a ballot prefix.
+// ~1k cycles instead of ~6k for the LDS bitonic sort; order inside the buffer is irrelevant until the final output sort.
+__device__ __forceinline__ unsigned long long wave_select_topk(unsigned long long *cc, int cnt, int k, int lane) {
+    const unsigned long long k0 = lane < cnt ? cc[lane] : 0ull, k1 = lane + kWave < cnt ? cc[lane + kWave] : 0ull;
+    unsigned long long T = 0ull;
+    for (int bit = 63; bit >= 0; --bit) {
+        const unsigned long long c = T | (1ull << bit);
+        const int n = __popcll(__ballot(k0 >= c)) + __popcll(__ballot(k1 >= c));
+        if (n >= k) T = c;
+    }
+    const unsigned long long m0 = __ballot(k0 >= T), m1 = __ballot(k1 >= T);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    __builtin_amdgcn_wave_barrier();
+    if (k0 >= T) cc[__popcll(m0 & lt)] = k0;
+    if (k1 >= T) cc[__popcll(m0) + __popcll(m1 & lt)] = k1;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    return T;
+}
+
 template <int D>
 __global__ __launch_bounds__(kBlock) void score_mask_topk_mfma_kernel(const float *__restrict__ Pu, const float *__restrict__ Pi, int U, int I,
                                                                        const int32_t *__restrict__ mrp, const int32_t *__restrict__ mcol, int k,
                                                                        int32_t *__restrict__ top_idx, float *__restrict__ top_val) {
     constexpr int H = D / 2;                  // k-steps = floats per lane fragment
     constexpr int LD = D + 4;                 // LDS row stride (floats): 16-B aligned rows, rows shifted by 4 banks
+    constexpr int MST = D <= 64 ? 64 : 32;    // items staged per block barrier
     extern __shared__ unsigned char smem_raw[];
     unsigned long long *cand = reinterpret_cast<unsigned long long *>(smem_raw);                 // [kMU][kMCap]
-    unsigned long long *thr = cand + kMU * kMCap;                                                // [kMU]
-    int *cnt = reinterpret_cast<int *>(thr + kMU);                                               // [kMU]
-    float *bt = reinterpret_cast<float *>(cnt + kMU);                                            // [2][kMI][LD]
+    float *bt = reinterpret_cast<float *>(cand + kMU * kMCap);                                   // [2][MST][LD]; sort scratch at the end
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int u_base = blockIdx.x * kMU + wv * 32;             // this wave's 32 users
-    // A fragment: user (u_base + r), columns [H*h, H*h + H)
-    float a[H];
+    float a[H];                                                // A fragment: user (u_base + r), columns [H*h, H*h + H)
     {
         const int u = u_base + r;
 #pragma unroll
@@ -844,96 +863,121 @@ __global__ __launch_bounds__(kBlock) void score_mask_topk_mfma_kernel(const floa
             a[t] = v.x; a[t + 1] = v.y; a[t + 2] = v.z; a[t + 3] = v.w;
         }
     }
-    for (int t = lane; t < 32 * kMCap; t += kWave) cand[(size_t)wv * 32 * kMCap + t] = 0ull;
-    if (lane < 32) { thr[wv * 32 + lane] = 0ull; cnt[wv * 32 + lane] = 0; }
-    // B staging: 32 items x D floats per tile = 8*D float4; thread tid moves float4 number tid, tid+256, ...
-    constexpr int F4 = kMI * D / 4;                         // float4 per tile
+    // B staging: MST items x D floats per stage; thread tid moves float4 number tid, tid+256, ...
+    constexpr int F4 = MST * D / 4;
     constexpr int PER = (F4 + kBlock - 1) / kBlock;
     float4 nb[PER];
-    const int ntiles = (I + kMI - 1) / kMI;
-    auto fetch = [&](int it) {
+    const int nstages = (I + MST - 1) / MST;
+    auto fetch = [&](int st) {
 #pragma unroll
         for (int p = 0; p < PER; ++p) {
+            // unconditional loads (index clamped, no select on the result): a select would force an s_waitcnt right after the
+            // issue and expose the whole HBM/Infinity-Cache latency every stage; rows past I are discarded by `item_ok` later
             const int f = tid + p * kBlock;
-            nb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < F4) {
-                const int row = f / (D / 4), c4 = f % (D / 4);
-                const int item = it * kMI + row;
-                if (item < I) nb[p] = *reinterpret_cast<const float4 *>(Pi + (size_t)item * D + c4 * 4);
-            }
+            const int row = f / (D / 4), c4 = f % (D / 4);
+            const int item = min(st * MST + row, I - 1);
+            nb[p] = *reinterpret_cast<const float4 *>(Pi + (size_t)item * D + c4 * 4);
         }
     };
+    static_assert(F4 % kBlock == 0, "staging assumes a whole number of float4 per thread");
+    // Per-user running state lives in REGISTERS: accumulator register `reg` of lane half h belongs to user row
+    // (reg&3)+8*(reg>>2)+4h for all 32 lanes of the half, so the half-wave agrees on it through ballots -- no LDS atomics,
+    // no LDS threshold reads.  thrf = the user's k-th best score so far (pre-filter, exact up to ties), cntr = keys held.
+    float thrf[16];
+    int cntr[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        thrf[reg] = (u_base + (reg & 3) + 8 * (reg >> 2) + 4 * h < U) ? -INFINITY : INFINITY;     // users past U never insert
+        cntr[reg] = 0;
+    }
+    const unsigned lt32 = (1u << r) - 1u;
+    const unsigned slot_base = (unsigned)((wv * 32 + 4 * h) * kMCap);     // first candidate slot of user row 4h of this wave
     fetch(0);
-    for (int it = 0; it < ntiles; ++it) {
-        float *buf = bt + (it & 1) * kMI * LD;
+    for (int st = 0; st < nstages; ++st) {
+        float *buf = bt + (st & 1) * MST * LD;
 #pragma unroll
         for (int p = 0; p < PER; ++p) {
             const int f = tid + p * kBlock;
-            if (f < F4) { const int row = f / (D / 4), c4 = f % (D / 4); *reinterpret_cast<float4 *>(buf + row * LD + c4 * 4) = nb[p]; }
+            const int row = f / (D / 4), c4 = f % (D / 4);
+            *reinterpret_cast<float4 *>(buf + row * LD + c4 * 4) = nb[p];
         }
-        __syncthreads();
-        if (it + 1 < ntiles) fetch(it + 1);
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const float *brow = buf + r * LD + H * h;
+        __syncthreads();                                       // the only block barrier per stage
+        if (st + 1 < nstages) fetch(st + 1);
+        for (int sub = 0; sub < MST / kMI; ++sub) {
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float *brow = buf + (sub * kMI + r) * LD + H * h;
 #pragma unroll
-        for (int t = 0; t < H; t += 4) {
-            const float4 b4 = *reinterpret_cast<const float4 *>(brow + t);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b4.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 1], b4.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 2], b4.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 3], b4.w, acc, 0, 0, 0);
-        }
-        const int item = it * kMI + r;
-        if (item < I) {
+            for (int t = 0; t < H; t += 4) {
+                const float4 b4 = *reinterpret_cast<const float4 *>(brow + t);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b4.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 1], b4.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 2], b4.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 3], b4.w, acc, 0, 0, 0);
+            }
+            const int item = st * MST + sub * kMI + r;
+            const bool item_ok = item < I;
+            bool full = false;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int ul = wv * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;       // user slot in the block
-                const int u = blockIdx.x * kMU + ul;
-                if (u >= U) continue;
-                unsigned long long key = pack_cand(acc[reg], item);
-                if (key > thr[ul]) {
-                    if (mrp) {
+                bool pass = item_ok && (acc[reg] >= thrf[reg]);
+                unsigned long long m = __ballot(pass);
+                if (m == 0ull) continue;                                           // wave-uniform: nobody beats a threshold
+                const int ul = wv * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                float sc = acc[reg];
+                if (mrp) {                                                         // interacted -> -10e8 (only for pre-filter survivors)
+                    if (pass) {
+                        const int u = blockIdx.x * kMU + ul;
                         int lo = mrp[u], hi = mrp[u + 1];
                         const int end = hi;
                         while (lo < hi) { const int mid = (lo + hi) >> 1; if (mcol[mid] < item) lo = mid + 1; else hi = mid; }
-                        if (lo < end && mcol[lo] == item) key = pack_cand(-10e8f, item);
+                        if (lo < end && mcol[lo] == item) { sc = -10e8f; pass = sc >= thrf[reg]; }
                     }
-                    if (key > thr[ul]) {
-                        const int slot = atomicAdd(&cnt[ul], 1);
-                        cand[(size_t)ul * kMCap + slot] = key;          // slot < 128: at most 96 held + 32 new per tile
+                    m = __ballot(pass);
+                }
+                const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)(m & 0xffffffffull);   // passing lanes of my half = same user
+                if (pass) cand[slot_base + ((reg & 3) + 8 * (reg >> 2)) * kMCap + cntr[reg] + __popc(mh & lt32)] = pack_cand(sc, item);
+                cntr[reg] += __popc(mh);
+                full |= cntr[reg] > kMCap - kMI;
+            }
+            if (__any(full)) {
+                // compaction of the users that could overflow during the next sub-tile (wave-local: no block barrier)
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int c = __shfl(cntr[reg], hh * 32);
+                        if (c > kMCap - kMI) {                                     // wave-uniform
+                            const int ul = wv * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                            const unsigned long long T = wave_select_topk(cand + (size_t)ul * kMCap, c, k, lane);
+                            if (h == hh) { cntr[reg] = k; thrf[reg] = cand_score(T); }
+                        }
                     }
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        for (int q = 0; q < 32; ++q) {                                     // this wave's users only: no block barrier needed
-            const int ul = wv * 32 + q;
-            const int c = cnt[ul];
-            if (c > kMCap - kMI) {
-                unsigned long long *cc = cand + (size_t)ul * kMCap;
-                for (int t = c + lane; t < kMCap; t += kWave) cc[t] = 0ull;
-                __builtin_amdgcn_wave_barrier();
-                __threadfence_block();
-                wave_sort_desc_128(cc, lane);
-                if (lane == 0) { thr[ul] = cc[k - 1]; cnt[ul] = k; }
-                __builtin_amdgcn_wave_barrier();
-                __threadfence_block();
-            }
-        }
     }
-    for (int q = 0; q < 32; ++q) {
-        const int ul = wv * 32 + q;
-        const int u = blockIdx.x * kMU + ul;
-        if (u >= U) continue;
-        unsigned long long *cc = cand + (size_t)ul * kMCap;
-        for (int t = cnt[ul] + lane; t < kMCap; t += kWave) cc[t] = 0ull;
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        wave_sort_desc_128(cc, lane);
-        for (int t = lane; t < k; t += kWave) {
-            top_idx[(size_t)u * k + t] = cand_item(cc[t]);
-            top_val[(size_t)u * k + t] = cand_score(cc[t]);
+    __syncthreads();                                           // the staging buffers become per-wave sort scratch (128 keys each)
+    unsigned long long *scratch = reinterpret_cast<unsigned long long *>(bt) + wv * 128;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int ul = wv * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+            const int u = blockIdx.x * kMU + ul;
+            const int c = __shfl(cntr[reg], hh * 32);
+            if (u >= U) continue;
+            for (int t = lane; t < 128; t += kWave) scratch[t] = t < c ? cand[(size_t)ul * kMCap + t] : 0ull;
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            wave_sort_desc_128(scratch, lane);
+            for (int t = lane; t < k; t += kWave) {
+                top_idx[(size_t)u * k + t] = cand_item(scratch[t]);
+                top_val[(size_t)u * k + t] = cand_score(scratch[t]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
         }
     }
 }
@@ -1279,8 +1323,7 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
     if (U < 0 || I <= 0 || U > 0x7fffffffll || I > 0x7fffffffll) return ARL_E_RANGE;
     if (U == 0) return ARL_OK;
     if (k <= 64 && (d == 16 || d == 32 || d == 64 || d == 128)) {        // matrix-core path
-        const size_t shm_m = sizeof(unsigned long long) * kMU * kMCap + sizeof(unsigned long long) * kMU + sizeof(int) * kMU +
-                             sizeof(float) * 2 * kMI * (size_t)(d + 4);
+        const size_t shm_m = sizeof(unsigned long long) * kMU * kMCap + sizeof(float) * 2 * (d <= 64 ? 64 : 32) * (size_t)(d + 4);
         const unsigned grid_m = (unsigned)((U + kMU - 1) / kMU);
 #define ARL_TOPK_CASE(DV)                                                                                                              \
         do {                                                                                                                           \
