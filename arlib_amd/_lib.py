@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libarlib_amd.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 
@@ -37,6 +37,7 @@ _SIGS = {
     'arl_spmm_csr_rows_workspace_bytes': (_i64, [_i64, _i64, _i64]),
     'arl_spmm_csr_rows_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _vp, _i64, _i64, _vp, _i64, _f, _vp, _vp, _vp]),
     'arl_mark_rows_u8': (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    'arl_mark_rows_bits_u32': (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     'arl_zero_rows_f32': (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     'arl_bpr_l2_workspace_bytes': (_i64, [_i64]),
     'arl_bpr_l2_fwd_bwd_f32': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _f, _f, _vp, _vp, _vp, _vp]),

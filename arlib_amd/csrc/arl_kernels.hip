@@ -200,74 +200,48 @@ __global__ __launch_bounds__(kBlock) void spmm_long_rows_kernel(CsrDev A, int d,
 }
 
 
-// ---- masked gather: the operand X is zero except on rows with xflags != 0 (the batch gradient G: <= 3B non-zero rows).
-// Per 64-edge window the flagged edges are compacted through a per-wave LDS slot array, so the work is proportional to
-// the flagged edges; `val` is only loaded for those.  Unflagged windows cost one coalesced col load + one byte gather.
-template <int LPR, int UNROLL>
-__device__ __forceinline__ float4 spmm_gather_masked(const int32_t *__restrict__ col, const float *__restrict__ val, int begin, int end,
-                                                     const float *__restrict__ X, int d, int lane, const uint8_t *__restrict__ xflags,
-                                                     int2 *__restrict__ slots) {
+// ---- masked hop: the operand X is zero except on rows whose bit is set in `xbits` (the batch gradient G: <= 3B rows).
+// The kernel is bound by its dependent-load chain (rowptr -> col -> flag bit -> G row) times the number of waves, not by
+// bandwidth, so every LPR-lane group of a wave owns its own row (4 rows per wave at d = 64): 4x fewer waves than wave-per-row,
+// no cross-group reduction; each group walks its edge list LPR edges at a time, tests one bit per edge and only gathers (and
+// only loads `val` for) the flagged ones.
+template <int LPR, int MODE>
+__global__ __launch_bounds__(kBlock) void spmm_rows_masked_gpr_kernel(CsrDev A, const float *__restrict__ X, int d, Epi ep,
+                                                                        const uint32_t *__restrict__ xbits) {
     constexpr int G = kWave / LPR;
+    const int lane = threadIdx.x & (kWave - 1);
     const int g = lane / LPR, q = lane % LPR;
+    const long long task = ((long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * G + g;
+    const long long total = (long long)A.n_chunks + A.n_rows;
+    int begin = 0, end = 0, row = -1, slot = -1;
+    if (task < A.n_chunks) {
+        slot = (int)task; begin = A.chunk_begin[slot]; end = A.chunk_end[slot];
+    } else if (task < total) {
+        row = (int)(task - A.n_chunks);
+        begin = A.rowptr[row]; end = A.rowptr[row + 1];
+        if (A.n_chunks > 0 && end - begin > A.chunk) { end = begin; row = -1; }     // long row: summed by spmm_long_rows_kernel
+    }
     const bool qact = (q * 4 < d);
     const float *xq = X + q * 4;
-    float4 acc[UNROLL];
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int base = begin; base < end; base += kWave) {
-        const int e = base + lane;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = begin; __any(base < end); base += LPR) {
+        const int e = base + q;
         int c = 0;
         bool f = false;
-        if (e < end) { c = col[e]; f = xflags[c] != 0; }
-        const unsigned long long mask = __ballot(f);
-        if (mask == 0ull) continue;
-        const int cnt = __popcll(mask);
-        if (f) {
-            const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-            slots[rank] = make_int2(c, __float_as_int(val[e]));
+        if (e < end) { c = A.col[e]; f = (xbits[c >> 5] >> (c & 31)) & 1u; }      // 1 bit per node: the item half of the bitmap (12.5 KB at cfg2) stays in L1
+        const unsigned long long wm = __ballot(f);
+        unsigned mask = (unsigned)((wm >> (g * LPR)) & ((LPR == 64) ? ~0ull : ((1ull << LPR) - 1ull)));
+        while (mask) {
+            const int j = __ffs((int)mask) - 1;
+            mask &= mask - 1;
+            const int cj = __shfl(c, g * LPR + j);
+            const float vj = A.val[base + j];
+            if (qact) fma4(acc, vj, *reinterpret_cast<const float4 *>(xq + (size_t)cj * d));
         }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        for (int j = 0; j < cnt; j += G * UNROLL) {
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int s = j + u * G + g;
-                if (qact && s < cnt) {
-                    const int2 cv = slots[s];
-                    const float4 x = *reinterpret_cast<const float4 *>(xq + (size_t)cv.x * d);
-                    fma4(acc[u], __int_as_float(cv.y), x);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
     }
-#pragma unroll
-    for (int u = 1; u < UNROLL; ++u) acc[0] = add4(acc[0], acc[u]);
-    return acc[0];
-}
-
-template <int LPR, int MODE>
-__global__ __launch_bounds__(kBlock) void spmm_rows_masked_kernel(CsrDev A, const float *__restrict__ X, int d, Epi ep, const uint8_t *__restrict__ xflags) {
-    __shared__ int2 slot_mem[kWavesPerBlock][kWave];
-    const int lane = threadIdx.x & (kWave - 1);
-    int2 *slots = slot_mem[threadIdx.x >> 6];
-    const long long task = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    const int q = lane % LPR;
-    if (task < A.n_chunks) {
-        const int t = (int)task;
-        float4 a = spmm_gather_masked<LPR, 2>(A.col, A.val, A.chunk_begin[t], A.chunk_end[t], X, d, lane, xflags, slots);
-        a = group_reduce<LPR>(a);
-        if (lane < LPR && q * 4 < d) *reinterpret_cast<float4 *>(A.partial + (size_t)t * d + q * 4) = a;
-        return;
-    }
-    const long long r = task - A.n_chunks;
-    if (r >= A.n_rows) return;
-    const int begin = A.rowptr[r], end = A.rowptr[r + 1];
-    if (A.n_chunks > 0 && end - begin > A.chunk) return;
-    float4 a = spmm_gather_masked<LPR, 2>(A.col, A.val, begin, end, X, d, lane, xflags, slots);
-    a = group_reduce<LPR>(a);
-    if (lane < LPR && q * 4 < d) spmm_epilogue<MODE>(ep, (int)r, d, q, a);
+    if (!qact) return;
+    if (slot >= 0) *reinterpret_cast<float4 *>(A.partial + (size_t)slot * d + q * 4) = acc;
+    else if (row >= 0) spmm_epilogue<MODE>(ep, row, d, q, acc);
 }
 
 // ---- row-subset SpMM: only the listed rows are produced (the last forward hop is consumed on the <= 3B batch rows only).
@@ -312,6 +286,13 @@ __global__ __launch_bounds__(kBlock) void mark_rows_kernel(uint8_t *__restrict__
     const int t = blockIdx.x * kBlock + threadIdx.x;
     if (t < n) flags[idx[t]] = (uint8_t)value;
 }
+__global__ __launch_bounds__(kBlock) void mark_bits_kernel(uint32_t *__restrict__ bits, const int32_t *__restrict__ idx, int n, int set) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n) return;
+    const int i = idx[t];
+    if (set) atomicOr(bits + (i >> 5), 1u << (i & 31));
+    else atomicAnd(bits + (i >> 5), ~(1u << (i & 31)));
+}
 __global__ __launch_bounds__(kBlock) void zero_rows_kernel(float *__restrict__ dst, const int32_t *__restrict__ idx, int n, int d) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -321,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void zero_rows_kernel(float *__restrict__ d
 }
 
 template <int MODE>
-int launch_spmm(const arl_csr *A, const float *X, int64_t d, const Epi &ep, hipStream_t st, const uint8_t *xflags = nullptr) {
+int launch_spmm(const arl_csr *A, const float *X, int64_t d, const Epi &ep, hipStream_t st, const uint32_t *xflags = nullptr) {
     if (!A || !X || !A->rowptr || (A->nnz > 0 && (!A->col || !A->val))) return ARL_E_NULL;
     if (d <= 0 || d > 256 || (d & 3)) return ARL_E_DIM;
     if (A->n_rows < 0 || A->n_rows > 0x7fffffffll || A->nnz > 0x7fffffffll || A->n_chunks > 0x7fffffffll) return ARL_E_RANGE;
@@ -340,7 +321,7 @@ int launch_spmm(const arl_csr *A, const float *X, int64_t d, const Epi &ep, hipS
     const int di = (int)d;
 #define ARL_SPMM_CASE(LPRV)                                                                              \
     do {                                                                                                 \
-        if (xflags) hipLaunchKernelGGL((spmm_rows_masked_kernel<LPRV, MODE>), dim3(grid), dim3(kBlock), 0, st, D, X, di, ep, xflags); \
+        if (xflags) hipLaunchKernelGGL((spmm_rows_masked_gpr_kernel<LPRV, MODE>), dim3((unsigned)((tasks + kWavesPerBlock * (kWave / LPRV) - 1) / (kWavesPerBlock * (kWave / LPRV)))), dim3(kBlock), 0, st, D, X, di, ep, xflags); \
         else hipLaunchKernelGGL((spmm_rows_kernel<LPRV, MODE>), dim3(grid), dim3(kBlock), 0, st, D, X, di, ep); \
         ARL_LAUNCH_CHECK();                                                                              \
         if (D.n_long > 0) {                                                                              \
@@ -1061,14 +1042,14 @@ int arl_spmm_csr_layersum_f32(const arl_csr *A, const float *X, int64_t d, const
     return launch_spmm<EPI_LAYERSUM>(A, X, d, ep, (hipStream_t)stream);
 }
 
-int arl_spmm_csr_flagged_f32(const arl_csr *A, const float *X, int64_t d, const uint8_t *xflags, float alpha, float beta, const float *Z,
+int arl_spmm_csr_flagged_f32(const arl_csr *A, const float *X, int64_t d, const uint32_t *xbits, float alpha, float beta, const float *Z,
                              const uint8_t *zflags, float *Y, arl_stream_t stream) {
     if (!Y) return ARL_E_NULL;
     if (beta != 0.f && !Z) return ARL_E_NULL;
     if (Y == X) return ARL_E_ARG;
     Epi ep = {};
     ep.alpha = alpha; ep.beta = beta; ep.Z = (beta != 0.f) ? Z : nullptr; ep.zflags = zflags; ep.Y = Y;
-    return launch_spmm<EPI_AXPBY>(A, X, d, ep, (hipStream_t)stream, xflags);
+    return launch_spmm<EPI_AXPBY>(A, X, d, ep, (hipStream_t)stream, xbits);
 }
 
 int arl_spmm_csr_adam_f32(const arl_csr *A, const float *X, int64_t d, float alpha, float beta, const float *Z, const uint8_t *zflags, float *P,
@@ -1128,6 +1109,15 @@ int arl_mark_rows_u8(uint8_t *flags, const int32_t *idx, int64_t n, int32_t valu
     if (n < 0 || n > 0x7fffffffll) return ARL_E_ARG;
     if (n == 0) return ARL_OK;
     hipLaunchKernelGGL(mark_rows_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, flags, idx, (int)n, (int)value);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_mark_rows_bits_u32(uint32_t *bits, const int32_t *idx, int64_t n, int32_t set, arl_stream_t stream) {
+    if (!bits || !idx) return ARL_E_NULL;
+    if (n < 0 || n > 0x7fffffffll) return ARL_E_ARG;
+    if (n == 0) return ARL_OK;
+    hipLaunchKernelGGL(mark_bits_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, bits, idx, (int)n, (int)set);
     ARL_LAUNCH_CHECK();
     return ARL_OK;
 }

@@ -197,6 +197,7 @@ class ShardedPropagationEngine:
         s = 1.0 / (L + 1)
         if getattr(self, '_sp_B', None) != B:
             self.flags = torch.zeros(self.Nl, dtype=torch.uint8, device=dev)
+            self.bits = torch.zeros((self.Nl + 31) // 32, dtype=torch.int32, device=dev)
             self.C = torch.zeros(3 * B, d, dtype=torch.float32, device=dev)
             self.Gc = torch.zeros(3 * B, d, dtype=torch.float32, device=dev)
             self.ar = torch.arange(B, dtype=torch.int32, device=dev)
@@ -230,8 +231,10 @@ class ShardedPropagationEngine:
         if lu.numel():
             k.scatter_add_rows(self.G, lu, self.Gc[loc].contiguous(), 1.0)
             k.mark_rows_(self.flags, lu, 1)
+            k.mark_bits_(self.bits, lu, True, self.Nl)
         k.scatter_add_rows(self.G, item_rows_packed, self.Gc[B:].contiguous(), 1.0)
         k.mark_rows_(self.flags, item_rows_packed, 1)
+        k.mark_bits_(self.bits, item_rows_packed, True, self.Nl)
         # backward (Horner).  hop 1: flag-masked gathers; later hops dense; G (complete on the item side) added through flags
         self.t += 1
         zu, zi = self.flags[:Ul], self.flags[Ul:]
@@ -242,7 +245,7 @@ class ShardedPropagationEngine:
             dst = self.hops[h % 2] if L <= 3 else self.hops[h % len(self.hops)]
             if dst is acc:
                 dst = self.hops[(h + 1) % len(self.hops)]
-            xf = self.flags if h == 0 else None
+            xf = self.bits if h == 0 else None
             di, du = dst[Ul:], dst[:Ul]
             k.spmm_flagged(self.Ai, acc, xf, a, 0.0, None, None, out=di)
             work = self.comm.all_reduce_async(di)
@@ -258,8 +261,10 @@ class ShardedPropagationEngine:
         if lu.numel():
             k.zero_rows_(self.G, lu)
             k.mark_rows_(self.flags, lu, 0)
+            k.mark_bits_(self.bits, lu, False, self.Nl)
         k.zero_rows_(self.G, item_rows_packed)
         k.mark_rows_(self.flags, item_rows_packed, 0)
+        k.mark_bits_(self.bits, item_rows_packed, False, self.Nl)
         return self.loss_out
 
     def gather_full_table(self):

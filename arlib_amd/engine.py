@@ -166,25 +166,28 @@ class PropagationEngine:
         ops.bpr_l2_fwd_bwd(self.out_c, B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self._ws, loss_out=self.loss_out, check_range=False)
         ops.scatter_add_rows(self.G, rows, self.Gc, 1.0, check_range=False)          # duplicates accumulate
         ops.mark_rows_(self.flags, rows, 1, check_range=False)
+        ops.mark_bits_(self.bits, rows, True, self.N, check_range=False)
         # backward (Horner): first hop gathers flagged rows only; G is read through the flags everywhere
         self.t += 1
         if L == 1:
-            ops.spmm_flagged(A, self.G, self.flags, s, s, self.G, self.flags, out=self.hops[0])
+            ops.spmm_flagged(A, self.G, self.bits, s, s, self.G, self.flags, out=self.hops[0])
             ops.adam_dense(self.E0, self.hops[0], self.m, self.v, self.lr, self.t, self.betas, self.eps)
         else:
-            acc = ops.spmm_flagged(A, self.G, self.flags, 1.0, 1.0, self.G, self.flags, out=self.hops[0])
+            acc = ops.spmm_flagged(A, self.G, self.bits, 1.0, 1.0, self.G, self.flags, out=self.hops[0])
             for k in range(1, L - 1):
                 acc = ops.spmm_flagged(A, acc, None, 1.0, 1.0, self.G, self.flags, out=self.hops[k % 2 if len(self.hops) == 2 else k])
             ops.spmm_adam(A, acc, s, s, self.G, self.E0, self.m, self.v, self.lr, self.t, self.betas, self.eps, zflags=self.flags)
         ops.zero_rows_(self.G, rows, check_range=False)
         ops.mark_rows_(self.flags, rows, 0, check_range=False)
+        ops.mark_bits_(self.bits, rows, False, self.N, check_range=False)
         return self.loss_out
 
     def _sparse_buffers(self, B):
         if getattr(self, '_sparse_B', None) == B:
             return
         dev, d = self.device, self.d
-        self.flags = torch.zeros(self.N, dtype=torch.uint8, device=dev)
+        self.flags = torch.zeros(self.N, dtype=torch.uint8, device=dev)          # byte per row: read once per OUTPUT row (epilogue)
+        self.bits = torch.zeros((self.N + 31) // 32, dtype=torch.int32, device=dev)   # bit per node: read once per EDGE (masked hop)
         self.Gc = torch.zeros(3 * B, d, dtype=torch.float32, device=dev)
         self.out_c = torch.empty(3 * B, d, dtype=torch.float32, device=dev)
         self.nsplit = 16

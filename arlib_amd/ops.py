@@ -212,16 +212,18 @@ def spmm_adam(A, X, alpha, beta, Z, P, M, V, lr, step, betas=(0.9, 0.999), eps=1
 
 
 def spmm_flagged(A, X, xflags=None, alpha=1.0, beta=0.0, Z=None, zflags=None, out=None):
-    """out = alpha*(A@X) + beta*Z where X is zero except on rows with xflags != 0 (masked gather) and Z is read only where
-    zflags != 0.  Either flag vector may be None (= dense)."""
+    """out = alpha*(A@X) + beta*Z where X is zero except on rows whose bit is set in the bitmap `xflags` (int32 words; see
+    mark_bits_) and Z is read only where the byte flag zflags != 0.  Either may be None (= dense)."""
     d = _check_xy(A, X, 'X', A.n_cols)
     Y = torch.empty(A.n_rows, d, dtype=torch.float32, device=X.device) if out is None else out
     if _check_xy(A, Y, 'out') != d or Y.data_ptr() == X.data_ptr():
         raise ValueError('spmm_flagged: out must be [n_rows, d] and must not alias X')
     if beta != 0.0 and (Z is None or _check_xy(A, Z, 'Z') != d):
         raise ValueError('spmm_flagged: Z [n_rows, d] required when beta != 0')
-    if xflags is not None:
-        _check_flags(xflags, A.n_cols, 'xflags')
+    if xflags is not None:          # bitmap: int32 words, bit c&31 of word c>>5
+        _dev(xflags, torch.int32, 'xflags (bitmap)', 1)
+        if xflags.numel() != (A.n_cols + 31) // 32:
+            raise ValueError('spmm_flagged: bitmap needs ceil(n_cols/32) int32 words')
     if zflags is not None:
         _check_flags(zflags, A.n_rows, 'zflags')
     s = A._struct(d)
@@ -269,6 +271,17 @@ def mark_rows_(flags, idx, value, check_range=True):
         raise IndexError('mark_rows_: index out of range')
     check(_lib.lib().arl_mark_rows_u8(_ptr(flags), _ptr(idx), idx.numel(), int(value), _stream()), 'arl_mark_rows_u8')
     return flags
+
+
+def mark_bits_(bits, idx, set_, n_nodes, check_range=True):
+    """Set / clear bits idx[t] of a node bitmap (int32 words)."""
+    _dev(bits, torch.int32, 'bits', 1); _dev(idx, torch.int32, 'idx', 1)
+    if bits.numel() != (n_nodes + 31) // 32:
+        raise ValueError('mark_bits_: bitmap size')
+    if check_range and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= n_nodes):
+        raise IndexError('mark_bits_: index out of range')
+    check(_lib.lib().arl_mark_rows_bits_u32(_ptr(bits), _ptr(idx), idx.numel(), 1 if set_ else 0, _stream()), 'arl_mark_rows_bits_u32')
+    return bits
 
 
 def zero_rows_(dst, idx, check_range=True):

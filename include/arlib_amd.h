@@ -106,22 +106,24 @@ int arl_spmm_csr_adam_f32(const arl_csr *A, const float *X, int64_t d, float alp
 /* Sparse-batch-gradient forms.  In one training step dL/d(out) (= G) is non-zero on at most 3B rows and the last forward
  * hop is consumed on those rows only, so two of the 2L full-graph hops of recommender/LightGCN.py:230-240 + autograd
  * collapse to work proportional to the batch neighbourhood (results identical to the dense hops):
- *   arl_spmm_csr_flagged_f32  Y = alpha*(A X) + beta*Z where X is zero except on rows with xflags != 0 (flagged edges are
- *                             compacted per 64-edge window; xflags == NULL = dense gather) and Z is read only where
- *                             zflags != 0 (NULL = everywhere).  xflags: [n_cols] bytes, zflags: [n_rows] bytes.
+ *   arl_spmm_csr_flagged_f32  Y = alpha*(A X) + beta*Z where X is zero except on rows whose bit is set in the bitmap xbits
+ *                             (uint32 words, bit c&31 of word c>>5; NULL = dense gather) and Z is read only where
+ *                             zflags != 0 (NULL = everywhere).  xbits: ceil(n_cols/32) words, zflags: [n_rows] bytes.
  *   arl_spmm_csr_rows_f32     out_c[t] = alpha * ( sum_k layers[k][rows[t]] + (A X)[rows[t]] ), t < n_rows_sel: only the
  *                             listed rows are produced (duplicates allowed).  Each row is cut into `nsplit` edge ranges;
  *                             workspace = arl_spmm_csr_rows_workspace_bytes(n_rows_sel, nsplit, d).  layers: HOST array of
  *                             n_layers (<= 8) device pointers to [n_rows, d] tables.
  *   arl_spmm_csr_adam_f32's zflags has the same meaning (NULL = read Z everywhere).
  *   arl_mark_rows_u8 / arl_zero_rows_f32: flags[idx[t]] = value / dst[idx[t], :] = 0 -- set and clear the batch's sparse state. */
-int arl_spmm_csr_flagged_f32(const arl_csr *A, const float *X, int64_t d, const uint8_t *xflags, float alpha, float beta,
+int arl_spmm_csr_flagged_f32(const arl_csr *A, const float *X, int64_t d, const uint32_t *xbits, float alpha, float beta,
                              const float *Z, const uint8_t *zflags, float *Y, arl_stream_t stream);
 int64_t arl_spmm_csr_rows_workspace_bytes(int64_t n_rows_sel, int64_t nsplit, int64_t d);
 int arl_spmm_csr_rows_f32(const arl_csr *A, const float *X, int64_t d, const int32_t *rows, int64_t n_rows_sel,
                           int64_t nsplit, const float *const *layers, int64_t n_layers, float alpha, float *out_c,
                           void *workspace, arl_stream_t stream);
 int arl_mark_rows_u8(uint8_t *flags, const int32_t *idx, int64_t n, int32_t value, arl_stream_t stream);
+/* set (set != 0) or clear the bits idx[t] of a bitmap with atomic OR / AND (duplicates allowed) */
+int arl_mark_rows_bits_u32(uint32_t *bits, const int32_t *idx, int64_t n, int32_t set, arl_stream_t stream);
 int arl_zero_rows_f32(float *dst, const int32_t *idx, int64_t n, int64_t d, arl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -68,8 +68,11 @@ def spmm_rows(A, X, rows, layers=(), alpha=1.0, nsplit=16, out=None, workspace=N
 
 def spmm_flagged(A, X, xflags=None, alpha=1.0, beta=0.0, Z=None, zflags=None, out=None):
     Xn = X.numpy()
-    if xflags is not None:
-        assert np.all(Xn[xflags.numpy() == 0] == 0), 'operand must be zero on unflagged rows'
+    if xflags is not None:          # bitmap
+        bits = xflags.numpy().view(np.uint32)
+        rows = np.arange(Xn.shape[0])
+        on = (bits[rows >> 5] >> (rows & 31)) & 1
+        assert np.all(Xn[on == 0] == 0), 'operand must be zero on rows whose bit is clear'
     Zn = None
     if beta != 0.0:
         Zn = Z.numpy().copy()
@@ -111,6 +114,14 @@ def scatter_add_rows(dst, idx, src, scale=1.0, check_range=True):
 def mark_rows_(flags, idx, value, check_range=True):
     flags[idx.long()] = value
     return flags
+
+
+def mark_bits_(bits, idx, set_, n_nodes, check_range=True):
+    b = bits.numpy().view(np.uint32)
+    for i in np.unique(idx.numpy()).astype(np.int64):
+        w, m = int(i) >> 5, 1 << (int(i) & 31)
+        b[w] = np.uint32((int(b[w]) | m) if set_ else (int(b[w]) & (~m & 0xFFFFFFFF)))
+    return bits
 
 
 def zero_rows_(dst, idx, check_range=True):

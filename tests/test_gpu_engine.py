@@ -157,7 +157,7 @@ def test_sparse_step_equals_dense_step(mods):
             assert np.allclose(la, lb, rtol=RTOL, atol=0), (L, k)
         assert rel_err(ea.E0.cpu().numpy(), eb.E0.cpu().numpy()) < RTOL, L
         assert rel_err(ea.m.cpu().numpy(), eb.m.cpu().numpy()) < RTOL and rel_err(ea.v.cpu().numpy(), eb.v.cpu().numpy()) < RTOL
-        assert float(ea.G.abs().max()) == 0.0 and int(ea.flags.max()) == 0       # sparse state is cleared after every step
+        assert float(ea.G.abs().max()) == 0.0 and int(ea.flags.max()) == 0 and int(ea.bits.abs().max()) == 0       # sparse state is cleared after every step
 
 
 def test_spmm_rows_and_flagged_primitives(mods):
@@ -184,12 +184,18 @@ def test_spmm_rows_and_flagged_primitives(mods):
     Gs[nz] = rng.standard_normal((300, d)).astype(np.float32)
     flags = np.zeros(N, np.uint8); flags[nz] = 1
     ref = O.spmm(csr, Gs, 1.0, 1.0, Gs)
-    got = ops.spmm_flagged(A, T(Gs), T(flags), 1.0, 1.0, T(Gs), T(flags)).cpu().numpy()
+    bits = torch.zeros((N + 31) // 32, dtype=torch.int32, device=DEV)
+    ops.mark_bits_(bits, T(np.concatenate([nz, nz[:7]]).astype(np.int32)), True, N)
+    bn = bits.cpu().numpy().view(np.uint32)
+    assert np.array_equal(((bn[np.arange(N) >> 5] >> (np.arange(N) & 31)) & 1).astype(np.uint8), flags)
+    got = ops.spmm_flagged(A, T(Gs), bits, 1.0, 1.0, T(Gs), T(flags)).cpu().numpy()
     assert rel_err(got, ref) < RTOL
     got2 = ops.spmm_flagged(A, T(X), None, 0.5, 0.5, T(Gs), T(flags)).cpu().numpy()
     assert rel_err(got2, O.spmm(csr, X, 0.5, 0.5, Gs)) < RTOL
     f = torch.zeros(N, dtype=torch.uint8, device=DEV)
     ops.mark_rows_(f, T(nz.astype(np.int32)), 1)
     assert np.array_equal(f.cpu().numpy(), flags)
+    ops.mark_bits_(bits, T(nz.astype(np.int32)), False, N)
+    assert int(bits.abs().max()) == 0
     Z = T(Gs.copy()); ops.zero_rows_(Z, T(nz.astype(np.int32)))
     assert float(Z.abs().max()) == 0.0
