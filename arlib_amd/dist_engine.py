@@ -210,17 +210,26 @@ class ShardedPropagationEngine:
         lu = (u[loc] - self.u0).to(torch.int32).contiguous()
         item_rows = torch.cat([p, n]).to(torch.int32).contiguous()              # item ids of ALL samples, [2B]
         item_rows_packed = item_rows + Ul
-        # forward
+        # forward.  Software pipeline over hops: the item-row all-reduce of hop h runs behind A_u(h) AND A_i(h+1) -- the
+        # item-side kernel of the next hop only gathers USER rows, which are local and already final.
         layers = [self.E0]
+        pending = None
         for h in range(L - 1):
-            self._hop(layers[-1], self.hops[h])
-            layers.append(self.hops[h])
+            src, dst = layers[-1], self.hops[h]
+            k.spmm(self.Ai, src, out=dst[Ul:])                 # partial item rows (gathers user rows of src)
+            if pending is not None:
+                pending.wait()                                 # src's item rows are complete from here on
+            pending = self.comm.all_reduce_async(dst[Ul:])
+            k.spmm(self.Au, src, out=dst[:Ul])                 # exact user rows (gathers item rows of src)
+            layers.append(dst)
         X = layers[-1]
         self.C.zero_()
+        self.C[B:] = k.spmm_rows(self.Ai, X, item_rows, (), 1.0)     # partial; overlaps the last full all-reduce
+        if pending is not None:
+            pending.wait()
         if lu.numel():
             cu = k.spmm_rows(self.Au, X, lu, [t[:Ul] for t in layers], 1.0)
             self.C[loc] = cu
-        self.C[B:] = k.spmm_rows(self.Ai, X, item_rows, (), 1.0)
         self.comm.all_reduce(self.C)
         for t in layers:
             self.C[B:] += k.gather_rows(t, item_rows_packed)
@@ -237,25 +246,28 @@ class ShardedPropagationEngine:
         k.mark_bits_(self.bits, item_rows_packed, True, self.Nl)
         # backward (Horner).  hop 1: flag-masked gathers; later hops dense; G (complete on the item side) added through flags
         self.t += 1
-        zu, zi = self.flags[:Ul], self.flags[Ul:]
+        zu = self.flags[:Ul]
         acc = self.G
+        pending, prev_items, prev_a = None, None, 1.0
         for h in range(L):
             last = h == L - 1
             a = s if last else 1.0
-            dst = self.hops[h % 2] if L <= 3 else self.hops[h % len(self.hops)]
+            dst = self.hops[h % len(self.hops)]
             if dst is acc:
                 dst = self.hops[(h + 1) % len(self.hops)]
             xf = self.bits if h == 0 else None
-            di, du = dst[Ul:], dst[:Ul]
-            k.spmm_flagged(self.Ai, acc, xf, a, 0.0, None, None, out=di)
-            work = self.comm.all_reduce_async(di)
+            k.spmm_flagged(self.Ai, acc, xf, a, 0.0, None, None, out=dst[Ul:])     # partial item rows (gathers acc's user rows)
+            if pending is not None:                                                # complete acc's item rows before A_u reads them
+                pending.wait()
+                prev_items.add_(self.G[Ul:], alpha=prev_a)
+            pending, prev_items, prev_a = self.comm.all_reduce_async(dst[Ul:]), dst[Ul:], a
             if last:
                 k.spmm_adam(self.Au, acc, a, a, self.G[:Ul], self.E0[:Ul], self.m[:Ul], self.v[:Ul], self.lr, self.t, self.betas, self.eps, zflags=zu)
             else:
-                k.spmm_flagged(self.Au, acc, xf, a, a, self.G[:Ul], zu, out=du)
-            work.wait()
-            di.add_(self.G[Ul:], alpha=a)
+                k.spmm_flagged(self.Au, acc, xf, a, a, self.G[:Ul], zu, out=dst[:Ul])
             acc = dst
+        pending.wait()
+        prev_items.add_(self.G[Ul:], alpha=prev_a)
         k.adam_dense(self.E0[Ul:], acc[Ul:], self.m[Ul:], self.v[Ul:], self.lr, self.t, self.betas, self.eps)
         # clear the sparse state
         if lu.numel():
