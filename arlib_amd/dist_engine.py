@@ -206,8 +206,10 @@ class ShardedPropagationEngine:
             self.hops = [self.Ea, self.Eb] + [torch.empty_like(self.Ea) for _ in range(max(0, L - 3))]
             self.G.zero_()
             self._sp_B = B
-        loc = ((u >= self.u0) & (u < self.u1)).nonzero().squeeze(1)            # positions of this rank's samples
-        lu = (u[loc] - self.u0).to(torch.int32).contiguous()
+        # static shapes, no host sync: samples of other ranks' users are kept with a clamped row id and a zero weight
+        own = ((u >= self.u0) & (u < self.u1))
+        ownf = own.to(torch.float32).unsqueeze(1)
+        lu = (u - self.u0).clamp_(0, max(Ul - 1, 0)).to(torch.int32).contiguous()
         item_rows = torch.cat([p, n]).to(torch.int32).contiguous()              # item ids of ALL samples, [2B]
         item_rows_packed = item_rows + Ul
         # forward.  Software pipeline over hops: the item-row all-reduce of hop h runs behind A_u(h) AND A_i(h+1) -- the
@@ -227,9 +229,8 @@ class ShardedPropagationEngine:
         self.C[B:] = k.spmm_rows(self.Ai, X, item_rows, (), 1.0)     # partial; overlaps the last full all-reduce
         if pending is not None:
             pending.wait()
-        if lu.numel():
-            cu = k.spmm_rows(self.Au, X, lu, [t[:Ul] for t in layers], 1.0)
-            self.C[loc] = cu
+        if Ul:
+            self.C[:B] = k.spmm_rows(self.Au, X, lu, [t[:Ul] for t in layers], 1.0) * ownf      # the owner contributes the row, others zeros
         self.comm.all_reduce(self.C)
         for t in layers:
             self.C[B:] += k.gather_rows(t, item_rows_packed)
@@ -237,8 +238,8 @@ class ShardedPropagationEngine:
         # loss on the whole batch (identical on every rank), compact per-sample gradients
         self.Gc.zero_()
         k.bpr_l2_fwd_bwd(self.C, B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self.ws, loss_out=self.loss_out, check_range=False)
-        if lu.numel():
-            k.scatter_add_rows(self.G, lu, self.Gc[loc].contiguous(), 1.0)
+        if Ul:
+            k.scatter_add_rows(self.G, lu, self.Gc[:B] * ownf, 1.0)        # foreign samples add exact zeros to a clamped row
             k.mark_rows_(self.flags, lu, 1)
             k.mark_bits_(self.bits, lu, True, self.Nl)
         k.scatter_add_rows(self.G, item_rows_packed, self.Gc[B:].contiguous(), 1.0)
@@ -270,7 +271,7 @@ class ShardedPropagationEngine:
         prev_items.add_(self.G[Ul:], alpha=prev_a)
         k.adam_dense(self.E0[Ul:], acc[Ul:], self.m[Ul:], self.v[Ul:], self.lr, self.t, self.betas, self.eps)
         # clear the sparse state
-        if lu.numel():
+        if Ul:
             k.zero_rows_(self.G, lu)
             k.mark_rows_(self.flags, lu, 0)
             k.mark_bits_(self.bits, lu, False, self.Nl)
