@@ -38,12 +38,6 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _same_device(*ts):
-    devs = {t.device for t in ts if t is not None}
-    if len(devs) > 1:
-        raise ValueError('tensors on different devices: %s' % devs)
-
-
 # ------------------------------------------------------------------------------------------------ graph
 class CSRGraph:
     """Device CSR of the normalised (U+I)^2 adjacency plus the long-row plan used by the SpMM kernels.
