@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libarlib_amd.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 
@@ -23,6 +23,12 @@ class arl_csr(C.Structure):
                 ('long_count', C.c_void_p), ('partial', C.c_void_p)]
 
 
+class arl_tiled(C.Structure):
+    _fields_ = [('n_sweeps', C.c_int64), ('n_slots', C.c_int64), ('cap', C.c_int64), ('n_cb', C.c_int64), ('nnz', C.c_int64),
+                ('n_groups', C.c_int64), ('bin_rows', C.c_void_p), ('seg_ptr', C.c_void_p), ('e_col', C.c_void_p), ('e_val', C.c_void_p),
+                ('e_row', C.c_void_p)]
+
+
 _vp, _i64, _i32, _f = C.c_void_p, C.c_int64, C.c_int32, C.c_float
 _SIGS = {
     'arl_abi_version': (C.c_int, []),
@@ -33,6 +39,8 @@ _SIGS = {
     'arl_spmm_csr_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _f, _f, _vp, _vp, _vp]),
     'arl_spmm_csr_layersum_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _vp, _vp, _vp, _vp]),
     'arl_spmm_csr_adam_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),
+    'arl_spmm_tiled_f32': (C.c_int, [C.POINTER(arl_tiled), _vp, _i64, _f, _f, _vp, _vp, _vp, _vp]),
+    'arl_spmm_tiled_adam_f32': (C.c_int, [C.POINTER(arl_tiled), _vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),
     'arl_spmm_csr_flagged_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _vp, _f, _f, _vp, _vp, _vp, _vp]),
     'arl_spmm_csr_rows_workspace_bytes': (_i64, [_i64, _i64, _i64]),
     'arl_spmm_csr_rows_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _vp, _i64, _i64, _vp, _i64, _f, _vp, _vp, _vp]),

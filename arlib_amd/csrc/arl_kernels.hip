@@ -301,15 +301,142 @@ __global__ __launch_bounds__(kBlock) void zero_rows_kernel(float *__restrict__ d
     for (int k = lane; k < d; k += kWave) o[k] = 0.f;
 }
 
+// ================================================================================================
+// L2-blocked ("tiled") SpMM.  The row-per-wave kernel above moves one 256-B row per edge through the Infinity-Cache fabric
+// (~8 TB/s).  Gathers that hit the XCD's 4 MB L2 run 2.2x faster (tools/l2_gather_bench.py: 15.8 TB/s from a 2 MB table), so
+// this form makes the gathered rows L2-resident:
+//   * columns are cut into blocks of Tc rows (Tc*4d bytes ~ 2 MB);
+//   * every workgroup (one per CU, persistent over `n_sweeps` sweeps) owns a BIN of up to `cap` output rows whose fp32
+//     accumulators live in LDS for a whole sweep, and walks the column blocks in ascending order -- all CUs of an XCD are on
+//     the same column block at about the same time (bins carry equal numbers of edges), so each gathered row is fetched from
+//     the fabric once per XCD and then served from L2 to every bin that needs it;
+//   * a bin's edges are stored sorted by (column block, local row, col); a 16-lane group accumulates a run of edges of one
+//     row in registers and flushes it to the LDS accumulator with ds_add_f32 (runs from different waves commute);
+//   * the epilogue (alpha*AX + beta*Z, or the fused Adam update) runs when a sweep's accumulators are written out.
+// No inter-workgroup communication: XCD co-scheduling only affects speed, never correctness.
+struct TiledDev {
+    int n_sweeps, n_slots, cap, n_cb, n_groups;   // bins = n_sweeps * n_slots; n_cb column blocks; n_groups = 16 waves * (64/LPR)
+    const int32_t *bin_rows;                   // [bins][cap] global row id or -1
+    const int32_t *seg_ptr;                    // [bins * n_groups + 1] edge offsets of the (bin, owner group) lists
+    const int32_t *e_col;                      // [nnz] column (global row of X)
+    const float *e_val;                        // [nnz]
+    const uint16_t *e_row;                     // [nnz] local row inside the bin
+};
+
+constexpr int kTiledThreads = 1024;
+constexpr int kTiledWaves = kTiledThreads / kWave;
+
+// Every LPR-lane group OWNS a fixed subset of the bin's local rows for the whole sweep and only ever touches the edges of
+// its own rows: the bin's edges are sorted by (owner group, column block, local row, column), so a group streams ONE
+// contiguous edge list per sweep (prefetched a round ahead) whose order walks the column blocks in ascending order.  Groups
+// hold equal numbers of edges (snake deal by degree), so all groups of all CUs cross the column blocks at about the same
+// time -- that is what keeps the gathered rows L2-resident -- without any barrier or per-block pointer.  LDS accumulators
+// are updated with plain read-add-write (exclusive ownership): no atomics, deterministic.
+template <int LPR, int MODE>
+__global__ __launch_bounds__(kTiledThreads) void spmm_tiled_kernel(TiledDev T, const float *__restrict__ X, int d, Epi ep) {
+    constexpr int G = kWave / LPR;
+    extern __shared__ float acc_lds[];                        // [cap][ld]
+    const int ld = d + 4;                                     // row stride: consecutive rows start 4 banks apart
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = lane / LPR, q = lane % LPR;
+    const int og = wv * G + g;                                // owner-group id inside the workgroup
+    const bool qact = q * 4 < d;
+    const float *xq = X + q * 4;
+    for (int sweep = 0; sweep < T.n_sweeps; ++sweep) {
+        const int bin = sweep * T.n_slots + blockIdx.x;
+        for (int t = tid; t < T.cap * ld; t += kTiledThreads) acc_lds[t] = 0.f;
+        const int lo = T.seg_ptr[(size_t)bin * T.n_groups + og], hi = T.seg_ptr[(size_t)bin * T.n_groups + og + 1];
+        __syncthreads();
+        // prefetch round 0
+        int c_n = 0, r_n = -1;
+        float v_n = 0.f;
+        if (lo + q < hi) { c_n = T.e_col[lo + q]; v_n = T.e_val[lo + q]; r_n = T.e_row[lo + q]; }
+        for (int base = lo; __any(base < hi); base += LPR) {
+            const int c = c_n, rloc = r_n;
+            const float v = v_n;
+            const int e2 = base + LPR + q;                     // next round's edge of this lane, in flight during this round
+            c_n = 0; v_n = 0.f; r_n = -1;
+            if (e2 < hi) { c_n = T.e_col[e2]; v_n = T.e_val[e2]; r_n = T.e_row[e2]; }
+            const int n = min(LPR, hi - base);                 // this group's edges in this round (<= 0: none)
+            float4 x[LPR];
+#pragma unroll
+            for (int j = 0; j < LPR; ++j) {                    // all gathers of the round in flight together
+                const int cj = __shfl(c, g * LPR + j);
+                x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (qact && j < n) x[j] = *reinterpret_cast<const float4 *>(xq + (size_t)cj * d);
+            }
+            float4 run = make_float4(0.f, 0.f, 0.f, 0.f);
+            int cur = -1;
+#pragma unroll
+            for (int j = 0; j < LPR; ++j) {
+                const float vj = __shfl(v, g * LPR + j);
+                const int rj = __shfl(rloc, g * LPR + j);
+                if (j < n) {
+                    if (rj != cur) {
+                        if (cur >= 0 && qact) { float4 *a = reinterpret_cast<float4 *>(acc_lds + cur * ld + q * 4); *a = add4(*a, run); }
+                        cur = rj;
+                        run = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    fma4(run, vj, x[j]);
+                }
+            }
+            if (cur >= 0 && qact) { float4 *a = reinterpret_cast<float4 *>(acc_lds + cur * ld + q * 4); *a = add4(*a, run); }
+        }
+        __syncthreads();
+        // write-out with the epilogue: one LPR-lane group per row of the bin
+        const int32_t *rows = T.bin_rows + (size_t)bin * T.cap;
+        for (int i = og; i < T.cap; i += kTiledWaves * G) {
+            const int r = rows[i];
+            if (r >= 0 && qact) {
+                const float4 a = *reinterpret_cast<const float4 *>(acc_lds + i * ld + q * 4);
+                spmm_epilogue<MODE>(ep, r, d, q, a);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int MODE>
+int launch_spmm_tiled(const arl_tiled *T, const float *X, int64_t d, const Epi &ep, hipStream_t st) {
+    if (!T || !X || !T->bin_rows || !T->seg_ptr || !T->e_col || !T->e_val || !T->e_row) return ARL_E_NULL;
+    if (d <= 0 || d > 256 || (d & 3)) return ARL_E_DIM;
+    if (T->n_sweeps < 0 || T->n_slots <= 0 || T->cap <= 0 || T->cap > 65535 || T->n_cb <= 0) return ARL_E_ARG;
+    {
+        const int64_t lpr = d <= 16 ? 4 : d <= 32 ? 8 : d <= 64 ? 16 : d <= 128 ? 32 : 64;
+        if (T->n_groups != kTiledWaves * (kWave / lpr)) return ARL_E_ARG;      // the plan is built for one embedding width class
+    }
+    if (T->n_sweeps == 0) return ARL_OK;
+    TiledDev D;
+    D.n_sweeps = (int)T->n_sweeps; D.n_slots = (int)T->n_slots; D.cap = (int)T->cap; D.n_cb = (int)T->n_cb; D.n_groups = (int)T->n_groups;
+    D.bin_rows = T->bin_rows; D.seg_ptr = T->seg_ptr; D.e_col = T->e_col; D.e_val = T->e_val; D.e_row = T->e_row;
+    const size_t shm = sizeof(float) * (size_t)D.cap * (size_t)(d + 4);
+    if (shm > 160 * 1024) return ARL_E_ARG;
+    const int di = (int)d;
+#define ARL_TILED_CASE(LPRV)                                                                                                   \
+    do {                                                                                                                       \
+        hipError_t e1 = hipFuncSetAttribute((const void *)spmm_tiled_kernel<LPRV, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+        if (e1 != hipSuccess) return (int)e1;                                                                                  \
+        hipLaunchKernelGGL((spmm_tiled_kernel<LPRV, MODE>), dim3((unsigned)D.n_slots), dim3(kTiledThreads), shm, st, D, X, di, ep); \
+    } while (0)
+    if (d <= 16) ARL_TILED_CASE(4);
+    else if (d <= 32) ARL_TILED_CASE(8);
+    else if (d <= 64) ARL_TILED_CASE(16);
+    else if (d <= 128) ARL_TILED_CASE(32);
+    else ARL_TILED_CASE(64);
+#undef ARL_TILED_CASE
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
 template <int MODE>
 int launch_spmm(const arl_csr *A, const float *X, int64_t d, const Epi &ep, hipStream_t st, const uint32_t *xflags = nullptr) {
-    if (!A || !X || !A->rowptr || (A->nnz > 0 && (!A->col || !A->val))) return ARL_E_NULL;
+    if (!A || !X || (A->n_rows > 0 && !A->rowptr) || (A->nnz > 0 && (!A->col || !A->val))) return ARL_E_NULL;
     if (d <= 0 || d > 256 || (d & 3)) return ARL_E_DIM;
     if (A->n_rows < 0 || A->n_rows > 0x7fffffffll || A->nnz > 0x7fffffffll || A->n_chunks > 0x7fffffffll) return ARL_E_RANGE;
     if (A->n_chunks > 0 && (!A->chunk_row || !A->chunk_begin || !A->chunk_end || !A->partial || A->chunk <= 0)) return ARL_E_NULL;
     if (A->n_long > 0 && (!A->long_row || !A->long_first || !A->long_count)) return ARL_E_NULL;
     if ((A->n_chunks > 0) != (A->n_long > 0)) return ARL_E_ARG;
-    if (A->n_rows == 0) return ARL_OK;
+    if (A->n_rows == 0 && A->n_chunks == 0) return ARL_OK;       // n_rows == 0 with a chunk plan = "long rows only" (hub pass of the tiled SpMM)
     CsrDev D;
     D.n_rows = (int)A->n_rows; D.rowptr = A->rowptr; D.col = A->col; D.val = A->val;
     D.chunk = A->chunk; D.n_chunks = (int)A->n_chunks; D.chunk_row = A->chunk_row; D.chunk_begin = A->chunk_begin;
@@ -1040,6 +1167,28 @@ int arl_spmm_csr_layersum_f32(const arl_csr *A, const float *X, int64_t d, const
     Epi ep = {};
     ep.S_in = S_in; ep.S = S; ep.Y = Y;
     return launch_spmm<EPI_LAYERSUM>(A, X, d, ep, (hipStream_t)stream);
+}
+
+int arl_spmm_tiled_f32(const arl_tiled *T, const float *X, int64_t d, float alpha, float beta, const float *Z, const uint8_t *zflags, float *Y,
+                       arl_stream_t stream) {
+    if (!Y) return ARL_E_NULL;
+    if (beta != 0.f && !Z) return ARL_E_NULL;
+    if (Y == X) return ARL_E_ARG;
+    Epi ep = {};
+    ep.alpha = alpha; ep.beta = beta; ep.Z = (beta != 0.f) ? Z : nullptr; ep.zflags = zflags; ep.Y = Y;
+    return launch_spmm_tiled<EPI_AXPBY>(T, X, d, ep, (hipStream_t)stream);
+}
+
+int arl_spmm_tiled_adam_f32(const arl_tiled *T, const float *X, int64_t d, float alpha, float beta, const float *Z, const uint8_t *zflags,
+                            float *P, float *M, float *V, float lr, float beta1, float beta2, float eps, int64_t step, arl_stream_t stream) {
+    if (!P || !M || !V) return ARL_E_NULL;
+    if (beta != 0.f && !Z) return ARL_E_NULL;
+    if (step < 1 || P == X) return ARL_E_ARG;
+    Epi ep = {};
+    ep.alpha = alpha; ep.beta = beta; ep.Z = (beta != 0.f) ? Z : nullptr; ep.zflags = zflags; ep.P = P; ep.M = M; ep.V = V;
+    ep.b1 = beta1; ep.b2 = beta2; ep.eps = eps;
+    adam_scalars(lr, beta1, beta2, step, &ep.step_size, &ep.inv_bc2_sqrt);
+    return launch_spmm_tiled<EPI_ADAM>(T, X, d, ep, (hipStream_t)stream);
 }
 
 int arl_spmm_csr_flagged_f32(const arl_csr *A, const float *X, int64_t d, const uint32_t *xbits, float alpha, float beta, const float *Z,

@@ -89,6 +89,29 @@ class CSRGraph:
         self._partial = None
         self.dinv = None
 
+    def chunks_only(self, rows, chunk=None):
+        """View that computes ONLY the given rows, all of them through the chunk plan (row tasks disabled: n_rows = 0)."""
+        chunk = self.chunk if chunk is None else int(chunk)
+        rows_h = rows.cpu().numpy().astype(np.int64)
+        rp = self.rowptr.cpu().numpy().astype(np.int64)
+        deg = rp[rows_h + 1] - rp[rows_h]
+        nch = np.maximum((deg + chunk - 1) // chunk, 1)
+        first = np.concatenate([[0], np.cumsum(nch)[:-1]])
+        crow = np.repeat(rows_h, nch)
+        k = np.arange(int(nch.sum())) - np.repeat(first, nch)
+        cbeg = rp[crow] + k * chunk
+        cend = np.minimum(cbeg + chunk, rp[crow + 1])
+        g = object.__new__(CSRGraph)
+        g.__dict__.update(self.__dict__)
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
+        g.chunk = chunk
+        g.chunk_row, g.chunk_begin, g.chunk_end = t(crow), t(cbeg), t(cend)
+        g.long_row, g.long_first, g.long_count = t(rows_h), t(first), t(nch)
+        g.n_chunks, g.n_long = int(nch.sum()), len(rows_h)
+        g._partial = None
+        g._rows_disabled = True
+        return g
+
     def with_values(self, val):
         """Same pattern and plan, different edge values (shares index tensors)."""
         g = object.__new__(CSRGraph)
@@ -102,7 +125,7 @@ class CSRGraph:
         if self.n_chunks and (self._partial is None or self._partial.numel() < self.n_chunks * d):
             self._partial = torch.empty(self.n_chunks * d, dtype=torch.float32, device=self.device)
         s = arl_csr()
-        s.n_rows, s.nnz = self.n_rows, self.nnz
+        s.n_rows, s.nnz = (0 if getattr(self, '_rows_disabled', False) else self.n_rows), self.nnz
         s.rowptr, s.col, s.val = self.rowptr.data_ptr(), self.col.data_ptr(), self.val.data_ptr()
         s.chunk, s.n_chunks, s.n_long = self.chunk, self.n_chunks, self.n_long
         if self.n_chunks:
@@ -468,3 +491,155 @@ def bpr_l2_backward(emb, item_off, u, p, n, reg, norms4, G, workspace, upstream=
     check(_lib.lib().arl_bpr_l2_backward_f32(_ptr(emb), emb.shape[1], item_off, _ptr(u), _ptr(p), _ptr(n), B, reg, upstream, _ptr(norms4), _ptr(G),
                                              _ptr(workspace), _stream()), 'arl_bpr_l2_backward_f32')
     return G
+
+
+# ------------------------------------------------------------------------------------------------ L2-blocked SpMM plan
+class TiledPlan:
+    """Schedule of the L2-blocked SpMM (include/arlib_amd.h: arl_tiled) for a CSRGraph.
+
+    row_groups: list of (lo, hi) row ranges binned separately (for the bipartite adjacency: [(0, U), (U, N)], so that a bin's
+    rows all gather from the same table and every sweep is homogeneous).  Rows are sorted by degree and dealt snake-wise into
+    bins of <= cap rows, which gives every bin (nearly) the same number of edges; the hottest rows land in different bins.
+    Built with torch ops on the graph's device (one stable sort of the edge list)."""
+
+    def __init__(self, A, row_groups=None, cap=384, col_block=16384, n_slots=256, d=64, hub_threshold=1024):
+        dev = A.device
+        lpr = 4 if d <= 16 else 8 if d <= 32 else 16 if d <= 64 else 32 if d <= 128 else 64
+        self.n_groups = 16 * (64 // lpr)                          # lane groups per 1024-thread workgroup
+        N = A.n_rows
+        rp = A.rowptr.to(torch.int64)
+        deg = (rp[1:] - rp[:-1])
+        if row_groups is None:
+            row_groups = [(0, N)]
+        if cap > 65535 or cap < 1:
+            raise ValueError('cap must be in [1, 65535]')
+        bin_of_row = torch.full((N,), -1, dtype=torch.int64, device=dev)
+        rloc = torch.zeros(N, dtype=torch.int64, device=dev)
+        self.hub_threshold = int(hub_threshold)
+        bins = 0
+        covered = 0
+        for lo, hi in row_groups:
+            covered += hi - lo
+            # rows longer than hub_threshold are left to the chunked CSR kernel (one lane group owning a 100k-edge row would
+            # serialise the whole sweep); they are few and carry a small share of the edges
+            order = torch.sort(deg[lo:hi], descending=True, stable=True)[1] + lo
+            order = order[deg[order] <= self.hub_threshold]
+            n = order.numel()
+            if n <= 0:
+                continue
+            nb = -(-n // cap)
+            nb = -(-nb // n_slots) * n_slots                      # whole sweeps
+            k = torch.arange(n, device=dev)
+            cyc, pos = k // nb, k % nb
+            b = torch.where(cyc % 2 == 0, pos, nb - 1 - pos)
+            bin_of_row[order] = bins + b
+            rloc[order] = cyc
+            bins += nb
+        if covered != N:
+            raise ValueError('row_groups must cover every row exactly once')
+        self.n_slots, self.cap, self.col_block = int(n_slots), int(cap), int(col_block)
+        self.n_sweeps = bins // n_slots
+        self.n_cb = -(-A.n_cols // col_block)
+        self.n_rows, self.n_cols, self.nnz, self.device = N, A.n_cols, A.nnz, dev
+        self._A = A
+        binned = bin_of_row >= 0
+        self.hub_rows = (~binned).nonzero().squeeze(1)             # handled by the chunked CSR kernel
+        bin_rows = torch.full((bins, cap), -1, dtype=torch.int32, device=dev)
+        bin_rows[bin_of_row[binned], rloc[binned]] = torch.arange(N, dtype=torch.int32, device=dev)[binned]
+        self.bin_rows = bin_rows.contiguous()
+        # owner group of a local row: snake over the groups (local rows are in descending-degree order inside a bin)
+        ng = self.n_groups
+        owner = torch.where((rloc // ng) % 2 == 0, rloc % ng, ng - 1 - rloc % ng)
+        row_e = torch.repeat_interleave(torch.arange(N, device=dev), deg)
+        keep = binned[row_e]
+        e_idx = keep.nonzero().squeeze(1)                          # CSR positions of the edges of binned rows
+        row_e = row_e[e_idx]
+        seg = bin_of_row[row_e] * ng + owner[row_e]                          # one contiguous edge list per (bin, owner group)
+        key = (seg * self.n_cb + (A.col[e_idx].to(torch.int64) // col_block)) * cap + rloc[row_e]
+        order = e_idx[torch.sort(key, stable=True)[1]]
+        self.order = order.to(torch.int32) if A.nnz < 2 ** 31 else order
+        self.e_col = A.col[order].contiguous()
+        self.e_val = A.val[order].contiguous()
+        self.e_row = rloc[torch.repeat_interleave(torch.arange(N, device=dev), deg)[order]].to(torch.int16).contiguous()
+        self.nnz_binned = int(order.numel())
+        # hub pass: the graph's chunk plan restricted to the hub rows, row tasks disabled (n_rows = 0)
+        self.hub_graph = A.chunks_only(self.hub_rows) if self.hub_rows.numel() else None
+        counts = torch.bincount(seg, minlength=bins * self.n_groups)
+        flat = torch.zeros(bins * self.n_groups + 1, dtype=torch.int64, device=dev)
+        flat[1:] = torch.cumsum(counts, 0)
+        self.seg_ptr = flat.to(torch.int32).contiguous()
+        self.group_edges_max, self.group_edges_mean = int(counts.max()), float(counts.float().mean())
+        idx = None
+        del row_e, seg, key, counts, flat, idx
+
+    def update_values(self, val):
+        """New edge values in CSR order (same pattern)."""
+        _dev(val, torch.float32, 'val', 1)
+        if val.numel() != self.nnz:
+            raise ValueError('update_values: wrong length')
+        self.e_val = val[self.order.long()].contiguous()
+        if self.hub_graph is not None:
+            self.hub_graph.val = val
+
+    def _struct(self):
+        t = _lib.arl_tiled()
+        t.n_sweeps, t.n_slots, t.cap, t.n_cb, t.nnz = self.n_sweeps, self.n_slots, self.cap, self.n_cb, self.nnz_binned
+        t.n_groups = self.n_groups
+        t.bin_rows, t.seg_ptr = self.bin_rows.data_ptr(), self.seg_ptr.data_ptr()
+        t.e_col, t.e_val, t.e_row = self.e_col.data_ptr(), self.e_val.data_ptr(), self.e_row.data_ptr()
+        return t
+
+
+def _check_tiled(P, X, name, rows):
+    _dev(X, torch.float32, name, 2)
+    if X.shape[0] != rows:
+        raise ValueError('%s: %d rows, expected %d' % (name, X.shape[0], rows))
+    if X.device != P.device:
+        raise ValueError('%s on %s, plan on %s' % (name, X.device, P.device))
+    d = X.shape[1]
+    if d % 4 or d > 256 or P.cap * (d + 4) * 4 > 160 * 1024:
+        raise ValueError('embedding size %d does not fit the plan (cap %d rows of LDS accumulators)' % (d, P.cap))
+    return d
+
+
+def spmm_tiled(P, X, alpha=1.0, beta=0.0, Z=None, zflags=None, out=None):
+    """out = alpha*(A@X) + beta*Z through the L2-blocked schedule `P` (same numbers as spmm up to fp32 summation order)."""
+    d = _check_tiled(P, X, 'X', P.n_cols)
+    Y = torch.empty(P.n_rows, d, dtype=torch.float32, device=X.device) if out is None else out
+    if _check_tiled(P, Y, 'out', P.n_rows) != d or Y.data_ptr() == X.data_ptr():
+        raise ValueError('spmm_tiled: out must be [n_rows, d] and must not alias X')
+    if beta != 0.0 and (Z is None or _check_tiled(P, Z, 'Z', P.n_rows) != d):
+        raise ValueError('spmm_tiled: Z [n_rows, d] required when beta != 0')
+    if zflags is not None:
+        _check_flags(zflags, P.n_rows, 'zflags')
+    t = P._struct()
+    tok = EVENT_HOOK.begin('axpby') if EVENT_HOOK is not None else None
+    check(_lib.lib().arl_spmm_tiled_f32(C.byref(t), _ptr(X), d, alpha, beta, _ptr(Z) if beta != 0.0 else None, _ptr(zflags), _ptr(Y), _stream()), 'arl_spmm_tiled_f32')
+    if P.hub_graph is not None:          # the few rows longer than hub_threshold: chunked CSR kernel, same epilogue
+        s = P.hub_graph._struct(d)
+        check(_lib.lib().arl_spmm_csr_flagged_f32(C.byref(s), _ptr(X), d, None, alpha, beta, _ptr(Z) if beta != 0.0 else None, _ptr(zflags), _ptr(Y), _stream()),
+              'arl_spmm_csr_flagged_f32 (hub rows)')
+    if tok is not None:
+        EVENT_HOOK.end(tok)
+    return Y
+
+
+def spmm_tiled_adam(P, X, alpha, beta, Z, Pm, M, V, lr, step, betas=(0.9, 0.999), eps=1e-8, zflags=None):
+    d = _check_tiled(P, X, 'X', P.n_cols)
+    for t_, nm in ((Pm, 'P'), (M, 'M'), (V, 'V')):
+        if _check_tiled(P, t_, nm, P.n_rows) != d or t_.data_ptr() == X.data_ptr():
+            raise ValueError('spmm_tiled_adam: %s shape/alias error' % nm)
+    if beta != 0.0 and (Z is None or _check_tiled(P, Z, 'Z', P.n_rows) != d):
+        raise ValueError('spmm_tiled_adam: Z shape mismatch')
+    if zflags is not None:
+        _check_flags(zflags, P.n_rows, 'zflags')
+    t = P._struct()
+    tok = EVENT_HOOK.begin('adam') if EVENT_HOOK is not None else None
+    check(_lib.lib().arl_spmm_tiled_adam_f32(C.byref(t), _ptr(X), d, alpha, beta, _ptr(Z) if beta != 0.0 else None, _ptr(zflags), _ptr(Pm), _ptr(M), _ptr(V),
+                                             lr, betas[0], betas[1], eps, int(step), _stream()), 'arl_spmm_tiled_adam_f32')
+    if P.hub_graph is not None:
+        s = P.hub_graph._struct(d)
+        check(_lib.lib().arl_spmm_csr_adam_f32(C.byref(s), _ptr(X), d, alpha, beta, _ptr(Z) if beta != 0.0 else None, _ptr(zflags), _ptr(Pm), _ptr(M), _ptr(V),
+                                               lr, betas[0], betas[1], eps, int(step), _stream()), 'arl_spmm_csr_adam_f32 (hub rows)')
+    if tok is not None:
+        EVENT_HOOK.end(tok)

@@ -126,6 +126,29 @@ int arl_mark_rows_u8(uint8_t *flags, const int32_t *idx, int64_t n, int32_t valu
 int arl_mark_rows_bits_u32(uint32_t *bits, const int32_t *idx, int64_t n, int32_t set, arl_stream_t stream);
 int arl_zero_rows_f32(float *dst, const int32_t *idx, int64_t n, int64_t d, arl_stream_t stream);
 
+/* L2-blocked ("tiled") SpMM: same results as arl_spmm_csr_f32 / _adam_f32 on the same adjacency, different schedule.
+ * Output rows are dealt into BINS of <= cap rows with equal edge counts; one persistent workgroup per CU keeps a bin's fp32
+ * accumulators in LDS for a sweep and walks column blocks of `col_block` rows in ascending order, so the gathered rows of X
+ * are served from the XCD's L2 instead of the fabric.  The plan is built once per graph (arlib_amd/ops.py:TiledPlan).
+ * Every local row of a bin is owned by one lane group for the whole sweep; a bin's edges are sorted by (owner group, column
+ * block, local row, column): each group streams one contiguous list that walks the column blocks in ascending order, LDS
+ * accumulators are updated without atomics and the result is deterministic.
+ * Summation order differs from the CSR kernel: results agree to fp32 rounding, not bitwise. */
+typedef struct arl_tiled {
+    int64_t n_sweeps, n_slots, cap, n_cb, nnz;
+    int64_t n_groups;           /* owner groups per workgroup = 16 waves * (64 / lanes-per-row); fixed by d's width class  */
+    const int32_t *bin_rows;    /* [n_sweeps*n_slots][cap] global row id, -1 = empty          */
+    const int32_t *seg_ptr;     /* [n_sweeps*n_slots*n_groups + 1] offsets of the (bin, owner group) edge lists          */
+    const int32_t *e_col;       /* [nnz] */
+    const float *e_val;         /* [nnz] */
+    const uint16_t *e_row;      /* [nnz] local row in the bin (cap <= 65535)                   */
+} arl_tiled;
+int arl_spmm_tiled_f32(const arl_tiled *T, const float *X, int64_t d, float alpha, float beta, const float *Z,
+                       const uint8_t *zflags, float *Y, arl_stream_t stream);
+int arl_spmm_tiled_adam_f32(const arl_tiled *T, const float *X, int64_t d, float alpha, float beta, const float *Z,
+                            const uint8_t *zflags, float *P, float *M, float *V, float lr, float beta1, float beta2,
+                            float eps, int64_t step, arl_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * BPR + un-squared L2 on gathered rows, forward + backward in one call.
  * Replaces util/loss.py:5-9 (bpr_loss, eps 10e-8), :25-29 (l2_reg_loss), the three gathers
