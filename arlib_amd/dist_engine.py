@@ -191,6 +191,8 @@ class ShardedPropagationEngine:
     # whole batch redundantly (a few microseconds) -- so the batch-wide mean/norms and the item-side gradient need no
     # further collective.  Full-size all-reduces per step: 2(L-1) + 1 instead of 2L + 1.
     def step_sparse(self, u, p, n):
+        # NOTE: batch indices must be range-checked by the caller (bench.py / the training loop do it once per batch chunk);
+        # every op below runs with check_range=False so the step has no host synchronisation
         k, L, Ul, d = self.k, self.L, self.Ul, self.d
         B = u.numel()
         dev = self.device
@@ -226,25 +228,25 @@ class ShardedPropagationEngine:
             layers.append(dst)
         X = layers[-1]
         self.C.zero_()
-        self.C[B:] = k.spmm_rows(self.Ai, X, item_rows, (), 1.0)     # partial; overlaps the last full all-reduce
+        self.C[B:] = k.spmm_rows(self.Ai, X, item_rows, (), 1.0, check_range=False)     # partial; overlaps the last full all-reduce
         if pending is not None:
             pending.wait()
         if Ul:
-            self.C[:B] = k.spmm_rows(self.Au, X, lu, [t[:Ul] for t in layers], 1.0) * ownf      # the owner contributes the row, others zeros
+            self.C[:B] = k.spmm_rows(self.Au, X, lu, [t[:Ul] for t in layers], 1.0, check_range=False) * ownf      # the owner contributes the row, others zeros
         self.comm.all_reduce(self.C)
         for t in layers:
-            self.C[B:] += k.gather_rows(t, item_rows_packed)
+            self.C[B:] += k.gather_rows(t, item_rows_packed, check_range=False)
         self.C.mul_(s)
         # loss on the whole batch (identical on every rank), compact per-sample gradients
         self.Gc.zero_()
         k.bpr_l2_fwd_bwd(self.C, B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self.ws, loss_out=self.loss_out, check_range=False)
         if Ul:
-            k.scatter_add_rows(self.G, lu, self.Gc[:B] * ownf, 1.0)        # foreign samples add exact zeros to a clamped row
-            k.mark_rows_(self.flags, lu, 1)
-            k.mark_bits_(self.bits, lu, True, self.Nl)
-        k.scatter_add_rows(self.G, item_rows_packed, self.Gc[B:].contiguous(), 1.0)
-        k.mark_rows_(self.flags, item_rows_packed, 1)
-        k.mark_bits_(self.bits, item_rows_packed, True, self.Nl)
+            k.scatter_add_rows(self.G, lu, self.Gc[:B] * ownf, 1.0, check_range=False)        # foreign samples add exact zeros to a clamped row
+            k.mark_rows_(self.flags, lu, 1, check_range=False)
+            k.mark_bits_(self.bits, lu, True, self.Nl, check_range=False)
+        k.scatter_add_rows(self.G, item_rows_packed, self.Gc[B:].contiguous(), 1.0, check_range=False)
+        k.mark_rows_(self.flags, item_rows_packed, 1, check_range=False)
+        k.mark_bits_(self.bits, item_rows_packed, True, self.Nl, check_range=False)
         # backward (Horner).  hop 1: flag-masked gathers; later hops dense; G (complete on the item side) added through flags
         self.t += 1
         zu = self.flags[:Ul]
@@ -272,12 +274,12 @@ class ShardedPropagationEngine:
         k.adam_dense(self.E0[Ul:], acc[Ul:], self.m[Ul:], self.v[Ul:], self.lr, self.t, self.betas, self.eps)
         # clear the sparse state
         if Ul:
-            k.zero_rows_(self.G, lu)
-            k.mark_rows_(self.flags, lu, 0)
-            k.mark_bits_(self.bits, lu, False, self.Nl)
-        k.zero_rows_(self.G, item_rows_packed)
-        k.mark_rows_(self.flags, item_rows_packed, 0)
-        k.mark_bits_(self.bits, item_rows_packed, False, self.Nl)
+            k.zero_rows_(self.G, lu, check_range=False)
+            k.mark_rows_(self.flags, lu, 0, check_range=False)
+            k.mark_bits_(self.bits, lu, False, self.Nl, check_range=False)
+        k.zero_rows_(self.G, item_rows_packed, check_range=False)
+        k.mark_rows_(self.flags, item_rows_packed, 0, check_range=False)
+        k.mark_bits_(self.bits, item_rows_packed, False, self.Nl, check_range=False)
         return self.loss_out
 
     def gather_full_table(self):
