@@ -116,11 +116,14 @@ def _shadow(data):
         memb = getattr(data, '_arl_memb', None)
         if memb is None:
             # training_set_u is fixed at DataLoader construction (util/DataLoader.py:41); users added later have an empty set
-            tsu = data.training_set_u
-            us = [u for u in tsu if len(tsu[u])]
-            mp = np.array([[data.user[u], data.item[i]] for u in us for i in tsu[u]], np.int32).reshape(-1, 2)
-            n_rows = (max(data.user[u] for u in us) + 1) if us else 0
-            memb = build_membership(mp, n_rows) if len(mp) else (np.zeros(1, np.int64), np.zeros(1, np.int32))
+            if hasattr(data, 'membership_csr'):
+                memb = data.membership_csr()
+            else:
+                tsu = data.training_set_u
+                us = [u for u in tsu if len(tsu[u])]
+                mp = np.array([[data.user[u], data.item[i]] for u in us for i in tsu[u]], np.int32).reshape(-1, 2)
+                n_rows = (max(data.user[u] for u in us) + 1) if us else 0
+                memb = build_membership(mp, n_rows) if len(mp) else (np.zeros(1, np.int64), np.zeros(1, np.int32))
             data._arl_memb = memb
         sh = PairSampler(pairs, len(data.item), memb)
         data._arl_sampler = sh

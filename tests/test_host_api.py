@@ -12,9 +12,8 @@ from conftest import golden, ROOT
 def make_data():
     from arlib_amd.util.DataLoader import DataLoader
     g = golden('ml100k_data.npz')
-    rows = lambda u, i, r: [[str(a), str(b), float(c)] for a, b, c in zip(u, i, r)]
-    return DataLoader(training_data=rows(g['train_u'], g['train_i'], g['train_r']), val_data=rows(g['val_u'], g['val_i'], g['val_r']),
-                      test_data=rows(g['test_u'], g['test_i'], g['test_r']), dataName='ml-100k')
+    return DataLoader.from_arrays((g['train_u'], g['train_i'], g['train_r']), (g['val_u'], g['val_i'], g['val_r']),
+                                  (g['test_u'], g['test_i'], g['test_r']), dataName='ml-100k')
 
 
 def test_abi_exports_match_header():
