@@ -182,6 +182,87 @@ class PropagationEngine:
         ops.mark_bits_(self.bits, rows, False, self.N, check_range=False)
         return self.loss_out
 
+    def step_simgcl(self, u, p, n, cl_rate=0.2, tau=0.2, eps=0.1, noises=None):
+        """One SimGCL training iteration (recommender/SimGCL.py:51-63,198-219) on the sparse-batch schedule.
+
+        Reference: 3 forwards (clean + two perturbed views) of L hops each and autograd through all of them = 6L full-graph
+        hops.  Here:
+          * hop 1 (A E0) is shared by the three forwards (the perturbation is added after it);
+          * every forward's last hop is only consumed on batch rows (BPR rows; InfoNCE rows are the unique batch users /
+            positive items) -> row-subset hops;
+          * the perturbation sign(E)*normalize(noise)*eps carries no gradient, so all three forwards have the SAME linear
+            backward operator (1/L) sum_{k=1..L} A^k: the three sparse output gradients are summed first and ONE Horner pass
+            (flag-masked first hop, Adam fused into the last) replaces three.
+        L = 2: 2 full hops + 1 masked + 3 row-subset hops instead of 12 full hops.
+        noises: optional [view][hop] full [N,d] tensors (parity tests); default torch.rand on the device, one [N,d] draw per
+        hop and view exactly like the reference's rand_like calls.  Returns (loss_out, cl_loss) device tensors."""
+        if not self.skip0 or self.optimizer != 'adam':
+            raise ValueError('step_simgcl needs a skip_layer0 engine with Adam')
+        L, A, U, N, d = self.L, self.A, self.U, self.N, self.d
+        B = u.numel()
+        self._sparse_buffers(B)
+        if getattr(self, '_G_dirty', True):
+            self.G.zero_(); self._G_dirty = False
+        inv = 1.0 / L
+        rows = torch.cat([u, p + U, n + U])
+        uidx = torch.unique(u.long())
+        iidx = torch.unique(p.long()) + U
+        rows_cl = torch.cat([uidx, iidx]).to(torch.int32)
+        nu = uidx.numel()
+        rnd = (lambda v, k: noises[v][k]) if noises is not None else (lambda v, k: torch.rand(N, d, device=self.device))
+        # ---- forwards
+        E1 = ops.spmm(A, self.E0, out=self.hops[0])                       # shared first hop
+        def finish(first, view):                                            # hops 2..L on table `first`; returns compact rows [rows_sel, d]
+            sel = rows if view is None else rows_cl
+            layers, cur = [first], first
+            for k in range(1, L - 1):
+                nxt = ops.spmm(A, cur)
+                if view is not None:
+                    ops.simgcl_perturb_(nxt, rnd(view, k), eps)
+                layers.append(nxt); cur = nxt
+            if L == 1:
+                return ops.gather_rows(first, sel, check_range=False)
+            if view is None:
+                return ops.spmm_rows(A, cur, sel, layers, inv, nsplit=self.nsplit, check_range=False)
+            last = ops.spmm_rows(A, cur, sel, (), 1.0, nsplit=self.nsplit, check_range=False)
+            ops.simgcl_perturb_(last, rnd(view, L - 1)[sel.long()].contiguous(), eps)
+            for t in layers:
+                last += ops.gather_rows(t, sel, check_range=False)
+            return last * inv
+        out_c = finish(E1, None)
+        self.Gc.zero_()
+        ops.bpr_l2_fwd_bwd(out_c, B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self._ws, loss_out=self.loss_out, check_range=False)
+        ops.scatter_add_rows(self.G, rows, self.Gc, 1.0, check_range=False)
+        views = []
+        for v in (0, 1):
+            E1p = E1.clone()
+            ops.simgcl_perturb_(E1p, rnd(v, 0), eps)
+            views.append(finish(E1p, v))
+        lu, du1, du2 = ops.infonce_fwd_bwd(views[0][:nu].contiguous(), views[1][:nu].contiguous(), tau)
+        li, di1, di2 = ops.infonce_fwd_bwd(views[0][nu:].contiguous(), views[1][nu:].contiguous(), tau)
+        cl_loss = cl_rate * (lu[0] + li[0])
+        gcl = torch.cat([du1 + du2, di1 + di2], 0)                         # both views differentiate through the same operator
+        ops.scatter_add_rows(self.G, rows_cl, gcl, cl_rate, check_range=False)
+        allrows = torch.cat([rows, rows_cl])
+        ops.mark_rows_(self.flags, allrows, 1, check_range=False)
+        ops.mark_bits_(self.bits, allrows, True, N, check_range=False)
+        # ---- one backward pass: acc = G; (L-1) x: acc = G + A acc; g = A acc / L
+        self.t += 1
+        acc, first = self.G, True
+        for k in range(L - 1):
+            dst = self.hops[1] if acc is not self.hops[1] else self.hops[0]
+            ops.spmm_flagged(A, acc, self.bits if first else None, 1.0, 1.0, self.G, self.flags, out=dst)
+            acc, first = dst, False
+        if first:       # L == 1: the only hop gathers the sparse G itself
+            tmp = ops.spmm_flagged(A, self.G, self.bits, inv, 0.0, None, None, out=self.hops[1])
+            ops.adam_dense(self.E0, tmp, self.m, self.v, self.lr, self.t, self.betas, self.eps)
+        else:
+            ops.spmm_adam(A, acc, inv, 0.0, None, self.E0, self.m, self.v, self.lr, self.t, self.betas, self.eps)
+        ops.zero_rows_(self.G, allrows, check_range=False)
+        ops.mark_rows_(self.flags, allrows, 0, check_range=False)
+        ops.mark_bits_(self.bits, allrows, False, N, check_range=False)
+        return self.loss_out, cl_loss
+
     def _sparse_buffers(self, B):
         if getattr(self, '_sparse_B', None) == B:
             return

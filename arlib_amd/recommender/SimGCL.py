@@ -31,6 +31,7 @@ class SimGCL_Encoder(GraphEncoder):
 class SimGCL(Recommender):
     print_every = 100
     has_extra_loss = True
+    fused_extra_loss = True
 
     def __init__(self, args, data):
         self._common_init(args, data, 'SimGCL')
@@ -38,6 +39,10 @@ class SimGCL(Recommender):
         self.cl_rate = 0.2
         self.eps = 0.1
         self.model = SimGCL_Encoder(self.data, self.args.emb_size, self.eps, self.n_layers)
+
+    def _fused_step(self, eng, u, p, n):
+        lo, self.last_cl_loss = eng.step_simgcl(u, p, n, cl_rate=self.cl_rate, tau=0.2, eps=self.eps)
+        return lo
 
     def _extra_loss(self, model, user_idx, pos_idx):
         return self.cl_rate * model.cal_cl_loss([user_idx, pos_idx])

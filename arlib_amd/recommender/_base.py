@@ -198,6 +198,10 @@ class Recommender:
     """train()/save()/predict()/evaluate()/test() shared by the three models (reference: LightGCN.py:29-161)."""
     print_every = 1000
     has_extra_loss = False
+    fused_extra_loss = False      # the model's extra loss has a fused engine step (SimGCL)
+
+    def _fused_step(self, eng, u, p, n):
+        return eng.step(u, p, n)
 
     def _common_init(self, args, data, name):
         print('Recommender: ' + name)
@@ -259,8 +263,10 @@ class Recommender:
         fused_kind = None
         if optimizer is None:
             optimizer = torch.optim.Adam(model.parameters(), lr=self.args.lRate)
-        if not requires_embgrad and not requires_adjgrad and not self.has_extra_loss:
+        if not requires_embgrad and not requires_adjgrad:
             fused_kind = self._fusable(optimizer)
+            if self.has_extra_loss and not (fused_kind == 'adam' and self.fused_extra_loss):
+                fused_kind = None
         self.optimizer = optimizer
         if requires_adjgrad:
             raise NotImplementedError('requires_adjgrad accumulates a dense N x N matrix in the reference (LightGCN.py:42-43, dead from the CLI); '
@@ -293,7 +299,7 @@ class Recommender:
                 p = torch.from_numpy(pos_idx).to(DEVICE, non_blocking=True)
                 ng = torch.from_numpy(neg_idx).to(DEVICE, non_blocking=True)
                 if eng is not None:
-                    lo = eng.step(u, p, ng)
+                    lo = self._fused_step(eng, u, p, ng)
                     if n % self.print_every == 0:
                         print('training:', epoch + 1, 'batch', n, 'batch_loss:', float(lo[0] + lo[1]))
                     continue

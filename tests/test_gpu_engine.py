@@ -231,3 +231,21 @@ def test_tiled_l2_blocked_spmm_matches_row_kernel(mods):
     P.update_values(T(val2))
     ref2 = ops.spmm(A.with_values(T(val2)), X)
     assert rel_err(ops.spmm_tiled(P, X).cpu().numpy(), ref2.cpu().numpy()) < 1e-5
+
+
+def test_simgcl_fused_step_matches_reference(mods, ml100k):
+    """Fused SimGCL step (shared first hop, row-subset last hops, ONE backward pass for the three forwards) against the
+    reference's step with the same injected noise: losses, and tables after the Adam update."""
+    ops, engine = mods
+    g = golden('g5_simgcl.npz')
+    U, I = ml100k['U'], ml100k['I']
+    E0 = np.concatenate([g['user0'], g['item0']])
+    eng = engine.PropagationEngine(ml_graph(ops, ml100k), U, I, 16, 2, 1e-4, 0.005, DEV, skip_layer0=True, table=T(E0))
+    noise = [T(x) for x in g['noise']]
+    lo, cl = eng.step_simgcl(T(g['batch_u']), T(g['batch_p']), T(g['batch_n']), noises=[noise[0:2], noise[2:4]])
+    lo = lo.cpu().numpy()
+    assert abs(lo[0] - g['rec_loss'][0]) <= RTOL * abs(g['rec_loss'][0])
+    assert abs(cl.item() - g['cl_loss'][0]) <= RTOL * abs(g['cl_loss'][0])
+    E = eng.E0.cpu().numpy()
+    assert rel_err(E[:U], g['user_k1']) < RTOL and rel_err(E[U:], g['item_k1']) < RTOL
+    assert float(eng.G.abs().max()) == 0.0 and int(eng.flags.max()) == 0
