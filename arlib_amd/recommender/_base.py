@@ -221,7 +221,8 @@ class Recommender:
         g = optimizer.param_groups[0]
         ps = g['params']
         mine = self._params()
-        if len(ps) != 2 or ps[0] is not mine[0] or ps[1] is not mine[1] or g.get('weight_decay', 0) != 0 or g.get('maximize', False):
+        # nn.ParameterDict sorts plain-dict keys, so parameters() yields item_emb before user_emb: compare as a set
+        if len(ps) != 2 or {id(ps[0]), id(ps[1])} != {id(mine[0]), id(mine[1])} or g.get('weight_decay', 0) != 0 or g.get('maximize', False):
             return None
         if type(optimizer) is torch.optim.Adam:
             if g.get('amsgrad', False) or g.get('capturable', False):

@@ -42,6 +42,7 @@ def test_train_two_epochs_matches_reference_run(name):
     with contextlib.redirect_stdout(io.StringIO()):
         rec.train(Epoch=2, evalNum=1)
         rec_list, measure = rec.test()
+    assert rec.model._eng is not None and rec.model._eng.t == 44            # the fused device engine ran all 2 x 22 steps (not autograd)
     assert random.random() == float(g[name + '_next_random'][0])          # sampler consumed python `random` bit-exactly
     assert rel_err(rec.model.embedding_dict['user_emb'].detach().cpu().numpy(), g[name + '_user']) < RTOL
     assert rel_err(rec.model.embedding_dict['item_emb'].detach().cpu().numpy(), g[name + '_item']) < RTOL
