@@ -5,7 +5,7 @@ graph by target hit-rate.
 
 Mechanics: streaming score+mask+top-k instead of the host U x I buffer (CLeaR.py:75-82); index tensors instead of Python
 list building of U*T triples (:83-88); propagation forward/backward through the SpMM kernels; AttackMetric through the
-top-k kernel.  The small dense SFA algebra on the gathered [3UT, d] matrix (:98-125) uses ATen matmuls (plumbing).
+top-k kernel; the CW + SFA losses and their gradients (:89-126) without materialising the [3UT, d] matrix (_CwSfaLoss).
 """
 import random
 from copy import deepcopy
@@ -17,14 +17,48 @@ import torch
 from ... import ops
 from ...util.metrics import AttackMetric
 from .._common import AttackBase, DEVICE, symmetric_adjacency, rebuild_interaction_matrix, reinit_with_tables, cw_pairs
-from .DLAttack import masked_topk
+from .DLAttack import masked_topk, device_mask
+from .PGA import cw_operator
 
 
-def spectral_feature_augmentation_loss(H, r0):
-    """F.l1_loss(SFA(H, 1), H) with r(0) = r0 (CLeaR.py:98-125): r = H^T H r0; H_aug = H - H r r^T / ||r||^2."""
-    r = H.T @ (H @ r0)
-    H_aug = H - (H @ torch.outer(r, r)) / torch.norm(r) ** 2
-    return torch.nn.functional.l1_loss(H_aug, H)
+def _packed(Pu, Pi):
+    """[U'+I, d] table holding both outputs: the encoder hands out two views of one buffer, otherwise concatenate."""
+    U, d = Pu.shape
+    if (Pu.is_contiguous() and Pi.is_contiguous() and Pi.data_ptr() == Pu.data_ptr() + U * d * Pu.element_size()
+            and Pu.untyped_storage().data_ptr() == Pi.untyped_storage().data_ptr()):
+        return torch.as_strided(Pu, (U + Pi.shape[0], d), (d, 1))
+    return torch.cat([Pu, Pi], 0).contiguous()
+
+
+class _CwSfaLoss(torch.autograd.Function):
+    """(CWloss, sfaloss) of CLeaR.py:89-126 from the propagated tables and the users' top-k lists.
+
+    H = cat(Pu[users], Pi[pos], Pi[neg]) has 3*U*T rows but only U + I distinct ones, so neither it nor the U*T index lists
+    are gathered: the CW term is bilinear in the packed table (one SpMM with the operator of PGA.cw_operator) and the SFA
+    term is three weighted passes over the table (ops.sfa_l1, row weight = multiplicity in H)."""
+
+    @staticmethod
+    def forward(ctx, Pu, Pi, top_idx, n_real, targets, r0):
+        X = _packed(Pu, Pi)
+        Up, I, d, T = Pu.shape[0], Pi.shape[0], Pu.shape[1], len(targets)
+        users, pos, neg = cw_pairs(top_idx, n_real, targets, pop=True)
+        M = cw_operator(Up + I, Up, users, pos, neg, X.device)
+        G_cw = ops.spmm(M, X)
+        cw = 0.5 * (X * G_cw).sum()
+        w = torch.zeros(Up + I, dtype=torch.float32, device=X.device)
+        w[:n_real] = float(T)
+        w[Up:] = torch.bincount(neg, minlength=I).to(torch.float32)
+        w.index_add_(0, pos[:T] + Up, torch.full((T,), float(n_real), device=X.device))
+        sfa, G_sfa = ops.sfa_l1(X, w, r0.to(X.device, torch.float32).contiguous(), 3 * n_real * T * d)
+        ctx.save_for_backward(G_cw, G_sfa)
+        ctx.Up = Up
+        return cw, sfa[0]
+
+    @staticmethod
+    def backward(ctx, g_cw, g_sfa):
+        G_cw, G_sfa = ctx.saved_tensors
+        G = g_cw * G_cw + g_sfa * G_sfa
+        return G[:ctx.Up], G[ctx.Up:], None, None, None, None
 
 
 class CLeaR(AttackBase):
@@ -33,17 +67,14 @@ class CLeaR(AttackBase):
         self.batchSize = 2048
 
     def surrogate_loss(self, model, uiAdj2, topk, r0=None):
-        """One evaluation of lossall = CWloss + sfaloss (CLeaR.py:74-126); returns (lossall, Pu, Pi, cw, sfa)."""
+        """One evaluation of lossall = CWloss + sfaloss (CLeaR.py:74-126); returns (lossall, Pu, Pi, cw, sfa).
+        `uiAdj2`: the poisoned U' x I interactions (scipy) or their device_mask()."""
         Pu, Pi = model()
         with torch.no_grad():
             top_idx, _ = masked_topk(Pu.detach(), Pi.detach(), uiAdj2, min(topk, self.itemNum))
-            users, pos, neg = cw_pairs(top_idx, self.userNum, self.targetItem, pop=True)
-        user_emb, pos_items_emb, neg_items_emb = Pu[users], Pi[pos], Pi[neg]
-        cw = ((user_emb * neg_items_emb).sum(1) - (user_emb * pos_items_emb).sum(1)).mean()
-        emb_cat = torch.cat((user_emb, pos_items_emb, neg_items_emb), dim=0)
         if r0 is None:
-            r0 = torch.randn(emb_cat.size(1)).to(emb_cat.device)          # CLeaR.py:100-103: CPU generator, then moved
-        sfa = spectral_feature_augmentation_loss(emb_cat, r0)
+            r0 = torch.randn(Pu.size(1))                                   # CLeaR.py:100-103: CPU generator, then moved
+        cw, sfa = _CwSfaLoss.apply(Pu, Pi, top_idx, self.userNum, self.targetItem, r0)
         return cw + sfa, Pu, Pi, cw, sfa
 
     def posionDataAttack(self, recommender):
@@ -59,8 +90,9 @@ class CLeaR(AttackBase):
             tmpRecommender.model._init_uiAdj(symmetric_adjacency(uiAdj2, Up, self.itemNum))
             optimizer_attack = torch.optim.Adam(tmpRecommender.model.parameters(), lr=recommender.args.lRate)
             Pu = Pi = None
+            mask = device_mask(uiAdj2)          # the poisoned pattern is fixed while the surrogate is trained
             for _ in range(self.outerEpoch):
-                lossall, Pu, Pi, _, _ = self.surrogate_loss(tmpRecommender.model, uiAdj2, topk)
+                lossall, Pu, Pi, _, _ = self.surrogate_loss(tmpRecommender.model, mask, topk)
                 optimizer_attack.zero_grad()
                 lossall.backward()
                 optimizer_attack.step()

@@ -18,12 +18,21 @@ from ...util.sampler import next_batch_pairwise
 from .._common import AttackBase, DEVICE, symmetric_adjacency, rebuild_interaction_matrix, reinit_with_tables, cw_pairs
 
 
-def masked_topk(Pu, Pi, ui_mat, k):
-    """top-k of Pu @ Pi.T with interacted entries set to -10e8 (DLAttack.py:73-83 / CLeaR.py:75-82), streamed."""
+def device_mask(ui_mat, device=DEVICE):
+    """CSR image (rowptr int32, sorted item ids int32) on the device of the nonzero pattern of a U x I interaction matrix:
+    the `interacted -> -10e8` mask of DLAttack.py:76-80 / CLeaR.py:78-80.  Built once per outer loop -- the pattern does
+    not change between the surrogate's steps."""
     m = sp.csr_matrix(ui_mat)
     m.eliminate_zeros(); m.sort_indices()
-    rp = torch.from_numpy(m.indptr.astype(np.int32)).to(Pu.device)
-    mc = torch.from_numpy(m.indices.astype(np.int32) if m.nnz else np.zeros(1, np.int32)).to(Pu.device)
+    rp = torch.from_numpy(m.indptr.astype(np.int32)).to(device)
+    mc = torch.from_numpy(m.indices.astype(np.int32) if m.nnz else np.zeros(1, np.int32)).to(device)
+    return rp, mc
+
+
+def masked_topk(Pu, Pi, mask, k):
+    """top-k of Pu @ Pi.T with interacted entries set to -10e8 (DLAttack.py:73-83 / CLeaR.py:75-82), streamed.
+    `mask` is a device_mask() pair or anything scipy can turn into a U x I sparse matrix."""
+    rp, mc = mask if isinstance(mask, tuple) else device_mask(mask, Pu.device)
     return ops.score_mask_topk(Pu.contiguous(), Pi.contiguous(), k, rp, mc)
 
 
@@ -49,10 +58,11 @@ class DLAttack(AttackBase):
             tmpRecommender.model._init_uiAdj(symmetric_adjacency(uiAdj2, U_now, self.itemNum))
             tmpRecommender.train(Epoch=self.innerEpoch, optimizer=optimizer, evalNum=5)
             optimizer_attack = torch.optim.Adam(tmpRecommender.model.parameters(), lr=recommender.args.lRate)
+            mask = device_mask(uiAdj2)
             for _ in range(self.outerEpoch):
                 with torch.no_grad():
                     Pu, Pi = tmpRecommender.model()
-                    top_idx, _ = masked_topk(Pu, Pi, uiAdj2, min(topk, self.itemNum))
+                    top_idx, _ = masked_topk(Pu, Pi, mask, min(topk, self.itemNum))
                     users, pos, neg = cw_pairs(top_idx, self.userNum, self.targetItem, pop=False)
                     # CW term of DLAttack.py:92-101: computed on detached tensors there, i.e. a logged constant
                     self.last_cw_loss = float(((Pu[users] * Pi[neg]).sum(1) - (Pu[users] * Pi[pos]).sum(1)).mean())

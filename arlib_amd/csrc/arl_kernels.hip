@@ -736,6 +736,113 @@ __global__ __launch_bounds__(kBlock) void simgcl_perturb_kernel(float *__restric
 }
 
 // ================================================================================================
+// CLeaR spectral-feature-augmentation L1 term (attack/White/CLeaR.py:98-125)
+// ================================================================================================
+// H = rows of X with multiplicities w (H is never materialised: a real user's row appears T times, a target's row U times,
+// a negative's row as often as it closes somebody's top-k list).  With q = H r0, r = H^T q, s = H r, Q = |r|^2:
+//   H_aug - H = -s r^T / Q   =>   loss = mean|H_aug - H| = (sum_i |s_i|)(sum_j |r_j|) / (numel(H) Q)
+// and, through everything (r is not detached in the reference),
+//   dloss/dh_i = c1 sgn(s_i) r + q_i g_r + (h_i . g_r) r0,   c1 = A/(numel Q),
+//   g_r = [ (A/Q) a + (S/Q) sgn(r) - (2 S A / Q^2) r ] / numel,   a = H^T sgn(s), S = sum|s|, A = sum|r|.
+constexpr int kSfaStride = 264;          // floats per partial record: d (<= 256) accumulators + 1 scalar, padded
+constexpr int kSfaMaxBlocks = 1024;
+
+__device__ __forceinline__ float sgnf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+
+// PASS 1: dotv = r0, rowdot -> q, acc = sum w q x.      PASS 2: dotv = r, rowdot -> s, acc = sum w sgn(s) x, scalar = sum w |s|.
+template <int PASS>
+__global__ __launch_bounds__(kBlock) void sfa_reduce_pass_kernel(const float *__restrict__ X, const float *__restrict__ w, const float *__restrict__ dotv,
+                                                                 int n, int d, float *__restrict__ rowdot, float *__restrict__ part) {
+    __shared__ float red[kWavesPerBlock][kSfaStride];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float v[4], acc[4] = {0.f, 0.f, 0.f, 0.f}, sc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (lane + 64 * j < d) ? dotv[lane + 64 * j] : 0.f;
+    for (int row = blockIdx.x * kWavesPerBlock + wave; row < n; row += gridDim.x * kWavesPerBlock) {
+        const float wr = w[row];
+        if (wr == 0.f) { if (lane == 0) rowdot[row] = 0.f; continue; }
+        float x[4], t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x[j] = (lane + 64 * j < d) ? X[(size_t)row * d + lane + 64 * j] : 0.f; t = fmaf(x[j], v[j], t); }
+        t = wave_sum(t);
+        if (lane == 0) rowdot[row] = t;
+        const float c = PASS == 1 ? wr * t : wr * sgnf(t);
+        if (PASS == 2) sc += wr * fabsf(t);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(c, x[j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (lane + 64 * j < d) red[wave][lane + 64 * j] = acc[j];
+    if (lane == 0) red[wave][kSfaStride - 1] = sc;
+    __syncthreads();
+    for (int k = threadIdx.x; k < kSfaStride; k += kBlock) {
+        if (k < d || k == kSfaStride - 1) {
+            float t = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < kWavesPerBlock; ++wv) t += red[wv][k];
+            part[(size_t)blockIdx.x * kSfaStride + k] = t;
+        }
+    }
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float *sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// coef layout: [0,256) r   [256,512) g_r   [512] c1   [513] loss
+__global__ __launch_bounds__(kBlock) void sfa_fold_r_kernel(const float *__restrict__ part, int nblk, int d, float *__restrict__ coef) {
+    const int k = threadIdx.x;
+    float t = 0.f;
+    if (k < d) for (int b = 0; b < nblk; ++b) t += part[(size_t)b * kSfaStride + k];
+    coef[k] = t;
+}
+
+__global__ __launch_bounds__(kBlock) void sfa_finalize_kernel(const float *__restrict__ part, int nblk, int d, float inv_numel, float *__restrict__ coef,
+                                                              float *__restrict__ loss_out) {
+    __shared__ float sh[4];
+    const int k = threadIdx.x;
+    float a = 0.f, S = 0.f;
+    if (k < d) for (int b = 0; b < nblk; ++b) a += part[(size_t)b * kSfaStride + k];
+    for (int b = k; b < nblk; b += kBlock) S += part[(size_t)b * kSfaStride + kSfaStride - 1];
+    S = block_sum_256(S, sh);
+    const float r = k < d ? coef[k] : 0.f;
+    const float A = block_sum_256(fabsf(r), sh);
+    const float Q = block_sum_256(r * r, sh);
+    if (k < d) coef[256 + k] = inv_numel * ((A / Q) * a + (S / Q) * sgnf(r) - (2.f * S * A / (Q * Q)) * r);
+    if (k == 0) { coef[512] = inv_numel * A / Q; coef[513] = inv_numel * S * A / Q; loss_out[0] = coef[513]; }
+}
+
+__global__ __launch_bounds__(kBlock) void sfa_grad_kernel(const float *__restrict__ X, const float *__restrict__ w, const float *__restrict__ r0,
+                                                          const float *__restrict__ q, const float *__restrict__ s, const float *__restrict__ coef,
+                                                          int n, int d, float scale, int accumulate, float *__restrict__ G) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float wr = w[row];
+    if (wr == 0.f) {
+        if (!accumulate) for (int k = lane; k < d; k += kWave) G[(size_t)row * d + k] = 0.f;
+        return;
+    }
+    float x[4], t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { x[j] = (lane + 64 * j < d) ? X[(size_t)row * d + lane + 64 * j] : 0.f; t = fmaf(x[j], (lane + 64 * j < d) ? coef[256 + lane + 64 * j] : 0.f, t); }
+    t = wave_sum(t);                                      // h . g_r
+    const float c_r = coef[512] * sgnf(s[row]), c_g = q[row], ws = wr * scale;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = lane + 64 * j;
+        if (k < d) {
+            const float g = ws * (c_r * coef[k] + c_g * coef[256 + k] + t * r0[k]);
+            G[(size_t)row * d + k] = accumulate ? G[(size_t)row * d + k] + g : g;
+        }
+    }
+}
+
+// ================================================================================================
 // Attack primitives
 // ================================================================================================
 // out[t, j] += <dY[rows[t]], X[col_off+j]>.  Block = 64 items staged in LDS (stride d+1: conflict-free column
@@ -1423,6 +1530,34 @@ int arl_simgcl_perturb_f32(float *E, const float *noise, int64_t n, int64_t d, f
     hipLaunchKernelGGL(simgcl_perturb_kernel, dim3((unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, E, noise,
                        (int)n, (int)d, eps);
     ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int64_t arl_sfa_workspace_bytes(int64_t n_rows, int64_t d) {
+    return (n_rows < 0 || d <= 0) ? 0 : (int64_t)sizeof(float) * (2 * n_rows + (int64_t)kSfaMaxBlocks * kSfaStride + 520);
+}
+
+int arl_sfa_l1_fwd_bwd_f32(const float *X, const float *w, const float *r0, int64_t n_rows, int64_t d, int64_t numel_h, float scale,
+                           int32_t accumulate, float *loss_out, float *G, void *workspace, arl_stream_t stream) {
+    if (!X || !w || !r0 || !loss_out || !workspace) return ARL_E_NULL;
+    if (n_rows <= 0 || n_rows > 0x7fffffffll || numel_h <= 0) return ARL_E_ARG;
+    if (d <= 0 || d > 256) return ARL_E_DIM;
+    hipStream_t st = (hipStream_t)stream;
+    float *q = (float *)workspace, *s = q + n_rows, *part = s + n_rows, *coef = part + (size_t)kSfaMaxBlocks * kSfaStride;
+    const int64_t want = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int nblk = (int)(want < kSfaMaxBlocks ? want : kSfaMaxBlocks);
+    hipLaunchKernelGGL((sfa_reduce_pass_kernel<1>), dim3(nblk), dim3(kBlock), 0, st, X, w, r0, (int)n_rows, (int)d, q, part);
+    ARL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sfa_fold_r_kernel, dim3(1), dim3(kBlock), 0, st, part, nblk, (int)d, coef);
+    ARL_LAUNCH_CHECK();
+    hipLaunchKernelGGL((sfa_reduce_pass_kernel<2>), dim3(nblk), dim3(kBlock), 0, st, X, w, coef, (int)n_rows, (int)d, s, part);
+    ARL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sfa_finalize_kernel, dim3(1), dim3(kBlock), 0, st, part, nblk, (int)d, (float)(1.0 / (double)numel_h), coef, loss_out);
+    ARL_LAUNCH_CHECK();
+    if (G) {
+        hipLaunchKernelGGL(sfa_grad_kernel, dim3((unsigned)want), dim3(kBlock), 0, st, X, w, r0, q, s, coef, (int)n_rows, (int)d, scale, (int)accumulate, G);
+        ARL_LAUNCH_CHECK();
+    }
     return ARL_OK;
 }
 

@@ -402,6 +402,30 @@ def simgcl_perturb_(E, noise, eps):
     return E
 
 
+def sfa_l1(X, w, r0, numel_h, want_grad=True, out=None, scale=1.0, accumulate=False):
+    """CLeaR's SFA L1 term over H = rows of X repeated w[row] times (attack/White/CLeaR.py:98-125).
+    Returns (loss[1], G) with G = (out +)= scale * dloss/dX, or (loss, None)."""
+    _dev(X, torch.float32, 'X', 2); _dev(w, torch.float32, 'w', 1); _dev(r0, torch.float32, 'r0', 1)
+    n, d = X.shape
+    if w.shape[0] != n or r0.shape[0] != d:
+        raise ValueError('sfa_l1: w must have one weight per row of X and r0 one entry per column')
+    if n == 0 or d > 256 or int(numel_h) <= 0:
+        raise ValueError('sfa_l1: unsupported shape %s / numel %d' % (tuple(X.shape), int(numel_h)))
+    G = None
+    if want_grad:
+        G = out if out is not None else torch.empty_like(X)
+        _dev(G, torch.float32, 'out', 2)
+        if G.shape != X.shape:
+            raise ValueError('sfa_l1: out must have the shape of X')
+    elif out is not None:
+        raise ValueError('sfa_l1: out given but want_grad is False')
+    ws = torch.empty(_lib.lib().arl_sfa_workspace_bytes(n, d) // 4, dtype=torch.float32, device=X.device)
+    loss = torch.empty(1, dtype=torch.float32, device=X.device)
+    check(_lib.lib().arl_sfa_l1_fwd_bwd_f32(_ptr(X), _ptr(w), _ptr(r0), n, d, int(numel_h), float(scale), int(bool(accumulate)), _ptr(loss), _ptr(G),
+                                            _ptr(ws), _stream()), 'arl_sfa_l1_fwd_bwd_f32')
+    return loss, G
+
+
 # ------------------------------------------------------------------------------------------------ attack primitives
 def sddmm_rows_dense(dY, X, rows, col_off, n_cols, out=None):
     _dev(dY, torch.float32, 'dY', 2); _dev(X, torch.float32, 'X', 2); _dev(rows, torch.int32, 'rows', 1)

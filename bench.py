@@ -150,6 +150,59 @@ def attack_leg(torch, ops, data, E0_dev, args):
             'setup_seconds': setup_s}
 
 
+def clear_leg(torch, ops, data, A, E0_dev, args):
+    """attack-grad steps/sec, CLeaR flavour (attack/White/CLeaR.py:73-129): one step = surrogate forward with grad, streaming
+    U x I score + interacted-mask + top-k, CW over (real user x target) pairs + SFA L1 term on the gathered [3UT, d] matrix,
+    backward through the propagation, Adam over both tables.  Surrogate = the clean cfg2 graph (the F appended rows of a
+    poisoned graph change the cost by F/U)."""
+    from types import SimpleNamespace
+    from arlib_amd.recommender._base import GraphEncoder, SparseNormAdj
+    from arlib_amd.attack.White.CLeaR import CLeaR
+    U, I, nnz = data.training_size()
+    L, d = args.layers, args.emb
+    dev = E0_dev.device
+    enc = GraphEncoder.__new__(GraphEncoder)
+    torch.nn.Module.__init__(enc)
+    enc.data = SimpleNamespace(user_num=U, item_num=I)
+    enc.latent_size = enc.emb_size = d
+    enc.n_prop_layers = L
+    enc._eng = None
+    packed = E0_dev.clone()
+    enc.embedding_dict = torch.nn.ParameterDict({'user_emb': torch.nn.Parameter(packed[:U]), 'item_emb': torch.nn.Parameter(packed[U:])})
+    adj = SparseNormAdj.__new__(SparseNormAdj)
+    adj.shape, adj.indptr, adj.indices, adj.values, adj._graph = (U + I, U + I), None, None, A.val, A
+    enc.sparse_norm_adj = adj
+    rowptr, col = data.adjacency_pattern()
+    mask = (torch.from_numpy(rowptr[:U + 1].astype(np.int32)).to(dev), torch.from_numpy((col[:nnz] - U).astype(np.int32)).to(dev))
+    deg_i = np.bincount(data.pairs0[:, 1], minlength=I)
+    atk = CLeaR.__new__(CLeaR)
+    atk.userNum, atk.itemNum, atk.targetItem = U, I, [int(t) for t in np.argsort(deg_i, kind='stable')[:5]]
+    opt = torch.optim.Adam(enc.parameters(), lr=0.005)
+    r0 = torch.randn(d, generator=torch.Generator().manual_seed(args.seed)).to(dev)
+    parts = {}
+
+    def step(timed=False):
+        t = time.perf_counter()
+        lossall, _, _, cw, sfa = atk.surrogate_loss(enc, mask, 50, r0=r0)
+        if timed:
+            torch.cuda.synchronize(); parts['forward+topk+loss'] = parts.get('forward+topk+loss', 0.0) + time.perf_counter() - t
+        opt.zero_grad()
+        lossall.backward()
+        opt.step()
+        return float(cw), float(sfa)
+    step(); torch.cuda.synchronize()
+    n = max(1, min(args.attack_steps, 5))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        cw, sfa = step(True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    return {'metric': 'attack-grad steps/sec (CLeaR surrogate step: CW + SFA, LightGCN d=%d L=%d)' % (d, L), 'value': 1.0 / dt, 'unit': 'steps/s',
+            'ms_per_step': 1e3 * dt, 'ms_forward_topk_loss': 1e3 * parts['forward+topk+loss'] / n, 'targets': 5, 'pairs': U * 5,
+            'cw_loss': cw, 'sfa_loss': sfa, 'score_flops_per_step': 2.0 * U * I * d,
+            'note': 'dominated by the U x I scoring pass (compute-bound line item, SURVEY 8d); peak memory %.1f GB' % (torch.cuda.max_memory_allocated() / 1e9)}
+
+
 def main():
     args = parse()
     import torch
@@ -166,8 +219,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    # test hook: ARL_BENCH_FORCE_SHARDED=1 at N=1 runs the sharded engine over a 1-rank RCCL group (exercises the real backend)
+    sharded = world > 1 or os.environ.get('ARL_BENCH_FORCE_SHARDED') == '1'
+    if sharded:
         import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)       # RCCL over xGMI
         else:
@@ -198,7 +257,7 @@ def main():
     dev_batches = host_batches.to(dev, non_blocking=True)
     assert int(dev_batches[:, 0].max()) < U and int(dev_batches[:, 1:].max()) < I and int(dev_batches.min()) >= 0
 
-    if world == 1:
+    if not sharded:
         w = torch.ones(2 * nnz, dtype=torch.float32, device=dev)
         col_d = torch.from_numpy(col).to(dev)
         val, _ = ops.norm_adj_values(torch.from_numpy(rowptr.astype(np.int32)).to(dev), col_d, w, N)
@@ -238,7 +297,7 @@ def main():
     ev.on = False
     ops.EVENT_HOOK = None
     loss = float(lo[0] + lo[1])
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -276,7 +335,7 @@ def main():
                     traffic = pm['traffic_corrected_bytes']
             except Exception:
                 traffic = None
-            if world == 1:
+            if not sharded:
                 res['roofline'] = {'bound': 'hbm', 'achieved': spmm_bytes / (avg_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                    'frac': spmm_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': traffic,
                                    'kernel': 'spmm_rows_kernel<LPR=%d> (+spmm_long_rows_kernel), avg over %d launches' % (max(4, d // 4), len(allv)),
@@ -285,7 +344,7 @@ def main():
                                    'gather_model_bytes_per_launch': E * (8 + 4 * d) + 4 * N * d}
             else:
                 res['spmm_events_ms'] = {k: v[0] for k, v in evs.items()}
-        if world == 1:
+        if not sharded:
             # A/B: the reference-shaped step (all 2L hops over the full graph), same engine state, few steps
             other = (lambda k: eng.step(dev_batches[k, 0], dev_batches[k, 1], dev_batches[k, 2], rows=dev_rows[k])) if args.dense_step else \
                     (lambda k: eng.step_dense(dev_batches[k, 0], dev_batches[k, 1], dev_batches[k, 2]))
@@ -297,16 +356,21 @@ def main():
             torch.cuda.synchronize()
             res['ab_compare'] = {'main_step': 'dense (2L full hops)' if args.dense_step else 'sparse-batch (2L-2 full hops + row-subset + flag-masked hop)',
                                  'other_step_ms': 1e3 * (time.perf_counter() - t1) / nn}
-        if world == 1 and args.attack_steps > 0:
+        if not sharded and args.attack_steps > 0:
             E0_snapshot = eng.E0.clone()
             del eng.Ea, eng.Eb, eng.S
             res['attack'] = attack_leg(torch, ops, data, E0_snapshot, args)
-        if world == 1 and args.cpu_baseline:
+            torch.cuda.empty_cache()
+            res['attack_clear'] = clear_leg(torch, ops, data, eng.A, E0_snapshot, args)
+            # DLAttack's inner step (attack/White/DLAttack.py:86-113) is the BPR/Adam step of the headline metric on the
+            # surrogate (its CW term is a detached constant); the scoring pass above runs once per outer epoch
+            res['attack_dlattack_inner'] = {'value': 1e3 / ms, 'unit': 'steps/s', 'note': 'same fused step as `value` (B=%d)' % B}
+        if not sharded and args.cpu_baseline:
             val_np = eng.A.val.cpu().numpy()
             batches = [(hb[k, 0].copy(), hb[k, 1].copy(), hb[k, 2].copy()) for k in range(min(n_batches, 8))]
             res['cpu_baseline'] = cpu_baseline(data, rowptr, col, val_np, E0.numpy(), batches, args, args.cpu_seconds)
         print(json.dumps(res))
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
         dist.destroy_process_group()
 

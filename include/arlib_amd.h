@@ -210,6 +210,19 @@ int arl_simgcl_perturb_f32(float *E, const float *noise, int64_t n, int64_t d, f
 /* ------------------------------------------------------------------------------------------------
  * White-box attack primitives.
  * ---------------------------------------------------------------------------------------------- */
+/* ------------------------------------------------------------------------------------------------
+ * CLeaR spectral-feature-augmentation L1 term -- replaces spectral_feature_augmentation(H, 1) + F.l1_loss(SFA, H)
+ * and their autograd (attack/White/CLeaR.py:98-125) for H = the rows of X taken w[row] times each
+ * (H = cat(Pu[users], Pi[pos], Pi[neg]) repeats table rows; it is never materialised).
+ *   r = H^T H r0;  loss_out[0] = mean| H - H r r^T/|r|^2  -  H |  over numel_h = rows(H) * d elements;
+ *   G[row] (= or +=, per `accumulate`) scale * d loss / d X[row]   (G may be NULL: loss only).
+ * X: [n_rows, d] row-major, d <= 256; w: [n_rows] multiplicities (0 = row not in H); r0: [d].
+ * workspace: arl_sfa_workspace_bytes(n_rows, d).  Deterministic (two-stage reductions, no atomics).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t arl_sfa_workspace_bytes(int64_t n_rows, int64_t d);
+int arl_sfa_l1_fwd_bwd_f32(const float *X, const float *w, const float *r0, int64_t n_rows, int64_t d, int64_t numel_h,
+                           float scale, int32_t accumulate, float *loss_out, float *G, void *workspace, arl_stream_t stream);
+
 /* Gradient w.r.t. adjacency values restricted to `rows`, dense over the item block (the only entries PGA
  * uses; replaces autograd.grad(Loss, sparse_norm_adj) + to_dense() + slicing, attack/White/PGA.py:117-134):
  *   out[t, j] += <dY[rows[t]], X[col_off + j]> ,  0 <= j < n_cols.   out: [n_rows_sel, n_cols]. */

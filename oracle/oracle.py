@@ -317,6 +317,41 @@ def cw_loss_grad(out, Up, users, pos, neg):
     return loss, G.astype(np.float32)
 
 
+def sfa_l1_loss_grad(H, r0):
+    """spectral_feature_augmentation(H, 1) + F.l1_loss(SFA, H) (CLeaR.py:98-125) on the explicit H, and dloss/dH by a literal
+    reverse pass over the same graph (nothing is detached in the reference, r included).  float64 throughout."""
+    H = np.asarray(H, np.float64); r0 = np.asarray(r0, np.float64)
+    q = H @ r0
+    r = H.T @ q                       # k = 1 power iteration: r = H^T H r0
+    Rm = np.outer(r, r)
+    P = H @ Rm
+    n2 = float(r @ r)                 # torch.norm(r) ** 2
+    Xm = P / n2
+    D = (H - Xm) - H                  # SFA - target of the l1_loss
+    loss = float(np.abs(D).mean())
+    gD = np.sign(D) / D.size
+    gXm = -gD                         # d/dH through `H -` and through the l1 target cancel exactly
+    gP = gXm / n2
+    gn2 = -float((gXm * P).sum()) / (n2 * n2)
+    gH = gP @ Rm.T
+    gRm = H.T @ gP
+    gr = (gRm + gRm.T) @ r + 2.0 * r * gn2
+    gH += np.outer(q, gr)             # r = H^T q
+    gq = H @ gr
+    gH += np.outer(gq, r0)            # q = H r0
+    return loss, gH
+
+
+def clear_loss_grad(out, Up, users, pos, neg, r0):
+    """lossall = CWloss + sfaloss of one CLeaR surrogate step (CLeaR.py:89-126) and dlossall/d(out); H = cat(u, p, n) rows."""
+    cw, G = cw_loss_grad(out, Up, users, pos, neg)
+    rows = np.concatenate([np.asarray(users), Up + np.asarray(pos), Up + np.asarray(neg)])
+    sfa, gH = sfa_l1_loss_grad(out[rows], r0)
+    G = G.astype(np.float64)
+    np.add.at(G, rows, gH)
+    return cw, sfa, G.astype(np.float32)
+
+
 def pga_weighted_graph(real_indptr, real_indices, U, F, I, S):
     """(U+F+I)^2 normalised adjacency of the real interactions plus the weighted fake block S (entries with S != 0 only:
     scipy's `ui_adj + ui_adj.T` drops explicit zeros) -- what PGA.py:93-97 hands to _init_uiAdj.  Returns (csr, dinv)."""

@@ -190,6 +190,32 @@ def test_simgcl_perturb(ops):
     assert rel_err(out, O.simgcl_perturb(E, noise, 0.1)) < 1e-6
 
 
+@pytest.mark.parametrize('n,d', [(1, 4), (777, 16), (5000, 64), (3001, 100), (9000, 256)])
+def test_sfa_l1_weighted_rows(ops, n, d):
+    """CLeaR's SFA term on H = table rows with multiplicities (kernel never builds H) vs the literal restatement on H."""
+    rng = np.random.default_rng(n + d)
+    X = (rng.normal(size=(n, d)) * 0.2).astype(np.float32)
+    w = rng.integers(0, 4, n).astype(np.float32)
+    w[0] = 2.0                                                   # at least one row in H
+    if n > 10:
+        w[5] = 1000.0                                            # a target item's row: once per real user
+    r0 = rng.normal(size=d).astype(np.float32)
+    rows = np.repeat(np.arange(n), w.astype(np.int64))
+    loss_ref, gH = O.sfa_l1_loss_grad(X[rows], r0)
+    G_ref = np.zeros((n, d)); np.add.at(G_ref, rows, gH)
+    loss, G = ops.sfa_l1(T(X), T(w), T(r0), len(rows) * d)
+    assert abs(loss.item() - loss_ref) <= RTOL * abs(loss_ref)
+    assert rel_err(G.cpu().numpy(), G_ref) < RTOL
+    assert not G.cpu().numpy()[w == 0].any()                     # rows outside H get exact zeros
+    base = torch.full_like(G, 0.5)
+    _, G2 = ops.sfa_l1(T(X), T(w), T(r0), len(rows) * d, out=base, scale=-2.0, accumulate=True)
+    assert rel_err(G2.cpu().numpy(), 0.5 - 2.0 * G_ref) < RTOL
+    loss_only, none = ops.sfa_l1(T(X), T(w), T(r0), len(rows) * d, want_grad=False)
+    assert none is None and loss_only.item() == loss.item()      # deterministic reductions
+    with pytest.raises(ValueError):
+        ops.sfa_l1(T(X), T(w[:-1]) if n > 1 else T(np.zeros(2, np.float32)), T(r0), len(rows) * d)
+
+
 def test_sddmm_rows_dense_and_pga_update(ops):
     rng = np.random.default_rng(5)
     N, d, I, off = 900, 64, 333, 500

@@ -39,3 +39,44 @@ def test_dlattack_masked_topk_and_project():
         out, ind = O.topn_project_rows(g['dl_proj_in'][r][None, :], int(g['dl_proj_n'][r]))
         assert np.array_equal(out[0], g['dl_proj_out'][r]) and np.array_equal(ind[0], g['dl_proj_idx'][r])
     assert list(g['dl_result_fake_rowsums']) == [5.0, 46.0]              # quirk Q6: the first fake user keeps only its targets
+
+
+def test_clear_surrogate_step_matches_reference_trace():
+    """CW + SFA loss and the parameter gradients of one CLeaR surrogate step (reference autograd, injected r0)."""
+    g = golden('g7_attacks.npz')
+    U, I, F, topk = (int(x) for x in g['cl_sizes'])
+    Up, L = U + F, 2
+    E0 = np.concatenate([g['cl_user_tab'], g['cl_item_tab']])
+    rows = np.repeat(np.arange(Up), np.diff(g['cl_ui_indptr']))
+    rowptr, col, w = O.bipartite_csr(rows, g['cl_ui_indices'], Up, I, g['cl_ui_data'])
+    csr = (rowptr, col, O.norm_adj_values(rowptr, col, w))
+    out = O.lightgcn_forward(csr, E0, L)
+    idx, _ = O.score_mask_topk(out[:Up], out[Up:], topk, (g['cl_ui_indptr'], g['cl_ui_indices']))
+    users, pos, neg = O.cw_pairs(idx, U, g['cl_targets'], pop=True)
+    cw, sfa, G = O.clear_loss_grad(out, Up, users, pos, neg, g['cl_r0'])
+    assert abs(cw + sfa - g['cl_loss'][0]) <= RTOL * abs(g['cl_loss'][0])
+    dE0 = O.lightgcn_backward(csr, G, L)
+    grads = {a.shape[0]: a for a in (g['cl_grad_user'], g['cl_grad_item'])}      # keyed by row count (945 users / 1412 items)
+    assert rel_err(dE0[:Up], grads[Up]) < RTOL
+    assert rel_err(dE0[Up:], grads[I]) < RTOL
+
+
+def test_sfa_closed_form_equals_literal_restatement():
+    """The weighted closed form the HIP kernel uses (loss = S A / (numel Q), rows with multiplicities) against the literal
+    reverse pass on the materialised H."""
+    rng = np.random.default_rng(3)
+    n, d = 40, 12
+    X = rng.normal(size=(n, d)).astype(np.float32) * 0.3
+    w = rng.integers(0, 4, n).astype(np.float64)
+    r0 = rng.normal(size=d).astype(np.float32)
+    rows = np.repeat(np.arange(n), w.astype(np.int64))
+    loss, gH = O.sfa_l1_loss_grad(X[rows], r0)
+    G = np.zeros((n, d)); np.add.at(G, rows, gH)
+    Xd = X.astype(np.float64)
+    q = Xd @ r0; r = Xd.T @ (w * q); s = Xd @ r
+    S, A, Q, numel = (w * np.abs(s)).sum(), np.abs(r).sum(), r @ r, w.sum() * d
+    a = Xd.T @ (w * np.sign(s))
+    g_r = ((A / Q) * a + (S / Q) * np.sign(r) - (2 * S * A / Q ** 2) * r) / numel
+    G2 = w[:, None] * ((A / (numel * Q)) * np.sign(s)[:, None] * r[None, :] + q[:, None] * g_r[None, :] + (Xd @ g_r)[:, None] * r0[None, :])
+    assert abs(S * A / (numel * Q) - loss) < 1e-12 * abs(loss)
+    assert rel_err(G2, G) < 1e-10

@@ -1,0 +1,50 @@
+"""Per-phase wall clock of one CLeaR surrogate step at cfg2 (run on the GPU box):  python3 tools/clear_profile.py"""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from arlib_amd import ops
+from arlib_amd.util import synthetic
+from arlib_amd.attack._common import cw_pairs
+from arlib_amd.attack.White.PGA import cw_operator
+
+U, I, d, L, T, k = 1_000_000, 100_000, 64, 3, 5, 50
+dev = torch.device('cuda', 0)
+data = synthetic.syn_v1(U, I, 32.0, 2018)
+nnz = data.training_size()[2]
+rowptr, col = data.adjacency_pattern()
+torch.manual_seed(2018)
+X = torch.cat([torch.nn.init.xavier_uniform_(torch.empty(U, d)), torch.nn.init.xavier_uniform_(torch.empty(I, d))], 0).to(dev)
+mask = (torch.from_numpy(rowptr[:U + 1].astype(np.int32)).to(dev), torch.from_numpy((col[:nnz] - U).astype(np.int32)).to(dev))
+targets = [int(t) for t in np.argsort(np.bincount(data.pairs0[:, 1], minlength=I), kind='stable')[:T]]
+r0 = torch.randn(d).to(dev)
+
+
+def timed(name, fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    torch.cuda.synchronize()
+    print('%-28s %8.2f ms' % (name, 1e3 * (time.perf_counter() - t) / reps), flush=True)
+    return out
+
+
+timed('score_topk (no mask)', lambda: ops.score_mask_topk(X[:U].contiguous(), X[U:].contiguous(), k))
+top_idx, _ = timed('score_mask_topk', lambda: ops.score_mask_topk(X[:U].contiguous(), X[U:].contiguous(), k, *mask))
+users, pos, neg = timed('cw_pairs', lambda: cw_pairs(top_idx, U, targets, pop=True))
+M = timed('cw_operator', lambda: cw_operator(U + I, U, users, pos, neg, dev))
+G = timed('spmm(M, X)', lambda: ops.spmm(M, X))
+timed('cw value', lambda: 0.5 * (X * G).sum())
+
+
+def weights():
+    w = torch.zeros(U + I, dtype=torch.float32, device=dev)
+    w[:U] = float(T)
+    w[U:] = torch.bincount(neg, minlength=I).to(torch.float32)
+    w.index_add_(0, pos[:T] + U, torch.full((T,), float(U), device=dev))
+    return w
+
+
+w = timed('row weights', weights)
+timed('sfa_l1', lambda: ops.sfa_l1(X, w, r0, 3 * U * T * d))
