@@ -1044,6 +1044,7 @@ __device__ __forceinline__ unsigned long long wave_select_topk(unsigned long lon
         const unsigned long long c = T | (1ull << bit);
         const int n = __popcll(__ballot(k0 >= c)) + __popcll(__ballot(k1 >= c));
         if (n >= k) T = c;
+        if (n == k) break;                    // exactly k keys are >= T: the cut is decided; T's low bits stay 0 (a lower bound)
     }
     const unsigned long long m0 = __ballot(k0 >= T), m1 = __ballot(k1 >= T);
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -1054,6 +1055,15 @@ __device__ __forceinline__ unsigned long long wave_select_topk(unsigned long lon
     __threadfence_block();
     return T;
 }
+
+// Section timers for tuning (compile with -DARL_TOPK_PROF; the per-wave cycle sums overwrite top_val[first user of the wave][0..5]).
+#ifdef ARL_TOPK_PROF
+#define ARL_PROF_DECL long long P_acc[4] = {0, 0, 0, 0}, P_t0 = clock64(); const long long P_start = P_t0;
+#define ARL_PROF_TICK(SLOT) { const long long P_t = clock64(); P_acc[SLOT] += P_t - P_t0; P_t0 = P_t; }
+#else
+#define ARL_PROF_DECL
+#define ARL_PROF_TICK(SLOT)
+#endif
 
 template <int D>
 __global__ __launch_bounds__(kBlock) void score_mask_topk_mfma_kernel(const float *__restrict__ Pu, const float *__restrict__ Pi, int U, int I,
@@ -1081,98 +1091,151 @@ __global__ __launch_bounds__(kBlock) void score_mask_topk_mfma_kernel(const floa
     // B staging: MST items x D floats per stage; thread tid moves float4 number tid, tid+256, ...
     constexpr int F4 = MST * D / 4;
     constexpr int PER = (F4 + kBlock - 1) / kBlock;
-    float4 nb[PER];
+    static_assert(PER >= 1 && PER <= 4, "staging registers are named, not indexed");
+    float4 nb0, nb1, nb2, nb3;      // named scalars: an indexed nb[PER] stayed an alloca (scratch memory), and its scratch stores
+                                    // waited on the global loads right at issue, exposing their whole latency every stage
+    nb0 = nb1 = nb2 = nb3 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int nstages = (I + MST - 1) / MST;
-    auto fetch = [&](int st) {
-#pragma unroll
-        for (int p = 0; p < PER; ++p) {
-            // unconditional loads (index clamped, no select on the result): a select would force an s_waitcnt right after the
-            // issue and expose the whole HBM/Infinity-Cache latency every stage; rows past I are discarded by `item_ok` later
-            const int f = tid + p * kBlock;
-            const int row = f / (D / 4), c4 = f % (D / 4);
-            const int item = min(st * MST + row, I - 1);
-            nb[p] = *reinterpret_cast<const float4 *>(Pi + (size_t)item * D + c4 * 4);
-        }
+    // unconditional loads (index clamped, no select on the result): a select would force an s_waitcnt right after the issue;
+    // rows past I are discarded by `item_ok` later
+    auto stage_ptr = [&](int st, int p) {
+        const int f = tid + p * kBlock;
+        const int row = f / (D / 4), c4 = f % (D / 4);
+        const int item = min(st * MST + row, I - 1);
+        return reinterpret_cast<const float4 *>(Pi + (size_t)item * D + c4 * 4);
     };
-    static_assert(F4 % kBlock == 0, "staging assumes a whole number of float4 per thread");
-    // Per-user running state lives in REGISTERS: accumulator register `reg` of lane half h belongs to user row
-    // (reg&3)+8*(reg>>2)+4h for all 32 lanes of the half, so the half-wave agrees on it through ballots -- no LDS atomics,
-    // no LDS threshold reads.  thrf = the user's k-th best score so far (pre-filter, exact up to ties), cntr = keys held.
-    float thrf[16];
-    int cntr[16];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        thrf[reg] = (u_base + (reg & 3) + 8 * (reg >> 2) + 4 * h < U) ? -INFINITY : INFINITY;     // users past U never insert
-        cntr[reg] = 0;
+    auto lds_ptr = [&](float *buf, int p) {
+        const int f = tid + p * kBlock;
+        return reinterpret_cast<float4 *>(buf + (f / (D / 4)) * LD + (f % (D / 4)) * 4);
+    };
+#define ARL_TOPK_FETCH(ST)                                      \
+    {                                                           \
+        nb0 = *stage_ptr((ST), 0);                              \
+        if constexpr (PER > 1) nb1 = *stage_ptr((ST), 1);       \
+        if constexpr (PER > 2) nb2 = *stage_ptr((ST), 2);       \
+        if constexpr (PER > 3) nb3 = *stage_ptr((ST), 3);       \
     }
-    const unsigned lt32 = (1u << r) - 1u;
-    const unsigned slot_base = (unsigned)((wv * 32 + 4 * h) * kMCap);     // first candidate slot of user row 4h of this wave
-    fetch(0);
+    static_assert(F4 % kBlock == 0, "staging assumes a whole number of float4 per thread");
+    // Per-user running state: thrf (the user's k-th best score so far: pre-filter, a lower bound of it at all times) lives in
+    // REGISTERS -- accumulator register `reg` of lane half h belongs to user row (reg&3)+8*(reg>>2)+4h of the wave for all 32
+    // lanes of the half; the number of keys held lives in LDS (cntl) and hands out slots with one ds_add_rtn per insert.
+    float thrf[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg)
+        thrf[reg] = (u_base + (reg & 3) + 8 * (reg >> 2) + 4 * h < U) ? -INFINITY : INFINITY;     // users past U never insert
+    int *cntl = reinterpret_cast<int *>(bt + 2 * MST * LD) + wv * 32;        // [32] keys held per user row of this wave
+    unsigned long long *wcand = cand + (size_t)wv * 32 * kMCap;             // this wave's candidate buffers
+    if (lane < 32) cntl[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    ARL_PROF_DECL
+    ARL_TOPK_FETCH(0)
     for (int st = 0; st < nstages; ++st) {
         float *buf = bt + (st & 1) * MST * LD;
-#pragma unroll
-        for (int p = 0; p < PER; ++p) {
-            const int f = tid + p * kBlock;
-            const int row = f / (D / 4), c4 = f % (D / 4);
-            *reinterpret_cast<float4 *>(buf + row * LD + c4 * 4) = nb[p];
-        }
+        *lds_ptr(buf, 0) = nb0;
+        if constexpr (PER > 1) *lds_ptr(buf, 1) = nb1;
+        if constexpr (PER > 2) *lds_ptr(buf, 2) = nb2;
+        if constexpr (PER > 3) *lds_ptr(buf, 3) = nb3;
         __syncthreads();                                       // the only block barrier per stage
-        if (st + 1 < nstages) fetch(st + 1);
-        for (int sub = 0; sub < MST / kMI; ++sub) {
-            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        ARL_PROF_TICK(0)
+        if (st + 1 < nstages) ARL_TOPK_FETCH(st + 1)
+        // all B fragments of the stage go to registers first (the loads overlap the MFMA chains instead of a read-wait-use
+        // sequence per 4 MFMAs), and the sub-tiles' accumulation chains are interleaved so no MFMA waits on its predecessor
+        constexpr int NSUB = MST / kMI;
+        float4 bf[NSUB][H / 4];
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
             const float *brow = buf + (sub * kMI + r) * LD + H * h;
 #pragma unroll
-            for (int t = 0; t < H; t += 4) {
-                const float4 b4 = *reinterpret_cast<const float4 *>(brow + t);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b4.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 1], b4.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 2], b4.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 3], b4.w, acc, 0, 0, 0);
-            }
+            for (int t = 0; t < H; t += 4) bf[sub][t / 4] = *reinterpret_cast<const float4 *>(brow + t);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 accs[NSUB];
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) accs[sub] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < H; t += 4) {
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bf[sub][t / 4].x, accs[sub], 0, 0, 0);
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 1], bf[sub][t / 4].y, accs[sub], 0, 0, 0);
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 2], bf[sub][t / 4].z, accs[sub], 0, 0, 0);
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 3], bf[sub][t / 4].w, accs[sub], 0, 0, 0);
+        }
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const f32x16 acc = accs[sub];
             const int item = st * MST + sub * kMI + r;
-            const bool item_ok = item < I;
-            bool full = false;
+#ifdef ARL_TOPK_PROF
+            if (sub == 0) { float sink = acc[0] + accs[NSUB - 1][15]; asm volatile("" ::"v"(sink)); ARL_PROF_TICK(1) }
+#endif
+            // Pre-filter in the vector unit only: one 16-bit pass mask per lane and ONE ballot per sub-tile.  (A ballot + branch
+            // per accumulator register is a VALU->SALU round trip each: 16 of them cost ~1.7k cycles per 2k cycles of MFMA.)
+            unsigned pm = 0u;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                bool pass = item_ok && (acc[reg] >= thrf[reg]);
-                unsigned long long m = __ballot(pass);
-                if (m == 0ull) continue;                                           // wave-uniform: nobody beats a threshold
-                const int ul = wv * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                float sc = acc[reg];
-                if (mrp) {                                                         // interacted -> -10e8 (only for pre-filter survivors)
-                    if (pass) {
-                        const int u = blockIdx.x * kMU + ul;
-                        int lo = mrp[u], hi = mrp[u + 1];
-                        const int end = hi;
-                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (mcol[mid] < item) lo = mid + 1; else hi = mid; }
-                        if (lo < end && mcol[lo] == item) { sc = -10e8f; pass = sc >= thrf[reg]; }
-                    }
-                    m = __ballot(pass);
-                }
-                const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)(m & 0xffffffffull);   // passing lanes of my half = same user
-                if (pass) cand[slot_base + ((reg & 3) + 8 * (reg >> 2)) * kMCap + cntr[reg] + __popc(mh & lt32)] = pack_cand(sc, item);
-                cntr[reg] += __popc(mh);
-                full |= cntr[reg] > kMCap - kMI;
-            }
-            if (__any(full)) {
-                // compaction of the users that could overflow during the next sub-tile (wave-local: no block barrier)
-                __builtin_amdgcn_wave_barrier();
-                __threadfence_block();
+            for (int reg = 0; reg < 16; ++reg) pm |= (acc[reg] >= thrf[reg]) ? (1u << reg) : 0u;
+            if (item >= I) pm = 0u;
+            if (__ballot(pm != 0u) != 0ull) {
+                // Insert path: every lane takes its lowest pending register per round (normally one round, one key per lane)
+                bool nearly_full = false;
+                do {
+                    if (pm != 0u) {
+                        const int reg = __ffs(pm) - 1;
+                        pm &= pm - 1u;
+                        const int ulw = (reg & 3) + 8 * (reg >> 2) + 4 * h;            // user row within the wave
+                        float sc = acc[0];
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
+                        for (int j = 1; j < 16; ++j) sc = (reg == j) ? acc[j] : sc;
+                        bool ins = true;
+                        if (mrp) {                                                     // interacted -> -10e8 (pre-filter survivors only)
+                            const int u = u_base + ulw;
+                            int lo = mrp[u], hi = mrp[u + 1];
+                            const int end = hi;
+                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (mcol[mid] < item) lo = mid + 1; else hi = mid; }
+                            if (lo < end && mcol[lo] == item) {
+                                sc = -10e8f;
+                                float th = thrf[0];
 #pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        const int c = __shfl(cntr[reg], hh * 32);
-                        if (c > kMCap - kMI) {                                     // wave-uniform
-                            const int ul = wv * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                            const unsigned long long T = wave_select_topk(cand + (size_t)ul * kMCap, c, k, lane);
-                            if (h == hh) { cntr[reg] = k; thrf[reg] = cand_score(T); }
+                                for (int j = 1; j < 16; ++j) th = (reg == j) ? thrf[j] : th;
+                                ins = sc >= th;
+                            }
+                        }
+                        if (ins) {
+                            const int slot = atomicAdd(&cntl[ulw], 1);                 // < kMCap: <= kMCap - kMI held at sub-tile start
+                            wcand[ulw * kMCap + slot] = pack_cand(sc, item);
+                            nearly_full |= slot + 1 > kMCap - kMI;
                         }
                     }
+                } while (__any(pm != 0u));
+                ARL_PROF_TICK(2)
+                if (__any(nearly_full)) {
+                    // compaction of the users that could overflow during the next sub-tile (wave-local: no block barrier)
+                    __builtin_amdgcn_wave_barrier();
+                    __threadfence_block();
+                    const int myc = lane < 32 ? cntl[lane] : 0;
+                    for (unsigned long long fm = __ballot(myc > kMCap - kMI); fm; fm &= fm - 1ull) {
+                        const int ulw = __ffsll((long long)fm) - 1;                    // wave-uniform
+                        const int c = __builtin_amdgcn_readlane(myc, ulw);
+                        const float nt = cand_score(wave_select_topk(wcand + (size_t)ulw * kMCap, c, k, lane));
+                        if (lane == 0) cntl[ulw] = k;
+                        const int treg = (ulw & 3) | ((ulw >> 3) << 2), th = (ulw >> 2) & 1;
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) thrf[reg] = (reg == treg && h == th) ? nt : thrf[reg];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    __threadfence_block();
                 }
+                ARL_PROF_TICK(3)
+            } else {
+                ARL_PROF_TICK(2)
             }
         }
     }
+#ifdef ARL_TOPK_PROF
+    const long long P_loop = clock64() - P_start;
+#endif
     __syncthreads();                                           // the staging buffers become per-wave sort scratch (128 keys each)
     unsigned long long *scratch = reinterpret_cast<unsigned long long *>(bt) + wv * 128;
 #pragma unroll
@@ -1181,8 +1244,8 @@ __global__ __launch_bounds__(kBlock) void score_mask_topk_mfma_kernel(const floa
         for (int hh = 0; hh < 2; ++hh) {
             const int ul = wv * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
             const int u = blockIdx.x * kMU + ul;
-            const int c = __shfl(cntr[reg], hh * 32);
             if (u >= U) continue;
+            const int c = cntl[ul - wv * 32];
             for (int t = lane; t < 128; t += kWave) scratch[t] = t < c ? cand[(size_t)ul * kMCap + t] : 0ull;
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
@@ -1195,6 +1258,12 @@ __global__ __launch_bounds__(kBlock) void score_mask_topk_mfma_kernel(const floa
             __threadfence_block();
         }
     }
+#ifdef ARL_TOPK_PROF
+    if (lane == 0 && u_base < U) {
+        float *o = top_val + (size_t)u_base * k;
+        o[0] = (float)P_acc[0]; o[1] = (float)P_acc[1]; o[2] = (float)P_acc[2]; o[3] = (float)P_acc[3]; o[4] = (float)P_loop; o[5] = (float)(clock64() - P_start);
+    }
+#endif
 }
 
 // per-row top-n by n rounds of block arg-max over a scratch copy (n ~ average user degree, small)
@@ -1597,7 +1666,7 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
     if (U < 0 || I <= 0 || U > 0x7fffffffll || I > 0x7fffffffll) return ARL_E_RANGE;
     if (U == 0) return ARL_OK;
     if (k <= 64 && (d == 16 || d == 32 || d == 64 || d == 128)) {        // matrix-core path
-        const size_t shm_m = sizeof(unsigned long long) * kMU * kMCap + sizeof(float) * 2 * (d <= 64 ? 64 : 32) * (size_t)(d + 4);
+        const size_t shm_m = sizeof(unsigned long long) * kMU * kMCap + sizeof(float) * 2 * (d <= 64 ? 64 : 32) * (size_t)(d + 4) + sizeof(int) * kMU;
         const unsigned grid_m = (unsigned)((U + kMU - 1) / kMU);
 #define ARL_TOPK_CASE(DV)                                                                                                              \
         do {                                                                                                                           \
