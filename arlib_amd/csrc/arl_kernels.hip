@@ -1003,19 +1003,17 @@ __global__ __launch_bounds__(kBlock) void score_mask_topk_kernel(const float *__
 }
 
 // ---- MFMA form of the streaming score + mask + top-k (d in {16,32,64,128}, k <= 64) ---------------------------------------
-// scores = Pu . Pi^T is the one dense contraction of the path (2*U*I*d flop; 1.3e13 at cfg2), so it goes on the matrix cores:
-// v_mfma_f32_32x32x2_f32 (exact f32, bitwise an fmaf chain).  One wave owns 32 users for the whole kernel: its A fragment
-// (32 users x d) stays in d/2 VGPRs; the block (4 waves = 128 users) streams 32-item tiles of Pi through a double-buffered LDS
-// image (one __syncthreads per tile, next tile's global loads in flight during the MFMAs).  Lane l supplies A[user l&31][k] and
-// B[k][item l&31] for k = (d/2)*(l>>5) + t at MFMA step t -- the k order is a permutation of 0..d-1, irrelevant to the sum, and
-// it makes every lane's fragment d/2 CONTIGUOUS floats (ds_read_b128).  C: item = lane&31, user = (reg&3)+8*(reg>>2)+4*(lane>>5).
-// Top-k per user: candidate keys above the user's running k-th best are appended to a 128-slot LDS buffer owned by the user's
-// wave (so compaction needs no block barrier); a 32-item tile can add at most 32, compaction (bitonic sort, keep k) runs when
-// more than 96 are held.  The interacted-item mask is only evaluated for the rare candidates that pass the threshold.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kMU = 128;         // users per block (32 per wave)
+// scores = Pu . Pi^T is the one dense contraction of the path (2*U*I*d flop; 1.3e13 at cfg2), so it goes on the matrix cores with
+// the exact-f32 MFMA (bitwise an fmaf chain).  A block owns 128 users for the whole kernel (their A fragments stay in registers)
+// and streams item tiles of Pi through a double-buffered LDS image (one __syncthreads per stage, the next stage's global loads in
+// flight during the MFMAs).  Top-k per user: candidate keys above the user's running k-th best are appended to a 108-slot LDS
+// buffer owned by the user's wave (so compaction needs no block barrier); a 32-item phase can add at most 32, compaction
+// (radix select, keep k) runs when more than 76 are held.  Measured on MI355X: the f32 MFMA shares the SIMD's issue with the VALU
+// (a second wave per SIMD hides latencies but its VALU work does NOT overlap the other wave's MFMAs), so every VALU instruction
+// of the pre-filter/insert path is paid in full -- hence one vector compare per score and one ballot per phase, nothing more.
+constexpr int kMU = 128;         // users per block
 constexpr int kMI = 32;          // items per tile
-constexpr int kMCap = 112;       // candidate slots per user (>= k_max 64 + 32 + slack; 128 x 112 x 8 B = 112 KiB of the 160 KiB LDS)
+constexpr int kMCap = 108;       // candidate slots per user (>= k_max 64 + 32 + slack; 128 x 108 x 8 B = 108 KiB of the 160 KiB LDS)
 
 __device__ void wave_sort_desc_128(unsigned long long *c, int lane) {
     for (int k = 2; k <= 128; k <<= 1) {
@@ -1065,198 +1063,208 @@ __device__ __forceinline__ unsigned long long wave_select_topk(unsigned long lon
 #define ARL_PROF_TICK(SLOT)
 #endif
 
+// ---- 16x16x4 form: 8 waves per block, 16 users per wave --------------------------------------------------------------------
+// Same streaming scheme with v_mfma_f32_16x16x4_f32 so that a wave owns 16 users instead of 32: the block still covers 128 users
+// (the candidate buffers fill the LDS either way) but with EIGHT waves, two per SIMD -- one wave's pre-filter, inserts, compaction
+// and barrier waits now overlap the other wave's MFMA chain instead of idling the matrix core.  Lane l supplies A[user l&15][k] and
+// B[k][item l&15] for k = (D/4)*(l>>4) + t at step t (a permutation of 0..D-1, contiguous per lane); C: item = l&15,
+// user = 4*(l>>4) + reg.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kM16Block = 512;
+constexpr int kBloomWords = 32;      // 1024 bits per user
+__device__ __forceinline__ unsigned bloom_hash(int item) { return ((unsigned)item * 2654435761u) >> 22; }
+
 template <int D>
-__global__ __launch_bounds__(kBlock) void score_mask_topk_mfma_kernel(const float *__restrict__ Pu, const float *__restrict__ Pi, int U, int I,
-                                                                       const int32_t *__restrict__ mrp, const int32_t *__restrict__ mcol, int k,
-                                                                       int32_t *__restrict__ top_idx, float *__restrict__ top_val) {
-    constexpr int H = D / 2;                  // k-steps = floats per lane fragment
-    constexpr int LD = D + 4;                 // LDS row stride (floats): 16-B aligned rows, rows shifted by 4 banks
-    constexpr int MST = D <= 64 ? 64 : 32;    // items staged per block barrier
+__global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const float *__restrict__ Pu, const float *__restrict__ Pi, int U, int I,
+                                                                            const int32_t *__restrict__ mrp, const int32_t *__restrict__ mcol, int k,
+                                                                            int32_t *__restrict__ top_idx, float *__restrict__ top_val) {
+    constexpr int Q = D / 4;                                       // k-steps = floats per lane fragment
+    constexpr int LD = D + 4;                                      // LDS row stride (floats)
+    constexpr int MST = D <= 16 ? 128 : (D <= 64 ? 64 : 32);       // items staged per block barrier
+    constexpr int NSUB = MST / 16;                                 // 16-item sub-tiles per stage
+    constexpr int NPH = NSUB / 2;                                  // insert phases per stage (32 items each)
     extern __shared__ unsigned char smem_raw[];
     unsigned long long *cand = reinterpret_cast<unsigned long long *>(smem_raw);                 // [kMU][kMCap]
     float *bt = reinterpret_cast<float *>(cand + kMU * kMCap);                                   // [2][MST][LD]; sort scratch at the end
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int u_base = blockIdx.x * kMU + wv * 32;             // this wave's 32 users
-    float a[H];                                                // A fragment: user (u_base + r), columns [H*h, H*h + H)
+    const int c = lane & 15, g = lane >> 4;
+    const int u_base = blockIdx.x * kMU + wv * 16;                 // this wave's 16 users
+    float a[Q];                                                    // A fragment: user (u_base + c), columns [Q*g, Q*g + Q)
     {
-        const int u = u_base + r;
+        const int u = u_base + c;
 #pragma unroll
-        for (int t = 0; t < H; t += 4) {
+        for (int t = 0; t < Q; t += 4) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u < U) v = *reinterpret_cast<const float4 *>(Pu + (size_t)u * D + H * h + t);
+            if (u < U) v = *reinterpret_cast<const float4 *>(Pu + (size_t)u * D + Q * g + t);
             a[t] = v.x; a[t + 1] = v.y; a[t + 2] = v.z; a[t + 3] = v.w;
         }
     }
-    // B staging: MST items x D floats per stage; thread tid moves float4 number tid, tid+256, ...
     constexpr int F4 = MST * D / 4;
-    constexpr int PER = (F4 + kBlock - 1) / kBlock;
-    static_assert(PER >= 1 && PER <= 4, "staging registers are named, not indexed");
-    float4 nb0, nb1, nb2, nb3;      // named scalars: an indexed nb[PER] stayed an alloca (scratch memory), and its scratch stores
-                                    // waited on the global loads right at issue, exposing their whole latency every stage
-    nb0 = nb1 = nb2 = nb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int PER = F4 / kM16Block;
+    static_assert(F4 % kM16Block == 0 && PER >= 1 && PER <= 2, "staging assumes one or two float4 per thread");
+    float4 nb0, nb1;                                               // named staging registers (an indexed array stayed in scratch)
+    nb0 = nb1 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int nstages = (I + MST - 1) / MST;
-    // unconditional loads (index clamped, no select on the result): a select would force an s_waitcnt right after the issue;
-    // rows past I are discarded by `item_ok` later
     auto stage_ptr = [&](int st, int p) {
-        const int f = tid + p * kBlock;
-        const int row = f / (D / 4), c4 = f % (D / 4);
-        const int item = min(st * MST + row, I - 1);
-        return reinterpret_cast<const float4 *>(Pi + (size_t)item * D + c4 * 4);
+        const int f = tid + p * kM16Block;
+        const int item = min(st * MST + f / (D / 4), I - 1);       // clamped, never selected on: rows past I are masked out of pm
+        return reinterpret_cast<const float4 *>(Pi + (size_t)item * D + (f % (D / 4)) * 4);
     };
     auto lds_ptr = [&](float *buf, int p) {
-        const int f = tid + p * kBlock;
+        const int f = tid + p * kM16Block;
         return reinterpret_cast<float4 *>(buf + (f / (D / 4)) * LD + (f % (D / 4)) * 4);
     };
-#define ARL_TOPK_FETCH(ST)                                      \
-    {                                                           \
-        nb0 = *stage_ptr((ST), 0);                              \
-        if constexpr (PER > 1) nb1 = *stage_ptr((ST), 1);       \
-        if constexpr (PER > 2) nb2 = *stage_ptr((ST), 2);       \
-        if constexpr (PER > 3) nb3 = *stage_ptr((ST), 3);       \
-    }
-    static_assert(F4 % kBlock == 0, "staging assumes a whole number of float4 per thread");
-    // Per-user running state: thrf (the user's k-th best score so far: pre-filter, a lower bound of it at all times) lives in
-    // REGISTERS -- accumulator register `reg` of lane half h belongs to user row (reg&3)+8*(reg>>2)+4h of the wave for all 32
-    // lanes of the half; the number of keys held lives in LDS (cntl) and hands out slots with one ds_add_rtn per insert.
-    float thrf[16];
+    float thrf[4];                                                 // running k-th best (lower bound) of user rows 4g + reg
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg)
-        thrf[reg] = (u_base + (reg & 3) + 8 * (reg >> 2) + 4 * h < U) ? -INFINITY : INFINITY;     // users past U never insert
-    int *cntl = reinterpret_cast<int *>(bt + 2 * MST * LD) + wv * 32;        // [32] keys held per user row of this wave
-    unsigned long long *wcand = cand + (size_t)wv * 32 * kMCap;             // this wave's candidate buffers
-    if (lane < 32) cntl[lane] = 0;
+    for (int reg = 0; reg < 4; ++reg) thrf[reg] = (u_base + 4 * g + reg < U) ? -INFINITY : INFINITY;      // users past U never insert
+    int *cntl = reinterpret_cast<int *>(bt + 2 * MST * LD) + wv * 16;          // keys held per user row of this wave
+    unsigned long long *wcand = cand + (size_t)wv * 16 * kMCap;
+    if (lane < 16) cntl[lane] = 0;
+    // Interacted-item mask: a 1024-bit Bloom filter per user in LDS answers "not interacted" for ~97 % of the pre-filter
+    // survivors with one LDS read; only filter hits pay the binary search in global memory (7 dependent L2 round trips).
+    unsigned *bloom = reinterpret_cast<unsigned *>(bt + 2 * MST * LD) + kMU + wv * 16 * kBloomWords;     // [16][kBloomWords]
+    if (mrp) {
+        for (int t = lane; t < 16 * kBloomWords; t += kWave) bloom[t] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        for (int ulw = 0; ulw < 16; ++ulw) {
+            const int u = u_base + ulw;
+            if (u >= U) break;
+            for (int e = mrp[u] + lane, end = mrp[u + 1]; e < end; e += kWave) {
+                const unsigned hb = bloom_hash(mcol[e]);
+                atomicOr(&bloom[ulw * kBloomWords + (hb >> 5)], 1u << (hb & 31u));
+            }
+        }
+    }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
-    ARL_PROF_DECL
-    ARL_TOPK_FETCH(0)
-    for (int st = 0; st < nstages; ++st) {
-        float *buf = bt + (st & 1) * MST * LD;
-        *lds_ptr(buf, 0) = nb0;
-        if constexpr (PER > 1) *lds_ptr(buf, 1) = nb1;
-        if constexpr (PER > 2) *lds_ptr(buf, 2) = nb2;
-        if constexpr (PER > 3) *lds_ptr(buf, 3) = nb3;
-        __syncthreads();                                       // the only block barrier per stage
-        ARL_PROF_TICK(0)
-        if (st + 1 < nstages) ARL_TOPK_FETCH(st + 1)
-        // all B fragments of the stage go to registers first (the loads overlap the MFMA chains instead of a read-wait-use
-        // sequence per 4 MFMAs), and the sub-tiles' accumulation chains are interleaved so no MFMA waits on its predecessor
-        constexpr int NSUB = MST / kMI;
-        float4 bf[NSUB][H / 4];
+    // Pre-filter + inserts + compaction for the scores of one stage (32 items x 16 users per phase: 8 scores per lane,
+    // bit b = 4*s2 + reg  <->  item item0 + 16*s2 + c, user row 4g + reg).
+    auto bookkeeping = [&](const f32x4 (&ac)[NSUB], int st) {
 #pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub) {
-            const float *brow = buf + (sub * kMI + r) * LD + H * h;
+        for (int ph = 0; ph < NPH; ++ph) {
+            const int item0 = st * MST + ph * 32;
+            float sc8[8];
 #pragma unroll
-            for (int t = 0; t < H; t += 4) bf[sub][t / 4] = *reinterpret_cast<const float4 *>(brow + t);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        f32x16 accs[NSUB];
-#pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub) accs[sub] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < H; t += 4) {
-#pragma unroll
-            for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bf[sub][t / 4].x, accs[sub], 0, 0, 0);
-#pragma unroll
-            for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 1], bf[sub][t / 4].y, accs[sub], 0, 0, 0);
-#pragma unroll
-            for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 2], bf[sub][t / 4].z, accs[sub], 0, 0, 0);
-#pragma unroll
-            for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t + 3], bf[sub][t / 4].w, accs[sub], 0, 0, 0);
-        }
-#pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub) {
-            const f32x16 acc = accs[sub];
-            const int item = st * MST + sub * kMI + r;
-#ifdef ARL_TOPK_PROF
-            if (sub == 0) { float sink = acc[0] + accs[NSUB - 1][15]; asm volatile("" ::"v"(sink)); ARL_PROF_TICK(1) }
-#endif
-            // Pre-filter in the vector unit only: one 16-bit pass mask per lane and ONE ballot per sub-tile.  (A ballot + branch
-            // per accumulator register is a VALU->SALU round trip each: 16 of them cost ~1.7k cycles per 2k cycles of MFMA.)
+            for (int b = 0; b < 8; ++b) sc8[b] = ac[2 * ph + (b >> 2)][b & 3];
             unsigned pm = 0u;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) pm |= (acc[reg] >= thrf[reg]) ? (1u << reg) : 0u;
-            if (item >= I) pm = 0u;
-            if (__ballot(pm != 0u) != 0ull) {
-                // Insert path: every lane takes its lowest pending register per round (normally one round, one key per lane)
-                bool nearly_full = false;
-                do {
-                    if (pm != 0u) {
-                        const int reg = __ffs(pm) - 1;
-                        pm &= pm - 1u;
-                        const int ulw = (reg & 3) + 8 * (reg >> 2) + 4 * h;            // user row within the wave
-                        float sc = acc[0];
+            for (int b = 0; b < 8; ++b) pm |= (sc8[b] >= thrf[b & 3]) ? (1u << b) : 0u;
+            if (item0 + c >= I) pm = 0u;
+            else if (item0 + 16 + c >= I) pm &= 0xfu;
+            if (__ballot(pm != 0u) == 0ull) continue;
+            bool nearly_full = false;
+            unsigned no_thr = 0u;                                          // user rows still without a threshold (-inf)
 #pragma unroll
-                        for (int j = 1; j < 16; ++j) sc = (reg == j) ? acc[j] : sc;
-                        bool ins = true;
-                        if (mrp) {                                                     // interacted -> -10e8 (pre-filter survivors only)
+            for (int reg = 0; reg < 4; ++reg) no_thr |= (thrf[reg] == -INFINITY) ? (1u << reg) : 0u;
+            do {
+                if (pm != 0u) {
+                    const int b = __ffs(pm) - 1;
+                    pm &= pm - 1u;
+                    const int reg = b & 3, ulw = 4 * g + reg;
+                    const int item = item0 + 16 * (b >> 2) + c;
+                    float sc = sc8[0];
+#pragma unroll
+                    for (int j = 1; j < 8; ++j) sc = (b == j) ? sc8[j] : sc;
+                    bool ins = true;
+                    if (mrp) {                                             // interacted -> -10e8 (pre-filter survivors only)
+                        const unsigned hb = bloom_hash(item);
+                        if ((bloom[ulw * kBloomWords + (hb >> 5)] >> (hb & 31u)) & 1u) {
                             const int u = u_base + ulw;
                             int lo = mrp[u], hi = mrp[u + 1];
                             const int end = hi;
                             while (lo < hi) { const int mid = (lo + hi) >> 1; if (mcol[mid] < item) lo = mid + 1; else hi = mid; }
-                            if (lo < end && mcol[lo] == item) {
+                            if (lo < end && mcol[lo] == item) {            // kept only while the user has no threshold yet
                                 sc = -10e8f;
-                                float th = thrf[0];
-#pragma unroll
-                                for (int j = 1; j < 16; ++j) th = (reg == j) ? thrf[j] : th;
-                                ins = sc >= th;
+                                ins = (no_thr >> reg) & 1u;
                             }
                         }
-                        if (ins) {
-                            const int slot = atomicAdd(&cntl[ulw], 1);                 // < kMCap: <= kMCap - kMI held at sub-tile start
-                            wcand[ulw * kMCap + slot] = pack_cand(sc, item);
-                            nearly_full |= slot + 1 > kMCap - kMI;
-                        }
                     }
-                } while (__any(pm != 0u));
-                ARL_PROF_TICK(2)
-                if (__any(nearly_full)) {
-                    // compaction of the users that could overflow during the next sub-tile (wave-local: no block barrier)
-                    __builtin_amdgcn_wave_barrier();
-                    __threadfence_block();
-                    const int myc = lane < 32 ? cntl[lane] : 0;
-                    for (unsigned long long fm = __ballot(myc > kMCap - kMI); fm; fm &= fm - 1ull) {
-                        const int ulw = __ffsll((long long)fm) - 1;                    // wave-uniform
-                        const int c = __builtin_amdgcn_readlane(myc, ulw);
-                        const float nt = cand_score(wave_select_topk(wcand + (size_t)ulw * kMCap, c, k, lane));
-                        if (lane == 0) cntl[ulw] = k;
-                        const int treg = (ulw & 3) | ((ulw >> 3) << 2), th = (ulw >> 2) & 1;
-#pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) thrf[reg] = (reg == treg && h == th) ? nt : thrf[reg];
+                    if (ins) {
+                        const int slot = atomicAdd(&cntl[ulw], 1);         // < kMCap: at most kMCap - kMI held when a phase starts
+                        wcand[ulw * kMCap + slot] = pack_cand(sc, item);
+                        nearly_full |= slot + 1 > kMCap - kMI;
                     }
-                    __builtin_amdgcn_wave_barrier();
-                    __threadfence_block();
                 }
-                ARL_PROF_TICK(3)
-            } else {
-                ARL_PROF_TICK(2)
+            } while (__any(pm != 0u));
+            if (__any(nearly_full)) {
+                // compaction of the users that could overflow during the next phase (wave-local: no block barrier)
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+                const int myc = lane < 16 ? cntl[lane] : 0;
+                for (unsigned long long fm = __ballot(myc > kMCap - kMI); fm; fm &= fm - 1ull) {
+                    const int ulw = __ffsll((long long)fm) - 1;            // wave-uniform
+                    const int cn = __builtin_amdgcn_readlane(myc, ulw);
+                    const float nt = cand_score(wave_select_topk(wcand + (size_t)ulw * kMCap, cn, k, lane));
+                    if (lane == 0) cntl[ulw] = k;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) thrf[reg] = (4 * g + reg == ulw) ? nt : thrf[reg];
+                }
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
             }
         }
+    };
+    ARL_PROF_DECL
+    nb0 = *stage_ptr(0, 0);
+    if constexpr (PER > 1) nb1 = *stage_ptr(0, 1);
+    for (int st = 0; st < nstages; ++st) {
+        float *buf = bt + (st & 1) * MST * LD;
+        *lds_ptr(buf, 0) = nb0;
+        if constexpr (PER > 1) *lds_ptr(buf, 1) = nb1;
+        __syncthreads();                                           // the only block barrier per stage
+        ARL_PROF_TICK(0)
+        if (st + 1 < nstages) {
+            nb0 = *stage_ptr(st + 1, 0);
+            if constexpr (PER > 1) nb1 = *stage_ptr(st + 1, 1);
+        }
+        float4 bf[NSUB][Q / 4];
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const float *brow = buf + (sub * 16 + c) * LD + Q * g;
+#pragma unroll
+            for (int t = 0; t < Q; t += 4) bf[sub][t / 4] = *reinterpret_cast<const float4 *>(brow + t);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 accs[NSUB];
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) accs[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < Q; t += 4) {
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bf[sub][t / 4].x, accs[sub], 0, 0, 0);
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t + 1], bf[sub][t / 4].y, accs[sub], 0, 0, 0);
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t + 2], bf[sub][t / 4].z, accs[sub], 0, 0, 0);
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t + 3], bf[sub][t / 4].w, accs[sub], 0, 0, 0);
+        }
+#ifdef ARL_TOPK_PROF
+        { float sink = accs[0][0] + accs[NSUB - 1][3]; asm volatile("" ::"v"(sink)); ARL_PROF_TICK(1) }
+#endif
+        bookkeeping(accs, st);
+        ARL_PROF_TICK(2)
     }
 #ifdef ARL_TOPK_PROF
     const long long P_loop = clock64() - P_start;
 #endif
-    __syncthreads();                                           // the staging buffers become per-wave sort scratch (128 keys each)
+    __syncthreads();                                               // the staging buffers become per-wave sort scratch (128 keys each)
     unsigned long long *scratch = reinterpret_cast<unsigned long long *>(bt) + wv * 128;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int ul = wv * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-            const int u = blockIdx.x * kMU + ul;
-            if (u >= U) continue;
-            const int c = cntl[ul - wv * 32];
-            for (int t = lane; t < 128; t += kWave) scratch[t] = t < c ? cand[(size_t)ul * kMCap + t] : 0ull;
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
-            wave_sort_desc_128(scratch, lane);
-            for (int t = lane; t < k; t += kWave) {
-                top_idx[(size_t)u * k + t] = cand_item(scratch[t]);
-                top_val[(size_t)u * k + t] = cand_score(scratch[t]);
-            }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
+    for (int ulw = 0; ulw < 16; ++ulw) {
+        const int u = u_base + ulw;
+        if (u >= U) break;
+        const int cn = cntl[ulw];
+        for (int t = lane; t < 128; t += kWave) scratch[t] = t < cn ? wcand[(size_t)ulw * kMCap + t] : 0ull;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        wave_sort_desc_128(scratch, lane);
+        for (int t = lane; t < k; t += kWave) {
+            top_idx[(size_t)u * k + t] = cand_item(scratch[t]);
+            top_val[(size_t)u * k + t] = cand_score(scratch[t]);
         }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
     }
 #ifdef ARL_TOPK_PROF
     if (lane == 0 && u_base < U) {
@@ -1666,13 +1674,15 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
     if (U < 0 || I <= 0 || U > 0x7fffffffll || I > 0x7fffffffll) return ARL_E_RANGE;
     if (U == 0) return ARL_OK;
     if (k <= 64 && (d == 16 || d == 32 || d == 64 || d == 128)) {        // matrix-core path
-        const size_t shm_m = sizeof(unsigned long long) * kMU * kMCap + sizeof(float) * 2 * (d <= 64 ? 64 : 32) * (size_t)(d + 4) + sizeof(int) * kMU;
+        const int mst = d <= 16 ? 128 : (d <= 64 ? 64 : 32);
+        const size_t shm_m = sizeof(unsigned long long) * kMU * kMCap + sizeof(float) * 2 * mst * (size_t)(d + 4) + sizeof(int) * kMU +
+                             (mask_rowptr ? sizeof(unsigned) * kMU * kBloomWords : 0);
         const unsigned grid_m = (unsigned)((U + kMU - 1) / kMU);
 #define ARL_TOPK_CASE(DV)                                                                                                              \
         do {                                                                                                                           \
-            hipError_t em = hipFuncSetAttribute((const void *)score_mask_topk_mfma_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m); \
+            hipError_t em = hipFuncSetAttribute((const void *)score_mask_topk_mfma16_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m); \
             if (em != hipSuccess) return (int)em;                                                                                      \
-            hipLaunchKernelGGL((score_mask_topk_mfma_kernel<DV>), dim3(grid_m), dim3(kBlock), shm_m, (hipStream_t)stream, Pu, Pi, (int)U, (int)I, \
+            hipLaunchKernelGGL((score_mask_topk_mfma16_kernel<DV>), dim3(grid_m), dim3(kM16Block), shm_m, (hipStream_t)stream, Pu, Pi, (int)U, (int)I, \
                                mask_rowptr, mask_col, (int)k, top_idx, top_val);                                                       \
         } while (0)
         if (d == 16) ARL_TOPK_CASE(16);
