@@ -1147,11 +1147,16 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
             float sc8[8];
 #pragma unroll
             for (int b = 0; b < 8; ++b) sc8[b] = ac[2 * ph + (b >> 2)][b & 3];
-            unsigned pm = 0u;
+            // sign(score - threshold) shifted into a mask: two VALU ops per score, no VCC round trip (score == threshold passes;
+            // threshold -inf always passes, +inf never)
+            unsigned fails = 0u;
 #pragma unroll
-            for (int b = 0; b < 8; ++b) pm |= (sc8[b] >= thrf[b & 3]) ? (1u << b) : 0u;
-            if (item0 + c >= I) pm = 0u;
-            else if (item0 + 16 + c >= I) pm &= 0xfu;
+            for (int b = 7; b >= 0; --b) fails = __builtin_amdgcn_alignbit(fails, __float_as_uint(sc8[b] - thrf[b & 3]), 31);
+            unsigned pm = ~fails & 0xffu;
+            if (st == nstages - 1) {                                       // rows past I were staged as copies of item I-1
+                if (item0 + c >= I) pm = 0u;
+                else if (item0 + 16 + c >= I) pm &= 0xfu;
+            }
             if (__ballot(pm != 0u) == 0ull) continue;
             bool nearly_full = false;
             unsigned no_thr = 0u;                                          // user rows still without a threshold (-inf)
@@ -1163,9 +1168,10 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
                     pm &= pm - 1u;
                     const int reg = b & 3, ulw = 4 * g + reg;
                     const int item = item0 + 16 * (b >> 2) + c;
-                    float sc = sc8[0];
-#pragma unroll
-                    for (int j = 1; j < 8; ++j) sc = (b == j) ? sc8[j] : sc;
+                    const float s01 = (b & 1) ? sc8[1] : sc8[0], s23 = (b & 1) ? sc8[3] : sc8[2];
+                    const float s45 = (b & 1) ? sc8[5] : sc8[4], s67 = (b & 1) ? sc8[7] : sc8[6];
+                    const float s03 = (b & 2) ? s23 : s01, s47 = (b & 2) ? s67 : s45;
+                    float sc = (b & 4) ? s47 : s03;
                     bool ins = true;
                     if (mrp) {                                             // interacted -> -10e8 (pre-filter survivors only)
                         const unsigned hb = bloom_hash(item);
