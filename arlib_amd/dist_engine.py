@@ -79,12 +79,13 @@ class ShardedPropagationEngine:
     """Rank-local state + step() of the user-sharded LightGCN (mean of L+1 layers) + BPR/L2 + dense Adam."""
 
     def __init__(self, blocks, n_users, n_items, emb_size, n_layers, reg, lr, device, rank, world, table, chunk=512,
-                 comm=None, kernels=None, betas=(0.9, 0.999), eps=1e-8):
+                 comm=None, kernels=None, betas=(0.9, 0.999), eps=1e-8, skip_layer0=False):
         if kernels is None:
             from . import ops as kernels         # the HIP kernels; fails loudly if libarlib_amd.so is missing
         self.k = kernels
         self.comm = comm if comm is not None else TorchDistComm()
         self.rank, self.world = rank, world
+        self.skip0 = bool(skip_layer0)             # SimGCL: layers 1..L averaged (step_simgcl); LightGCN: 0..L (step / step_sparse)
         self.U, self.I, self.d, self.L = int(n_users), int(n_items), int(emb_size), int(n_layers)
         if self.L < 1:
             raise ValueError('the sharded engine is for graph models (n_layers >= 1)')
@@ -134,6 +135,8 @@ class ShardedPropagationEngine:
 
     def forward(self):
         """Propagated tables for the local users and all items: mean(E_0..E_L) (recommender/LightGCN.py:230-240)."""
+        if self.skip0:
+            raise ValueError('forward()/step()/step_sparse() are the LightGCN mean over layers 0..L; a skip_layer0 engine uses step_simgcl()')
         L = self.L
         cur, nxt = self.Ea, self.Eb
         self._hop(self.E0, cur)
@@ -193,6 +196,8 @@ class ShardedPropagationEngine:
     def step_sparse(self, u, p, n):
         # NOTE: batch indices must be range-checked by the caller (bench.py / the training loop do it once per batch chunk);
         # every op below runs with check_range=False so the step has no host synchronisation
+        if self.skip0:
+            raise ValueError('step_sparse() is the LightGCN step; a skip_layer0 engine uses step_simgcl()')
         k, L, Ul, d = self.k, self.L, self.Ul, self.d
         B = u.numel()
         dev = self.device
@@ -281,6 +286,89 @@ class ShardedPropagationEngine:
         k.mark_rows_(self.flags, item_rows_packed, 0, check_range=False)
         k.mark_bits_(self.bits, item_rows_packed, False, self.Nl, check_range=False)
         return self.loss_out
+
+    # ---- SimGCL (recommender/SimGCL.py:51-63,198-219) on the user-sharded layout -- BASELINE config 4's training step.
+    # Three forwards (clean + two perturbed views; layer 0 is not averaged in), BPR + L2 on the clean one, InfoNCE between the
+    # views at the batch's unique users and unique positive items.  The perturbation carries no gradient, so the three output
+    # gradients share ONE backward operator (1/L) sum_{k=1..L} A^k and are summed first.
+    # Exchanges: one I x d all-reduce per hop (3L forward + L backward), one [2*nu, d] all-reduce for the user rows of the
+    # two views (each rank contributes the rows it owns), the 3 loss sums, and G's item rows before the backward pass.
+    def step_simgcl(self, u, p, n, cl_rate=0.2, tau=0.2, eps=0.1, noises=None):
+        """noises: optional [view][hop] tensors over the LOCAL packed rows [Ul + I, d].  By default user rows draw from the
+        rank's generator and the replicated item rows from a generator every rank seeds identically (step counter)."""
+        if not self.skip0:
+            raise ValueError('step_simgcl needs skip_layer0=True (SimGCL averages layers 1..L)')
+        k, L, Ul, d, dev = self.k, self.L, self.Ul, self.d, self.device
+        B = u.numel()
+        inv = 1.0 / L
+        if not hasattr(self, 'S1'):
+            self.S1, self.S2 = torch.zeros_like(self.S), torch.zeros_like(self.S)
+
+        def noise(view, hop):
+            if noises is not None:
+                return noises[view][hop]
+            g = torch.Generator(device=dev)
+            g.manual_seed(0x51AC1 + 7919 * self.t + 2 * hop + view)                 # identical on every rank: replicated item rows
+            item = torch.rand(self.I, d, generator=g, device=dev)
+            return torch.cat([torch.rand(Ul, d, device=dev), item], 0)
+
+        def forward(view, acc):
+            cur, bufs = self.E0, [self.Ea, self.Eb]
+            for h in range(L):
+                dst = bufs[h % 2]
+                self._hop(cur, dst)
+                if view is not None:
+                    k.simgcl_perturb_(dst, noise(view, h), eps)
+                if h == 0:
+                    acc.copy_(dst)
+                else:
+                    acc.add_(dst)
+                cur = dst
+            return acc.mul_(inv)
+
+        out = forward(None, self.S)
+        v1, v2 = forward(0, self.S1), forward(1, self.S2)
+        # ---- rec loss on the clean forward (as in step())
+        lu, lp, ln = self._local_batch(u, p, n)
+        if self.ws is None or self.ws.numel() < 4 * max(B, 1):
+            self.ws = torch.empty(4 * max(B, 1), dtype=torch.float32, device=dev)
+        k.bpr_l2_partial(out, Ul, lu, lp, ln, B, self.ws, self.sums)
+        self.comm.all_reduce(self.sums)
+        nu_, np_ = torch.sqrt(self.sums[1]), torch.sqrt(self.sums[2])
+        self.loss_out[0] = self.sums[0] / B
+        self.loss_out[1] = self.reg * (nu_ + np_)
+        self.loss_out[2] = nu_
+        self.loss_out[3] = np_
+        self.G.zero_()
+        if lu.numel():
+            k.bpr_l2_backward(out, Ul, lu, lp, ln, self.reg, self.loss_out, self.G, self.ws)
+        self.comm.all_reduce(self.G[Ul:])                                        # item rows: per-rank partials -> complete
+        # ---- contrastive loss: unique users of the GLOBAL batch (rows live on their owners), unique positive items (replicated)
+        uidx = torch.unique(u.long())
+        iidx = torch.unique(p.long())
+        nu = uidx.numel()
+        own = (uidx >= self.u0) & (uidx < self.u1)
+        loc = (uidx - self.u0).clamp_(0, max(Ul - 1, 0))
+        Cv = torch.zeros(2 * nu, d, dtype=torch.float32, device=dev)
+        if Ul:
+            ownf = own.to(torch.float32).unsqueeze(1)
+            Cv[:nu] = v1[loc] * ownf
+            Cv[nu:] = v2[loc] * ownf
+        self.comm.all_reduce(Cv)
+        l_u, du1, du2 = k.infonce_fwd_bwd(Cv[:nu].contiguous(), Cv[nu:].contiguous(), tau)
+        l_i, di1, di2 = k.infonce_fwd_bwd(v1[Ul + iidx].contiguous(), v2[Ul + iidx].contiguous(), tau)
+        cl_loss = cl_rate * (l_u[0] + l_i[0])
+        if Ul:
+            self.G.index_add_(0, loc[own], (du1 + du2)[own] * cl_rate)           # only the owner holds the row
+        self.G.index_add_(0, Ul + iidx, (di1 + di2) * cl_rate)                    # identical on every rank, after the reduction
+        # ---- one backward pass for the three forwards, Adam on the local block + the item replica
+        self.t += 1
+        acc, bufs = self.G, [self.Ea, self.Eb]
+        for h in range(L - 1):
+            acc = self._hop(acc, bufs[h % 2], 1.0, 1.0, self.G)
+        grad = self._hop(acc, bufs[(L - 1) % 2], inv)
+        k.adam_dense(self.E0, grad, self.m, self.v, self.lr, self.t, self.betas, self.eps)
+        return self.loss_out, cl_loss
 
     def gather_full_table(self):
         """[U+I, d] table assembled on every rank (tests / checkpoints): all-gather of the user blocks + the replica."""

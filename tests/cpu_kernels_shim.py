@@ -127,3 +127,14 @@ def mark_bits_(bits, idx, set_, n_nodes, check_range=True):
 def zero_rows_(dst, idx, check_range=True):
     dst[idx.long()] = 0
     return dst
+
+
+def simgcl_perturb_(E, noise, eps):
+    E.copy_(torch.from_numpy(O.simgcl_perturb(E.numpy().copy(), noise.numpy(), eps)))
+    return E
+
+
+def infonce_fwd_bwd(v1, v2, tau, want_grad=True, upstream=1.0):
+    loss, d1, d2 = O.infonce(v1.numpy(), v2.numpy(), tau, want_grad)
+    t = lambda a: None if a is None else torch.from_numpy(a * np.float32(upstream))
+    return torch.tensor([loss], dtype=torch.float32), t(d1), t(d2)

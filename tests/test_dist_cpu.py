@@ -78,3 +78,64 @@ def test_sharded_engine_gloo_matches_single_process_oracle(world, sparse):
     mp.spawn(_worker, args=(world, port, ret, sparse), nprocs=world, join=True)
     assert np.allclose(ret['losses'], ref_losses, rtol=RTOL, atol=0)
     assert rel_err(ret['table'], ref_table) < RTOL
+
+
+def simgcl_problem():
+    U, I, d, _, pairs, E0, batches = small_problem()
+    rng = np.random.default_rng(5)
+    L = 2
+    noise = rng.random((2, L, U + I, d)).astype(np.float32)          # [view][hop] global rows; every rank slices its own
+    return U, I, d, L, pairs, E0, batches[0], noise
+
+
+def oracle_simgcl_step(U, I, d, L, pairs, E0, batch, noise, cl_rate=0.2, tau=0.2, eps=0.1):
+    """Single-process restatement of one SimGCL iteration (same composition test_oracle_golden pins on g5_simgcl)."""
+    rowptr, col, w = O.bipartite_csr(pairs[:, 0], pairs[:, 1], U, I)
+    csr = (rowptr, col, O.norm_adj_values(rowptr, col, w))
+    bu, bp, bn = batch
+    out = O.lightgcn_forward(csr, E0, L, skip0=True)
+    lb, lr_, G = O.bpr_l2(out, U, bu, bp, bn, 1e-4)
+    v1 = O.lightgcn_forward(csr, E0, L, skip0=True, noises=noise[0], eps=eps)
+    v2 = O.lightgcn_forward(csr, E0, L, skip0=True, noises=noise[1], eps=eps)
+    cl = 0.0
+    G = G.astype(np.float64)
+    for idx in (np.unique(bu), np.unique(bp) + U):
+        l, d1, d2 = O.infonce(v1[idx], v2[idx], tau)
+        cl += l
+        G[idx] += cl_rate * (d1.astype(np.float64) + d2)
+    grad = O.lightgcn_backward(csr, G.astype(np.float32), L, skip0=True)
+    m = np.zeros_like(E0); v = np.zeros_like(E0); E = E0.copy()
+    O.adam_step(E, grad, m, v, 0.005, 1)
+    return E, lb + lr_, cl_rate * cl
+
+
+def _simgcl_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import torch.distributed as dist
+    import cpu_kernels_shim as shim
+    from arlib_amd.dist_engine import ShardedPropagationEngine
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    U, I, d, L, pairs, E0, batch, noise = simgcl_problem()
+    eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cpu', rank, world, torch.from_numpy(E0), kernels=shim, skip_layer0=True)
+    local = lambda a: torch.from_numpy(np.concatenate([a[eng.u0:eng.u1], a[U:]]))
+    lo, cl = eng.step_simgcl(*(torch.from_numpy(x) for x in batch), noises=[[local(noise[v][h]) for h in range(L)] for v in range(2)])
+    full = eng.gather_full_table().numpy()
+    with pytest.raises(ValueError):
+        eng.step_sparse(*(torch.from_numpy(x) for x in batch))       # a skip_layer0 engine refuses the LightGCN step
+    if rank == 0:
+        ret['table'], ret['rec'], ret['cl'] = full, float(lo[0] + lo[1]), float(cl)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_simgcl_step_gloo_matches_single_process_oracle(world):
+    ref_table, ref_rec, ref_cl = oracle_simgcl_step(*simgcl_problem())
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_simgcl_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert abs(ret['rec'] - ref_rec) <= RTOL * abs(ref_rec)
+    assert abs(ret['cl'] - ref_cl) <= RTOL * abs(ref_cl)
+    assert rel_err(ret['table'], ref_table) < RTOL

@@ -65,3 +65,43 @@ def test_sharded_engine_two_ranks_hip_kernels(sparse):
     mp.spawn(_worker, args=(2, port, ret, sparse), nprocs=2, join=True)
     assert np.allclose(ret['losses'], ref_losses, rtol=RTOL, atol=0)
     assert rel_err(ret['table'], ref_table) < RTOL
+
+
+def _simgcl_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import torch.distributed as dist
+    from arlib_amd.dist_engine import ShardedPropagationEngine
+    from test_dist_cpu import simgcl_problem
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    U, I, d, L, pairs, E0, batch, noise = simgcl_problem()
+    eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cuda:0', rank, world, torch.from_numpy(E0), comm=HostStagedComm(),
+                                              skip_layer0=True)
+    local = lambda a: torch.from_numpy(np.concatenate([a[eng.u0:eng.u1], a[U:]])).cuda()
+    lo, cl = eng.step_simgcl(*(torch.from_numpy(x).cuda() for x in batch), noises=[[local(noise[v][h]) for h in range(L)] for v in range(2)])
+    full = eng.gather_full_table().cpu().numpy()
+    # the default noise path: replicated item rows must receive identical noise on every rank (tables stay replicas)
+    eng.step_simgcl(*(torch.from_numpy(x).cuda() for x in batch))
+    items = eng.E0[eng.Ul:].detach().cpu()
+    gathered = [torch.zeros_like(items) for _ in range(world)]
+    dist.all_gather(gathered, items)
+    if rank == 0:
+        ret['table'], ret['rec'], ret['cl'] = full, float(lo[0] + lo[1]), float(cl)
+        ret['replica_diff'] = float((gathered[0] - gathered[1]).abs().max())
+    dist.destroy_process_group()
+
+
+def test_sharded_simgcl_two_ranks_hip_kernels():
+    if not torch.cuda.is_available():
+        pytest.fail('GPU tests need a GPU')
+    from test_dist_cpu import simgcl_problem, oracle_simgcl_step
+    ref_table, ref_rec, ref_cl = oracle_simgcl_step(*simgcl_problem())
+    ctx = mp.get_context('spawn')
+    ret = ctx.Manager().dict()
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_simgcl_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert abs(ret['rec'] - ref_rec) <= RTOL * abs(ref_rec)
+    assert abs(ret['cl'] - ref_cl) <= RTOL * abs(ref_cl)
+    assert rel_err(ret['table'], ref_table) < RTOL
+    assert ret['replica_diff'] == 0.0
