@@ -88,3 +88,53 @@ def test_sampler_epoch_properties_full_size(cfg2):
             row = items[rp[uu]:rp[uu + 1]]
             j = np.searchsorted(row, nn)
             assert not (j < len(row) and row[j] == nn)
+
+
+def test_score_mask_topk_full_size_against_dense_rows(cfg2):
+    """Streaming masked top-50 over 1M x 100K against dense fp32 scoring + torch.topk on sampled users; every returned item of
+    EVERY user is un-interacted (membership via the CSR) and the lists are sorted."""
+    ops, U, I, nnz = cfg2['ops'], cfg2['U'], cfg2['I'], cfg2['nnz']
+    torch.manual_seed(3)
+    X = torch.cat([torch.nn.init.xavier_uniform_(torch.empty(U, 64)), torch.nn.init.xavier_uniform_(torch.empty(I, 64))], 0).to(DEV)
+    X = ops.spmm(cfg2['A'], X)                                                 # propagated tables: popularity-skewed scores
+    Pu, Pi = X[:U].contiguous(), X[U:].contiguous()
+    rp = torch.from_numpy(cfg2['rowptr'][:U + 1].astype(np.int32)).to(DEV)
+    mc = (cfg2['A'].col[:nnz] - U).to(torch.int32).contiguous()
+    idx, val = ops.score_mask_topk(Pu, Pi, 50, rp, mc)
+    assert bool((val[:, :-1] >= val[:, 1:]).all())
+    # no interacted item anywhere: (user, item) keys of the result vs the sorted interaction keys
+    keys = (torch.arange(U, device=DEV, dtype=torch.int64)[:, None] * I + idx.long()).flatten()
+    inter = torch.repeat_interleave(torch.arange(U, device=DEV, dtype=torch.int64), (rp[1:] - rp[:-1]).long()) * I + mc.long()
+    pos = torch.searchsorted(inter, keys).clamp_(max=inter.numel() - 1)
+    assert not bool((inter[pos] == keys).any())
+    sample = torch.from_numpy(np.random.default_rng(0).choice(U, 512, replace=False)).to(DEV)
+    sc = Pu[sample] @ Pi.T
+    for r, u in enumerate(sample.tolist()):
+        sc[r, mc[rp[u]:rp[u + 1]].long()] = -10e8
+    rv, ri = torch.topk(sc, 50)
+    assert (ri == idx[sample].long()).float().mean().item() > 0.999           # ties / last-ulp orderings aside
+    assert torch.allclose(rv, val[sample], rtol=1e-5, atol=1e-7)
+
+
+def test_sfa_full_size_against_float64_closed_form(cfg2):
+    """CLeaR's SFA term at cfg2 multiplicities (5 per real user, U per target, histogram of negatives) vs the same closed
+    form evaluated in float64 (the closed form itself is pinned against the literal restatement in the CPU suite)."""
+    ops, U, I = cfg2['ops'], cfg2['U'], cfg2['I']
+    g = torch.Generator().manual_seed(11)
+    X = (torch.randn(U + I, 64, generator=g) * 0.1).to(DEV)
+    w = torch.zeros(U + I, device=DEV)
+    w[:U] = 5.0
+    neg = torch.randint(0, I, (5 * U,), generator=g).to(DEV)
+    w[U:] = torch.bincount(neg, minlength=I).float()
+    w[U + torch.arange(5, device=DEV) * 977] += float(U)
+    r0 = torch.randn(64, generator=g).to(DEV)
+    numel = 3 * U * 5 * 64
+    loss, G = ops.sfa_l1(X, w, r0, numel)
+    Xd, wd, r0d = X.double(), w.double(), r0.double()
+    q = Xd @ r0d; r = Xd.T @ (wd * q); s = Xd @ r
+    S, A, Q = (wd * s.abs()).sum(), r.abs().sum(), r @ r
+    a = Xd.T @ (wd * torch.sign(s))
+    g_r = ((A / Q) * a + (S / Q) * torch.sign(r) - (2 * S * A / Q ** 2) * r) / numel
+    Gd = wd[:, None] * ((A / (numel * Q)) * torch.sign(s)[:, None] * r[None, :] + q[:, None] * g_r[None, :] + (Xd @ g_r)[:, None] * r0d[None, :])
+    assert abs(loss.item() - (S * A / (numel * Q)).item()) <= 1e-4 * abs((S * A / (numel * Q)).item())
+    assert ((G.double() - Gd).norm() / Gd.norm()).item() < 1e-4
