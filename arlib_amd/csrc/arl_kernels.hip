@@ -1074,18 +1074,45 @@ constexpr int kM16Block = 512;
 constexpr int kBloomWords = 32;      // 1024 bits per user
 __device__ __forceinline__ unsigned bloom_hash(int item) { return ((unsigned)item * 2654435761u) >> 22; }
 
-template <int D>
-__global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const float *__restrict__ Pu, const float *__restrict__ Pi, int U, int I,
+// SPLIT = true: the contraction runs on the bf16 matrix path with every fp32 operand split into three bf16 pieces
+// (x = hi + mid + lo exactly up to 2^-25 |x|) and the six partial products hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi
+// accumulated in fp32, smallest first: the dropped terms are <= 3 * 2^-24 of |a||b| per product, the size of the rounding
+// differences between two fp32 summation orders.  Six bf16 MFMAs at 16x the fp32 rate = 2.7x fewer matrix cycles, and -- unlike
+// the fp32 MFMA -- they leave the SIMD's vector issue free for the other wave's pre-filter and inserts.  `Pi` is then the
+// pre-split image [I][3][D] bf16 written by split_bf16x3_kernel.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(kBlock) void split_bf16x3_kernel(const float *__restrict__ X, long long n, int d, __bf16 *__restrict__ out) {
+    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;          // one element each
+    if (t >= n) return;
+    const long long row = t / d;
+    const int kcol = (int)(t - row * d);
+    const float x = X[t];
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)m);
+    __bf16 *o = out + row * 3 * d + kcol;
+    o[0] = h; o[d] = m; o[2 * d] = l;
+}
+
+template <int D, bool SPLIT>
+__global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const float *__restrict__ Pu, const void *__restrict__ Pi_image, int U, int I,
                                                                             const int32_t *__restrict__ mrp, const int32_t *__restrict__ mcol, int k,
                                                                             int32_t *__restrict__ top_idx, float *__restrict__ top_val) {
-    constexpr int Q = D / 4;                                       // k-steps = floats per lane fragment
-    constexpr int LD = D + 4;                                      // LDS row stride (floats)
-    constexpr int MST = D <= 16 ? 128 : (D <= 64 ? 64 : 32);       // items staged per block barrier
+    constexpr int Q = D / 4;                                       // contraction indices per lane: [Q*g, Q*g + Q)
+    constexpr int SRCB = SPLIT ? 3 * D * 2 : D * 4;                // bytes per item row in global memory
+    constexpr int ROWB = SRCB + 16;                                // LDS row stride: 16-B aligned, consecutive rows shifted by 4 banks
+    constexpr int MST = SPLIT ? (D <= 64 ? 32 : 16) : (D <= 16 ? 128 : (D <= 64 ? 64 : 32));      // items staged per block barrier
     constexpr int NSUB = MST / 16;                                 // 16-item sub-tiles per stage
-    constexpr int NPH = NSUB / 2;                                  // insert phases per stage (32 items each)
+    constexpr int SPP = NSUB >= 2 ? 2 : 1;                         // sub-tiles per insert phase (at most 32 items)
+    constexpr int NPH = NSUB / SPP;
+    constexpr int NSC = 4 * SPP;                                   // scores per lane and phase
+    static_assert(!SPLIT || (D % 32 == 0), "the bf16 path contracts 32 indices per MFMA");
     extern __shared__ unsigned char smem_raw[];
     unsigned long long *cand = reinterpret_cast<unsigned long long *>(smem_raw);                 // [kMU][kMCap]
-    float *bt = reinterpret_cast<float *>(cand + kMU * kMCap);                                   // [2][MST][LD]; sort scratch at the end
+    unsigned char *bt = reinterpret_cast<unsigned char *>(cand + kMU * kMCap);                   // [2][MST][ROWB]; sort scratch at the end
+    const unsigned char *Pi = reinterpret_cast<const unsigned char *>(Pi_image);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int u_base = blockIdx.x * kMU + wv * 16;                 // this wave's 16 users
@@ -1099,30 +1126,45 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
             a[t] = v.x; a[t + 1] = v.y; a[t + 2] = v.z; a[t + 3] = v.w;
         }
     }
-    constexpr int F4 = MST * D / 4;
-    constexpr int PER = F4 / kM16Block;
-    static_assert(F4 % kM16Block == 0 && PER >= 1 && PER <= 2, "staging assumes one or two float4 per thread");
+    constexpr int KS = SPLIT ? Q / 8 : 1;                          // bf16 MFMAs (8 indices per lane each) per operand pair
+    bf16x8 af[3][KS];
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int t = 0; t < Q; ++t) {
+            const __bf16 h = (__bf16)a[t];
+            const float r1 = a[t] - (float)h;
+            const __bf16 m = (__bf16)r1;
+            af[0][t / 8][t % 8] = h; af[1][t / 8][t % 8] = m; af[2][t / 8][t % 8] = (__bf16)(r1 - (float)m);
+        }
+    }
+    constexpr int C16 = SRCB / 16;                                 // 16-byte pieces per item row
+    constexpr int F4 = MST * C16;
+    constexpr int PER = (F4 + kM16Block - 1) / kM16Block;
+    static_assert(PER >= 1 && PER <= 2, "staging assumes one or two 16-byte pieces per thread");
     float4 nb0, nb1;                                               // named staging registers (an indexed array stayed in scratch)
     nb0 = nb1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool second = tid + kM16Block < F4;                      // this thread moves a second piece
     const int nstages = (I + MST - 1) / MST;
     auto stage_ptr = [&](int st, int p) {
         const int f = tid + p * kM16Block;
-        const int item = min(st * MST + f / (D / 4), I - 1);       // clamped, never selected on: rows past I are masked out of pm
-        return reinterpret_cast<const float4 *>(Pi + (size_t)item * D + (f % (D / 4)) * 4);
+        const int item = min(st * MST + f / C16, I - 1);           // clamped, never selected on: rows past I are masked out of pm
+        return reinterpret_cast<const float4 *>(Pi + (size_t)item * SRCB + (f % C16) * 16);
     };
-    auto lds_ptr = [&](float *buf, int p) {
+    auto lds_ptr = [&](unsigned char *buf, int p) {
         const int f = tid + p * kM16Block;
-        return reinterpret_cast<float4 *>(buf + (f / (D / 4)) * LD + (f % (D / 4)) * 4);
+        return reinterpret_cast<float4 *>(buf + (f / C16) * ROWB + (f % C16) * 16);
     };
     float thrf[4];                                                 // running k-th best (lower bound) of user rows 4g + reg
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) thrf[reg] = (u_base + 4 * g + reg < U) ? -INFINITY : INFINITY;      // users past U never insert
-    int *cntl = reinterpret_cast<int *>(bt + 2 * MST * LD) + wv * 16;          // keys held per user row of this wave
+    int *cntl = reinterpret_cast<int *>(bt + 2 * MST * ROWB) + wv * 16;        // keys held per user row of this wave
     unsigned long long *wcand = cand + (size_t)wv * 16 * kMCap;
+    int *needf = reinterpret_cast<int *>(bt + 2 * MST * ROWB) + kMU;          // [2] scheduled-compaction flags, by stage parity
     if (lane < 16) cntl[lane] = 0;
+    if (tid < 2) needf[tid] = 0;
     // Interacted-item mask: a 1024-bit Bloom filter per user in LDS answers "not interacted" for ~97 % of the pre-filter
     // survivors with one LDS read; only filter hits pay the binary search in global memory (7 dependent L2 round trips).
-    unsigned *bloom = reinterpret_cast<unsigned *>(bt + 2 * MST * LD) + kMU + wv * 16 * kBloomWords;     // [16][kBloomWords]
+    unsigned *bloom = reinterpret_cast<unsigned *>(bt + 2 * MST * ROWB) + kMU + 4 + wv * 16 * kBloomWords;   // [16][kBloomWords]
     if (mrp) {
         for (int t = lane; t < 16 * kBloomWords; t += kWave) bloom[t] = 0u;
         __builtin_amdgcn_wave_barrier();
@@ -1138,27 +1180,50 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
-    // Pre-filter + inserts + compaction for the scores of one stage (32 items x 16 users per phase: 8 scores per lane,
+    // Cut every user row of this wave holding more than `limit` keys down to its k largest and raise its threshold
+    // (wave-local: no block barrier).
+    auto compact_rows = [&](int limit) {
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        const int myc = lane < 16 ? cntl[lane] : 0;
+        for (unsigned long long fm = __ballot(myc > limit); fm; fm &= fm - 1ull) {
+            const int ulw = __ffsll((long long)fm) - 1;                    // wave-uniform
+            const int cn = __builtin_amdgcn_readlane(myc, ulw);
+            const float nt = cand_score(wave_select_topk(wcand + (size_t)ulw * kMCap, cn, k, lane));
+            if (lane == 0) cntl[ulw] = k;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) thrf[reg] = (4 * g + reg == ulw) ? nt : thrf[reg];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    };
+    // Compaction is the one long, irregular piece of a stage (a radix select per user), and with one block barrier per stage a
+    // wave that compacts alone stalls the other seven.  So it is scheduled: a row that passes the SOFT limit only raises a
+    // block-wide flag, and at the next stage boundary every wave compacts all of its rows at once (the stalls coincide, and every
+    // row's threshold tightens early).  The hard limit (a row that could overflow in the next phase) still compacts on the spot.
+    const int soft_limit = min(k + 16, kMCap - kMI);
+    // Pre-filter + inserts + compaction for the scores of one stage (16*SPP items x 16 users per phase: NSC scores per lane,
     // bit b = 4*s2 + reg  <->  item item0 + 16*s2 + c, user row 4g + reg).
     auto bookkeeping = [&](const f32x4 (&ac)[NSUB], int st) {
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
-            const int item0 = st * MST + ph * 32;
-            float sc8[8];
+            const int item0 = st * MST + ph * 16 * SPP;
+            float scv[NSC];
 #pragma unroll
-            for (int b = 0; b < 8; ++b) sc8[b] = ac[2 * ph + (b >> 2)][b & 3];
+            for (int b = 0; b < NSC; ++b) scv[b] = ac[SPP * ph + (b >> 2)][b & 3];
             // sign(score - threshold) shifted into a mask: two VALU ops per score, no VCC round trip (score == threshold passes;
             // threshold -inf always passes, +inf never)
             unsigned fails = 0u;
 #pragma unroll
-            for (int b = 7; b >= 0; --b) fails = __builtin_amdgcn_alignbit(fails, __float_as_uint(sc8[b] - thrf[b & 3]), 31);
-            unsigned pm = ~fails & 0xffu;
+            for (int b = NSC - 1; b >= 0; --b) fails = __builtin_amdgcn_alignbit(fails, __float_as_uint(scv[b] - thrf[b & 3]), 31);
+            unsigned pm = ~fails & ((1u << NSC) - 1u);
             if (st == nstages - 1) {                                       // rows past I were staged as copies of item I-1
-                if (item0 + c >= I) pm = 0u;
-                else if (item0 + 16 + c >= I) pm &= 0xfu;
+#pragma unroll
+                for (int s2 = 0; s2 < SPP; ++s2)
+                    if (item0 + 16 * s2 + c >= I) pm &= ~(0xfu << (4 * s2));
             }
             if (__ballot(pm != 0u) == 0ull) continue;
-            bool nearly_full = false;
+            bool nearly_full = false, over_soft = false;
             unsigned no_thr = 0u;                                          // user rows still without a threshold (-inf)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) no_thr |= (thrf[reg] == -INFINITY) ? (1u << reg) : 0u;
@@ -1168,10 +1233,13 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
                     pm &= pm - 1u;
                     const int reg = b & 3, ulw = 4 * g + reg;
                     const int item = item0 + 16 * (b >> 2) + c;
-                    const float s01 = (b & 1) ? sc8[1] : sc8[0], s23 = (b & 1) ? sc8[3] : sc8[2];
-                    const float s45 = (b & 1) ? sc8[5] : sc8[4], s67 = (b & 1) ? sc8[7] : sc8[6];
-                    const float s03 = (b & 2) ? s23 : s01, s47 = (b & 2) ? s67 : s45;
-                    float sc = (b & 4) ? s47 : s03;
+                    const float s01 = (b & 1) ? scv[1] : scv[0], s23 = (b & 1) ? scv[3] : scv[2];
+                    float sc = (b & 2) ? s23 : s01;
+                    if constexpr (NSC == 8) {
+                        const float s45 = (b & 1) ? scv[5] : scv[4], s67 = (b & 1) ? scv[7] : scv[6];
+                        const float s47 = (b & 2) ? s67 : s45;
+                        sc = (b & 4) ? s47 : sc;
+                    }
                     bool ins = true;
                     if (mrp) {                                             // interacted -> -10e8 (pre-filter survivors only)
                         const unsigned hb = bloom_hash(item);
@@ -1190,67 +1258,105 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
                         const int slot = atomicAdd(&cntl[ulw], 1);         // < kMCap: at most kMCap - kMI held when a phase starts
                         wcand[ulw * kMCap + slot] = pack_cand(sc, item);
                         nearly_full |= slot + 1 > kMCap - kMI;
+                        over_soft |= slot + 1 > soft_limit;
                     }
                 }
             } while (__any(pm != 0u));
-            if (__any(nearly_full)) {
-                // compaction of the users that could overflow during the next phase (wave-local: no block barrier)
-                __builtin_amdgcn_wave_barrier();
-                __threadfence_block();
-                const int myc = lane < 16 ? cntl[lane] : 0;
-                for (unsigned long long fm = __ballot(myc > kMCap - kMI); fm; fm &= fm - 1ull) {
-                    const int ulw = __ffsll((long long)fm) - 1;            // wave-uniform
-                    const int cn = __builtin_amdgcn_readlane(myc, ulw);
-                    const float nt = cand_score(wave_select_topk(wcand + (size_t)ulw * kMCap, cn, k, lane));
-                    if (lane == 0) cntl[ulw] = k;
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) thrf[reg] = (4 * g + reg == ulw) ? nt : thrf[reg];
-                }
-                __builtin_amdgcn_wave_barrier();
-                __threadfence_block();
-            }
+            if (__any(nearly_full)) compact_rows(kMCap - kMI);
+            else if (__any(over_soft) && lane == 0) needf[(st + 1) & 1] = 1;
         }
     };
     ARL_PROF_DECL
-    nb0 = *stage_ptr(0, 0);
-    if constexpr (PER > 1) nb1 = *stage_ptr(0, 1);
-    for (int st = 0; st < nstages; ++st) {
-        float *buf = bt + (st & 1) * MST * LD;
-        *lds_ptr(buf, 0) = nb0;
-        if constexpr (PER > 1) *lds_ptr(buf, 1) = nb1;
-        __syncthreads();                                           // the only block barrier per stage
-        ARL_PROF_TICK(0)
-        if (st + 1 < nstages) {
-            nb0 = *stage_ptr(st + 1, 0);
-            if constexpr (PER > 1) nb1 = *stage_ptr(st + 1, 1);
-        }
-        float4 bf[NSUB][Q / 4];
-#pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub) {
-            const float *brow = buf + (sub * 16 + c) * LD + Q * g;
-#pragma unroll
-            for (int t = 0; t < Q; t += 4) bf[sub][t / 4] = *reinterpret_cast<const float4 *>(brow + t);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+    // Scores of one staged tile + their bookkeeping.
+    auto compute = [&](const unsigned char *buf, int st) {
         f32x4 accs[NSUB];
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) accs[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (SPLIT) {
+            bf16x8 bfr[NSUB][3][KS];
 #pragma unroll
-        for (int t = 0; t < Q; t += 4) {
+            for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
-            for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bf[sub][t / 4].x, accs[sub], 0, 0, 0);
+                for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-            for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t + 1], bf[sub][t / 4].y, accs[sub], 0, 0, 0);
+                    for (int ks = 0; ks < KS; ++ks)
+                        bfr[sub][pl][ks] = *reinterpret_cast<const bf16x8 *>(buf + (sub * 16 + c) * ROWB + pl * (D * 2) + (Q * g + 8 * ks) * 2);
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};      // (A piece, B piece), smallest products first
 #pragma unroll
-            for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t + 2], bf[sub][t / 4].z, accs[sub], 0, 0, 0);
+            for (int term = 0; term < 6; ++term)
 #pragma unroll
-            for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t + 3], bf[sub][t / 4].w, accs[sub], 0, 0, 0);
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int sub = 0; sub < NSUB; ++sub)
+                        accs[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[TA[term]][ks], bfr[sub][TB[term]][ks], accs[sub], 0, 0, 0);
+        } else {
+            // all B fragments of the stage go to registers first (the loads overlap the MFMA chains instead of a read-wait-use
+            // sequence per 4 MFMAs), and the sub-tiles' accumulation chains are interleaved so no MFMA waits on its predecessor
+            float4 bf[NSUB][Q / 4];
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) {
+                const float *brow = reinterpret_cast<const float *>(buf + (sub * 16 + c) * ROWB) + Q * g;
+#pragma unroll
+                for (int t = 0; t < Q; t += 4) bf[sub][t / 4] = *reinterpret_cast<const float4 *>(brow + t);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < Q; t += 4) {
+#pragma unroll
+                for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bf[sub][t / 4].x, accs[sub], 0, 0, 0);
+#pragma unroll
+                for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t + 1], bf[sub][t / 4].y, accs[sub], 0, 0, 0);
+#pragma unroll
+                for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t + 2], bf[sub][t / 4].z, accs[sub], 0, 0, 0);
+#pragma unroll
+                for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t + 3], bf[sub][t / 4].w, accs[sub], 0, 0, 0);
+            }
         }
 #ifdef ARL_TOPK_PROF
         { float sink = accs[0][0] + accs[NSUB - 1][3]; asm volatile("" ::"v"(sink)); ARL_PROF_TICK(1) }
 #endif
         bookkeeping(accs, st);
         ARL_PROF_TICK(2)
+    };
+    // Global -> register -> LDS staging runs TWO stages ahead (register sets nb* / nc* alternate; the loop is unrolled by two so
+    // that no register copy has to wait for a load): with the short stages of the bf16 path one stage of lead did not cover
+    // the load latency and the wait showed up in front of every barrier.
+    float4 nc0, nc1;
+    nc0 = nc1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    nb0 = *stage_ptr(0, 0);
+    if constexpr (PER > 1) { if (second) nb1 = *stage_ptr(0, 1); }
+    if (nstages > 1) {
+        nc0 = *stage_ptr(1, 0);
+        if constexpr (PER > 1) { if (second) nc1 = *stage_ptr(1, 1); }
+    }
+    for (int st = 0; st < nstages; st += 2) {
+        unsigned char *buf = bt;
+        *lds_ptr(buf, 0) = nb0;
+        if constexpr (PER > 1) { if (second) *lds_ptr(buf, 1) = nb1; }
+        __syncthreads();                                           // one block barrier per stage
+        ARL_PROF_TICK(0)
+        if (st + 2 < nstages) {
+            nb0 = *stage_ptr(st + 2, 0);
+            if constexpr (PER > 1) { if (second) nb1 = *stage_ptr(st + 2, 1); }
+        }
+        if (needf[0]) compact_rows(k);                             // scheduled at the previous stage (flag is block-uniform here)
+        compute(buf, st);
+        if (tid == 0) needf[0] = 0;                                // nobody sets this parity before the next barrier
+        if (st + 1 < nstages) {                                    // block-uniform
+            buf = bt + MST * ROWB;
+            *lds_ptr(buf, 0) = nc0;
+            if constexpr (PER > 1) { if (second) *lds_ptr(buf, 1) = nc1; }
+            __syncthreads();
+            ARL_PROF_TICK(0)
+            if (st + 3 < nstages) {
+                nc0 = *stage_ptr(st + 3, 0);
+                if constexpr (PER > 1) { if (second) nc1 = *stage_ptr(st + 3, 1); }
+            }
+            if (needf[1]) compact_rows(k);
+            compute(buf, st + 1);
+            if (tid == 0) needf[1] = 0;
+        }
     }
 #ifdef ARL_TOPK_PROF
     const long long P_loop = clock64() - P_start;
@@ -1671,8 +1777,10 @@ int arl_pga_update_f32(float *S, const float *grad, const float *dinv_rows, cons
     return ARL_OK;
 }
 
+int64_t arl_score_mask_topk_workspace_bytes(int64_t I, int64_t d) { return (I <= 0 || d <= 0) ? 0 : 6 * I * d; }
+
 int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t I, int64_t d, const int32_t *mask_rowptr, const int32_t *mask_col,
-                            int64_t k, int32_t *top_idx, float *top_val, arl_stream_t stream) {
+                            int64_t k, int32_t *top_idx, float *top_val, void *workspace, arl_stream_t stream) {
     if (!Pu || !Pi || !top_idx || !top_val) return ARL_E_NULL;
     if (mask_rowptr && !mask_col) return ARL_E_NULL;
     if (d <= 0 || d > 256 || (d & 3)) return ARL_E_DIM;
@@ -1680,21 +1788,31 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
     if (U < 0 || I <= 0 || U > 0x7fffffffll || I > 0x7fffffffll) return ARL_E_RANGE;
     if (U == 0) return ARL_OK;
     if (k <= 64 && (d == 16 || d == 32 || d == 64 || d == 128)) {        // matrix-core path
-        const int mst = d <= 16 ? 128 : (d <= 64 ? 64 : 32);
-        const size_t shm_m = sizeof(unsigned long long) * kMU * kMCap + sizeof(float) * 2 * mst * (size_t)(d + 4) + sizeof(int) * kMU +
+        const bool split = workspace != nullptr && (d == 64 || d == 128);
+        const int mst = split ? (d <= 64 ? 32 : 16) : (d <= 16 ? 128 : (d <= 64 ? 64 : 32));
+        const size_t rowb = (split ? 6 * (size_t)d : 4 * (size_t)d) + 16;
+        const size_t shm_m = sizeof(unsigned long long) * kMU * kMCap + 2 * mst * rowb + sizeof(int) * (kMU + 4) +
                              (mask_rowptr ? sizeof(unsigned) * kMU * kBloomWords : 0);
         const unsigned grid_m = (unsigned)((U + kMU - 1) / kMU);
-#define ARL_TOPK_CASE(DV)                                                                                                              \
+        const void *image = Pi;
+        if (split) {
+            const long long n = (long long)I * d;
+            hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, Pi, n, (int)d,
+                               (__bf16 *)workspace);
+            ARL_LAUNCH_CHECK();
+            image = workspace;
+        }
+#define ARL_TOPK_CASE(DV, SP)                                                                                                          \
         do {                                                                                                                           \
-            hipError_t em = hipFuncSetAttribute((const void *)score_mask_topk_mfma16_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m); \
+            hipError_t em = hipFuncSetAttribute((const void *)score_mask_topk_mfma16_kernel<DV, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m); \
             if (em != hipSuccess) return (int)em;                                                                                      \
-            hipLaunchKernelGGL((score_mask_topk_mfma16_kernel<DV>), dim3(grid_m), dim3(kM16Block), shm_m, (hipStream_t)stream, Pu, Pi, (int)U, (int)I, \
+            hipLaunchKernelGGL((score_mask_topk_mfma16_kernel<DV, SP>), dim3(grid_m), dim3(kM16Block), shm_m, (hipStream_t)stream, Pu, image, (int)U, (int)I, \
                                mask_rowptr, mask_col, (int)k, top_idx, top_val);                                                       \
         } while (0)
-        if (d == 16) ARL_TOPK_CASE(16);
-        else if (d == 32) ARL_TOPK_CASE(32);
-        else if (d == 64) ARL_TOPK_CASE(64);
-        else ARL_TOPK_CASE(128);
+        if (d == 16) ARL_TOPK_CASE(16, false);
+        else if (d == 32) ARL_TOPK_CASE(32, false);
+        else if (d == 64) { if (split) ARL_TOPK_CASE(64, true); else ARL_TOPK_CASE(64, false); }
+        else { if (split) ARL_TOPK_CASE(128, true); else ARL_TOPK_CASE(128, false); }
 #undef ARL_TOPK_CASE
         ARL_LAUNCH_CHECK();
         return ARL_OK;

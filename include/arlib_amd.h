@@ -237,10 +237,16 @@ int arl_pga_update_f32(float *S, const float *grad, const float *dinv_rows, cons
 /* Streaming scores + interacted mask + top-k, never materialising U x I.  Replaces the chunked Pu@Pi.T into a
  * host buffer, scores[nonzero] = -10e8 and torch.topk (attack/White/DLAttack.py:73-83, CLeaR.py:75-82,
  * PGA.py:100-102 with mask_rowptr == NULL).  Output sorted by descending score, ties by ascending item id.
- * k <= 128.  workspace: none. */
+ * k <= 128.
+ * workspace == NULL: scores are the exact fp32 contraction (bitwise an fmaf chain over d).
+ * workspace != NULL (arl_score_mask_topk_workspace_bytes(I, d) bytes) and d in {64, 128}: the contraction runs on
+ * the bf16 matrix path with every fp32 operand split in three bf16 pieces, six partial products accumulated in
+ * fp32 -- scores within ~2e-7 relative of the exact ones (the size of fp32 summation-order differences), 2x faster;
+ * the workspace receives the split image of Pi.  Other d ignore the workspace. */
+int64_t arl_score_mask_topk_workspace_bytes(int64_t I, int64_t d);
 int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t I, int64_t d,
                             const int32_t *mask_rowptr, const int32_t *mask_col, int64_t k, int32_t *top_idx,
-                            float *top_val, arl_stream_t stream);
+                            float *top_val, void *workspace, arl_stream_t stream);
 /* Per-row top-n -> {0,1} rows (+ indices, descending value, ties ascending column).  Replaces project()
  * (attack/White/PGA.py:153-158, CLeaR.py:161-166, DLAttack.py:127-132).  scratch: [rows*cols] fp32. */
 int arl_topn_project_rows_f32(const float *M, int64_t rows, int64_t cols, int64_t n, float *out, int32_t *idx,

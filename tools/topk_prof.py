@@ -9,10 +9,10 @@ U, I, d, k = int(os.environ.get('U', 204800)), 100000, int(os.environ.get('D', 6
 torch.manual_seed(0)
 Pu = torch.randn(U, d, device='cuda') * 0.1
 Pi = torch.randn(I, d, device='cuda') * 0.1
-ops.score_mask_topk(Pu[:256].contiguous(), Pi, k)
+ops.score_mask_topk(Pu[:256].contiguous(), Pi, k, exact=os.environ.get('EXACT', '0') == '1')
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-idx, val = ops.score_mask_topk(Pu, Pi, k)
+idx, val = ops.score_mask_topk(Pu, Pi, k, exact=os.environ.get('EXACT', '0') == '1')
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 v = val.view(U // 128, 8, 16 * k)[:, :, :6].double().mean(0).cpu().numpy()      # [wave, section]
