@@ -1003,58 +1003,16 @@ __global__ __launch_bounds__(kBlock) void score_mask_topk_kernel(const float *__
 }
 
 // ---- MFMA form of the streaming score + mask + top-k (d in {16,32,64,128}, k <= 64) ---------------------------------------
-// scores = Pu . Pi^T is the one dense contraction of the path (2*U*I*d flop; 1.3e13 at cfg2), so it goes on the matrix cores with
-// the exact-f32 MFMA (bitwise an fmaf chain).  A block owns 128 users for the whole kernel (their A fragments stay in registers)
-// and streams item tiles of Pi through a double-buffered LDS image (one __syncthreads per stage, the next stage's global loads in
-// flight during the MFMAs).  Top-k per user: candidate keys above the user's running k-th best are appended to a 108-slot LDS
-// buffer owned by the user's wave (so compaction needs no block barrier); a 32-item phase can add at most 32, compaction
-// (radix select, keep k) runs when more than 76 are held.  Measured on MI355X: the f32 MFMA shares the SIMD's issue with the VALU
-// (a second wave per SIMD hides latencies but its VALU work does NOT overlap the other wave's MFMAs), so every VALU instruction
-// of the pre-filter/insert path is paid in full -- hence one vector compare per score and one ballot per phase, nothing more.
+// scores = Pu . Pi^T is the one dense contraction of the path (2*U*I*d flop; 1.3e13 at cfg2), so it goes on the matrix cores.
+// A block owns 128 users for the whole kernel (their A fragments stay in registers) and streams item tiles of Pi through a
+// double-buffered LDS image (one __syncthreads per stage, global loads two stages ahead).  8 waves, 16 users each
+// (16x16 MFMA shapes): lane l supplies A[user l&15][k] and B[k][item l&15] for its contiguous k range [Q*(l>>4), Q*(l>>4)+Q)
+// (a permutation of the contraction index, irrelevant to the sum); C: item = l&15, user row = 4*(l>>4) + reg.
+// Top-k per user is a sorted list in registers (see `tk_hi/tk_lo` in the kernel).
+// Measured on MI355X: the f32 MFMA shares the SIMD's issue with the VALU (a second wave per SIMD hides latencies but its VALU
+// work does NOT overlap the other wave's f32 MFMAs), so every VALU instruction of the pre-filter/insert path is paid in full --
+// hence one subtract + one funnel shift per score, one ballot per phase, and the split-bf16 form below for the contraction.
 constexpr int kMU = 128;         // users per block
-constexpr int kMI = 32;          // items per tile
-constexpr int kMCap = 108;       // candidate slots per user (>= k_max 64 + 32 + slack; 128 x 108 x 8 B = 108 KiB of the 160 KiB LDS)
-
-__device__ void wave_sort_desc_128(unsigned long long *c, int lane) {
-    for (int k = 2; k <= 128; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = lane; t < 128; t += kWave) {
-                const int ixj = t ^ j;
-                if (ixj > t) {
-                    const unsigned long long a = c[t], b = c[ixj];
-                    const bool desc = ((t & k) == 0);
-                    if (desc ? (a < b) : (a > b)) { c[t] = b; c[ixj] = a; }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
-        }
-    }
-}
-
-// Cut a user's <= 128 candidate keys down to the k largest without sorting: radix-select the k-th largest 64-bit key bit by
-// bit with wave ballots (keys are distinct: the item id is part of the key), then compact the survivors with a ballot prefix.
-// ~1k cycles instead of ~6k for the LDS bitonic sort; order inside the buffer is irrelevant until the final output sort.
-__device__ __forceinline__ unsigned long long wave_select_topk(unsigned long long *cc, int cnt, int k, int lane) {
-    const unsigned long long k0 = lane < cnt ? cc[lane] : 0ull, k1 = lane + kWave < cnt ? cc[lane + kWave] : 0ull;
-    unsigned long long T = 0ull;
-    for (int bit = 63; bit >= 0; --bit) {
-        const unsigned long long c = T | (1ull << bit);
-        const int n = __popcll(__ballot(k0 >= c)) + __popcll(__ballot(k1 >= c));
-        if (n >= k) T = c;
-        if (n == k) break;                    // exactly k keys are >= T: the cut is decided; T's low bits stay 0 (a lower bound)
-    }
-    const unsigned long long m0 = __ballot(k0 >= T), m1 = __ballot(k1 >= T);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    __builtin_amdgcn_wave_barrier();
-    if (k0 >= T) cc[__popcll(m0 & lt)] = k0;
-    if (k1 >= T) cc[__popcll(m0) + __popcll(m1 & lt)] = k1;
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    return T;
-}
-
-// Section timers for tuning (compile with -DARL_TOPK_PROF; the per-wave cycle sums overwrite top_val[first user of the wave][0..5]).
 #ifdef ARL_TOPK_PROF
 #define ARL_PROF_DECL long long P_acc[4] = {0, 0, 0, 0}, P_t0 = clock64(); const long long P_start = P_t0;
 #define ARL_PROF_TICK(SLOT) { const long long P_t = clock64(); P_acc[SLOT] += P_t - P_t0; P_t0 = P_t; }
@@ -1063,13 +1021,8 @@ __device__ __forceinline__ unsigned long long wave_select_topk(unsigned long lon
 #define ARL_PROF_TICK(SLOT)
 #endif
 
-// ---- 16x16x4 form: 8 waves per block, 16 users per wave --------------------------------------------------------------------
-// Same streaming scheme with v_mfma_f32_16x16x4_f32 so that a wave owns 16 users instead of 32: the block still covers 128 users
-// (the candidate buffers fill the LDS either way) but with EIGHT waves, two per SIMD -- one wave's pre-filter, inserts, compaction
-// and barrier waits now overlap the other wave's MFMA chain instead of idling the matrix core.  Lane l supplies A[user l&15][k] and
-// B[k][item l&15] for k = (D/4)*(l>>4) + t at step t (a permutation of 0..D-1, contiguous per lane); C: item = l&15,
-// user = 4*(l>>4) + reg.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
 constexpr int kM16Block = 512;
 constexpr int kBloomWords = 32;      // 1024 bits per user
 __device__ __forceinline__ unsigned bloom_hash(int item) { return ((unsigned)item * 2654435761u) >> 22; }
@@ -1103,15 +1056,14 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
     constexpr int Q = D / 4;                                       // contraction indices per lane: [Q*g, Q*g + Q)
     constexpr int SRCB = SPLIT ? 3 * D * 2 : D * 4;                // bytes per item row in global memory
     constexpr int ROWB = SRCB + 16;                                // LDS row stride: 16-B aligned, consecutive rows shifted by 4 banks
-    constexpr int MST = SPLIT ? (D <= 64 ? 32 : 16) : (D <= 16 ? 128 : (D <= 64 ? 64 : 32));      // items staged per block barrier
+    constexpr int MST = D <= 16 ? 128 : (D <= 64 ? 64 : 32);       // items staged per block barrier
     constexpr int NSUB = MST / 16;                                 // 16-item sub-tiles per stage
     constexpr int SPP = NSUB >= 2 ? 2 : 1;                         // sub-tiles per insert phase (at most 32 items)
     constexpr int NPH = NSUB / SPP;
     constexpr int NSC = 4 * SPP;                                   // scores per lane and phase
     static_assert(!SPLIT || (D % 32 == 0), "the bf16 path contracts 32 indices per MFMA");
     extern __shared__ unsigned char smem_raw[];
-    unsigned long long *cand = reinterpret_cast<unsigned long long *>(smem_raw);                 // [kMU][kMCap]
-    unsigned char *bt = reinterpret_cast<unsigned char *>(cand + kMU * kMCap);                   // [2][MST][ROWB]; sort scratch at the end
+    unsigned char *bt = smem_raw;                                  // [2][MST][ROWB] staged item tiles, then the Bloom filters
     const unsigned char *Pi = reinterpret_cast<const unsigned char *>(Pi_image);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
@@ -1140,10 +1092,10 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
     constexpr int C16 = SRCB / 16;                                 // 16-byte pieces per item row
     constexpr int F4 = MST * C16;
     constexpr int PER = (F4 + kM16Block - 1) / kM16Block;
-    static_assert(PER >= 1 && PER <= 2, "staging assumes one or two 16-byte pieces per thread");
-    float4 nb0, nb1;                                               // named staging registers (an indexed array stayed in scratch)
-    nb0 = nb1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool second = tid + kM16Block < F4;                      // this thread moves a second piece
+    static_assert(PER >= 1 && PER <= 3, "staging assumes one to three 16-byte pieces per thread");
+    float4 nb0, nb1, nb2;                                          // named staging registers (an indexed array stayed in scratch)
+    nb0 = nb1 = nb2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool second = tid + kM16Block < F4, third = tid + 2 * kM16Block < F4;      // this thread moves a second / third piece
     const int nstages = (I + MST - 1) / MST;
     auto stage_ptr = [&](int st, int p) {
         const int f = tid + p * kM16Block;
@@ -1154,17 +1106,18 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
         const int f = tid + p * kM16Block;
         return reinterpret_cast<float4 *>(buf + (f / C16) * ROWB + (f % C16) * 16);
     };
-    float thrf[4];                                                 // running k-th best (lower bound) of user rows 4g + reg
+    float thrf[4];                                                 // exact running k-th best score of user rows 4g + reg (pre-filter)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) thrf[reg] = (u_base + 4 * g + reg < U) ? -INFINITY : INFINITY;      // users past U never insert
-    int *cntl = reinterpret_cast<int *>(bt + 2 * MST * ROWB) + wv * 16;        // keys held per user row of this wave
-    unsigned long long *wcand = cand + (size_t)wv * 16 * kMCap;
-    int *needf = reinterpret_cast<int *>(bt + 2 * MST * ROWB) + kMU;          // [2] scheduled-compaction flags, by stage parity
-    if (lane < 16) cntl[lane] = 0;
-    if (tid < 2) needf[tid] = 0;
+    // The running top-k of each of the wave's 16 users is a SORTED list held in registers: lane j of tk[r] is the j-th largest key
+    // of user row r (k <= 64 = one key per lane; 0 = empty, below every real key).  An insert is one 64-bit compare + ballot for
+    // the position and a one-lane DPP shift of the tail -- no candidate buffers, no compaction, no final sort, and the threshold
+    // (lane k-1) is exact after every insert, so exactly the stream's record-setters (about k ln(I/k) per user) are ever handled.
+    // (two 16-register vectors indexed by the wave-uniform row number: the compiler addresses them through M0, no 16-way branch)
+    u32x16 tk_hi = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk_lo = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // Interacted-item mask: a 1024-bit Bloom filter per user in LDS answers "not interacted" for ~97 % of the pre-filter
     // survivors with one LDS read; only filter hits pay the binary search in global memory (7 dependent L2 round trips).
-    unsigned *bloom = reinterpret_cast<unsigned *>(bt + 2 * MST * ROWB) + kMU + 4 + wv * 16 * kBloomWords;   // [16][kBloomWords]
+    unsigned *bloom = reinterpret_cast<unsigned *>(bt + 2 * MST * ROWB) + wv * 16 * kBloomWords;          // [16][kBloomWords]
     if (mrp) {
         for (int t = lane; t < 16 * kBloomWords; t += kWave) bloom[t] = 0u;
         __builtin_amdgcn_wave_barrier();
@@ -1180,29 +1133,24 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
-    // Cut every user row of this wave holding more than `limit` keys down to its k largest and raise its threshold
-    // (wave-local: no block barrier).
-    auto compact_rows = [&](int limit) {
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        const int myc = lane < 16 ? cntl[lane] : 0;
-        for (unsigned long long fm = __ballot(myc > limit); fm; fm &= fm - 1ull) {
-            const int ulw = __ffsll((long long)fm) - 1;                    // wave-uniform
-            const int cn = __builtin_amdgcn_readlane(myc, ulw);
-            const float nt = cand_score(wave_select_topk(wcand + (size_t)ulw * kMCap, cn, k, lane));
-            if (lane == 0) cntl[ulw] = k;
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) thrf[reg] = (4 * g + reg == ulw) ? nt : thrf[reg];
+    // insert `key` into the sorted list of user row `row` (wave-uniform); returns the row's new k-th best score = its threshold
+    auto insert_sorted = [&](int row, unsigned long long key) -> float {
+        const unsigned Kh = tk_hi[row], Kl = tk_lo[row];
+        const unsigned long long K = ((unsigned long long)Kh << 32) | Kl;
+        const int pos = __popcll(__ballot(K > key));               // keys above the new one: a prefix of the lanes
+        unsigned nh = Kh, nl = Kl;
+        if (pos < k) {                                             // wave-uniform
+            const unsigned sl = __builtin_amdgcn_update_dpp(Kl, Kl, 0x138, 0xf, 0xf, false);            // wave_shr:1
+            const unsigned sh = __builtin_amdgcn_update_dpp(Kh, Kh, 0x138, 0xf, 0xf, false);
+            nl = lane < pos ? Kl : (lane == pos ? (unsigned)key : sl);
+            nh = lane < pos ? Kh : (lane == pos ? (unsigned)(key >> 32) : sh);
+            tk_hi[row] = nh; tk_lo[row] = nl;
         }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
+        const unsigned th = (unsigned)__builtin_amdgcn_readlane((int)nh, k - 1);
+        const unsigned tl = (unsigned)__builtin_amdgcn_readlane((int)nl, k - 1);
+        return (th | tl) ? cand_score((unsigned long long)th << 32) : -INFINITY;
     };
-    // Compaction is the one long, irregular piece of a stage (a radix select per user), and with one block barrier per stage a
-    // wave that compacts alone stalls the other seven.  So it is scheduled: a row that passes the SOFT limit only raises a
-    // block-wide flag, and at the next stage boundary every wave compacts all of its rows at once (the stalls coincide, and every
-    // row's threshold tightens early).  The hard limit (a row that could overflow in the next phase) still compacts on the spot.
-    const int soft_limit = min(k + 16, kMCap - kMI);
-    // Pre-filter + inserts + compaction for the scores of one stage (16*SPP items x 16 users per phase: NSC scores per lane,
+    // Pre-filter + inserts for the scores of one stage (16*SPP items x 16 users per phase: NSC scores per lane,
     // bit b = 4*s2 + reg  <->  item item0 + 16*s2 + c, user row 4g + reg).
     auto bookkeeping = [&](const f32x4 (&ac)[NSUB], int st) {
 #pragma unroll
@@ -1222,48 +1170,42 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
                 for (int s2 = 0; s2 < SPP; ++s2)
                     if (item0 + 16 * s2 + c >= I) pm &= ~(0xfu << (4 * s2));
             }
-            if (__ballot(pm != 0u) == 0ull) continue;
-            bool nearly_full = false, over_soft = false;
-            unsigned no_thr = 0u;                                          // user rows still without a threshold (-inf)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) no_thr |= (thrf[reg] == -INFINITY) ? (1u << reg) : 0u;
-            do {
-                if (pm != 0u) {
-                    const int b = __ffs(pm) - 1;
-                    pm &= pm - 1u;
-                    const int reg = b & 3, ulw = 4 * g + reg;
-                    const int item = item0 + 16 * (b >> 2) + c;
-                    const float s01 = (b & 1) ? scv[1] : scv[0], s23 = (b & 1) ? scv[3] : scv[2];
-                    float sc = (b & 2) ? s23 : s01;
-                    if constexpr (NSC == 8) {
-                        const float s45 = (b & 1) ? scv[5] : scv[4], s67 = (b & 1) ? scv[7] : scv[6];
-                        const float s47 = (b & 2) ? s67 : s45;
-                        sc = (b & 4) ? s47 : sc;
-                    }
-                    bool ins = true;
-                    if (mrp) {                                             // interacted -> -10e8 (pre-filter survivors only)
-                        const unsigned hb = bloom_hash(item);
-                        if ((bloom[ulw * kBloomWords + (hb >> 5)] >> (hb & 31u)) & 1u) {
-                            const int u = u_base + ulw;
-                            int lo = mrp[u], hi = mrp[u + 1];
-                            const int end = hi;
-                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (mcol[mid] < item) lo = mid + 1; else hi = mid; }
-                            if (lo < end && mcol[lo] == item) {            // kept only while the user has no threshold yet
-                                sc = -10e8f;
-                                ins = (no_thr >> reg) & 1u;
-                            }
-                        }
-                    }
-                    if (ins) {
-                        const int slot = atomicAdd(&cntl[ulw], 1);         // < kMCap: at most kMCap - kMI held when a phase starts
-                        wcand[ulw * kMCap + slot] = pack_cand(sc, item);
-                        nearly_full |= slot + 1 > kMCap - kMI;
-                        over_soft |= slot + 1 > soft_limit;
+            // Survivors are taken one at a time by the whole wave.  Each pending lane first prepares ITS lowest pending candidate
+            // (score select, key packing) in parallel; the serial part only broadcasts it.
+            for (unsigned long long pend = __ballot(pm != 0u); pend != 0ull;) {
+                const int b = __ffs(pm) - 1;                               // per lane (garbage where pm == 0: never read)
+                const float s01 = (b & 1) ? scv[1] : scv[0], s23 = (b & 1) ? scv[3] : scv[2];
+                float sc = (b & 2) ? s23 : s01;
+                if constexpr (NSC == 8) {
+                    const float s45 = (b & 1) ? scv[5] : scv[4], s67 = (b & 1) ? scv[7] : scv[6];
+                    const float s47 = (b & 2) ? s67 : s45;
+                    sc = (b & 4) ? s47 : sc;
+                }
+                const int item = item0 + 16 * (b >> 2) + c;
+                const int ulw = 4 * g + (b & 3);
+                if (mrp && pm != 0u) {                                     // interacted -> -10e8 (pre-filter survivors only)
+                    const unsigned hb = bloom_hash(item);
+                    if ((bloom[ulw * kBloomWords + (hb >> 5)] >> (hb & 31u)) & 1u) {
+                        const int u = u_base + ulw;
+                        int lo = mrp[u], hi = mrp[u + 1];
+                        const int end = hi;
+                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (mcol[mid] < item) lo = mid + 1; else hi = mid; }
+                        if (lo < end && mcol[lo] == item) sc = -10e8f;      // stays in the list only while it holds fewer than k real items
                     }
                 }
-            } while (__any(pm != 0u));
-            if (__any(nearly_full)) compact_rows(kMCap - kMI);
-            else if (__any(over_soft) && lane == 0) needf[(st + 1) & 1] = 1;
+                const unsigned long long mykey = pack_cand(sc, item);
+                pm &= pm - 1u;                                             // this round's candidate leaves the mask (0 stays 0)
+                for (unsigned long long round = pend; round != 0ull; round &= round - 1ull) {
+                    const int src = __ffsll((long long)round) - 1;
+                    const unsigned kh = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mykey >> 32), src);
+                    const unsigned kl = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mykey, src);
+                    const int row = __builtin_amdgcn_readlane(ulw, src);
+                    const float nt = insert_sorted(row, ((unsigned long long)kh << 32) | kl);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) thrf[j] = (4 * g + j == row) ? nt : thrf[j];
+                }
+                pend = __ballot(pm != 0u);
+            }
         }
     };
     ARL_PROF_DECL
@@ -1322,61 +1264,45 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
     // Global -> register -> LDS staging runs TWO stages ahead (register sets nb* / nc* alternate; the loop is unrolled by two so
     // that no register copy has to wait for a load): with the short stages of the bf16 path one stage of lead did not cover
     // the load latency and the wait showed up in front of every barrier.
-    float4 nc0, nc1;
-    nc0 = nc1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    nb0 = *stage_ptr(0, 0);
-    if constexpr (PER > 1) { if (second) nb1 = *stage_ptr(0, 1); }
-    if (nstages > 1) {
-        nc0 = *stage_ptr(1, 0);
-        if constexpr (PER > 1) { if (second) nc1 = *stage_ptr(1, 1); }
-    }
+    float4 nc0, nc1, nc2;
+    nc0 = nc1 = nc2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int st, float4 &r0, float4 &r1, float4 &r2) {
+        r0 = *stage_ptr(st, 0);
+        if constexpr (PER > 1) { if (second) r1 = *stage_ptr(st, 1); }
+        if constexpr (PER > 2) { if (third) r2 = *stage_ptr(st, 2); }
+    };
+    auto stash = [&](unsigned char *buf, const float4 &r0, const float4 &r1, const float4 &r2) {
+        *lds_ptr(buf, 0) = r0;
+        if constexpr (PER > 1) { if (second) *lds_ptr(buf, 1) = r1; }
+        if constexpr (PER > 2) { if (third) *lds_ptr(buf, 2) = r2; }
+    };
+    fetch(0, nb0, nb1, nb2);
+    if (nstages > 1) fetch(1, nc0, nc1, nc2);
     for (int st = 0; st < nstages; st += 2) {
-        unsigned char *buf = bt;
-        *lds_ptr(buf, 0) = nb0;
-        if constexpr (PER > 1) { if (second) *lds_ptr(buf, 1) = nb1; }
+        stash(bt, nb0, nb1, nb2);
         __syncthreads();                                           // one block barrier per stage
         ARL_PROF_TICK(0)
-        if (st + 2 < nstages) {
-            nb0 = *stage_ptr(st + 2, 0);
-            if constexpr (PER > 1) { if (second) nb1 = *stage_ptr(st + 2, 1); }
-        }
-        if (needf[0]) compact_rows(k);                             // scheduled at the previous stage (flag is block-uniform here)
-        compute(buf, st);
-        if (tid == 0) needf[0] = 0;                                // nobody sets this parity before the next barrier
+        if (st + 2 < nstages) fetch(st + 2, nb0, nb1, nb2);
+        compute(bt, st);
         if (st + 1 < nstages) {                                    // block-uniform
-            buf = bt + MST * ROWB;
-            *lds_ptr(buf, 0) = nc0;
-            if constexpr (PER > 1) { if (second) *lds_ptr(buf, 1) = nc1; }
+            stash(bt + MST * ROWB, nc0, nc1, nc2);
             __syncthreads();
             ARL_PROF_TICK(0)
-            if (st + 3 < nstages) {
-                nc0 = *stage_ptr(st + 3, 0);
-                if constexpr (PER > 1) { if (second) nc1 = *stage_ptr(st + 3, 1); }
-            }
-            if (needf[1]) compact_rows(k);
-            compute(buf, st + 1);
-            if (tid == 0) needf[1] = 0;
+            if (st + 3 < nstages) fetch(st + 3, nc0, nc1, nc2);
+            compute(bt + MST * ROWB, st + 1);
         }
     }
 #ifdef ARL_TOPK_PROF
     const long long P_loop = clock64() - P_start;
 #endif
-    __syncthreads();                                               // the staging buffers become per-wave sort scratch (128 keys each)
-    unsigned long long *scratch = reinterpret_cast<unsigned long long *>(bt) + wv * 128;
-    for (int ulw = 0; ulw < 16; ++ulw) {
-        const int u = u_base + ulw;
-        if (u >= U) break;
-        const int cn = cntl[ulw];
-        for (int t = lane; t < 128; t += kWave) scratch[t] = t < cn ? wcand[(size_t)ulw * kMCap + t] : 0ull;
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        wave_sort_desc_128(scratch, lane);
-        for (int t = lane; t < k; t += kWave) {
-            top_idx[(size_t)u * k + t] = cand_item(scratch[t]);
-            top_val[(size_t)u * k + t] = cand_score(scratch[t]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int u = u_base + r;
+        if (u < U && lane < k) {
+            const unsigned long long key = ((unsigned long long)tk_hi[r] << 32) | tk_lo[r];
+            top_idx[(size_t)u * k + lane] = cand_item(key);
+            top_val[(size_t)u * k + lane] = cand_score(key);
         }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
     }
 #ifdef ARL_TOPK_PROF
     if (lane == 0 && u_base < U) {
@@ -1789,10 +1715,9 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
     if (U == 0) return ARL_OK;
     if (k <= 64 && (d == 16 || d == 32 || d == 64 || d == 128)) {        // matrix-core path
         const bool split = workspace != nullptr && (d == 64 || d == 128);
-        const int mst = split ? (d <= 64 ? 32 : 16) : (d <= 16 ? 128 : (d <= 64 ? 64 : 32));
+        const int mst = d <= 16 ? 128 : (d <= 64 ? 64 : 32);
         const size_t rowb = (split ? 6 * (size_t)d : 4 * (size_t)d) + 16;
-        const size_t shm_m = sizeof(unsigned long long) * kMU * kMCap + 2 * mst * rowb + sizeof(int) * (kMU + 4) +
-                             (mask_rowptr ? sizeof(unsigned) * kMU * kBloomWords : 0);
+        const size_t shm_m = 2 * mst * rowb + (mask_rowptr ? sizeof(unsigned) * kMU * kBloomWords : 0);
         const unsigned grid_m = (unsigned)((U + kMU - 1) / kMU);
         const void *image = Pi;
         if (split) {
