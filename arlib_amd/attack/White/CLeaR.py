@@ -18,7 +18,7 @@ from ... import ops
 from ...util.metrics import AttackMetric
 from .._common import AttackBase, DEVICE, symmetric_adjacency, rebuild_interaction_matrix, reinit_with_tables, cw_pairs
 from .DLAttack import masked_topk, device_mask
-from .PGA import cw_operator
+from .PGA import cw_operator_from_topk
 
 
 def _packed(Pu, Pi):
@@ -41,14 +41,15 @@ class _CwSfaLoss(torch.autograd.Function):
     def forward(ctx, Pu, Pi, top_idx, n_real, targets, r0):
         X = _packed(Pu, Pi)
         Up, I, d, T = Pu.shape[0], Pi.shape[0], Pu.shape[1], len(targets)
-        users, pos, neg = cw_pairs(top_idx, n_real, targets, pop=True)
-        M = cw_operator(Up + I, Up, users, pos, neg, X.device)
+        ranks = top_idx.shape[1] - 1 - torch.arange(T, device=X.device)                 # successive .pop()s (CLeaR.py:84-88)
+        neg = top_idx[:n_real][:, ranks].long()                                         # [n_real, T]
+        M, neg_cnt = cw_operator_from_topk(Up + I, Up, n_real, targets, neg, X.device)
         G_cw = ops.spmm(M, X)
         cw = 0.5 * (X * G_cw).sum()
         w = torch.zeros(Up + I, dtype=torch.float32, device=X.device)
         w[:n_real] = float(T)
-        w[Up:] = torch.bincount(neg, minlength=I).to(torch.float32)
-        w.index_add_(0, pos[:T] + Up, torch.full((T,), float(n_real), device=X.device))
+        w[Up:] = neg_cnt.to(torch.float32)
+        w.index_add_(0, torch.as_tensor(targets, device=X.device, dtype=torch.int64) + Up, torch.full((T,), float(n_real), device=X.device))
         sfa, G_sfa = ops.sfa_l1(X, w, r0.to(X.device, torch.float32).contiguous(), 3 * n_real * T * d)
         ctx.save_for_backward(G_cw, G_sfa)
         ctx.Up = Up

@@ -95,6 +95,45 @@ def cw_operator(n_nodes, Up, users, pos, neg, device):
     return ops.CSRGraph(rowptr.cpu().numpy(), cols[order].contiguous(), vals[order].contiguous(), device)
 
 
+def cw_operator_from_topk(n_nodes, Up, n_real, targets, neg, device):
+    """The same operator as cw_operator() built from its structure instead of a 4*U*T-entry sort + histogram (which is what a
+    per-step rebuild, as in CLeaR, cannot afford: the five target rows alone serialise a million atomic increments each):
+      * a real user's row is [neg(u,0..T-1) (+c), targets (-c)]: 2T entries at a fixed stride, no sort;
+      * item rows = the negatives grouped by item (one stable sort of U*T keys; row starts by binary search, no atomics)
+        followed, for a target, by its dense row of all real users (-c).
+    neg: [n_real, T] int64 item ids.  Returns (CSRGraph, neg_counts[I] int64 -- how often each item closes a top-k list)."""
+    T = len(targets)
+    I = n_nodes - Up
+    c = 1.0 / (n_real * T)
+    dev = neg.device
+    tg = torch.as_tensor(targets, device=dev, dtype=torch.int64)
+    ar_u = torch.arange(n_real, device=dev, dtype=torch.int64)
+    flat = neg.reshape(-1)
+    sorted_items, order = torch.sort(flat, stable=True)
+    neg_ptr = torch.searchsorted(sorted_items, torch.arange(I + 1, device=dev, dtype=torch.int64))
+    neg_cnt = neg_ptr[1:] - neg_ptr[:-1]
+    item_len = neg_cnt.clone()
+    item_len[tg] += n_real
+    n_user_entries = 2 * T * n_real
+    rowptr = torch.empty(n_nodes + 1, dtype=torch.int64, device=dev)
+    rowptr[:n_real + 1] = 2 * T * torch.arange(n_real + 1, device=dev, dtype=torch.int64)
+    rowptr[n_real + 1:Up + 1] = n_user_entries
+    rowptr[Up + 1:] = n_user_entries + torch.cumsum(item_len, 0)
+    nnz = 2 * n_user_entries
+    col = torch.empty(nnz, dtype=torch.int32, device=dev)
+    val = torch.empty(nnz, dtype=torch.float32, device=dev)
+    col[:n_user_entries] = torch.cat([neg + Up, (tg + Up).expand(n_real, T)], 1).reshape(-1).to(torch.int32)
+    val[:n_user_entries] = torch.cat([torch.full((n_real, T), c, device=dev), torch.full((n_real, T), -c, device=dev)], 1).reshape(-1)
+    item_start = rowptr[Up:Up + I]
+    pos = item_start[sorted_items] + (torch.arange(n_real * T, device=dev, dtype=torch.int64) - neg_ptr[sorted_items])
+    col[pos] = (order // T).to(torch.int32)
+    val[pos] = c
+    tpos = ((item_start[tg] + neg_cnt[tg])[:, None] + ar_u[None, :]).reshape(-1)
+    col[tpos] = ar_u.to(torch.int32).repeat(T)
+    val[tpos] = -c
+    return ops.CSRGraph(rowptr, col, val, device, validate=False), neg_cnt
+
+
 def cw_loss_and_grad_op(M, out):
     G = ops.spmm(M, out)
     return 0.5 * (out * G).sum(), G

@@ -793,22 +793,22 @@ __device__ __forceinline__ float block_sum_256(float v, float *sh) {
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-// coef layout: [0,256) r   [256,512) g_r   [512] c1   [513] loss
-__global__ __launch_bounds__(kBlock) void sfa_fold_r_kernel(const float *__restrict__ part, int nblk, int d, float *__restrict__ coef) {
-    const int k = threadIdx.x;
+// coef layout: [0,256) r   [256,512) a, then g_r   [512] c1   [513] loss   [514] S
+// Column-wise fold of the per-block partial records in a fixed order: block j sums column j (j < d) or the scalar slot (j == d).
+__global__ __launch_bounds__(kBlock) void sfa_fold_kernel(const float *__restrict__ part, int nblk, int d, float *__restrict__ out, float *__restrict__ scalar_out) {
+    __shared__ float sh[4];
+    const int j = blockIdx.x;
+    const int slot = j < d ? j : kSfaStride - 1;
     float t = 0.f;
-    if (k < d) for (int b = 0; b < nblk; ++b) t += part[(size_t)b * kSfaStride + k];
-    coef[k] = t;
+    for (int b = threadIdx.x; b < nblk; b += kBlock) t += part[(size_t)b * kSfaStride + slot];
+    t = block_sum_256(t, sh);
+    if (threadIdx.x == 0) { if (j < d) out[j] = t; else scalar_out[0] = t; }
 }
 
-__global__ __launch_bounds__(kBlock) void sfa_finalize_kernel(const float *__restrict__ part, int nblk, int d, float inv_numel, float *__restrict__ coef,
-                                                              float *__restrict__ loss_out) {
+__global__ __launch_bounds__(kBlock) void sfa_finalize_kernel(int d, float inv_numel, float *__restrict__ coef, float *__restrict__ loss_out) {
     __shared__ float sh[4];
     const int k = threadIdx.x;
-    float a = 0.f, S = 0.f;
-    if (k < d) for (int b = 0; b < nblk; ++b) a += part[(size_t)b * kSfaStride + k];
-    for (int b = k; b < nblk; b += kBlock) S += part[(size_t)b * kSfaStride + kSfaStride - 1];
-    S = block_sum_256(S, sh);
+    const float a = k < d ? coef[256 + k] : 0.f, S = coef[514];
     const float r = k < d ? coef[k] : 0.f;
     const float A = block_sum_256(fabsf(r), sh);
     const float Q = block_sum_256(r * r, sh);
@@ -1663,11 +1663,13 @@ int arl_sfa_l1_fwd_bwd_f32(const float *X, const float *w, const float *r0, int6
     const int nblk = (int)(want < kSfaMaxBlocks ? want : kSfaMaxBlocks);
     hipLaunchKernelGGL((sfa_reduce_pass_kernel<1>), dim3(nblk), dim3(kBlock), 0, st, X, w, r0, (int)n_rows, (int)d, q, part);
     ARL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sfa_fold_r_kernel, dim3(1), dim3(kBlock), 0, st, part, nblk, (int)d, coef);
+    hipLaunchKernelGGL(sfa_fold_kernel, dim3((unsigned)d), dim3(kBlock), 0, st, part, nblk, (int)d, coef, coef + 514);
     ARL_LAUNCH_CHECK();
     hipLaunchKernelGGL((sfa_reduce_pass_kernel<2>), dim3(nblk), dim3(kBlock), 0, st, X, w, coef, (int)n_rows, (int)d, s, part);
     ARL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sfa_finalize_kernel, dim3(1), dim3(kBlock), 0, st, part, nblk, (int)d, (float)(1.0 / (double)numel_h), coef, loss_out);
+    hipLaunchKernelGGL(sfa_fold_kernel, dim3((unsigned)d + 1), dim3(kBlock), 0, st, part, nblk, (int)d, coef + 256, coef + 514);
+    ARL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sfa_finalize_kernel, dim3(1), dim3(kBlock), 0, st, (int)d, (float)(1.0 / (double)numel_h), coef, loss_out);
     ARL_LAUNCH_CHECK();
     if (G) {
         hipLaunchKernelGGL(sfa_grad_kernel, dim3((unsigned)want), dim3(kBlock), 0, st, X, w, r0, q, s, coef, (int)n_rows, (int)d, scale, (int)accumulate, G);

@@ -142,3 +142,28 @@ def test_posion_data_attack_end_to_end(name, tmp_path, monkeypatch):
         assert sums == [float(x) for x in g['dl_result_fake_rowsums']]
     else:
         assert sums == [float(x) for x in g['cl_result_fake_rowsums']]
+
+
+def test_cw_operator_structured_build_equals_sorted_build():
+    """CLeaR's per-step CW operator (built from its structure, no 4UT-entry sort/histogram) against the generic builder PGA
+    uses once per inner epoch: same SpMM result and loss; negative counts = histogram of the negatives."""
+    from arlib_amd import ops
+    from arlib_amd.attack.White.PGA import cw_operator, cw_operator_from_topk
+    from arlib_amd.attack._common import cw_pairs
+    g = torch.Generator().manual_seed(5)
+    U, F, I, T, k, d = 3000, 7, 400, 5, 50, 16
+    Up = U + F
+    top_idx = torch.stack([torch.randperm(I, generator=g)[:k] for _ in range(Up)]).to(torch.int32).cuda()
+    top_idx[:50, k - 1] = 3                                                  # a hot negative: a long item row
+    targets = [9, 17, 3, 250, 399]                                           # item 3 is both a target and a negative
+    X = torch.randn(Up + I, d, generator=g).cuda()
+    users, pos, neg = cw_pairs(top_idx, U, targets, pop=True)
+    M_ref = cw_operator(Up + I, Up, users, pos, neg, X.device)
+    ranks = k - 1 - torch.arange(T, device='cuda')
+    negm = top_idx[:U][:, ranks].long()
+    M, cnt = cw_operator_from_topk(Up + I, Up, U, targets, negm, X.device)
+    assert M.nnz == M_ref.nnz == 4 * U * T
+    G, G_ref = ops.spmm(M, X), ops.spmm(M_ref, X)
+    assert rel_err(G.cpu().numpy(), G_ref.cpu().numpy()) < 1e-5
+    assert torch.equal(cnt, torch.bincount(neg, minlength=I))
+    assert not G[U:Up].any()                                                 # fake users carry no CW gradient
