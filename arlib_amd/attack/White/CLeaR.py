@@ -16,7 +16,7 @@ import torch
 
 from ... import ops
 from ...util.metrics import AttackMetric
-from .._common import AttackBase, DEVICE, symmetric_adjacency, rebuild_interaction_matrix, reinit_with_tables, cw_pairs
+from .._common import AttackBase, DEVICE, symmetric_adjacency, rebuild_interaction_matrix, reinit_with_tables, cw_pairs, with_fake_rows, append_rows
 from .DLAttack import masked_topk, device_mask
 from .PGA import cw_operator_from_topk
 
@@ -80,7 +80,7 @@ class CLeaR(AttackBase):
 
     def posionDataAttack(self, recommender):
         self.fakeUserInject(recommender)
-        uiAdj = recommender.data.matrix().tolil()
+        uiAdj = sp.csr_matrix(recommender.data.matrix())              # CSR throughout (the reference keeps a lil matrix)
         optimizer = torch.optim.Adam(recommender.model.parameters(), lr=recommender.args.lRate / 10)
         topk = min(recommender.topN)
         bestTargetHitRate, bestAdj = -1, None
@@ -103,7 +103,7 @@ class CLeaR(AttackBase):
                 scores = (Pu[fake] @ Pi.T).contiguous()
             proj, _ = ops.topn_project_rows(scores, int(self.maliciousFeedbackNum))
             proj[:, self.targetItem] = 1
-            uiAdj2[self.fakeUser, :] = proj.cpu().numpy()
+            uiAdj2 = with_fake_rows(uiAdj2, self.userNum, proj.cpu().numpy())
             uiAdj = uiAdj2.copy()
             recommender.model._init_uiAdj(symmetric_adjacency(uiAdj, Up, self.itemNum))
             recommender.train(Epoch=self.innerEpoch, optimizer=optimizer, evalNum=5)
@@ -134,7 +134,6 @@ class CLeaR(AttackBase):
         self.fakeUser = list(range(self.userNum, self.userNum + self.fakeUserNum))
         for u in self.fakeUser:
             # random.sample(set(range(I)), n) in the reference (CLeaR.py:187): CPython samples from tuple(set)
-            for i in random.sample(tuple(set(range(self.itemNum))), int(self.maliciousFeedbackNum)):
-                data.training_data.append((data.id2user[u], data.id2item[i]))
+            append_rows(data, [(data.id2user[u], data.id2item[i]) for i in random.sample(tuple(set(range(self.itemNum))), int(self.maliciousFeedbackNum))])
         _, _, data.interaction_mat = rebuild_interaction_matrix(data)
         reinit_with_tables(recommender, Pu, Pi)

@@ -15,7 +15,7 @@ import torch
 
 from ... import ops
 from ...util.sampler import next_batch_pairwise
-from .._common import AttackBase, DEVICE, symmetric_adjacency, rebuild_interaction_matrix, reinit_with_tables, cw_pairs
+from .._common import AttackBase, DEVICE, symmetric_adjacency, rebuild_interaction_matrix, reinit_with_tables, cw_pairs, with_fake_rows, append_rows
 
 
 def device_mask(ui_mat, device=DEVICE):
@@ -53,7 +53,7 @@ class DLAttack(AttackBase):
             self.fakeUserInject(recommender, user)
             uiAdj = recommender.data.matrix()           # rebuilt from training_data: earlier fake users keep only their targets (quirk Q6)
             tmpRecommender = deepcopy(recommender)
-            uiAdj2 = uiAdj.tolil(copy=True)
+            uiAdj2 = sp.csr_matrix(uiAdj, copy=True)
             U_now = tmpRecommender.data.user_num
             tmpRecommender.model._init_uiAdj(symmetric_adjacency(uiAdj2, U_now, self.itemNum))
             tmpRecommender.train(Epoch=self.innerEpoch, optimizer=optimizer, evalNum=5)
@@ -71,7 +71,7 @@ class DLAttack(AttackBase):
                 Pu, Pi = tmpRecommender.model()
                 r = (Pu[user, :] @ Pi.T) * p
             m, ind = self.project(r, self.maliciousFeedbackNum)
-            uiAdj2[user, :] = m.cpu().numpy()
+            uiAdj2 = with_fake_rows(uiAdj2, user, m.cpu().numpy().reshape(1, -1))     # `user` is the row just appended
             p[ind] = p[ind] * sigma
             if p.max() < 1:
                 p = torch.ones(self.itemNum, device=DEVICE)
@@ -94,7 +94,6 @@ class DLAttack(AttackBase):
         data.user_num += 1
         data.user['fakeuser{}'.format(data.user_num)] = len(data.user)
         data.id2user[len(data.user) - 1] = 'fakeuser{}'.format(data.user_num)
-        for i in self.targetItem:
-            data.training_data.append((data.id2user[user], data.id2item[i]))
+        append_rows(data, [(data.id2user[user], data.id2item[i]) for i in self.targetItem])
         _, _, data.interaction_mat = rebuild_interaction_matrix(data)
         reinit_with_tables(recommender, Pu, Pi)

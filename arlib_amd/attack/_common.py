@@ -42,8 +42,11 @@ def symmetric_adjacency(ui, n_users, n_items):
 
 def rebuild_interaction_matrix(data):
     """interaction_mat from training_data with the current id maps (attack/White/PGA.py:185-192, CLeaR.py:192-199)."""
-    u = np.fromiter((data.user[p[0]] for p in data.training_data), dtype=np.int64, count=len(data.training_data))
-    i = np.fromiter((data.item[p[1]] for p in data.training_data), dtype=np.int64, count=len(data.training_data))
+    if hasattr(data, '_ids'):
+        u, i = data._ids()                                    # the sampler's int image when there is one (appends cost only the tail)
+    else:
+        u = np.fromiter((data.user[p[0]] for p in data.training_data), dtype=np.int64, count=len(data.training_data))
+        i = np.fromiter((data.item[p[1]] for p in data.training_data), dtype=np.int64, count=len(data.training_data))
     return u, i, sp.csr_matrix((np.ones(len(u), np.float64), (u, i)), shape=(data.user_num, data.item_num), dtype=np.float32)
 
 
@@ -70,3 +73,21 @@ def cw_pairs(top_idx, n_real_users, targets, pop=True):
         ranks = torch.full((n_real_users * T,), k - 1, device=top_idx.device, dtype=torch.long)
     neg = top_idx[users, ranks].long()
     return users, pos, neg
+
+
+def with_fake_rows(ui, first_fake_row, block):
+    """`uiAdj2[fake rows, :] = block` for fake users occupying the LAST rows (attack/White/CLeaR.py:130-135, DLAttack.py:118):
+    a CSR vstack instead of a lil row assignment (lil construction/copies are O(nnz) Python objects)."""
+    ui = sp.csr_matrix(ui)
+    block = sp.csr_matrix(np.asarray(block, dtype=np.float32))
+    if first_fake_row + block.shape[0] != ui.shape[0] or block.shape[1] != ui.shape[1]:
+        raise ValueError('with_fake_rows: the block must cover the last rows of the matrix')
+    return sp.vstack([ui[:first_fake_row], block], format='csr', dtype=np.float32)
+
+
+def append_rows(data, rows):
+    """data.training_data.append(row) for each row (attack/White/CLeaR.py:190-191, DLAttack.py:146-147)."""
+    if hasattr(data, 'append_training_rows'):
+        data.append_training_rows(rows)              # our DataLoader: keeps a pending sampler permutation pending
+    else:
+        data.training_data.extend(rows)

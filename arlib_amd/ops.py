@@ -16,7 +16,14 @@ DEFAULT_CHUNK = 512
 EVENT_HOOK = None      # bench.py installs an object with begin(tag)/end(token) to bracket SpMM launches with HIP events
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    """The caller's current HIP stream (raw handle).  torch.cuda.current_stream() builds a Stream object per call (~8 us, on
+    every kernel launch); the raw getter is the same lookup without the object."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

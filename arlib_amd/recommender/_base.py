@@ -19,7 +19,7 @@ from .. import ops
 from ..engine import PropagationEngine
 from ..util.sampler import next_batch_pairwise
 from ..util.loss import bpr_l2_loss, InfoNCE
-from ..util.metrics import ranking_evaluation
+from ..util.metrics import ranking_evaluation, ranking_evaluation_topk
 
 DEVICE = 'cuda'
 
@@ -383,8 +383,9 @@ class Recommender:
     # streaming score+mask+top-k kernel launch over all test users.
     def evaluate(self, epoch):
         print('Evaluating the model...')
-        rec_list, _ = self.test()
-        measure = ranking_evaluation(self.data.test_set, rec_list, [self.max_N])
+        users, idx, _ = self._test_topk()                  # the per-epoch evaluation needs the measures only, not rec_list
+        sys.stdout.write('\rProgress: [' + '+' * 50 + ']100%\n')
+        measure = ranking_evaluation_topk(self.data, idx, [self.max_N]) if users else ranking_evaluation(self.data.test_set, {}, [self.max_N])
         performance = {}
         for m in measure[1:]:
             k, v = m.strip().split(':')
@@ -412,28 +413,39 @@ class Recommender:
         print('-' * 120)
         return measure
 
-    def test(self):
+    def _test_topk(self):
+        """(test users in test_set order, top-max_N item ids [n, k], scores) with interacted items masked (LightGCN.py:137-161)."""
         users = list(self.data.test_set)
-        rec_list = {}
-        if users:
-            uid = torch.tensor([self.data.user[u] for u in users], dtype=torch.long, device=self.user_emb.device)
-            Pu = self.user_emb[uid].contiguous()
-            Pi = self.item_emb.contiguous()
-            # interacted-item mask (candidates[rated] = -10e8, LightGCN.py:153-154) as CSR over the selected users
+        if not users:
+            return users, np.zeros((0, 0), np.int64), np.zeros((0, 0), np.float32)
+        uid = torch.tensor([self.data.user[u] for u in users], dtype=torch.long, device=self.user_emb.device)
+        Pu = self.user_emb[uid].contiguous()
+        Pi = self.item_emb.contiguous()
+        mask = getattr(self.data, '_arl_test_mask', None)
+        if mask is None or mask[0] != len(users):
+            # interacted-item mask (candidates[rated] = -10e8, LightGCN.py:153-154) as CSR over the selected users; the training
+            # sets of the test users never change (fake users are not test users), so it is built once per data object
             cols = [np.fromiter((self.data.item[it] for it in self.data.training_set_u[u]), dtype=np.int32) for u in users]
             rp = np.zeros(len(users) + 1, np.int32)
             np.cumsum([len(c) for c in cols], out=rp[1:])
             mc = np.concatenate([np.sort(c) for c in cols]) if rp[-1] else np.zeros(1, np.int32)
-            k = min(self.max_N, Pi.shape[0])
-            if Pu.shape[1] % 4 == 0 and k <= 128:
-                idx, val = ops.score_mask_topk(Pu, Pi, k, torch.from_numpy(rp).to(Pu.device), torch.from_numpy(mc.astype(np.int32)).to(Pu.device))
-            else:       # embedding sizes the kernel does not cover: torch plumbing
-                sc = Pu @ Pi.T
-                rows = torch.from_numpy(np.repeat(np.arange(len(users)), np.diff(rp))).to(Pu.device)
-                sc[rows, torch.from_numpy(mc[:rp[-1]].astype(np.int64)).to(Pu.device)] = -10e8
-                val, idx = torch.topk(sc, k)
-            idx, val = idx.cpu().numpy(), val.cpu().numpy()
-            for r, user in enumerate(users):
-                rec_list[user] = [(self.data.id2item[int(i)], float(s)) for i, s in zip(idx[r], val[r])]
+            mask = (len(users), rp, mc.astype(np.int32))
+            self.data._arl_test_mask = mask
+        _, rp, mc = mask
+        k = min(self.max_N, Pi.shape[0])
+        if Pu.shape[1] % 4 == 0 and k <= 128:
+            idx, val = ops.score_mask_topk(Pu, Pi, k, torch.from_numpy(rp).to(Pu.device), torch.from_numpy(mc).to(Pu.device))
+        else:       # embedding sizes the kernel does not cover: torch plumbing
+            sc = Pu @ Pi.T
+            rows = torch.from_numpy(np.repeat(np.arange(len(users)), np.diff(rp))).to(Pu.device)
+            sc[rows, torch.from_numpy(mc[:rp[-1]].astype(np.int64)).to(Pu.device)] = -10e8
+            val, idx = torch.topk(sc, k)
+        return users, idx.cpu().numpy(), val.cpu().numpy()
+
+    def test(self):
+        users, idx, val = self._test_topk()
+        rec_list = {}
+        for r, user in enumerate(users):
+            rec_list[user] = [(self.data.id2item[int(i)], float(s)) for i, s in zip(idx[r], val[r])]
         sys.stdout.write('\rProgress: [' + '+' * 50 + ']100%\n')
-        return rec_list, ranking_evaluation(self.data.test_set, rec_list, self.topN)
+        return rec_list, ranking_evaluation_topk(self.data, idx, self.topN) if users else ranking_evaluation(self.data.test_set, rec_list, self.topN)

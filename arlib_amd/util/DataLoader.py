@@ -12,6 +12,41 @@ from .FileIO import FileIO
 
 
 class DataLoader():
+    # `training_data` is the reference's list of [user, item, rating] rows, shuffled in place by the sampler every epoch
+    # (util/sampler.py:9).  Re-ordering 10^6..10^8 Python references per epoch costs more than the epoch's GPU work, so the
+    # sampler (which shuffles its int image natively) only records the permutation here; the list is brought up to date the
+    # moment anybody reads the attribute.
+    @property
+    def training_data(self):
+        pend = self.__dict__.get('_td_pending')
+        if pend is not None:
+            td = self.__dict__['_td']
+            td[:] = [td[k] for k in pend.tolist()]
+            self.__dict__['_td_pending'] = None
+        return self.__dict__['_td']
+
+    @training_data.setter
+    def training_data(self, rows):
+        self.__dict__['_td'] = rows
+        self.__dict__['_td_pending'] = None
+
+    def _defer_td_permutation(self, perm):
+        """new_list[j] = old_list[perm[j]], applied lazily (composes with a permutation that is still pending)."""
+        pend = self.__dict__.get('_td_pending')
+        self.__dict__['_td_pending'] = np.array(perm, dtype=np.int64) if pend is None else pend[perm]
+
+    def append_training_rows(self, rows):
+        """training_data.extend(rows) without forcing a pending permutation: the new rows go to the end either way."""
+        td, pend = self.__dict__['_td'], self.__dict__.get('_td_pending')
+        n = len(td)
+        td.extend(rows)
+        if pend is not None:
+            self.__dict__['_td_pending'] = np.concatenate([pend, np.arange(n, len(td), dtype=np.int64)])
+
+    def _raw_training_data(self):
+        """(list in its last materialised order, pending permutation or None) -- for the sampler's own bookkeeping."""
+        return self.__dict__['_td'], self.__dict__.get('_td_pending')
+
     def __init__(self, args=None, training_data=None, val_data=None, test_data=None, dataName=None):
         if args is not None:
             base = args.data_path + args.dataset
@@ -49,6 +84,12 @@ class DataLoader():
 
     # ---- matrices
     def _ids(self):
+        """(user ids, item ids) of training_data in its current order.  Served from the sampler's int image (kept in step with
+        the list by util/sampler.py, extended on appends) once it exists; the O(nnz) Python mapping otherwise."""
+        if getattr(self, '_arl_sampler', None) is not None:
+            from .sampler import _shadow
+            p = _shadow(self).pairs
+            return p[:, 0].astype(np.int64), p[:, 1].astype(np.int64)
         u = np.fromiter((self.user[r[0]] for r in self.training_data), dtype=np.int64, count=len(self.training_data))
         i = np.fromiter((self.item[r[1]] for r in self.training_data), dtype=np.int64, count=len(self.training_data))
         return u, i
@@ -93,7 +134,7 @@ class DataLoader():
         return self.item.get(i)
 
     def training_size(self):
-        return len(self.user), len(self.item), len(self.training_data)
+        return len(self.user), len(self.item), len(self.__dict__['_td'])
 
     def val_size(self):
         return len(self.val_set), len(self.val_set_item), len(self.val_data)
@@ -167,8 +208,42 @@ class DataLoader():
         m.sort_indices()
         return ops.CSRGraph(m.indptr.astype(np.int64), m.indices.astype(np.int32), m.data.astype(np.float32), device)
 
-    # pickling / deepcopy: drop the sampler's cached int image (rebuilt on demand)
+    # pickling: drop the sampler's cached int image (rebuilt on demand)
     def __getstate__(self):
+        self.training_data                                       # materialise a pending permutation first
         st = dict(self.__dict__)
         st.pop('_arl_sampler', None)
         return st
+
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(recommender) is how the attacks fork a surrogate (attack/White/CLeaR.py:66, DLAttack.py:62).  A generic
+        deep copy walks ~8 Python objects per interaction (12 s at 1.6 M interactions); nothing mutates the rows or the inner
+        dicts in place (the sampler permutes the LIST, attacks append to it and add keys to the id maps), so the copy owns
+        its containers and shares the leaves."""
+        import copy
+        new = object.__new__(type(self))
+        memo[id(self)] = new
+        shared_leaves = ('training_set_u', 'training_set_i', 'val_set', 'test_set')
+        for k, v in self.__dict__.items():
+            if k == '_td':
+                new.__dict__['_td'] = list(v)                    # a pending permutation stays pending on both sides
+            elif k == '_td_pending':
+                new.__dict__['_td_pending'] = None if v is None else v.copy()
+            elif k in ('val_data', 'test_data'):
+                setattr(new, k, v)                               # never written after construction
+            elif k in shared_leaves:
+                c = type(v)(v.default_factory) if isinstance(v, defaultdict) else type(v)()
+                c.update(v)
+                setattr(new, k, c)
+            elif k in ('user', 'item', 'id2user', 'id2item'):
+                setattr(new, k, dict(v))
+            elif k in ('val_set_item', 'test_set_item'):
+                setattr(new, k, set(v))
+            elif k == '_arl_sampler':
+                from .sampler import PairSampler
+                new._arl_sampler = PairSampler(v.pairs.copy(), v.n_items, (v.memb_rowptr, v.memb_items))
+            elif k == '_arl_memb':
+                new._arl_memb = v
+            else:
+                setattr(new, k, copy.deepcopy(v, memo))
+        return new

@@ -56,6 +56,55 @@ def ranking_evaluation(origin, res, N):
     return measure
 
 
+def test_set_image(data):
+    """Per test user (in test_set order): how many test items it has, and the (row, internal item id) keys of those the model
+    knows, sorted -- built once per data object (the test split never changes)."""
+    img = getattr(data, '_arl_test_image', None)
+    if img is None or img[0] != len(data.test_set):
+        users = list(data.test_set)
+        lens = np.array([len(data.test_set[u]) for u in users], np.int64)
+        I = len(data.item)
+        keys = np.array(sorted(r * I + data.item[it] for r, u in enumerate(users) for it in data.test_set[u] if it in data.item), np.int64)
+        img = (len(users), users, lens, keys)
+        data._arl_test_image = img
+    return img
+
+
+def ranking_evaluation_topk(data, idx, N):
+    """The measure lines of ranking_evaluation(data.test_set, rec_list, N) computed from the top-k index array idx
+    [test users in test_set order, >= max(N)] without building rec_list.  Same arithmetic in the same order (integer hit
+    counts; rank-ordered DCG terms; the user-ordered Python float accumulations), hence the same strings."""
+    _, users, lens, keys = test_set_image(data)
+    I = len(data.item)
+    idx = np.asarray(idx, np.int64)
+    pk = np.arange(idx.shape[0], dtype=np.int64)[:, None] * I + idx
+    pos = np.searchsorted(keys, pk)
+    H = keys[np.minimum(pos, max(len(keys) - 1, 0))] == pk if len(keys) else np.zeros(pk.shape, bool)
+    total = int(lens.sum())
+    measure = []
+    for n in N:
+        Hn = H[:, :n]
+        hits = Hn.sum(1).astype(np.int64)
+        s_hits = int(hits.sum())
+        w = [1.0 / math.log(r + 2) for r in range(n)]
+        dcg = np.zeros(idx.shape[0], np.float64)
+        for r in range(min(n, Hn.shape[1])):
+            dcg = dcg + np.where(Hn[:, r], w[r], 0.0)
+        pref = [0]
+        for r in range(n):
+            pref.append(pref[-1] + w[r])
+        idcg = np.array([pref[m] for m in np.minimum(lens, n).tolist()], np.float64)
+        ndcg_total = 0
+        for v in (dcg / idcg).tolist():
+            ndcg_total += v
+        measure.append('Top ' + str(n) + '\n')
+        measure.append('Hit Ratio:' + str(s_hits / total) + '\n')
+        measure.append('Precision:' + str(s_hits / (len(hits) * n)) + '\n')
+        measure.append('Recall:' + str(sum((hits / lens).tolist()) / len(hits)) + '\n')
+        measure.append('NDCG:' + str(ndcg_total / len(hits)) + '\n')
+    return measure
+
+
 class AttackMetric(object):
     """targetItem: internal item ids.  Rankings are over ALL items without masking interacted ones, as in the
     reference (np.argsort(-score)[:k], util/metrics.py:141)."""

@@ -106,27 +106,63 @@ class PairSampler:
             b += cnt
 
 
+def _rows(data):
+    """(list, pending permutation): row j of the CURRENT order is list[perm[j]] (perm None = identity)."""
+    if hasattr(data, '_raw_training_data'):
+        return data._raw_training_data()
+    return data.training_data, None
+
+
+def _in_sync(sh, data, n=None):
+    """Does the int image still describe the first `n` rows of data.training_data?  Sampled check (first, last, 64 random rows):
+    the only writers of that list are this module (which permutes image and list together) and the attacks (which append)."""
+    td, perm = _rows(data)
+    n = sh.nnz if n is None else n
+    if n == 0:
+        return True
+    if n > len(td):
+        return False
+    idx = np.unique(np.concatenate([[0, n - 1], np.random.default_rng(n).integers(0, n, 64)]))
+    try:
+        for j in idx.tolist():
+            r = td[j if perm is None else int(perm[j])]
+            if data.user[r[0]] != sh.pairs[j, 0] or data.item[r[1]] != sh.pairs[j, 1]:
+                return False
+        return True
+    except KeyError:
+        return False
+
+
 def _shadow(data):
-    """int32 image of data.training_data for the list-based DataLoader API (rebuilt when the list length changed,
-    e.g. after an attack appended fake-user interactions: attack/White/CLeaR.py:190-191)."""
+    """int32 image of data.training_data for the list-based DataLoader API.  Kept across appends (an attack adding fake-user
+    interactions, attack/White/CLeaR.py:190-191, only costs the mapping of the new tail) and rebuilt from scratch otherwise."""
     sh = getattr(data, '_arl_sampler', None)
-    td = data.training_data
-    if sh is None or sh.nnz != len(td) or sh.n_items != len(data.item):
-        pairs = np.array([[data.user[r[0]], data.item[r[1]]] for r in td], np.int32).reshape(-1, 2)
-        memb = getattr(data, '_arl_memb', None)
-        if memb is None:
-            # training_set_u is fixed at DataLoader construction (util/DataLoader.py:41); users added later have an empty set
-            if hasattr(data, 'membership_csr'):
-                memb = data.membership_csr()
-            else:
-                tsu = data.training_set_u
-                us = [u for u in tsu if len(tsu[u])]
-                mp = np.array([[data.user[u], data.item[i]] for u in us for i in tsu[u]], np.int32).reshape(-1, 2)
-                n_rows = (max(data.user[u] for u in us) + 1) if us else 0
-                memb = build_membership(mp, n_rows) if len(mp) else (np.zeros(1, np.int64), np.zeros(1, np.int32))
-            data._arl_memb = memb
-        sh = PairSampler(pairs, len(data.item), memb)
+    if sh is not None and sh.n_items == len(data.item) and sh.nnz == len(_rows(data)[0]) and _in_sync(sh, data):
+        return sh                                                  # steady state: nothing touched the list since the last epoch
+    raw, perm = _rows(data)
+    if (sh is not None and sh.n_items == len(data.item) and sh.nnz < len(raw) and _in_sync(sh, data)
+            and (perm is None or np.array_equal(perm[sh.nnz:], np.arange(sh.nnz, len(raw))))):
+        # rows appended since the last epoch (a deferred permutation never moves them: DataLoader.append_training_rows)
+        tail = np.array([[data.user[r[0]], data.item[r[1]]] for r in raw[sh.nnz:]], np.int32).reshape(-1, 2)
+        sh = PairSampler(np.concatenate([sh.pairs, tail]), len(data.item), (sh.memb_rowptr, sh.memb_items))
         data._arl_sampler = sh
+        return sh
+    td = data.training_data                                        # (brings a deferred permutation up to date)
+    pairs = np.array([[data.user[r[0]], data.item[r[1]]] for r in td], np.int32).reshape(-1, 2)
+    memb = getattr(data, '_arl_memb', None)
+    if memb is None:
+        # training_set_u is fixed at DataLoader construction (util/DataLoader.py:41); users added later have an empty set
+        if hasattr(data, 'membership_csr'):
+            memb = data.membership_csr()
+        else:
+            tsu = data.training_set_u
+            us = [u for u in tsu if len(tsu[u])]
+            mp = np.array([[data.user[u], data.item[i]] for u in us for i in tsu[u]], np.int32).reshape(-1, 2)
+            n_rows = (max(data.user[u] for u in us) + 1) if us else 0
+            memb = build_membership(mp, n_rows) if len(mp) else (np.zeros(1, np.int64), np.zeros(1, np.int32))
+        data._arl_memb = memb
+    sh = PairSampler(pairs, len(data.item), memb)
+    data._arl_sampler = sh
     return sh
 
 
@@ -144,8 +180,11 @@ def next_batch_pairwise(data, batch_size):
     sh.shuffle(mt, also=order)
     mt.to_python()
     if order is not None:                            # keep the Python list in the same (shuffled) order: in-place carry-over
-        td = data.training_data
-        td[:] = [td[k] for k in order[:, 0]]
+        if hasattr(data, '_defer_td_permutation'):
+            data._defer_td_permutation(order[:, 0])  # applied when somebody reads data.training_data
+        else:
+            td = data.training_data
+            td[:] = [td[k] for k in order[:, 0]]
     b = 0
     while b < sh.nnz:
         cnt = min(batch_size, sh.nnz - b)

@@ -114,3 +114,80 @@ def test_synthetic_generator_is_deterministic_and_valid():
     for (u, pp, n), (ou, op, on) in zip(d.pair_sampler.epoch(mt, 777), O.next_batch_pairwise(st, pairs_o, 777, 300, memb)):
         assert np.array_equal(u, ou) and np.array_equal(pp, op) and np.array_equal(n, on)
     assert np.array_equal(mt.words, st)
+
+
+def test_deferred_list_permutation_and_cheap_deepcopy(ml100k):
+    """The sampler only records each epoch's permutation of data.training_data; reading the attribute applies what is pending
+    (two epochs compose).  copy.deepcopy(data) -- how the attacks fork a surrogate -- owns its list and id maps, shares the rows."""
+    import copy
+    from arlib_amd.util.sampler import next_batch_pairwise
+    g = golden('g1_sampler.npz')
+    data = make_data()
+    rows_before = {id(r) for r in data._raw_training_data()[0]}
+    random.seed(2018)
+    for ep in range(2):
+        for _ in next_batch_pairwise(data, 2048):
+            pass
+        assert data._raw_training_data()[1] is not None                     # nothing read the list: still pending
+    fork = copy.deepcopy(data)                                               # the pending permutation is carried, not applied
+    assert data._raw_training_data()[1] is not None and fork._raw_training_data()[1] is not None
+    ids = [data.user[r[0]] for r in data.training_data]
+    assert ids[:2048] == list(g['ep1_u'][:2048]) and len(ids) == ml100k['nnz']
+    assert {id(r) for r in data.training_data} == rows_before                # same row objects, re-ordered
+    assert fork.training_data == data.training_data and fork.training_data is not data.training_data
+    assert fork.training_data[0] is data.training_data[0] and fork.user == data.user and fork.user is not data.user
+    fork.user['fakeuser0'] = len(fork.user)
+    fork.training_data.append(('fakeuser0', '465'))
+    assert 'fakeuser0' not in data.user and len(data.training_data) == ml100k['nnz']
+    # the fork's sampler image came along and is extended by the appended tail only
+    u, i = fork._ids()
+    assert len(u) == ml100k['nnz'] + 1 and u[-1] == fork.user['fakeuser0'] and list(u[:100]) == ids[:100]
+    # a third epoch on the original continues the reference's stream exactly as if the list had been shuffled eagerly
+    eager = make_data()
+    random.seed(2018)
+    for ep in range(3):
+        last = [b for b in next_batch_pairwise(eager, 2048)]
+        eager.training_data                                                  # force materialisation every epoch
+    random.seed(2018)
+    lazy = make_data()
+    for ep in range(3):
+        last_lazy = [b for b in next_batch_pairwise(lazy, 2048)]
+    assert all(np.array_equal(a[k], b[k]) for a, b in zip(last, last_lazy) for k in range(3))
+    assert [r[0] for r in lazy.training_data] == [r[0] for r in eager.training_data]
+
+
+def test_vectorised_ranking_evaluation_is_string_identical():
+    """evaluate() computes its measure lines from the top-k index array; they must be the reference's strings exactly."""
+    from arlib_amd.util.metrics import ranking_evaluation, ranking_evaluation_topk
+    data = make_data()
+    rng = np.random.default_rng(0)
+    users = list(data.test_set)
+    I = len(data.item)
+    idx = np.stack([rng.permutation(I)[:50] for _ in users])
+    for r, u in enumerate(users):                                           # plant some hits at assorted ranks
+        its = [data.item[i] for i in data.test_set[u] if i in data.item]
+        for j, it in enumerate(its[:3]):
+            if it not in idx[r]:
+                idx[r, (7 * j + r) % 50] = it
+    rec = {u: [(data.id2item[int(i)], 0.0) for i in idx[r]] for r, u in enumerate(users)}
+    assert ranking_evaluation_topk(data, idx, [10, 20, 50]) == ranking_evaluation(data.test_set, rec, [10, 20, 50])
+
+
+def test_append_while_a_permutation_is_pending(ml100k):
+    """An attack appends fake-user rows right after a training epoch: the sampler image grows by the tail only and the list,
+    once read, is the shuffled order followed by the new rows."""
+    from arlib_amd.util.sampler import next_batch_pairwise, _shadow
+    data = make_data()
+    random.seed(7)
+    for _ in next_batch_pairwise(data, 4096):
+        pass
+    assert data._raw_training_data()[1] is not None
+    image_before = _shadow(data).pairs.copy()
+    data.user['fakeuser0'] = len(data.user); data.id2user[len(data.user) - 1] = 'fakeuser0'
+    data.append_training_rows([('fakeuser0', '465'), ('fakeuser0', '222')])
+    assert data._raw_training_data()[1] is not None                          # still pending
+    u, i = data._ids()
+    assert np.array_equal(u[:-2], image_before[:, 0]) and list(u[-2:]) == [data.user['fakeuser0']] * 2
+    assert data._raw_training_data()[1] is not None                          # the image was extended without touching the list
+    rows = data.training_data
+    assert [data.user[r[0]] for r in rows] == u.tolist() and [data.item[r[1]] for r in rows] == i.tolist()
