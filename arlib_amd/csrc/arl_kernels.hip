@@ -718,6 +718,54 @@ __global__ __launch_bounds__(kBlock) void nce_grad_kernel(const float *__restric
 }
 
 // ================================================================================================
+// NGCF layer glue (recommender/NGCF.py:200-208): E' = leaky_relu((P + E) W1 + (P * E) W2), P = A E.
+// The two d x d products run as ONE rocBLAS GEMM on [S | T] (N x 2d) by [W1; W2]; these kernels are the element-wise passes
+// around it, each touching every operand once (the ATen expression graph makes ~18 passes forward, ~30 backward).
+// ================================================================================================
+__global__ __launch_bounds__(kBlock) void ngcf_combine_kernel(const float4 *__restrict__ P, const float4 *__restrict__ E, float4 *__restrict__ ST,
+                                                              long long n4, int d4) {
+    for (long long t = (long long)blockIdx.x * kBlock + threadIdx.x; t < n4; t += (long long)gridDim.x * kBlock) {
+        const long long row = t / d4;
+        const int c = (int)(t - row * d4);
+        const float4 p = P[t], e = E[t];
+        ST[row * 2 * d4 + c] = make_float4(p.x + e.x, p.y + e.y, p.z + e.z, p.w + e.w);
+        ST[row * 2 * d4 + d4 + c] = make_float4(p.x * e.x, p.y * e.y, p.z * e.z, p.w * e.w);
+    }
+}
+
+// Z <- leaky_relu(Z) in place; acc += Z (the running layer sum), when acc != NULL
+__global__ __launch_bounds__(kBlock) void ngcf_act_kernel(float4 *__restrict__ Z, float4 *__restrict__ acc, long long n4, float slope) {
+    for (long long t = (long long)blockIdx.x * kBlock + threadIdx.x; t < n4; t += (long long)gridDim.x * kBlock) {
+        float4 z = Z[t];
+        z.x = z.x > 0.f ? z.x : z.x * slope; z.y = z.y > 0.f ? z.y : z.y * slope;
+        z.z = z.z > 0.f ? z.z : z.z * slope; z.w = z.w > 0.f ? z.w : z.w * slope;
+        Z[t] = z;
+        if (acc) { float4 a = acc[t]; a.x += z.x; a.y += z.y; a.z += z.z; a.w += z.w; acc[t] = a; }
+    }
+}
+
+// gZ = gOut * (Out > 0 ? 1 : slope)   (sign(Out) == sign(Z) for slope > 0; at 0 torch uses the negative-side slope)
+__global__ __launch_bounds__(kBlock) void ngcf_act_bwd_kernel(const float4 *__restrict__ gOut, const float4 *__restrict__ Out, float4 *__restrict__ gZ,
+                                                              long long n4, float slope) {
+    for (long long t = (long long)blockIdx.x * kBlock + threadIdx.x; t < n4; t += (long long)gridDim.x * kBlock) {
+        const float4 g = gOut[t], o = Out[t];
+        gZ[t] = make_float4(g.x * (o.x > 0.f ? 1.f : slope), g.y * (o.y > 0.f ? 1.f : slope), g.z * (o.z > 0.f ? 1.f : slope), g.w * (o.w > 0.f ? 1.f : slope));
+    }
+}
+
+// gP = gS + gT * E;  gE = gS + gT * P   from gST = [gS | gT]
+__global__ __launch_bounds__(kBlock) void ngcf_combine_bwd_kernel(const float4 *__restrict__ gST, const float4 *__restrict__ P, const float4 *__restrict__ E,
+                                                                  float4 *__restrict__ gP, float4 *__restrict__ gE, long long n4, int d4) {
+    for (long long t = (long long)blockIdx.x * kBlock + threadIdx.x; t < n4; t += (long long)gridDim.x * kBlock) {
+        const long long row = t / d4;
+        const int c = (int)(t - row * d4);
+        const float4 gs = gST[row * 2 * d4 + c], gt = gST[row * 2 * d4 + d4 + c], p = P[t], e = E[t];
+        gP[t] = make_float4(fmaf(gt.x, e.x, gs.x), fmaf(gt.y, e.y, gs.y), fmaf(gt.z, e.z, gs.z), fmaf(gt.w, e.w, gs.w));
+        gE[t] = make_float4(fmaf(gt.x, p.x, gs.x), fmaf(gt.y, p.y, gs.y), fmaf(gt.z, p.z, gs.z), fmaf(gt.w, p.w, gs.w));
+    }
+}
+
+// ================================================================================================
 // SimGCL perturbation (recommender/SimGCL.py:203-205)
 // ================================================================================================
 __global__ __launch_bounds__(kBlock) void simgcl_perturb_kernel(float *__restrict__ E, const float *__restrict__ noise, int n, int d, float eps) {
@@ -1635,6 +1683,47 @@ int arl_infonce_fwd_bwd_f32(const float *v1, const float *v2, int64_t n, int64_t
         hipLaunchKernelGGL((nce_grad_kernel<false>), dim3((unsigned)n), dim3(kBlock), shm, st, b, a, ttl, n2, (int)n, (int)d, inv_tau, scale, dv2);
         ARL_LAUNCH_CHECK();
     }
+    return ARL_OK;
+}
+
+static unsigned stream_grid(long long n4) { const long long b = (n4 + kBlock - 1) / kBlock; return (unsigned)(b < 16384 ? (b > 0 ? b : 1) : 16384); }
+
+int arl_ngcf_combine_f32(const float *P, const float *E, int64_t n, int64_t d, float *ST, arl_stream_t stream) {
+    if (!P || !E || !ST) return ARL_E_NULL;
+    if (n < 0 || d <= 0 || (d & 3)) return ARL_E_DIM;
+    if (n == 0) return ARL_OK;
+    hipLaunchKernelGGL(ngcf_combine_kernel, dim3(stream_grid(n * d / 4)), dim3(kBlock), 0, (hipStream_t)stream, (const float4 *)P, (const float4 *)E, (float4 *)ST,
+                       (long long)(n * d / 4), (int)(d / 4));
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_ngcf_act_f32(float *Z, float *acc, int64_t n, int64_t d, float slope, arl_stream_t stream) {
+    if (!Z) return ARL_E_NULL;
+    if (n < 0 || d <= 0 || (d & 3)) return ARL_E_DIM;
+    if (n == 0) return ARL_OK;
+    hipLaunchKernelGGL(ngcf_act_kernel, dim3(stream_grid(n * d / 4)), dim3(kBlock), 0, (hipStream_t)stream, (float4 *)Z, (float4 *)acc, (long long)(n * d / 4), slope);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_ngcf_act_bwd_f32(const float *gOut, const float *Out, int64_t n, int64_t d, float slope, float *gZ, arl_stream_t stream) {
+    if (!gOut || !Out || !gZ) return ARL_E_NULL;
+    if (n < 0 || d <= 0 || (d & 3)) return ARL_E_DIM;
+    if (n == 0) return ARL_OK;
+    hipLaunchKernelGGL(ngcf_act_bwd_kernel, dim3(stream_grid(n * d / 4)), dim3(kBlock), 0, (hipStream_t)stream, (const float4 *)gOut, (const float4 *)Out,
+                       (float4 *)gZ, (long long)(n * d / 4), slope);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_ngcf_combine_bwd_f32(const float *gST, const float *P, const float *E, int64_t n, int64_t d, float *gP, float *gE, arl_stream_t stream) {
+    if (!gST || !P || !E || !gP || !gE) return ARL_E_NULL;
+    if (n < 0 || d <= 0 || (d & 3)) return ARL_E_DIM;
+    if (n == 0) return ARL_OK;
+    hipLaunchKernelGGL(ngcf_combine_bwd_kernel, dim3(stream_grid(n * d / 4)), dim3(kBlock), 0, (hipStream_t)stream, (const float4 *)gST, (const float4 *)P,
+                       (const float4 *)E, (float4 *)gP, (float4 *)gE, (long long)(n * d / 4), (int)(d / 4));
+    ARL_LAUNCH_CHECK();
     return ARL_OK;
 }
 

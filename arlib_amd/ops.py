@@ -504,6 +504,46 @@ def topn_project_rows(M, n):
     return out, idx[:, :n]
 
 
+# ------------------------------------------------------------------------------------------------ NGCF layer glue
+def ngcf_combine(P, E, out=None):
+    """[P + E | P * E]  -> [n, 2d] (recommender/NGCF.py:204-206, the operands of the layer's two d x d products)."""
+    _dev(P, torch.float32, 'P', 2); _dev(E, torch.float32, 'E', 2)
+    if P.shape != E.shape or P.shape[1] % 4:
+        raise ValueError('ngcf_combine: P and E must have the same [n, d] shape with d % 4 == 0')
+    n, d = P.shape
+    ST = out if out is not None else torch.empty(n, 2 * d, dtype=torch.float32, device=P.device)
+    check(_lib.lib().arl_ngcf_combine_f32(_ptr(P), _ptr(E), n, d, _ptr(ST), _stream()), 'arl_ngcf_combine_f32')
+    return ST
+
+
+def ngcf_act_(Z, acc=None, slope=0.01):
+    """Z <- leaky_relu(Z) in place; acc += Z when given."""
+    _dev(Z, torch.float32, 'Z', 2)
+    if Z.shape[1] % 4 or (acc is not None and _dev(acc, torch.float32, 'acc', 2).shape != Z.shape):
+        raise ValueError('ngcf_act_: bad shapes')
+    check(_lib.lib().arl_ngcf_act_f32(_ptr(Z), _ptr(acc), Z.shape[0], Z.shape[1], float(slope), _stream()), 'arl_ngcf_act_f32')
+    return Z
+
+
+def ngcf_act_bwd(gOut, Out, slope=0.01):
+    _dev(gOut, torch.float32, 'gOut', 2); _dev(Out, torch.float32, 'Out', 2)
+    if gOut.shape != Out.shape or Out.shape[1] % 4:
+        raise ValueError('ngcf_act_bwd: bad shapes')
+    gZ = torch.empty_like(Out)
+    check(_lib.lib().arl_ngcf_act_bwd_f32(_ptr(gOut), _ptr(Out), Out.shape[0], Out.shape[1], float(slope), _ptr(gZ), _stream()), 'arl_ngcf_act_bwd_f32')
+    return gZ
+
+
+def ngcf_combine_bwd(gST, P, E):
+    _dev(gST, torch.float32, 'gST', 2); _dev(P, torch.float32, 'P', 2); _dev(E, torch.float32, 'E', 2)
+    n, d = P.shape
+    if E.shape != P.shape or gST.shape != (n, 2 * d) or d % 4:
+        raise ValueError('ngcf_combine_bwd: bad shapes')
+    gP, gE = torch.empty_like(P), torch.empty_like(E)
+    check(_lib.lib().arl_ngcf_combine_bwd_f32(_ptr(gST), _ptr(P), _ptr(E), n, d, _ptr(gP), _ptr(gE), _stream()), 'arl_ngcf_combine_bwd_f32')
+    return gP, gE
+
+
 # ------------------------------------------------------------------------------------------------ user-sharded loss
 def bpr_l2_partial(emb, item_off, u, p, n, B_global, workspace, sums_out):
     """Per-sample BPR coefficients (into `workspace`) + local sums [sum loss terms, sum|u|^2, sum|p|^2] (into sums_out)."""

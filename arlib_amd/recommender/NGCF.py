@@ -1,28 +1,43 @@
 """NGCF (simplified, as in the reference's recommender/NGCF.py:173-212): per layer
     E' = leaky_relu( A(E W1) + E W1 + ((A E) * E) W2 ),   mean of L+1 layers.
 Since A(E W1) = (A E) W1 the layer needs ONE sparse hop, not the reference's two:  P = A E;  E' = leaky_relu((P + E) W1 + (P * E) W2).
-The hop (forward and its backward A^T dY = A dY) is the HIP SpMM kernel; the small dense d x d products and the element-wise
-glue go through ATen (rocBLAS) this round -- a fused MFMA epilogue is the follow-up.
+The hop (forward and its backward A^T dY = A dY) is the HIP SpMM kernel; the layer is one autograd node (`_Layer`) whose
+element-wise passes are HIP kernels and whose d x d products are one (forward) / two (backward) rocBLAS GEMMs on [S | T].
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import ops
 from ._base import GraphEncoder, Recommender, TorchGraphInterface
 
 
-class _Hop(torch.autograd.Function):
-    """Y = A X with the normalised (symmetric) adjacency; backward is the same kernel on the incoming gradient."""
+class _Layer(torch.autograd.Function):
+    """One NGCF layer  E' = leaky_relu((P + E) W1 + (P * E) W2),  P = A E,  forward and backward by hand:
+    forward  : SpMM kernel, one element-wise pass building [S | T], ONE GEMM with [W1; W2], one activation pass (in place);
+    backward : activation pass, two GEMMs (gST = gZ [W1; W2]^T and [gW1; gW2] = [S | T]^T gZ), one element-wise pass for
+               (gP, gE), and the SpMM kernel with its AXPBY epilogue: gE_total = A gP + gE  (A is symmetric).
+    Saved per layer: E, P, [S | T], E'  (the ATen expression graph keeps about twice that)."""
 
     @staticmethod
-    def forward(ctx, X, graph):
-        ctx.graph = graph
-        return ops.spmm(graph, X.contiguous())
+    def forward(ctx, ego, W1, W2, graph, slope):
+        ego = ego.contiguous()
+        P = ops.spmm(graph, ego)
+        ST = ops.ngcf_combine(P, ego)
+        Wcat = torch.cat([W1, W2], 0)
+        out = ops.ngcf_act_(torch.mm(ST, Wcat), None, slope)
+        ctx.save_for_backward(ego, P, ST, out, Wcat)
+        ctx.graph, ctx.slope = graph, slope
+        return out
 
     @staticmethod
-    def backward(ctx, gY):
-        return ops.spmm(ctx.graph, gY.contiguous()), None
+    def backward(ctx, g_out):
+        ego, P, ST, out, Wcat = ctx.saved_tensors
+        d = ego.shape[1]
+        gZ = ops.ngcf_act_bwd(g_out.contiguous(), out, ctx.slope)
+        gW = torch.mm(ST.t(), gZ)
+        gP, gE = ops.ngcf_combine_bwd(torch.mm(gZ, Wcat.t()), P, ego)
+        g_ego = ops.spmm(ctx.graph, gP, 1.0, 1.0, gE)
+        return g_ego, gW[:d], gW[d:], None, None
 
 
 class NGCF_Encoder(GraphEncoder):
@@ -53,8 +68,7 @@ class NGCF_Encoder(GraphEncoder):
         ego = torch.cat([u, i], 0)
         acc = ego
         for k in range(self.layers):
-            P = _Hop.apply(ego, graph)
-            ego = F.leaky_relu(torch.mm(P + ego, self.W['w1_' + str(k)]) + torch.mm(P * ego, self.W['w2_' + str(k)]))
+            ego = _Layer.apply(ego, self.W['w1_' + str(k)], self.W['w2_' + str(k)], graph, 0.01)      # F.leaky_relu default slope
             acc = acc + ego
         out = acc / (self.layers + 1)
         U = self.data.user_num

@@ -208,6 +208,21 @@ int arl_infonce_fwd_bwd_f32(const float *v1, const float *v2, int64_t n, int64_t
 int arl_simgcl_perturb_f32(float *E, const float *noise, int64_t n, int64_t d, float eps, arl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * NGCF layer glue -- recommender/NGCF.py:200-208:  E' = leaky_relu((P + E) W1 + (P * E) W2),  P = A_hat E.
+ * The d x d products are ONE GEMM of [S | T] (N x 2d) with [W1; W2] (the caller's BLAS); these are the passes around it.
+ *   combine      : ST[row] = [ P[row] + E[row] | P[row] * E[row] ]                       (ST: [n, 2d])
+ *   act          : Z <- leaky_relu(Z, slope) in place;  acc += Z when acc != NULL        (layer sum)
+ *   act_bwd      : gZ = gOut * (Out > 0 ? 1 : slope)
+ *   combine_bwd  : from gST = [gS | gT]:  gP = gS + gT * E,  gE = gS + gT * P
+ * d % 4 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+int arl_ngcf_combine_f32(const float *P, const float *E, int64_t n, int64_t d, float *ST, arl_stream_t stream);
+int arl_ngcf_act_f32(float *Z, float *acc, int64_t n, int64_t d, float slope, arl_stream_t stream);
+int arl_ngcf_act_bwd_f32(const float *gOut, const float *Out, int64_t n, int64_t d, float slope, float *gZ, arl_stream_t stream);
+int arl_ngcf_combine_bwd_f32(const float *gST, const float *P, const float *E, int64_t n, int64_t d, float *gP, float *gE,
+                             arl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * White-box attack primitives.
  * ---------------------------------------------------------------------------------------------- */
 /* ------------------------------------------------------------------------------------------------
