@@ -172,11 +172,26 @@ def attack_leg(torch, ops, data, E0_dev, args):
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t2) / args.attack_steps
+    cpu = None
+    if args.cpu_baseline:
+        # the same PGA step through the oracle on the host cores: per-step graph rebuild + renormalisation (what PGA.py:93-97 does
+        # with scipy), L-hop forward, CW gradient, L-1 hop backward, SDDMM block, tanh/clamp update -- one step, it takes seconds
+        from oracle import oracle as O
+        O.build()
+        rowptr, col = data.adjacency_pattern()
+        users_h, pos_h, neg_h = (t.cpu().numpy() for t in cw_pairs(top_idx, U, targets, pop=True))
+        S_h, E0_h = S.cpu().numpy(), E0.cpu().numpy()
+        tc = time.perf_counter()
+        _, S_next, cw_h = O.pga_step(rowptr[:U + 1].astype(np.int64), (col[:nnz] - U).astype(np.int64), U, F, I, S_h, E0_h, L, users_h, pos_h, neg_h)
+        cpu_s = time.perf_counter() - tc
+        cpu = {'value': 1.0 / cpu_s, 'unit': 'steps/s', 'cores': O.num_threads(), 'kind': 'port', 'seconds_per_step': cpu_s,
+               'sample': '1 PGA step of the same workload (oracle: numpy graph rebuild + OpenMP SpMM + scipy CW product)', 'cw_loss': float(cw_h)}
     Ep, Np = 2 * nnz + 2 * F * I, U + F + I
     step_bytes = L * (8 * Ep + 4 * Np + 16 * Np * d) + (L - 1) * (8 * Ep + 4 * Np + 8 * Np * d) + L * (2 * F * I * 4 + 2 * I * d * 4 + 2 * F * d * 4) + 3 * F * I * 4
     return {'metric': 'attack-grad steps/sec (PGA gradient w.r.t. fake interactions, LightGCN d=%d L=%d surrogate)' % (d, L),
             'value': 1.0 / dt, 'unit': 'steps/s', 'ms_per_step': 1e3 * dt, 'fake_users': F, 'targets': 5, 'cw_loss': float(loss),
             'algorithmic_bytes_per_step': step_bytes, 'hbm_frac': step_bytes / dt / 1e9 / HBM_PEAK_GBS,
+            'cpu_baseline': cpu,
             'score_topk_pass': {'seconds': topk_s, 'tflops': 2.0 * (U + F) * I * d / topk_s / 1e12, 'note': 'once per inner epoch, not per step'},
             'setup_seconds': setup_s}
 

@@ -307,14 +307,19 @@ def cw_pairs(top_idx, n_real_users, targets, pop=True):
 
 def cw_loss_grad(out, Up, users, pos, neg):
     """CWloss = mean(neg_score - pos_score) (PGA.py:109-116) and dL/d(out)."""
+    import scipy.sparse as sp
+    users = np.asarray(users, np.int64); pos = np.asarray(pos, np.int64); neg = np.asarray(neg, np.int64)
     ue, pe, ne = out[users], out[Up + pos], out[Up + neg]
     loss = float(np.mean((ue.astype(np.float64) * ne).sum(1) - (ue.astype(np.float64) * pe).sum(1)))
     c = 1.0 / len(users)
-    G = np.zeros(out.shape, np.float64)
-    np.add.at(G, users, c * (ne.astype(np.float64) - pe))
-    np.add.at(G, Up + neg, c * ue.astype(np.float64))
-    np.add.at(G, Up + pos, -c * ue.astype(np.float64))
-    return loss, G.astype(np.float32)
+    # the three scatter-adds (du += c (n - p), dn += c u, dp -= c u) as one sparse product: duplicates are summed by the
+    # COO -> CSR conversion, in float64 (np.add.at does the same arithmetic two orders of magnitude slower)
+    n = out.shape[0]
+    rows = np.concatenate([users, users, Up + neg, Up + pos])
+    cols = np.concatenate([Up + neg, Up + pos, users, users])
+    vals = np.concatenate([np.full(len(users), c), np.full(len(users), -c)] * 2)
+    G = sp.csr_matrix((vals, (rows, cols)), shape=(n, n)) @ out.astype(np.float64)
+    return loss, np.asarray(G, np.float32)
 
 
 def sfa_l1_loss_grad(H, r0):
