@@ -263,6 +263,91 @@ class PropagationEngine:
         ops.mark_bits_(self.bits, allrows, False, N, check_range=False)
         return self.loss_out, cl_loss
 
+    def step_xsimgcl(self, u, p, n, cl_rate=0.2, tau=0.1, eps=0.1, layer_cl=1, noises=None):
+        """One XSimGCL training iteration (recommender/XSimGCL.py:62-75,205-223): ONE perturbed forward; BPR + L2 on the mean of
+        layers 1..L; InfoNCE (temperature tau) between that mean and the layer-`layer_cl` output at the batch's unique users and
+        unique positive items.  Sparse-batch schedule: L-1 full hops + a row-subset hop forward; backward
+            acc_L = c_L,  acc_k = c_k + A acc_{k+1},  dE0 = A acc_1,   c_k = G_mean / L + [k == layer_cl] G_cl
+        with the first hop gathering flagged rows only and Adam fused into the last (default L=2: 2 full hops in all).
+        noises: optional [hop] full [N,d] tensors (parity tests); default one torch.rand draw per hop like the reference's
+        rand_like.  Returns (loss_out, cl_loss)."""
+        if not self.skip0 or self.optimizer != 'adam':
+            raise ValueError('step_xsimgcl needs a skip_layer0 engine with Adam')
+        L, A, U, N, d = self.L, self.A, self.U, self.N, self.d
+        if not (1 <= layer_cl <= L):
+            raise ValueError('layer_cl must be in [1, L]')
+        B = u.numel()
+        self._sparse_buffers(B)
+        if getattr(self, '_G_dirty', True):
+            self.G.zero_(); self._G_dirty = False
+        inv = 1.0 / L
+        rows = torch.cat([u, p + U, n + U])
+        uidx = torch.unique(u.long())
+        iidx = torch.unique(p.long()) + U
+        rows_cl = torch.cat([uidx, iidx]).to(torch.int32)
+        nu = uidx.numel()
+        sel = torch.cat([rows, rows_cl])                                    # compact rows: [0,3B) BPR, then the CL rows
+        rnd = (lambda k: noises[k]) if noises is not None else (lambda k: torch.rand(N, d, device=self.device))
+        # ---- forward
+        layers, cur = [], self.E0
+        for k in range(L - 1):
+            nxt = ops.spmm(A, cur, out=self.hops[k % len(self.hops)] if L <= 3 else None)
+            ops.simgcl_perturb_(nxt, rnd(k), eps)
+            layers.append(nxt); cur = nxt
+        last = ops.spmm_rows(A, cur, sel, (), 1.0, nsplit=self.nsplit, check_range=False)
+        ops.simgcl_perturb_(last, rnd(L - 1)[sel.long()].contiguous(), eps)
+        mean_c = last.clone()
+        for t in layers:
+            mean_c += ops.gather_rows(t, sel, check_range=False)
+        mean_c *= inv
+        cl_c = last[3 * B:] if layer_cl == L else ops.gather_rows(layers[layer_cl - 1], rows_cl, check_range=False)
+        # ---- losses and compact gradients
+        self.Gc.zero_()
+        ops.bpr_l2_fwd_bwd(mean_c[:3 * B].contiguous(), B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self._ws, loss_out=self.loss_out,
+                           check_range=False)
+        mcl = mean_c[3 * B:]
+        lu, du1, du2 = ops.infonce_fwd_bwd(mcl[:nu].contiguous(), cl_c[:nu].contiguous(), tau)
+        li, di1, di2 = ops.infonce_fwd_bwd(mcl[nu:].contiguous(), cl_c[nu:].contiguous(), tau)
+        cl_loss = cl_rate * (lu[0] + li[0])
+        g_mean_cl = torch.cat([du1, di1], 0)                                # w.r.t. the mean at the CL rows
+        g_layer = torch.cat([du2, di2], 0) * cl_rate                        # w.r.t. the layer-`layer_cl` output at the CL rows
+        # G <- G_mean / L  (sparse rows; G is all-zero between steps)
+        ops.scatter_add_rows(self.G, rows, self.Gc, inv, check_range=False)
+        ops.scatter_add_rows(self.G, rows_cl, g_mean_cl, cl_rate * inv, check_range=False)
+        allrows = sel
+        ops.mark_rows_(self.flags, allrows, 1, check_range=False)
+        ops.mark_bits_(self.bits, allrows, True, N, check_range=False)
+        # ---- backward
+        self.t += 1
+        bufs = [self.hops[1], self.hops[0]] if len(self.hops) >= 2 else [torch.empty_like(self.E0), torch.empty_like(self.E0)]
+        if L == 1:
+            src = self.G
+            if layer_cl == 1:                                               # acc_1 = G + G_cl: both sparse, on the same flagged rows
+                ops.scatter_add_rows(self.G, rows_cl, g_layer, 1.0, check_range=False)
+            tmp = ops.spmm_flagged(A, src, self.bits, 1.0, 0.0, None, None, out=bufs[0])
+            ops.adam_dense(self.E0, tmp, self.m, self.v, self.lr, self.t, self.betas, self.eps)
+        else:
+            if layer_cl == L:                                               # acc_L = G + G_cl (sparse); later levels add G alone
+                first_src = self.G.clone()
+                ops.scatter_add_rows(first_src, rows_cl, g_layer, 1.0, check_range=False)
+            else:
+                first_src = self.G
+            acc = ops.spmm_flagged(A, first_src, self.bits, 1.0, 1.0, self.G, self.flags, out=bufs[0])       # level L-1
+            level = L - 1
+            while True:
+                if level == layer_cl:
+                    ops.scatter_add_rows(acc, rows_cl, g_layer, 1.0, check_range=False)
+                if level == 1:
+                    break
+                dst = bufs[1] if acc is bufs[0] else bufs[0]
+                acc = ops.spmm_flagged(A, acc, None, 1.0, 1.0, self.G, self.flags, out=dst)
+                level -= 1
+            ops.spmm_adam(A, acc, 1.0, 0.0, None, self.E0, self.m, self.v, self.lr, self.t, self.betas, self.eps)
+        ops.zero_rows_(self.G, allrows, check_range=False)
+        ops.mark_rows_(self.flags, allrows, 0, check_range=False)
+        ops.mark_bits_(self.bits, allrows, False, N, check_range=False)
+        return self.loss_out, cl_loss
+
     def _sparse_buffers(self, B):
         if getattr(self, '_sparse_B', None) == B:
             return

@@ -199,6 +199,7 @@ class Recommender:
     print_every = 1000
     has_extra_loss = False
     fused_extra_loss = False      # the model's extra loss has a fused engine step (SimGCL)
+    train_forward_perturbed = False   # the training forward is model(True) and hands extra outputs to _extra_loss (XSimGCL)
 
     def _fused_step(self, eng, u, p, n):
         return eng.step(u, p, n)
@@ -305,12 +306,13 @@ class Recommender:
                         print('training:', epoch + 1, 'batch', n, 'batch_loss:', float(lo[0] + lo[1]))
                     continue
                 model.train()
-                rec_user_emb, rec_item_emb = model()
+                outs = model(True) if self.train_forward_perturbed else model()
+                rec_user_emb, rec_item_emb = outs[0], outs[1]
                 ul, pl, nl = u.long(), p.long(), ng.long()
                 user_emb, pos_item_emb, neg_item_emb = rec_user_emb[ul], rec_item_emb[pl], rec_item_emb[nl]
                 batch_loss = bpr_l2_loss(user_emb, pos_item_emb, neg_item_emb, self.args.reg)
                 if self.has_extra_loss:
-                    batch_loss = batch_loss + self._extra_loss(model, ul, pl)
+                    batch_loss = batch_loss + (self._extra_loss(model, ul, pl, *outs) if self.train_forward_perturbed else self._extra_loss(model, ul, pl))
                 optimizer.zero_grad()
                 batch_loss.backward()
                 if requires_embgrad and maxEpoch - epoch < gradIterationNum:
@@ -349,10 +351,11 @@ class Recommender:
             if eng is not None:
                 last = eng.step(u, p, ng)
                 continue
-            rec_user_emb, rec_item_emb = model()
+            outs = model(True) if self.train_forward_perturbed else model()
+            rec_user_emb, rec_item_emb = outs[0], outs[1]
             loss = bpr_l2_loss(rec_user_emb[u.long()], rec_item_emb[p.long()], rec_item_emb[ng.long()], self.args.reg)
             if self.has_extra_loss:
-                loss = loss + self._extra_loss(model, u.long(), p.long())
+                loss = loss + (self._extra_loss(model, u.long(), p.long(), *outs) if self.train_forward_perturbed else self._extra_loss(model, u.long(), p.long()))
             optimizer.zero_grad()
             loss.backward()
             optimizer.step()

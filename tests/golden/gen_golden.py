@@ -571,7 +571,63 @@ def gen_ngcf():
     save('g9_ngcf.npz', **o)
 
 
+# --------------------------------------------------------------------------- G11: XSimGCL (LightGCN + one extra term)
+def gen_xsimgcl(data):
+    """One reference XSimGCL iteration (recommender/XSimGCL.py:62-75,205-223) with injected noise: ONE perturbed forward whose
+    mean is used for BPR and, against its own layer-1 output, for the InfoNCE terms (temperature 0.1)."""
+    from recommender.XSimGCL import XSimGCL
+    args = rec_args(emb_size=16, n_layers=2, model_name='XSimGCL')
+    seedSet(2018)
+    rec = XSimGCL(args, data)
+    model = rec.model
+    N = data.user_num + data.item_num
+    g = torch.Generator().manual_seed(78)
+    noises = [torch.rand(N, 16, generator=g) for _ in range(2)]       # one per hop
+    o = {'user0': model.embedding_dict['user_emb'].detach().numpy().copy(),
+         'item0': model.embedding_dict['item_emb'].detach().numpy().copy(),
+         'noise': torch.stack(noises).numpy(),
+         'hyper': np.array([rec.n_layers, rec.layer_cl, rec.cl_rate, rec.eps, rec.temp], np.float64)}
+    random.seed(2018)
+    d2 = copy.copy(data); d2.training_data = [list(r) for r in data_training0]
+    user_idx, pos_idx, neg_idx = next(iter(ref_sampler.next_batch_pairwise(d2, 2048)))
+    with torch.no_grad():
+        u0, i0 = model()
+    o['fwd_user'] = u0.numpy().copy(); o['fwd_item'] = i0.numpy().copy()
+    orig = torch.rand_like
+    it = iter(noises)
+    torch.rand_like = lambda x, *a, **k: next(it)
+    try:
+        optim = torch.optim.Adam(model.parameters(), lr=args.lRate)
+        ru, ri, cu, ci = model(True)
+        o['fwdp_user'] = ru.detach().numpy().copy(); o['fwdp_item'] = ri.detach().numpy().copy()
+        o['cl_user'] = cu.detach().numpy().copy(); o['cl_item'] = ci.detach().numpy().copy()
+        user_emb, pos_item_emb, neg_item_emb = ru[user_idx], ri[pos_idx], ri[neg_idx]
+        rec_loss = ref_loss.bpr_loss(user_emb, pos_item_emb, neg_item_emb)
+        cl_loss = rec.cl_rate * rec.cal_cl_loss([user_idx, pos_idx], ru, cu, ri, ci)
+        batch_loss = rec_loss + ref_loss.l2_reg_loss(args.reg, user_emb, pos_item_emb) + cl_loss
+        optim.zero_grad()
+        batch_loss.backward()
+        o['grad_user'] = model.embedding_dict['user_emb'].grad.numpy().copy()
+        o['grad_item'] = model.embedding_dict['item_emb'].grad.numpy().copy()
+        optim.step()
+    finally:
+        torch.rand_like = orig
+    o['rec_loss'] = np.array([rec_loss.item()], np.float32)
+    o['cl_loss'] = np.array([cl_loss.item()], np.float32)
+    o['user_k1'] = model.embedding_dict['user_emb'].detach().numpy().copy()
+    o['item_k1'] = model.embedding_dict['item_emb'].detach().numpy().copy()
+    o['batch_u'] = np.asarray(user_idx, np.int32); o['batch_p'] = np.asarray(pos_idx, np.int32); o['batch_n'] = np.asarray(neg_idx, np.int32)
+    save('g11_xsimgcl.npz', **o)
+
+
 if __name__ == '__main__':
+    only = set(sys.argv[1:])                          # e.g. `gen_golden.py xsimgcl` regenerates that fixture alone
+    if only:
+        data = DataLoader(rec_args())
+        data_training0 = [list(r) for r in data.training_data]
+        if 'xsimgcl' in only:
+            gen_xsimgcl(data)
+        sys.exit(0)
     gen_dataset()
     data = gen_sampler()
     # the sampler shuffled data.training_data in place; keep a pristine file-order copy for the step fixtures
@@ -585,4 +641,5 @@ if __name__ == '__main__':
     gen_train_api()
     gen_attacks()
     gen_ngcf()
+    gen_xsimgcl(data)
     print('done; scratch dir', SCRATCH)

@@ -203,3 +203,38 @@ def test_ngcf_forward(ml100k):
     out = O.ngcf_forward(csr, np.concatenate([g['user0'], g['item0']]), [g['w1_0'], g['w1_1']], [g['w2_0'], g['w2_1']])
     U = ml100k['U']
     assert rel_err(out[:U], g['fwd_user']) < RTOL and rel_err(out[U:], g['fwd_item']) < RTOL
+
+
+def test_xsimgcl_forward_and_step(ml100k):
+    """XSimGCL restated with the oracle's pieces against the reference's own iteration (g11, injected noise)."""
+    g = golden('g11_xsimgcl.npz')
+    csr = _ml100k_csr(ml100k)
+    U = ml100k['U']
+    L, lc, cl_rate, eps, temp = int(g['hyper'][0]), int(g['hyper'][1]), float(g['hyper'][2]), float(g['hyper'][3]), float(g['hyper'][4])
+    E0 = np.concatenate([g['user0'], g['item0']])
+    out = O.lightgcn_forward(csr, E0, L, skip0=True)
+    assert rel_err(out[:U], g['fwd_user']) < RTOL and rel_err(out[U:], g['fwd_item']) < RTOL
+    mean, layers = O.lightgcn_forward(csr, E0, L, skip0=True, noises=g['noise'], eps=eps, return_layers=True)
+    cl = layers[lc]
+    assert rel_err(mean[:U], g['fwdp_user']) < RTOL and rel_err(mean[U:], g['fwdp_item']) < RTOL
+    assert rel_err(cl[:U], g['cl_user']) < RTOL and rel_err(cl[U:], g['cl_item']) < RTOL
+    bu, bp, bn = g['batch_u'], g['batch_p'], g['batch_n']
+    lb, lr_, G = O.bpr_l2(mean, U, bu, bp, bn, 1e-4)                          # BPR + L2 read the PERTURBED mean
+    assert abs(lb - g['rec_loss'][0]) <= RTOL * abs(g['rec_loss'][0])
+    G = G.astype(np.float64); Gcl = np.zeros_like(G)
+    closs = 0.0
+    for idx in (np.unique(bu), np.unique(bp) + U):
+        l, d1, d2 = O.infonce(mean[idx], cl[idx], temp)
+        closs += l
+        G[idx] += cl_rate * d1; Gcl[idx] += cl_rate * d2
+    assert abs(cl_rate * closs - g['cl_loss'][0]) <= RTOL * abs(g['cl_loss'][0])
+    # acc_L = c_L, acc_k = c_k + A acc_{k+1}, dE0 = A acc_1 with c_k = G/L + [k == layer_cl] G_cl
+    acc = None
+    for k in range(L, 0, -1):
+        c = (G / L + (Gcl if k == lc else 0.0)).astype(np.float32)
+        acc = c if acc is None else O.spmm(csr, acc, 1.0, 1.0, c)
+    grad = O.spmm(csr, acc)
+    assert rel_err(grad[:U], g['grad_user']) < RTOL and rel_err(grad[U:], g['grad_item']) < RTOL
+    m = np.zeros_like(E0); v = np.zeros_like(E0); E = E0.copy()
+    O.adam_step(E, grad, m, v, 0.005, 1)
+    assert rel_err(E[:U], g['user_k1']) < RTOL and rel_err(E[U:], g['item_k1']) < RTOL
