@@ -67,12 +67,13 @@ class CLeaR(AttackBase):
         super().__init__(arg, data)
         self.batchSize = 2048
 
-    def surrogate_loss(self, model, uiAdj2, topk, r0=None):
+    def surrogate_loss(self, model, uiAdj2, topk, r0=None, warm=None):
         """One evaluation of lossall = CWloss + sfaloss (CLeaR.py:74-126); returns (lossall, Pu, Pi, cw, sfa).
         `uiAdj2`: the poisoned U' x I interactions (scipy) or their device_mask()."""
         Pu, Pi = model()
         with torch.no_grad():
-            top_idx, _ = masked_topk(Pu.detach(), Pi.detach(), uiAdj2, min(topk, self.itemNum))
+            top_idx, _ = masked_topk(Pu.detach(), Pi.detach(), uiAdj2, min(topk, self.itemNum), warm=warm)
+            self.last_top_idx = top_idx                                    # next step's warm start (same users, same mask)
         if r0 is None:
             r0 = torch.randn(Pu.size(1))                                   # CLeaR.py:100-103: CPU generator, then moved
         cw, sfa = _CwSfaLoss.apply(Pu, Pi, top_idx, self.userNum, self.targetItem, r0)
@@ -92,8 +93,10 @@ class CLeaR(AttackBase):
             optimizer_attack = torch.optim.Adam(tmpRecommender.model.parameters(), lr=recommender.args.lRate)
             Pu = Pi = None
             mask = device_mask(uiAdj2)          # the poisoned pattern is fixed while the surrogate is trained
+            warm = None
             for _ in range(self.outerEpoch):
-                lossall, Pu, Pi, _, _ = self.surrogate_loss(tmpRecommender.model, mask, topk)
+                lossall, Pu, Pi, _, _ = self.surrogate_loss(tmpRecommender.model, mask, topk, warm=warm)
+                warm = self.last_top_idx
                 optimizer_attack.zero_grad()
                 lossall.backward()
                 optimizer_attack.step()

@@ -29,11 +29,14 @@ def device_mask(ui_mat, device=DEVICE):
     return rp, mc
 
 
-def masked_topk(Pu, Pi, mask, k):
+def masked_topk(Pu, Pi, mask, k, warm=None):
     """top-k of Pu @ Pi.T with interacted entries set to -10e8 (DLAttack.py:73-83 / CLeaR.py:75-82), streamed.
-    `mask` is a device_mask() pair or anything scipy can turn into a U x I sparse matrix."""
+    `mask` is a device_mask() pair or anything scipy can turn into a U x I sparse matrix; `warm` = the previous step's lists
+    for the same users and mask (the surrogate moved a little since): result-neutral, about a third faster."""
     rp, mc = mask if isinstance(mask, tuple) else device_mask(mask, Pu.device)
-    return ops.score_mask_topk(Pu.contiguous(), Pi.contiguous(), k, rp, mc)
+    if warm is not None and tuple(warm.shape) != (Pu.shape[0], k):
+        warm = None
+    return ops.score_mask_topk(Pu.contiguous(), Pi.contiguous(), k, rp, mc, warm_idx=warm)
 
 
 class DLAttack(AttackBase):
@@ -59,10 +62,11 @@ class DLAttack(AttackBase):
             tmpRecommender.train(Epoch=self.innerEpoch, optimizer=optimizer, evalNum=5)
             optimizer_attack = torch.optim.Adam(tmpRecommender.model.parameters(), lr=recommender.args.lRate)
             mask = device_mask(uiAdj2)
+            top_idx = None
             for _ in range(self.outerEpoch):
                 with torch.no_grad():
                     Pu, Pi = tmpRecommender.model()
-                    top_idx, _ = masked_topk(Pu, Pi, mask, min(topk, self.itemNum))
+                    top_idx, _ = masked_topk(Pu, Pi, mask, min(topk, self.itemNum), warm=top_idx)
                     users, pos, neg = cw_pairs(top_idx, self.userNum, self.targetItem, pop=False)
                     # CW term of DLAttack.py:92-101: computed on detached tensors there, i.e. a logged constant
                     self.last_cw_loss = float(((Pu[users] * Pi[neg]).sum(1) - (Pu[users] * Pi[pos]).sum(1)).mean())

