@@ -235,8 +235,10 @@ def test_sddmm_rows_dense_and_pga_update(ops):
     assert got.min() >= 9.9e-8 and np.all(got[1, :40] == np.float32(10e-8))
 
 
-@pytest.mark.parametrize('U,I,d,k,masked', [(100, 1412, 64, 50, True), (37, 300, 16, 5, False), (70, 5000, 32, 128, True), (17, 60, 64, 50, True)])
-def test_score_mask_topk(ops, U, I, d, k, masked):
+@pytest.mark.parametrize('exact', [False, True])
+@pytest.mark.parametrize('U,I,d,k,masked', [(100, 1412, 64, 50, True), (37, 300, 16, 5, False), (70, 5000, 32, 128, True), (17, 60, 64, 50, True),
+                                            (300, 2000, 128, 64, True), (130, 700, 64, 64, False), (129, 65, 64, 1, True), (5, 4000, 48, 20, False)])
+def test_score_mask_topk(ops, U, I, d, k, masked, exact):
     rng = np.random.default_rng(U + I)
     Pu = rng.standard_normal((U, d)).astype(np.float32); Pi = rng.standard_normal((I, d)).astype(np.float32)
     mask = None
@@ -249,10 +251,10 @@ def test_score_mask_topk(ops, U, I, d, k, masked):
         mask = (rp, np.concatenate(cols).astype(np.int32) if rp[-1] else np.zeros(0, np.int32))
     ridx, rval = O.score_mask_topk(Pu, Pi, k, mask)
     if mask is None:
-        idx, val = ops.score_mask_topk(T(Pu), T(Pi), k)
+        idx, val = ops.score_mask_topk(T(Pu), T(Pi), k, exact=exact)
     else:
         mc = mask[1] if len(mask[1]) else np.zeros(1, np.int32)
-        idx, val = ops.score_mask_topk(T(Pu), T(Pi), k, T(mask[0].astype(np.int32)), T(mc))
+        idx, val = ops.score_mask_topk(T(Pu), T(Pi), k, T(mask[0].astype(np.int32)), T(mc), exact=exact)
     idx, val = idx.cpu().numpy(), val.cpu().numpy()
     assert rel_err(val, rval) < RTOL
     # indices: identical except where two scores tie within fp32 rounding of the different summation orders
