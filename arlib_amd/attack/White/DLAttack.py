@@ -14,7 +14,7 @@ import scipy.sparse as sp
 import torch
 
 from ... import ops
-from ...util.sampler import next_batch_pairwise
+from ...util.sampler import next_batch_pairwise, device_epoch
 from .._common import AttackBase, DEVICE, symmetric_adjacency, rebuild_interaction_matrix, reinit_with_tables, cw_pairs, with_fake_rows, append_rows
 
 
@@ -70,7 +70,7 @@ class DLAttack(AttackBase):
                     users, pos, neg = cw_pairs(top_idx, self.userNum, self.targetItem, pop=False)
                     # CW term of DLAttack.py:92-101: computed on detached tensors there, i.e. a logged constant
                     self.last_cw_loss = float(((Pu[users] * Pi[neg]).sum(1) - (Pu[users] * Pi[pos]).sum(1)).mean())
-                tmpRecommender.train_batches(next_batch_pairwise(self.data, tmpRecommender.args.batch_size), optimizer_attack)
+                tmpRecommender.train_batches(device_epoch(self.data, tmpRecommender.args.batch_size, DEVICE, tmpRecommender.data.user_num, self.itemNum), optimizer_attack)
             with torch.no_grad():
                 Pu, Pi = tmpRecommender.model()
                 r = (Pu[user, :] @ Pi.T) * p

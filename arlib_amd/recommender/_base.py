@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..engine import PropagationEngine
-from ..util.sampler import next_batch_pairwise
+from ..util.sampler import next_batch_pairwise, device_epoch
 from ..util.loss import bpr_l2_loss, InfoNCE
 from ..util.metrics import ranking_evaluation, ranking_evaluation_topk
 
@@ -291,15 +291,15 @@ class Recommender:
             self._bind_optimizer_state(eng, optimizer, fused_kind)
         U, I = self.data.user_num, self.data.item_num
         for epoch in range(maxEpoch):
-            for n, batch in enumerate(next_batch_pairwise(self.data, self.args.batch_size)):
-                user_idx, pos_idx, neg_idx = batch
-                if inert:
-                    continue
-                if int(user_idx.max()) >= U or int(max(pos_idx.max(), neg_idx.max())) >= I:
-                    raise IndexError('sampler produced an index outside the embedding tables')
-                u = torch.from_numpy(user_idx).to(DEVICE, non_blocking=True)
-                p = torch.from_numpy(pos_idx).to(DEVICE, non_blocking=True)
-                ng = torch.from_numpy(neg_idx).to(DEVICE, non_blocking=True)
+            # nothing in this loop draws from Python's `random`: the epoch's negatives are sampled in one native call, checked and
+            # uploaded once; the batches are views of that device image
+            if inert:
+                for _ in next_batch_pairwise(self.data, self.args.batch_size, whole_epoch=True):
+                    pass
+                batches = ()
+            else:
+                batches = device_epoch(self.data, self.args.batch_size, DEVICE, U, I)
+            for n, (u, p, ng) in enumerate(batches):
                 if eng is not None:
                     lo = self._fused_step(eng, u, p, ng)
                     if n % self.print_every == 0:
@@ -345,9 +345,12 @@ class Recommender:
             self._bind_optimizer_state(eng, optimizer, kind)
         last = None
         for user_idx, pos_idx, neg_idx in batches:
-            if int(user_idx.max()) >= U or int(max(pos_idx.max(), neg_idx.max())) >= I:
-                raise IndexError('batch index outside the embedding tables')
-            u, p, ng = (torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32)).to(DEVICE) for x in (user_idx, pos_idx, neg_idx))
+            if isinstance(user_idx, torch.Tensor):            # device_epoch(): already range-checked and resident
+                u, p, ng = user_idx, pos_idx, neg_idx
+            else:
+                if int(user_idx.max()) >= U or int(max(pos_idx.max(), neg_idx.max())) >= I:
+                    raise IndexError('batch index outside the embedding tables')
+                u, p, ng = (torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32)).to(DEVICE) for x in (user_idx, pos_idx, neg_idx))
             if eng is not None:
                 last = eng.step(u, p, ng)
                 continue

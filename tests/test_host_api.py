@@ -191,3 +191,18 @@ def test_append_while_a_permutation_is_pending(ml100k):
     assert data._raw_training_data()[1] is not None                          # the image was extended without touching the list
     rows = data.training_data
     assert [data.user[r[0]] for r in rows] == u.tolist() and [data.item[r[1]] for r in rows] == i.tolist()
+
+
+def test_whole_epoch_sampling_is_the_same_stream(ml100k):
+    """whole_epoch=True (one native call per epoch, used by the training loops) yields the reference's batches and leaves
+    Python's RNG where the per-batch form leaves it."""
+    from arlib_amd.util.sampler import next_batch_pairwise
+    g = golden('g1_sampler.npz')
+    data = make_data()
+    random.seed(2018)
+    for ep in range(2):
+        bs = list(next_batch_pairwise(data, 2048, whole_epoch=True))
+        assert [len(bs), len(bs[-1][0])] == list(g['ep%d_nb' % ep])
+        for k, key in enumerate(('u', 'p', 'n')):
+            assert np.array_equal(np.concatenate([b[k] for b in bs]), g['ep%d_%s' % (ep, key)])
+    assert random.random() == float(g['next_random'][0])
