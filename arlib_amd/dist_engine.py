@@ -370,6 +370,16 @@ class ShardedPropagationEngine:
         k.adam_dense(self.E0, grad, self.m, self.v, self.lr, self.t, self.betas, self.eps)
         return self.loss_out, cl_loss
 
+    def score_topk(self, table, k, mask_rowptr=None, mask_col=None, warm_idx=None):
+        """Masked top-k item lists of THIS rank's users from a propagated local table [Ul + I, d] (forward() / the SimGCL views):
+        the scoring pass of the attack loops and of the evaluation is embarrassingly parallel over the user shards -- local user
+        rows against the replicated item rows, no exchange.  mask_*: CSR over the local users."""
+        Ul = self.Ul
+        if Ul == 0:
+            return (torch.zeros(0, k, dtype=torch.int32, device=self.device), torch.zeros(0, k, dtype=torch.float32, device=self.device))
+        kw = {} if warm_idx is None else {'warm_idx': warm_idx}
+        return self.k.score_mask_topk(table[:Ul].contiguous(), table[Ul:].contiguous(), k, mask_rowptr, mask_col, **kw)
+
     def gather_full_table(self):
         """[U+I, d] table assembled on every rank (tests / checkpoints): all-gather of the user blocks + the replica."""
         full = torch.zeros(self.U + self.I, self.d, dtype=torch.float32, device=self.device)

@@ -48,6 +48,14 @@ def test_virtual_ranks_partial_item_sums_add_up(world):
     assert rel_err(item_sum, full[U:]) < 1e-6                             # item rows = sum of per-rank partials
 
 
+def sp_mask(pairs, U, I, u0, u1):
+    """interacted-item CSR over users [u0, u1) (pairs are user-major sorted)"""
+    sel = (pairs[:, 0] >= u0) & (pairs[:, 0] < u1)
+    rp = np.zeros(u1 - u0 + 1, np.int64)
+    np.cumsum(np.bincount(pairs[sel, 0] - u0, minlength=u1 - u0), out=rp[1:])
+    return rp, np.ascontiguousarray(pairs[sel, 1].astype(np.int32)) if sel.any() else np.zeros(1, np.int32)
+
+
 def _worker(rank, world, port, ret, sparse):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import torch.distributed as dist
@@ -63,8 +71,14 @@ def _worker(rank, world, port, ret, sparse):
         lo = (eng.step_sparse if sparse else eng.step)(torch.from_numpy(u), torch.from_numpy(p), torch.from_numpy(n))
         losses.append(float(lo[0] + lo[1]))
     full = eng.gather_full_table().numpy()
+    # sharded scoring: every rank ranks its own users against the replicated items; rank-ordered concatenation = global lists
+    out = eng.forward()
+    m = sp_mask(pairs, U, I, eng.u0, eng.u1)
+    idx, _ = eng.score_topk(out, 10, torch.from_numpy(m[0].astype(np.int32)), torch.from_numpy(m[1]))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, idx.numpy())
     if rank == 0:
-        ret['table'], ret['losses'] = full, losses
+        ret['table'], ret['losses'], ret['top10'] = full, losses, np.concatenate(gathered)
     dist.destroy_process_group()
 
 
@@ -78,6 +92,11 @@ def test_sharded_engine_gloo_matches_single_process_oracle(world, sparse):
     mp.spawn(_worker, args=(world, port, ret, sparse), nprocs=world, join=True)
     assert np.allclose(ret['losses'], ref_losses, rtol=RTOL, atol=0)
     assert rel_err(ret['table'], ref_table) < RTOL
+    # the sharded masked top-10 equals the single-process one on the trained table
+    rowptr, col, w = O.bipartite_csr(pairs[:, 0], pairs[:, 1], U, I)
+    out = O.lightgcn_forward((rowptr, col, O.norm_adj_values(rowptr, col, w)), ref_table, L)
+    ref_idx, _ = O.score_mask_topk(out[:U], out[U:], 10, sp_mask(pairs, U, I, 0, U))
+    assert (ret['top10'] == ref_idx).mean() > 0.995
 
 
 def simgcl_problem():
