@@ -224,19 +224,29 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_masked_gpr_kernel(CsrDev A, 
     const bool qact = (q * 4 < d);
     const float *xq = X + q * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int base = begin; __any(base < end); base += LPR) {
-        const int e = base + q;
-        int c = 0;
-        bool f = false;
-        if (e < end) { c = A.col[e]; f = (xbits[c >> 5] >> (c & 31)) & 1u; }      // 1 bit per node: the item half of the bitmap (12.5 KB at cfg2) stays in L1
-        const unsigned long long wm = __ballot(f);
-        unsigned mask = (unsigned)((wm >> (g * LPR)) & ((LPR == 64) ? ~0ull : ((1ull << LPR) - 1ull)));
-        while (mask) {
-            const int j = __ffs((int)mask) - 1;
-            mask &= mask - 1;
-            const int cj = __shfl(c, g * LPR + j);
-            const float vj = A.val[base + j];
-            if (qact) fma4(acc, vj, *reinterpret_cast<const float4 *>(xq + (size_t)cj * d));
+    // two LPR-edge windows per trip, their column loads and bit tests issued back to back: a 32-edge user row is one dependent
+    // load -> load -> ballot chain instead of two
+    for (int base = begin; __any(base < end); base += 2 * LPR) {
+        const int e0 = base + q, e1 = base + LPR + q;
+        int c0 = 0, c1 = 0;
+        if (e0 < end) c0 = A.col[e0];
+        if (e1 < end) c1 = A.col[e1];
+        bool f0 = false, f1 = false;
+        if (e0 < end) f0 = (xbits[c0 >> 5] >> (c0 & 31)) & 1u;                     // 1 bit per node: the bitmap (137 KB at cfg2) stays in L1/L2
+        if (e1 < end) f1 = (xbits[c1 >> 5] >> (c1 & 31)) & 1u;
+        const unsigned long long wm0 = __ballot(f0), wm1 = __ballot(f1);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const unsigned long long wm = half ? wm1 : wm0;
+            const int c = half ? c1 : c0;
+            unsigned mask = (unsigned)((wm >> (g * LPR)) & ((LPR == 64) ? ~0ull : ((1ull << LPR) - 1ull)));
+            while (mask) {
+                const int j = __ffs((int)mask) - 1;
+                mask &= mask - 1;
+                const int cj = __shfl(c, g * LPR + j);
+                const float vj = A.val[base + half * LPR + j];
+                if (qact) fma4(acc, vj, *reinterpret_cast<const float4 *>(xq + (size_t)cj * d));
+            }
         }
     }
     if (!qact) return;
