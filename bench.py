@@ -77,7 +77,7 @@ class SpmmEvents:
         return {k: (float(np.mean(v)), len(v)) for k, v in out.items()}
 
 
-def cpu_baseline(data, rowptr, col, val_np, E0, batches, args, target_s):
+def cpu_baseline(data, rowptr, col, val_np, E0, batches, args, target_s, gpu_replay=None):
     """Oracle ('port') timed on the host cores: same graph, same tables, same batches, OpenMP over rows."""
     from oracle import oracle as O
     O.build()
@@ -92,10 +92,18 @@ def cpu_baseline(data, rowptr, col, val_np, E0, batches, args, target_s):
         st.step(b[0], b[1], b[2])
         t_used += time.perf_counter() - t0
         done += 1
-    return {'value': args.batch * done / t_used, 'unit': 'interactions/s', 'cores': O.num_threads(), 'kind': 'port',
-            'sample': '%d full training steps of the same workload (same graph, tables and batches), %.1f s of CPU work, '
-                      'oracle/arl_oracle.c with OpenMP over rows' % (done, t_used),
-            'ms_per_step': 1e3 * t_used / done}
+    out = {'value': args.batch * done / t_used, 'unit': 'interactions/s', 'cores': O.num_threads(), 'kind': 'port',
+           'sample': '%d full training steps of the same workload (same graph, tables and batches), %.1f s of CPU work, '
+                     'oracle/arl_oracle.c with OpenMP over rows' % (done, t_used),
+           'ms_per_step': 1e3 * t_used / done}
+    if gpu_replay is not None:
+        # the same `done` steps from the same start on the GPU engine: the full-size parity figure (the suite's size-independent
+        # properties aside, this is the one place where product and oracle meet at cfg2)
+        table = gpu_replay(done)
+        ref = st.E0
+        out['parity_vs_gpu'] = {'steps': done, 'table_rel_err': float(np.linalg.norm(table - ref) / np.linalg.norm(ref)),
+                                'max_abs_err': float(np.abs(table - ref).max())}
+    return out
 
 
 def cpu_torch_baseline(torch, rowptr, col, val_np, E0, batches, U, args, n_steps):
@@ -417,7 +425,12 @@ def main():
         if not sharded and args.cpu_baseline:
             val_np = eng.A.val.cpu().numpy()
             batches = [(hb[k, 0].copy(), hb[k, 1].copy(), hb[k, 2].copy()) for k in range(min(n_batches, 8))]
-            res['cpu_baseline'] = cpu_baseline(data, rowptr, col, val_np, E0.numpy(), batches, args, args.cpu_seconds)
+            def gpu_replay(k_steps):
+                e2 = engine.PropagationEngine(eng.A, U, I, d, L, 1e-4, 0.005, dev, table=E0.to(dev))
+                for k in range(k_steps):
+                    e2.step(dev_batches[k, 0], dev_batches[k, 1], dev_batches[k, 2])
+                return e2.E0.cpu().numpy()
+            res['cpu_baseline'] = cpu_baseline(data, rowptr, col, val_np, E0.numpy(), batches, args, args.cpu_seconds, gpu_replay)
             if args.cpu_torch > 0:
                 res['cpu_baseline_torch'] = cpu_torch_baseline(torch, rowptr, col, val_np, E0, batches, U, args, min(args.cpu_torch + 1, len(batches)))
         print(json.dumps(res))
