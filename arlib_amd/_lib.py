@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ARLIB_AMD_LIB') or os.path.join(_HERE, 'lib', 'libarlib_amd.so')      # override: developer builds (e.g. `make prof`)
-ABI_VERSION = 8
+ABI_VERSION = 9
 _lib = None
 
 
@@ -34,6 +34,7 @@ _SIGS = {
     'arl_abi_version': (C.c_int, []),
     'arl_mt_seed': (C.c_int, [_vp, _vp, _i64]),
     'arl_sampler_shuffle': (C.c_int, [_vp, _vp, _i64]),
+    'arl_mt_sample_range': (C.c_int, [_vp, _i64, _i64, C.c_int32, _vp, _vp]),
     'arl_sampler_next_batch': (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp]),
     'arl_norm_adj_values_f32': (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     'arl_spmm_csr_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _f, _f, _vp, _vp, _vp]),

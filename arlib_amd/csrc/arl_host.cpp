@@ -85,7 +85,7 @@ inline bool user_has_item(const int64_t *rowptr, const int32_t *items, int64_t r
 
 extern "C" {
 
-int arl_abi_version(void) { return 8; }
+int arl_abi_version(void) { return 9; }
 
 int arl_mt_seed(uint32_t *mt_state, const uint32_t *key, int64_t key_len) {
     if (!mt_state || !key) return ARL_E_NULL;
@@ -108,6 +108,33 @@ int arl_sampler_shuffle(uint32_t *mt_state, int32_t *pairs, int64_t nnz) {
             const int64_t t = rows[i]; rows[i] = rows[j]; rows[j] = t;
         } else {
             for (int c = 0; c < 2; ++c) { const int32_t t = pairs[2 * i + c]; pairs[2 * i + c] = pairs[2 * j + c]; pairs[2 * j + c] = t; }
+        }
+    }
+    return ARL_OK;
+}
+
+int arl_mt_sample_range(uint32_t *mt_state, int64_t n, int64_t k, int32_t use_pool, int32_t *out, int32_t *scratch) {
+    // random.sample(range(n), k) of CPython 3.10 (Lib/random.py:sample): the pool form when the caller's set-size rule says so
+    // (scratch: n int32), rejection against the already selected values otherwise (scratch: (n + 31) / 32 words, zeroed here).
+    if (!mt_state || (!out && k > 0) || !scratch) return ARL_E_NULL;
+    if (n < 0 || k < 0 || k > n || n > 0x7FFFFFFFll) return ARL_E_ARG;
+    if (mt_state[624] > 624) return ARL_E_ARG;
+    PyMersenne rng(mt_state);
+    if (use_pool) {
+        for (int64_t i = 0; i < n; ++i) scratch[i] = (int32_t)i;
+        for (int64_t i = 0; i < k; ++i) {
+            const uint32_t j = rng.below((uint32_t)(n - i));
+            out[i] = scratch[j];
+            scratch[j] = scratch[n - i - 1];
+        }
+    } else {
+        uint32_t *seen = reinterpret_cast<uint32_t *>(scratch);
+        for (int64_t w = 0; w < (n + 31) / 32; ++w) seen[w] = 0u;
+        for (int64_t i = 0; i < k; ++i) {
+            uint32_t j = rng.below((uint32_t)n);
+            while ((seen[j >> 5] >> (j & 31)) & 1u) j = rng.below((uint32_t)n);
+            seen[j >> 5] |= 1u << (j & 31);
+            out[i] = (int32_t)j;
         }
     }
     return ARL_OK;

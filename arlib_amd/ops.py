@@ -157,6 +157,27 @@ def norm_adj_values(rowptr, col, w, n_rows):
     return val, dinv
 
 
+def bipartite_graph(u, i, n_users, n_items, device=None, weights=None):
+    """Normalised symmetric adjacency D^-1/2 [[0, R], [R^T, 0]] D^-1/2 as a CSRGraph, built on the device from the (user, item)
+    pairs of R sorted by (user, item) -- what DataLoader.convert_to_laplacian_mat does with scipy on the host
+    (util/DataLoader.py:57-87, isolated nodes get weight 0).  u, i: int64/int32 device tensors."""
+    dev = u.device if device is None else torch.device(device)
+    u = u.to(dev, torch.int64); i = i.to(dev, torch.int64)
+    nnz = u.numel()
+    U, I = int(n_users), int(n_items)
+    w = torch.ones(nnz, dtype=torch.float32, device=dev) if weights is None else weights.to(dev, torch.float32)
+    rp_u = torch.searchsorted(u, torch.arange(U + 1, device=dev, dtype=torch.int64))
+    it_sorted, order = torch.sort(i, stable=True)                            # users stay ascending inside an item row
+    rp_i = torch.searchsorted(it_sorted, torch.arange(I + 1, device=dev, dtype=torch.int64))
+    rowptr = torch.cat([rp_u, nnz + rp_i[1:]])
+    col = torch.cat([i + U, u[order]]).to(torch.int32)
+    ww = torch.cat([w, w[order]])
+    val, dinv = norm_adj_values(rowptr.to(torch.int32), col, ww, U + I)
+    g = CSRGraph(rowptr, col, val, dev, validate=False)
+    g.dinv = dinv
+    return g
+
+
 def _check_xy(A, X, name='X', rows=None):
     _dev(X, torch.float32, name, 2)
     want = A.n_rows if rows is None else rows

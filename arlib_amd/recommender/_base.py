@@ -259,6 +259,9 @@ class Recommender:
     def _extra_loss(self, model, user_idx, pos_idx):
         return None
 
+    def _on_epoch_start(self, model):
+        pass
+
     def _train_loop(self, Epoch, optimizer, evalNum, requires_embgrad=False, requires_adjgrad=False, gradIterationNum=10):
         self.bestPerformance = []
         model = self.model.cuda()
@@ -291,6 +294,7 @@ class Recommender:
             self._bind_optimizer_state(eng, optimizer, fused_kind)
         U, I = self.data.user_num, self.data.item_num
         for epoch in range(maxEpoch):
+            self._on_epoch_start(model)                              # e.g. SGL draws its two graph views here, BEFORE the sampler shuffles (also when inert: same RNG stream)
             # nothing in this loop draws from Python's `random`: the epoch's negatives are sampled in one native call, checked and
             # uploaded once; the batches are views of that device image
             if inert:

@@ -45,6 +45,25 @@ class MTState:
         random.setstate((st[0], tuple(int(x) for x in self.words), st[2]))
 
 
+def sample_range(n, k):
+    """random.sample(range(n), k) -- same values, same consumption of Python's global RNG -- as an int32 array, natively
+    (the reference's graph augmentations draw 90 % of all edges this way every epoch, recommender/SGL.py:281-299)."""
+    import math
+    n, k = int(n), int(k)
+    if not 0 <= k <= n:
+        raise ValueError('Sample larger than population or is negative')
+    setsize = 21
+    if k > 5:
+        setsize += 4 ** math.ceil(math.log(k * 3, 4))
+    use_pool = n <= setsize
+    out = np.empty(max(k, 1), np.int32)
+    scratch = np.empty(max(n if use_pool else (n + 31) // 32, 1), np.int32)
+    mt = MTState.from_python()
+    _lib.check(_lib.lib().arl_mt_sample_range(_vp(mt.words), n, k, int(use_pool), _vp(out), _vp(scratch)), 'arl_mt_sample_range')
+    mt.to_python()
+    return out[:k]
+
+
 def build_membership(pairs, n_users):
     """CSR image of training_set_u (util/DataLoader.py:41): sorted, de-duplicated item ids per user."""
     pairs = np.asarray(pairs)

@@ -47,6 +47,10 @@ int arl_abi_version(void);
 int arl_mt_seed(uint32_t *mt_state, const uint32_t *key, int64_t key_len);
 /* util/sampler.py:9   shuffle(training_data) in place; pairs = int32 [nnz][2] (user id, item id) */
 int arl_sampler_shuffle(uint32_t *mt_state, int32_t *pairs, int64_t nnz);
+/* random.sample(range(n), k) of CPython 3.10 on the caller's MT19937 state -- what the graph augmentations of the
+ * contrastive encoders draw (recommender/SGL.py:281-299: edge / node dropout).  use_pool: the caller evaluates CPython's
+ * set-size rule (n <= 21 + (k > 5 ? 4 ** ceil(log(3k, 4)) : 0)).  scratch: n int32 (pool form) or (n+31)/32 int32. */
+int arl_mt_sample_range(uint32_t *mt_state, int64_t n, int64_t k, int32_t use_pool, int32_t *out, int32_t *scratch);
 /* util/sampler.py:12-29  one batch: positives pairs[begin..begin+count), one negative per positive drawn
  * by choice(item_list) with rejection against training_set_u[user] (given as a CSR with sorted item
  * ids; users >= memb_rows have an empty set, which is what the reference's defaultdict gives users

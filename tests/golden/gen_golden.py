@@ -620,6 +620,56 @@ def gen_xsimgcl(data):
     save('g11_xsimgcl.npz', **o)
 
 
+# --------------------------------------------------------------------------- G12: SGL (edge-dropout views)
+def gen_sgl(data):
+    """Reference SGL (recommender/SGL.py): the two edge-dropped graphs of an epoch (Python `random.sample` over the edges) and one
+    training iteration on them (clean forward for BPR, InfoNCE between the two views' concatenated user/item rows, temp 0.2)."""
+    from recommender.SGL import SGL
+    args = rec_args(emb_size=16, n_layers=2, model_name='SGL')
+    seedSet(2018)
+    rec = SGL(args, data)
+    model = rec.model
+    U, I = data.user_num, data.item_num
+    o = {'user0': model.embedding_dict['user_emb'].detach().numpy().copy(),
+         'item0': model.embedding_dict['item_emb'].detach().numpy().copy(),
+         'hyper': np.array([rec.n_layers, rec.cl_rate, rec.drop_rate, rec.temp, rec.aug_type], np.float64)}
+    random.seed(2018)
+    adj1 = model.graph_reconstruction()
+    adj2 = model.graph_reconstruction()
+    o['next_random'] = np.array([random.random()], np.float64)
+    for tag, adj in (('1', adj1), ('2', adj2)):
+        a = adj.coalesce()
+        r, c, v = a.indices()[0].numpy(), a.indices()[1].numpy(), a.values().numpy()
+        sel = r < U
+        order = np.lexsort((c[sel], r[sel]))
+        o['keep' + tag] = (r[sel][order].astype(np.int64) * I + (c[sel][order] - U)).astype(np.int32)      # kept (user, item) pairs, sorted
+        o['val' + tag] = v[sel][order].astype(np.float32)                                                   # their normalised weights
+    random.seed(2018)
+    d2 = copy.copy(data); d2.training_data = [list(r) for r in data_training0]
+    user_idx, pos_idx, neg_idx = next(iter(ref_sampler.next_batch_pairwise(d2, 2048)))
+    optim = torch.optim.Adam(model.parameters(), lr=args.lRate)
+    rec_user_emb, rec_item_emb = model()
+    o['fwd_user'] = rec_user_emb.detach().numpy().copy(); o['fwd_item'] = rec_item_emb.detach().numpy().copy()
+    user_emb, pos_item_emb, neg_item_emb = rec_user_emb[user_idx], rec_item_emb[pos_idx], rec_item_emb[neg_idx]
+    rec_loss = ref_loss.bpr_loss(user_emb, pos_item_emb, neg_item_emb)
+    cl_loss = rec.cl_rate * model.cal_cl_loss([user_idx, pos_idx], adj1, adj2)
+    batch_loss = rec_loss + ref_loss.l2_reg_loss(args.reg, user_emb, pos_item_emb) + cl_loss
+    optim.zero_grad()
+    batch_loss.backward()
+    o['grad_user'] = model.embedding_dict['user_emb'].grad.numpy().copy()
+    o['grad_item'] = model.embedding_dict['item_emb'].grad.numpy().copy()
+    optim.step()
+    o['rec_loss'] = np.array([rec_loss.item()], np.float32)
+    o['cl_loss'] = np.array([cl_loss.item()], np.float32)
+    o['user_k1'] = model.embedding_dict['user_emb'].detach().numpy().copy()
+    o['item_k1'] = model.embedding_dict['item_emb'].detach().numpy().copy()
+    o['batch_u'] = np.asarray(user_idx, np.int32); o['batch_p'] = np.asarray(pos_idx, np.int32); o['batch_n'] = np.asarray(neg_idx, np.int32)
+    with torch.no_grad():
+        v1u, v1i = model(adj1)
+    o['view1_user'] = v1u.numpy().copy(); o['view1_item'] = v1i.numpy().copy()      # (after the step: tables user_k1/item_k1)
+    save('g12_sgl.npz', **o)
+
+
 if __name__ == '__main__':
     only = set(sys.argv[1:])                          # e.g. `gen_golden.py xsimgcl` regenerates that fixture alone
     if only:
@@ -627,6 +677,8 @@ if __name__ == '__main__':
         data_training0 = [list(r) for r in data.training_data]
         if 'xsimgcl' in only:
             gen_xsimgcl(data)
+        if 'sgl' in only:
+            gen_sgl(data)
         sys.exit(0)
     gen_dataset()
     data = gen_sampler()
@@ -642,4 +694,5 @@ if __name__ == '__main__':
     gen_attacks()
     gen_ngcf()
     gen_xsimgcl(data)
+    gen_sgl(data)
     print('done; scratch dir', SCRATCH)

@@ -211,3 +211,51 @@ def test_xsimgcl_step_with_injected_noise_matches_reference():
         rec.train(Epoch=1, evalNum=1)
     assert rec.model._eng is not None and rec.model._eng.t >= 22               # the fused step ran
     assert np.isfinite(rec.user_emb.cpu().numpy()).all()
+
+
+def test_sgl_views_and_step_match_reference():
+    """SGL: the epoch's two edge-dropped views are the reference's (same kept edges -- Python's RNG stream is
+    consumed natively --, same normalised weights), and one iteration on them matches its losses, gradients and Adam update."""
+    from arlib_amd.recommender.SGL import SGL
+    from arlib_amd.util.loss import bpr_loss, l2_reg_loss
+    g = golden('g12_sgl.npz')
+    data = make_data()
+    rec = SGL(rec_args(emb_size=16, n_layers=2, model_name='SGL'), data)
+    model = rec.model.cuda()
+    U, I = data.user_num, data.item_num
+    with torch.no_grad():
+        model.embedding_dict['user_emb'][:] = torch.from_numpy(g['user0']).cuda()
+        model.embedding_dict['item_emb'][:] = torch.from_numpy(g['item0']).cuda()
+    random.seed(2018)
+    adj1 = model.graph_reconstruction()
+    adj2 = model.graph_reconstruction()
+    assert random.random() == float(g['next_random'][0])
+    for adj, tag in ((adj1, '1'), (adj2, '2')):
+        rp = adj.rowptr.cpu().numpy().astype(np.int64)
+        n_user_edges = int(rp[U])
+        rows = np.repeat(np.arange(U), np.diff(rp[:U + 1]))
+        keep = rows * I + (adj.col[:n_user_edges].cpu().numpy().astype(np.int64) - U)
+        assert np.array_equal(keep.astype(np.int32), g['keep' + tag])
+        assert rel_err(adj.val[:n_user_edges].cpu().numpy(), g['val' + tag]) < 1e-6
+        assert adj.nnz == 2 * len(g['keep' + tag])
+    u, p, n = (torch.from_numpy(g[x].astype(np.int64)).cuda() for x in ('batch_u', 'batch_p', 'batch_n'))
+    opt = torch.optim.Adam(model.parameters(), lr=0.005)
+    ue, ie = model()
+    assert rel_err(ue.detach().cpu().numpy(), g['fwd_user']) < RTOL and rel_err(ie.detach().cpu().numpy(), g['fwd_item']) < RTOL
+    rec_loss = bpr_loss(ue[u], ie[p], ie[n])
+    cl_loss = rec.cl_rate * model.cal_cl_loss([u, p], adj1, adj2)
+    loss = rec_loss + l2_reg_loss(1e-4, ue[u], ie[p]) + cl_loss
+    opt.zero_grad(); loss.backward()
+    assert abs(rec_loss.item() - g['rec_loss'][0]) <= RTOL * abs(g['rec_loss'][0])
+    assert abs(cl_loss.item() - g['cl_loss'][0]) <= RTOL * abs(g['cl_loss'][0])
+    assert rel_err(model.embedding_dict['user_emb'].grad.cpu().numpy(), g['grad_user']) < RTOL
+    assert rel_err(model.embedding_dict['item_emb'].grad.cpu().numpy(), g['grad_item']) < RTOL
+    opt.step()
+    assert rel_err(model.embedding_dict['user_emb'].detach().cpu().numpy(), g['user_k1']) < RTOL
+    assert rel_err(model.embedding_dict['item_emb'].detach().cpu().numpy(), g['item_k1']) < RTOL
+    with torch.no_grad():
+        v1u, v1i = model(adj1)
+    assert rel_err(v1u.cpu().numpy(), g['view1_user']) < RTOL and rel_err(v1i.cpu().numpy(), g['view1_item']) < RTOL
+    with contextlib.redirect_stdout(io.StringIO()):
+        rec.train(Epoch=1, evalNum=1)
+    assert np.isfinite(rec.user_emb.cpu().numpy()).all()

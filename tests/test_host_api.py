@@ -206,3 +206,14 @@ def test_whole_epoch_sampling_is_the_same_stream(ml100k):
         for k, key in enumerate(('u', 'p', 'n')):
             assert np.array_equal(np.concatenate([b[k] for b in bs]), g['ep%d_%s' % (ep, key)])
     assert random.random() == float(g['next_random'][0])
+
+
+@pytest.mark.parametrize('n,k', [(44212, 39790), (943, 94), (100000, 17), (30, 5), (10, 10), (5, 0)])
+def test_native_sample_range_is_pythons(n, k):
+    """random.sample(range(n), k) natively: both of CPython's algorithms (pool / rejection), same values, same RNG consumption."""
+    from arlib_amd.util.sampler import sample_range
+    random.seed(11); want = random.sample(range(n), k); after = random.random()
+    random.seed(11); got = sample_range(n, k)
+    assert got.tolist() == want and random.random() == after
+    with pytest.raises(ValueError):
+        sample_range(3, 4)

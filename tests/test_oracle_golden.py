@@ -238,3 +238,53 @@ def test_xsimgcl_forward_and_step(ml100k):
     m = np.zeros_like(E0); v = np.zeros_like(E0); E = E0.copy()
     O.adam_step(E, grad, m, v, 0.005, 1)
     assert rel_err(E[:U], g['user_k1']) < RTOL and rel_err(E[U:], g['item_k1']) < RTOL
+
+
+def _sgl_views(ml100k, seed=2018, drop=0.1):
+    """The two edge-dropped graphs of one SGL epoch, restated (recommender/SGL.py:211-229,288-299): the edges in CSR order of the
+    interaction matrix, `random.sample(range(E), int(E * (1 - drop)))` kept, bipartite Laplacian with the isolated-node guard."""
+    import random
+    p = ml100k['pairs0']
+    U, I = ml100k['U'], ml100k['I']
+    lin = np.unique(p[:, 0].astype(np.int64) * I + p[:, 1])                 # sp_adj.nonzero(): row-major, sorted columns
+    random.seed(seed)
+    views = []
+    for _ in range(2):
+        keep = np.sort(lin[np.asarray(random.sample(range(len(lin)), int(len(lin) * (1 - drop))))])
+        rowptr, col, w = O.bipartite_csr(keep // I, keep % I, U, I)
+        views.append((keep, (rowptr, col, O.norm_adj_values(rowptr, col, w))))
+    return views, random.random()
+
+
+def test_sgl_views_and_step(ml100k):
+    g = golden('g12_sgl.npz')
+    U, I = ml100k['U'], ml100k['I']
+    L, cl_rate, drop, temp = int(g['hyper'][0]), float(g['hyper'][1]), float(g['hyper'][2]), float(g['hyper'][3])
+    views, nxt = _sgl_views(ml100k, 2018, drop)
+    assert nxt == float(g['next_random'][0])
+    for (keep, csr_k), tag in zip(views, ('1', '2')):
+        assert np.array_equal(keep.astype(np.int32), g['keep' + tag])
+        rows = np.repeat(np.arange(U + I), np.diff(csr_k[0]))
+        sel = rows < U
+        assert rel_err(csr_k[2][sel], g['val' + tag]) < 1e-6                 # normalised weights of the user rows (CSR order)
+    csr = _ml100k_csr(ml100k)
+    E0 = np.concatenate([g['user0'], g['item0']])
+    out = O.lightgcn_forward(csr, E0, L)
+    assert rel_err(out[:U], g['fwd_user']) < RTOL and rel_err(out[U:], g['fwd_item']) < RTOL
+    bu, bp, bn = g['batch_u'], g['batch_p'], g['batch_n']
+    lb, lr_, G = O.bpr_l2(out, U, bu, bp, bn, 1e-4)
+    assert abs(lb - g['rec_loss'][0]) <= RTOL * abs(g['rec_loss'][0])
+    v1 = O.lightgcn_forward(views[0][1], E0, L)
+    v2 = O.lightgcn_forward(views[1][1], E0, L)
+    idx = np.concatenate([np.unique(bu), np.unique(bp) + U])                 # ONE InfoNCE over the concatenated user and item rows
+    l, d1, d2 = O.infonce(v1[idx], v2[idx], temp)
+    assert abs(cl_rate * l - g['cl_loss'][0]) <= RTOL * abs(g['cl_loss'][0])
+    G1 = np.zeros_like(E0); G2 = np.zeros_like(E0)
+    G1[idx] = cl_rate * d1; G2[idx] = cl_rate * d2
+    grad = O.lightgcn_backward(csr, G, L) + O.lightgcn_backward(views[0][1], G1, L) + O.lightgcn_backward(views[1][1], G2, L)
+    assert rel_err(grad[:U], g['grad_user']) < RTOL and rel_err(grad[U:], g['grad_item']) < RTOL
+    m = np.zeros_like(E0); v = np.zeros_like(E0); E = E0.copy()
+    O.adam_step(E, grad, m, v, 0.005, 1)
+    assert rel_err(E[:U], g['user_k1']) < RTOL and rel_err(E[U:], g['item_k1']) < RTOL
+    w1 = O.lightgcn_forward(views[0][1], np.concatenate([g['user_k1'], g['item_k1']]), L)
+    assert rel_err(w1[:U], g['view1_user']) < RTOL and rel_err(w1[U:], g['view1_item']) < RTOL
