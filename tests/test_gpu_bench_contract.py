@@ -1,0 +1,36 @@
+"""bench.py's output contract on a small instance: one JSON line with the driver's fields, the roofline and cpu_baseline objects,
+and the attack legs.  Keeps the contract from regressing while the benchmark itself runs at cfg2 size."""
+import json
+import os
+import subprocess
+import sys
+import pytest
+import torch
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_json_contract_small_instance():
+    if not torch.cuda.is_available():
+        pytest.fail('GPU tests need a GPU')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--users', '30000', '--items', '3000', '--steps', '3', '--warmup', '1',
+           '--attack-steps', '2', '--fake-users', '8', '--cpu-seconds', '0.5']
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    for key, typ in (('metric', str), ('value', float), ('unit', str), ('n_gpus', int), ('steps', int), ('warmup', int), ('ms_per_step', float),
+                     ('higher_is_better', bool), ('scaling', str), ('dtype', str), ('data', str), ('config', dict)):
+        assert isinstance(r[key], typ), key
+    assert r['n_gpus'] == 1 and r['steps'] == 3 and r['warmup'] == 1 and r['vs_baseline'] is None and 'workload' in r['config']
+    roof = r['roofline']
+    assert roof['bound'] == 'hbm' and roof['unit'] == 'GB/s' and roof['peak'] == 8000.0
+    assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-9 and 'traffic' in roof
+    cb = r['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and 'sample' in cb
+    assert cb['parity_vs_gpu']['table_rel_err'] < 1e-4                      # product vs oracle on the same steps
+    assert r['attack']['value'] > 0 and r['attack']['cpu_baseline']['value'] > 0
+    assert abs(r['attack']['cw_loss'] - r['attack']['cpu_baseline']['cw_loss']) <= 1e-4 * abs(r['attack']['cpu_baseline']['cw_loss'])
+    assert r['attack_clear']['value'] > 0 and r['attack_dlattack_inner']['value'] > 0
