@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(kBlock) void split_bf16x3_kernel(const float *__res
     o[0] = h; o[d] = m; o[2 * d] = l;
 }
 
-template <int D, bool SPLIT>
+template <int D, bool SPLIT, bool WARM>
 __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const float *__restrict__ Pu, const void *__restrict__ Pi_image, int U, int I,
                                                                             const int32_t *__restrict__ mrp, const int32_t *__restrict__ mcol, int k,
                                                                             int32_t *__restrict__ top_idx, float *__restrict__ top_val,
@@ -1173,7 +1173,7 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
     // record-setters of a cold stream shrink to about k.  (A candidate that has become masked breaks the guarantee: rows that end
     // with fewer than k keys raise `underflow` and the caller repeats the call cold.)
     float thr0v = -INFINITY;                                       // lane r: starting threshold of user row r
-    if (warm_idx) {
+    if constexpr (WARM) {
         for (int r = 0; r < 16; ++r) {
             const int u = u_base + r;
             if (u >= U) break;
@@ -1196,7 +1196,7 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
     float thrf[4];                                                 // exact running k-th best score of user rows 4g + reg (pre-filter)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-        const float t0 = __shfl(thr0v, 4 * g + reg);
+        const float t0 = WARM ? __shfl(thr0v, 4 * g + reg) : -INFINITY;
         thrf[reg] = (u_base + 4 * g + reg < U) ? t0 : INFINITY;    // users past U never insert
     }
     // The running top-k of each of the wave's 16 users is a SORTED list held in registers: lane j of tk[r] is the j-th largest key
@@ -1238,8 +1238,9 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
         }
         const unsigned th = (unsigned)__builtin_amdgcn_readlane((int)nh, k - 1);
         const unsigned tl = (unsigned)__builtin_amdgcn_readlane((int)nl, k - 1);
+        if constexpr (!WARM) return (th | tl) ? cand_score((unsigned long long)th << 32) : -INFINITY;
         const float t0 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(thr0v), row));
-        return (th | tl) ? fmaxf(cand_score((unsigned long long)th << 32), t0) : t0;     // t0: the warm-start bound (-inf when cold)
+        return (th | tl) ? fmaxf(cand_score((unsigned long long)th << 32), t0) : t0;     // t0: the warm-start bound
     };
     // Pre-filter + inserts for the scores of one stage (16*SPP items x 16 users per phase: NSC scores per lane,
     // bit b = 4*s2 + reg  <->  item item0 + 16*s2 + c, user row 4g + reg).
@@ -1393,7 +1394,7 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
             const unsigned long long key = ((unsigned long long)tk_hi[r] << 32) | tk_lo[r];
             top_idx[(size_t)u * k + lane] = cand_item(key);
             top_val[(size_t)u * k + lane] = cand_score(key);
-            if (warm_idx && lane == k - 1 && key == 0ull) atomicOr(underflow, 1);      // the warm threshold excluded too much
+            if (WARM && lane == k - 1 && key == 0ull) atomicOr(underflow, 1);          // the warm threshold excluded too much
         }
     }
 #ifdef ARL_TOPK_PROF
@@ -1864,17 +1865,19 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
             ARL_LAUNCH_CHECK();
             image = workspace;
         }
-#define ARL_TOPK_CASE(DV, SP)                                                                                                          \
+#define ARL_TOPK_CASE2(DV, SP, WM)                                                                                                     \
         do {                                                                                                                           \
-            hipError_t em = hipFuncSetAttribute((const void *)score_mask_topk_mfma16_kernel<DV, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m); \
+            hipError_t em = hipFuncSetAttribute((const void *)score_mask_topk_mfma16_kernel<DV, SP, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m); \
             if (em != hipSuccess) return (int)em;                                                                                      \
-            hipLaunchKernelGGL((score_mask_topk_mfma16_kernel<DV, SP>), dim3(grid_m), dim3(kM16Block), shm_m, (hipStream_t)stream, Pu, image, (int)U, (int)I, \
+            hipLaunchKernelGGL((score_mask_topk_mfma16_kernel<DV, SP, WM>), dim3(grid_m), dim3(kM16Block), shm_m, (hipStream_t)stream, Pu, image, (int)U, (int)I, \
                                mask_rowptr, mask_col, (int)k, top_idx, top_val, Pi, warm_idx, underflow);                              \
         } while (0)
+#define ARL_TOPK_CASE(DV, SP) do { if (warm_idx) ARL_TOPK_CASE2(DV, SP, true); else ARL_TOPK_CASE2(DV, SP, false); } while (0)
         if (d == 16) ARL_TOPK_CASE(16, false);
         else if (d == 32) ARL_TOPK_CASE(32, false);
         else if (d == 64) { if (split) ARL_TOPK_CASE(64, true); else ARL_TOPK_CASE(64, false); }
         else { if (split) ARL_TOPK_CASE(128, true); else ARL_TOPK_CASE(128, false); }
+#undef ARL_TOPK_CASE2
 #undef ARL_TOPK_CASE
         ARL_LAUNCH_CHECK();
         return ARL_OK;
