@@ -239,10 +239,10 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_masked_gpr_kernel(CsrDev A, 
         for (int half = 0; half < 2; ++half) {
             const unsigned long long wm = half ? wm1 : wm0;
             const int c = half ? c1 : c0;
-            unsigned mask = (unsigned)((wm >> (g * LPR)) & ((LPR == 64) ? ~0ull : ((1ull << LPR) - 1ull)));
+            unsigned long long mask = (wm >> (g * LPR)) & ((LPR == 64) ? ~0ull : ((1ull << (LPR & 63)) - 1ull));      // 64 bits: LPR = 64 at d = 256
             while (mask) {
-                const int j = __ffs((int)mask) - 1;
-                mask &= mask - 1;
+                const int j = __ffsll((long long)mask) - 1;
+                mask &= mask - 1ull;
                 const int cj = __shfl(c, g * LPR + j);
                 const float vj = A.val[base + half * LPR + j];
                 if (qact) fma4(acc, vj, *reinterpret_cast<const float4 *>(xq + (size_t)cj * d));

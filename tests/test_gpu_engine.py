@@ -160,10 +160,11 @@ def test_sparse_step_equals_dense_step(mods):
         assert float(ea.G.abs().max()) == 0.0 and int(ea.flags.max()) == 0 and int(ea.bits.abs().max()) == 0       # sparse state is cleared after every step
 
 
-def test_spmm_rows_and_flagged_primitives(mods):
+@pytest.mark.parametrize('d', [32, 8, 128, 256])          # 256: one row per wave, the flag mask needs all 64 lanes (found by tools/spmm_fuzz.py)
+def test_spmm_rows_and_flagged_primitives(mods, d):
     ops, engine = mods
     rng = np.random.default_rng(10)
-    U, I, d = 3000, 500, 32
+    U, I = 3000, 500
     us = np.repeat(np.arange(U), 8)
     its = np.floor(I * rng.random(len(us)) ** 2).astype(np.int64)
     key = np.unique(us * I + its)
