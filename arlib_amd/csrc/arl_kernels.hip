@@ -1115,15 +1115,16 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
                                                                             int *__restrict__ underflow) {
     constexpr int Q = D / 4;                                       // contraction indices per lane: [Q*g, Q*g + Q)
     constexpr int SRCB = SPLIT ? 3 * D * 2 : D * 4;                // bytes per item row in global memory
-    constexpr int ROWB = SRCB + 16;                                // LDS row stride (f32 image): 16-B aligned, consecutive rows shifted by 4 banks
-    // LDS image of the split-bf16 tile: the hardware services a ds_read_b128 in four fixed 16-lane groups that mix lanes of two
-    // k-groups (g, g+1); with [row][plane][k] rows every group hit two banks twice (SQ_LDS_BANK_CONFLICT = 44 % of the LDS
+    // LDS image of a staged tile.  The hardware services a ds_read_b128 in four fixed 16-lane groups that mix lanes of two
+    // k-groups (g, g+1); with plain [row][plane][k] rows every group hit two banks twice (SQ_LDS_BANK_CONFLICT = 44 % of the LDS
     // cycles).  Two half images -- k-groups with g even / g odd -- a multiple of 256 B apart, rows of an odd number of 16-B units:
-    // every group tiles the 64 banks exactly.  offset(row, plane, g, ks) = (g&1)*HALF + row*RH + ((plane*2 + (g>>1))*KS + ks)*16
-    constexpr int KSL = SPLIT ? Q / 8 : 1;
-    constexpr int RH = 96 * KSL + 16;
+    // every group tiles the 64 banks exactly.
+    //   offset(row, plane, g, piece) = (g&1)*HALF + row*RH + ((plane*2 + (g>>1))*PPG + piece)*16
+    constexpr int NPL = SPLIT ? 3 : 1;                             // planes (bf16 pieces of the split) per item row
+    constexpr int PPG = SPLIT ? Q / 8 : Q / 4;                     // 16-byte pieces per k-group and plane
+    constexpr int RH = NPL * 2 * PPG * 16 + 16;
     constexpr int HALF = (D <= 16 ? 128 : (D <= 64 ? 64 : 32)) * RH;
-    static_assert(!SPLIT || (HALF % 256 == 0 && (RH / 16) % 2 == 1), "half images must be bank-aligned");
+    static_assert(HALF % 256 == 0 && (RH / 16) % 2 == 1, "half images must be bank-aligned");
     constexpr int MST = D <= 16 ? 128 : (D <= 64 ? 64 : 32);       // items staged per block barrier
     constexpr int NSUB = MST / 16;                                 // 16-item sub-tiles per stage
     constexpr int SPP = NSUB >= 2 ? 2 : 1;                         // sub-tiles per insert phase (at most 32 items)
@@ -1172,13 +1173,9 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
     };
     auto lds_ptr = [&](unsigned char *buf, int p) {
         const int f = tid + p * kM16Block;
-        if constexpr (SPLIT) {
-            const int row = f / C16, piece = f % C16;              // piece = plane * (D/8) + j, j-th 16-B run of the plane
-            const int pl = piece / (D / 8), j = piece % (D / 8), gq = j / KSL, ks = j % KSL;
-            return reinterpret_cast<float4 *>(buf + (gq & 1) * HALF + row * RH + ((pl * 2 + (gq >> 1)) * KSL + ks) * 16);
-        } else {
-            return reinterpret_cast<float4 *>(buf + (f / C16) * ROWB + (f % C16) * 16);
-        }
+        const int row = f / C16, piece = f % C16;                  // piece = plane * (4*PPG) + j, j-th 16-B run of the plane
+        const int pl = piece / (4 * PPG), j = piece % (4 * PPG), gq = j / PPG, ks = j % PPG;
+        return reinterpret_cast<float4 *>(buf + (gq & 1) * HALF + row * RH + ((pl * 2 + (gq >> 1)) * PPG + ks) * 16);
     };
     // Warm start (optional): `warm_idx` holds k distinct candidate items per user -- typically the previous call's result, when the
     // tables moved a little (the surrogate loops of CLeaR / DLAttack, the per-epoch evaluation).  Their scores under the CURRENT
@@ -1221,7 +1218,7 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
     u32x16 tk_hi = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk_lo = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // Interacted-item mask: a 1024-bit Bloom filter per user in LDS answers "not interacted" for ~97 % of the pre-filter
     // survivors with one LDS read; only filter hits pay the binary search in global memory (7 dependent L2 round trips).
-    constexpr int STAGEB = SPLIT ? 2 * HALF : MST * ROWB;
+    constexpr int STAGEB = 2 * HALF;
     unsigned *bloom = reinterpret_cast<unsigned *>(bt + 2 * STAGEB) + wv * 16 * kBloomWords;               // [16][kBloomWords]
     if (mrp) {
         for (int t = lane; t < 16 * kBloomWords; t += kWave) bloom[t] = 0u;
@@ -1329,7 +1326,7 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
                 for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
-                        bfr[sub][pl][ks] = *reinterpret_cast<const bf16x8 *>(buf + (g & 1) * HALF + (sub * 16 + c) * RH + ((pl * 2 + (g >> 1)) * KSL + ks) * 16);
+                        bfr[sub][pl][ks] = *reinterpret_cast<const bf16x8 *>(buf + (g & 1) * HALF + (sub * 16 + c) * RH + ((pl * 2 + (g >> 1)) * PPG + ks) * 16);
             __builtin_amdgcn_sched_barrier(0);
             constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};      // (A piece, B piece), smallest products first
 #pragma unroll
@@ -1345,7 +1342,7 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
             float4 bf[NSUB][Q / 4];
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub) {
-                const float *brow = reinterpret_cast<const float *>(buf + (sub * 16 + c) * ROWB) + Q * g;
+                const float *brow = reinterpret_cast<const float *>(buf + (g & 1) * HALF + (sub * 16 + c) * RH + (g >> 1) * PPG * 16);
 #pragma unroll
                 for (int t = 0; t < Q; t += 4) bf[sub][t / 4] = *reinterpret_cast<const float4 *>(brow + t);
             }
@@ -1869,7 +1866,7 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
     if (k <= 64 && (d == 16 || d == 32 || d == 64 || d == 128)) {        // matrix-core path
         const bool split = workspace != nullptr && (d == 64 || d == 128);
         const int mst = d <= 16 ? 128 : (d <= 64 ? 64 : 32);
-        const size_t stageb = split ? 2 * (size_t)mst * (96 * (size_t)(d / 32) + 16) : (size_t)mst * (4 * (size_t)d + 16);      // see STAGEB in the kernel
+        const size_t stageb = 2 * (size_t)mst * ((split ? 6 : 4) * (size_t)d / 2 + 16);     // two half images of mst rows (STAGEB in the kernel)
         const size_t shm_m = 2 * stageb + (mask_rowptr ? sizeof(unsigned) * kMU * kBloomWords : 0);
         const unsigned grid_m = (unsigned)((U + kMU - 1) / kMU);
         const void *image = Pi;
