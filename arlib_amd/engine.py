@@ -348,6 +348,69 @@ class PropagationEngine:
         ops.mark_bits_(self.bits, allrows, False, N, check_range=False)
         return self.loss_out, cl_loss
 
+    def step_sgl(self, u, p, n, view1, view2, cl_rate=0.2, tau=0.2):
+        """One SGL training iteration (recommender/SGL.py:54-64,231-256) on the sparse-batch schedule.  Three LightGCN passes --
+        the clean graph for BPR + L2, two perturbed graphs (`view1`, `view2`: CSRGraphs of this epoch's edge/node dropout) for ONE
+        InfoNCE over the batch's unique users and unique positive items -- each with L-1 full hops + a row-subset hop forward and a
+        flag-masked first hop backward; the three table gradients are summed and applied by one dense Adam.  6(L-1) full hops
+        instead of the 6L of three autograd passes.  Returns (loss_out, cl_loss)."""
+        if self.skip0 or self.optimizer != 'adam' or self.L < 1:
+            raise ValueError('step_sgl needs a LightGCN-style engine (layers 0..L averaged) with Adam')
+        L, U, N, d = self.L, self.U, self.N, self.d
+        B = u.numel()
+        self._sparse_buffers(B)
+        if getattr(self, '_G_dirty', True):
+            self.G.zero_(); self._G_dirty = False
+        s = 1.0 / (L + 1)
+        rows = torch.cat([u, p + U, n + U])
+        rows_cl = torch.cat([torch.unique(u.long()), torch.unique(p.long()) + U]).to(torch.int32)
+        if not hasattr(self, '_sgl_acc'):
+            self._sgl_acc = torch.empty_like(self.E0)
+            self._sgl_hops = [torch.empty_like(self.E0) for _ in range(max(L - 1, 1))]
+
+        def forward_rows(graph, sel):                                        # mean of layers 0..L at the rows `sel`
+            layers = [self.E0]
+            for k in range(L - 1):
+                layers.append(ops.spmm(graph, layers[-1], out=self._sgl_hops[k]))
+            return ops.spmm_rows(graph, layers[-1], sel, layers, s, nsplit=self.nsplit, check_range=False)
+
+        def backward_into(graph, sel, grad_c, dst, accumulate):             # dst (+)= dL/dE0 of a pass whose output gradient is grad_c at rows sel
+            ops.scatter_add_rows(self.G, sel, grad_c, 1.0, check_range=False)
+            ops.mark_rows_(self.flags, sel, 1, check_range=False)
+            ops.mark_bits_(self.bits, sel, True, N, check_range=False)
+            beta, Z = (1.0, dst) if accumulate else (0.0, None)
+            if L == 1:
+                tmp = ops.spmm_flagged(graph, self.G, self.bits, s, s, self.G, self.flags, out=self._sgl_hops[0])
+            else:
+                acc = ops.spmm_flagged(graph, self.G, self.bits, 1.0, 1.0, self.G, self.flags, out=self._sgl_hops[0])
+                for k in range(1, L - 1):
+                    acc = ops.spmm_flagged(graph, acc, None, 1.0, 1.0, self.G, self.flags, out=self._sgl_hops[k])
+                tmp = ops.spmm_flagged(graph, acc, None, s, s, self.G, self.flags, out=self.hops[0])
+            if accumulate:
+                dst.add_(tmp)
+            else:
+                dst.copy_(tmp)
+            ops.zero_rows_(self.G, sel, check_range=False)
+            ops.mark_rows_(self.flags, sel, 0, check_range=False)
+            ops.mark_bits_(self.bits, sel, False, N, check_range=False)
+
+        # clean pass: BPR + L2 on the batch rows
+        out_c = forward_rows(self.A, rows)
+        self.Gc.zero_()
+        ops.bpr_l2_fwd_bwd(out_c, B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self._ws, loss_out=self.loss_out, check_range=False)
+        # the two views at the contrastive rows, one InfoNCE over users and items together
+        v1 = forward_rows(view1, rows_cl)
+        v2 = forward_rows(view2, rows_cl)
+        lcl, d1, d2 = ops.infonce_fwd_bwd(v1, v2, tau)
+        cl_loss = cl_rate * lcl[0]
+        # backward: three passes into one gradient table, then Adam
+        backward_into(self.A, rows, self.Gc, self._sgl_acc, False)
+        backward_into(view1, rows_cl, d1 * cl_rate, self._sgl_acc, True)
+        backward_into(view2, rows_cl, d2 * cl_rate, self._sgl_acc, True)
+        self.t += 1
+        ops.adam_dense(self.E0, self._sgl_acc, self.m, self.v, self.lr, self.t, self.betas, self.eps)
+        return self.loss_out, cl_loss
+
     def _sparse_buffers(self, B):
         if getattr(self, '_sparse_B', None) == B:
             return

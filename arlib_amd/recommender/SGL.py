@@ -124,6 +124,11 @@ class SGL_Encoder(GraphEncoder):
 class SGL(Recommender):
     print_every = 100
     has_extra_loss = True
+    fused_extra_loss = True
+
+    def _fused_step(self, eng, u, p, n):
+        lo, self.last_cl_loss = eng.step_sgl(u, p, n, self.dropped_adj1, self.dropped_adj2, cl_rate=self.cl_rate, tau=self.temp)
+        return lo
 
     def __init__(self, args, data):
         self._common_init(args, data, 'SGL')

@@ -256,6 +256,18 @@ def test_sgl_views_and_step_match_reference():
     with torch.no_grad():
         v1u, v1i = model(adj1)
     assert rel_err(v1u.cpu().numpy(), g['view1_user']) < RTOL and rel_err(v1i.cpu().numpy(), g['view1_item']) < RTOL
+    # the fused engine step (sparse-batch schedule over the three graphs) from the same start
+    from arlib_amd import engine
+    E0 = torch.from_numpy(np.concatenate([g['user0'], g['item0']])).cuda()
+    for L in (2,):
+        eng = engine.PropagationEngine(model._graph(), U, I, 16, L, 1e-4, 0.005, 'cuda:0', table=E0.clone())
+        lo, cl = eng.step_sgl(u.int(), p.int(), n.int(), adj1, adj2, cl_rate=rec.cl_rate, tau=rec.temp)
+        assert abs(float(lo[0]) - g['rec_loss'][0]) <= RTOL * abs(g['rec_loss'][0])
+        assert abs(cl.item() - g['cl_loss'][0]) <= RTOL * abs(g['cl_loss'][0])
+        E = eng.E0.cpu().numpy()
+        assert rel_err(E[:U], g['user_k1']) < RTOL and rel_err(E[U:], g['item_k1']) < RTOL
+        assert float(eng.G.abs().max()) == 0.0 and int(eng.flags.max()) == 0
     with contextlib.redirect_stdout(io.StringIO()):
         rec.train(Epoch=1, evalNum=1)
+    assert rec.model._eng is not None and rec.model._eng.t >= 22               # the fused step ran
     assert np.isfinite(rec.user_emb.cpu().numpy()).all()

@@ -289,3 +289,41 @@ def test_xsimgcl_fused_step_equals_autograd_route_for_other_depths(mods, ml100k,
     assert abs(cl2.item() - cl.item()) <= RTOL * abs(cl.item())
     assert rel_err(eng.E0.cpu().numpy(), ref) < RTOL
     assert float(eng.G.abs().max()) == 0.0 and int(eng.flags.max()) == 0
+
+
+@pytest.mark.parametrize('L', [1, 3])
+def test_sgl_fused_step_equals_autograd_route_for_other_depths(mods, ml100k, L):
+    """step_sgl (three graphs, sparse-batch schedule) at depths the reference's hard-coded L=2 golden does not reach, against the
+    encoder's autograd passes (pinned on the golden at L=2)."""
+    ops, engine = mods
+    from types import SimpleNamespace
+    from arlib_amd.recommender.SGL import SGL_Encoder
+    from arlib_amd.util.loss import bpr_loss, l2_reg_loss
+    import scipy.sparse as sp
+    rng = np.random.default_rng(L)
+    U, I, d, B = ml100k['U'], ml100k['I'], 16, 1024
+    p0 = ml100k['pairs0']
+    R = sp.csr_matrix((np.ones(len(p0), np.float32), (p0[:, 0], p0[:, 1])), shape=(U, I))
+    half = sp.csr_matrix((np.ones(len(p0), np.float32), (p0[:, 0], p0[:, 1] + U)), shape=(U + I, U + I))
+    adj = half + half.T
+    dinv = 1.0 / np.sqrt(np.asarray(adj.sum(1)).ravel())
+    data = SimpleNamespace(user_num=U, item_num=I, norm_adj=(sp.diags(dinv) @ adj @ sp.diags(dinv)).tocsr(), interaction_mat=R)
+    enc = SGL_Encoder(data, d, 0.1, L, 0.2, 2).cuda()
+    E0 = torch.cat([enc.embedding_dict['user_emb'].detach(), enc.embedding_dict['item_emb'].detach()], 0).clone() * 20
+    with torch.no_grad():
+        enc.embedding_dict['user_emb'][:] = E0[:U]; enc.embedding_dict['item_emb'][:] = E0[U:]
+    v1, v2 = enc.graph_reconstruction(), enc.graph_reconstruction()
+    sel = rng.integers(0, len(p0), B)
+    u, p = T(p0[sel, 0].astype(np.int64)), T(p0[sel, 1].astype(np.int64))
+    n = T(rng.integers(0, I, B).astype(np.int64))
+    opt = torch.optim.Adam(enc.parameters(), lr=0.005)
+    ue, ie = enc()
+    cl = 0.2 * enc.cal_cl_loss([u, p], v1, v2)
+    loss = bpr_loss(ue[u], ie[p], ie[n]) + l2_reg_loss(1e-4, ue[u], ie[p]) + cl
+    opt.zero_grad(); loss.backward(); opt.step()
+    ref = torch.cat([enc.embedding_dict['user_emb'], enc.embedding_dict['item_emb']], 0).detach().cpu().numpy()
+    eng = engine.PropagationEngine(enc._graph(), U, I, d, L, 1e-4, 0.005, DEV, table=E0.clone())
+    lo, cl2 = eng.step_sgl(u.int(), p.int(), n.int(), v1, v2, cl_rate=0.2, tau=0.2)
+    assert abs(cl2.item() - cl.item()) <= RTOL * abs(cl.item())
+    assert rel_err(eng.E0.cpu().numpy(), ref) < RTOL
+    assert float(eng.G.abs().max()) == 0.0 and int(eng.flags.max()) == 0
