@@ -16,7 +16,7 @@ import torch
 
 from ... import ops
 from ...util.metrics import AttackMetric
-from .._common import AttackBase, DEVICE, symmetric_adjacency, rebuild_interaction_matrix, reinit_with_tables, cw_pairs, with_fake_rows, append_rows
+from .._common import AttackBase, DEVICE, symmetric_adjacency, init_graph, rebuild_interaction_matrix, reinit_with_tables, cw_pairs, with_fake_rows, append_rows
 from .DLAttack import masked_topk, device_mask
 from .PGA import cw_operator_from_topk
 
@@ -89,7 +89,7 @@ class CLeaR(AttackBase):
         for epoch in range(self.Epoch):
             tmpRecommender = deepcopy(recommender)
             uiAdj2 = uiAdj.copy()
-            tmpRecommender.model._init_uiAdj(symmetric_adjacency(uiAdj2, Up, self.itemNum))
+            init_graph(tmpRecommender.model, uiAdj2, Up, self.itemNum)
             optimizer_attack = torch.optim.Adam(tmpRecommender.model.parameters(), lr=recommender.args.lRate)
             Pu = Pi = None
             mask = device_mask(uiAdj2)          # the poisoned pattern is fixed while the surrogate is trained
@@ -108,7 +108,7 @@ class CLeaR(AttackBase):
             proj[:, self.targetItem] = 1
             uiAdj2 = with_fake_rows(uiAdj2, self.userNum, proj.cpu().numpy())
             uiAdj = uiAdj2.copy()
-            recommender.model._init_uiAdj(symmetric_adjacency(uiAdj, Up, self.itemNum))
+            init_graph(recommender.model, uiAdj, Up, self.itemNum)
             recommender.train(Epoch=self.innerEpoch, optimizer=optimizer, evalNum=5)
             targetHitRate = AttackMetric(recommender, self.targetItem, [topk]).hitRate()[0]
             print(targetHitRate)

@@ -15,7 +15,7 @@ import torch
 
 from ... import ops
 from ...util.sampler import next_batch_pairwise, device_epoch
-from .._common import AttackBase, DEVICE, symmetric_adjacency, rebuild_interaction_matrix, reinit_with_tables, cw_pairs, with_fake_rows, append_rows
+from .._common import AttackBase, DEVICE, symmetric_adjacency, init_graph, rebuild_interaction_matrix, reinit_with_tables, cw_pairs, with_fake_rows, append_rows
 
 
 def device_mask(ui_mat, device=DEVICE):
@@ -58,7 +58,7 @@ class DLAttack(AttackBase):
             tmpRecommender = deepcopy(recommender)
             uiAdj2 = sp.csr_matrix(uiAdj, copy=True)
             U_now = tmpRecommender.data.user_num
-            tmpRecommender.model._init_uiAdj(symmetric_adjacency(uiAdj2, U_now, self.itemNum))
+            init_graph(tmpRecommender.model, uiAdj2, U_now, self.itemNum)
             tmpRecommender.train(Epoch=self.innerEpoch, optimizer=optimizer, evalNum=5)
             optimizer_attack = torch.optim.Adam(tmpRecommender.model.parameters(), lr=recommender.args.lRate)
             mask = device_mask(uiAdj2)
@@ -79,7 +79,7 @@ class DLAttack(AttackBase):
             p[ind] = p[ind] * sigma
             if p.max() < 1:
                 p = torch.ones(self.itemNum, device=DEVICE)
-            recommender.model._init_uiAdj(symmetric_adjacency(uiAdj2, recommender.data.user_num, self.itemNum))
+            init_graph(recommender.model, uiAdj2, recommender.data.user_num, self.itemNum)
             uiAdj = uiAdj2
         self.interact = uiAdj
         return self.interact

@@ -17,7 +17,7 @@ import scipy.sparse as sp
 import torch
 
 from ... import ops
-from .._common import AttackBase, DEVICE, symmetric_adjacency, rebuild_interaction_matrix, reinit_with_tables, cw_pairs
+from .._common import AttackBase, DEVICE, symmetric_adjacency, init_graph, rebuild_interaction_matrix, reinit_with_tables, cw_pairs
 
 
 class FakeBlockGraph:
@@ -214,7 +214,7 @@ class PGA(AttackBase):
         for epoch in range(self.outerEpoch):
             # outer optimisation: victim retrain on the current poisoned graph
             uiAdj = sp.vstack([real, sp.csr_matrix(S.cpu().numpy())]).tocsr()
-            recommender.model._init_uiAdj(symmetric_adjacency(uiAdj, U + F, I))
+            init_graph(recommender.model, uiAdj, U + F, I)
             recommender.train(Epoch=self.Epoch, optimizer=optimizer, evalNum=3)
             # inner optimisation on a frozen copy of the victim's tables
             E0 = recommender.model._pack().detach().clone()

@@ -91,3 +91,12 @@ def append_rows(data, rows):
         data.append_training_rows(rows)              # our DataLoader: keeps a pending sampler permutation pending
     else:
         data.training_data.extend(rows)
+
+
+def init_graph(model, ui, n_users, n_items):
+    """model._init_uiAdj(ui_adj + ui_adj.T) for the U' x I interaction matrix `ui` -- on the device when the model offers it
+    (our encoders), through the (U'+I)^2 scipy matrix otherwise (any model with the reference's interface)."""
+    if hasattr(model, '_init_uiAdj_from_interactions') and sp.csr_matrix(ui).shape == (n_users, n_items):
+        model._init_uiAdj_from_interactions(ui)
+    else:
+        model._init_uiAdj(symmetric_adjacency(ui, n_users, n_items))

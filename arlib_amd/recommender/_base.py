@@ -140,6 +140,22 @@ class GraphEncoder(nn.Module):
         self.sparse_norm_adj = adj
         self._eng = None
 
+    def _init_uiAdj_from_interactions(self, ui):
+        """Same result as `_init_uiAdj(ui_adj + ui_adj.T)` with ui_adj's upper-right block = `ui` (the U' x I, possibly weighted,
+        interaction matrix every attack assembles: attack/White/PGA.py:79-83, CLeaR.py:66-71, DLAttack.py:57-61), but the
+        (U'+I)^2 adjacency is never built on the host: the symmetric CSR is assembled and normalised on the device."""
+        m = sp.csr_matrix(ui, dtype=np.float32)
+        m.eliminate_zeros(); m.sort_indices()
+        U, I = m.shape
+        u = torch.from_numpy(np.repeat(np.arange(U, dtype=np.int64), np.diff(m.indptr))).to(DEVICE)
+        g = ops.bipartite_graph(u, torch.from_numpy(m.indices.astype(np.int64)).to(DEVICE), U, I, weights=torch.from_numpy(m.data).to(DEVICE))
+        adj = SparseNormAdj.__new__(SparseNormAdj)
+        adj.shape = (U + I, U + I)
+        adj.indptr, adj.indices = g.rowptr.cpu().numpy().astype(np.int64), g.col.cpu().numpy()
+        adj.values, adj.dinv, adj._graph = g.val, g.dinv, g
+        self.sparse_norm_adj = adj
+        self._eng = None
+
     def attack_emb(self, users_emb_grad, items_emb_grad):
         with torch.no_grad():
             self.embedding_dict['user_emb'] += users_emb_grad
