@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ARLIB_AMD_LIB') or os.path.join(_HERE, 'lib', 'libarlib_amd.so')      # override: developer builds (e.g. `make prof`)
-ABI_VERSION = 9
+ABI_VERSION = 10
 _lib = None
 
 
@@ -21,6 +21,11 @@ class arl_csr(C.Structure):
                 ('chunk', C.c_int32), ('n_chunks', C.c_int64), ('chunk_row', C.c_void_p), ('chunk_begin', C.c_void_p),
                 ('chunk_end', C.c_void_p), ('n_long', C.c_int64), ('long_row', C.c_void_p), ('long_first', C.c_void_p),
                 ('long_count', C.c_void_p), ('partial', C.c_void_p)]
+
+
+class arl_blocked(C.Structure):
+    _fields_ = [('n_waves', C.c_int64), ('rows_per_wave', C.c_int64), ('wave_ptr', C.c_void_p), ('wave_rows', C.c_void_p), ('rec_col', C.c_void_p),
+                ('rec_val', C.c_void_p)]
 
 
 class arl_tiled(C.Structure):
@@ -40,6 +45,10 @@ _SIGS = {
     'arl_spmm_csr_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _f, _f, _vp, _vp, _vp]),
     'arl_spmm_csr_layersum_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _vp, _vp, _vp, _vp]),
     'arl_spmm_csr_adam_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),
+    'arl_spmm_blocked_f32': (C.c_int, [C.POINTER(arl_blocked), _vp, _i64, _f, _f, _vp, _vp, _vp, _vp]),
+    'arl_spmm_blocked_layersum_f32': (C.c_int, [C.POINTER(arl_blocked), _vp, _i64, _vp, _vp, _vp, _vp]),
+    'arl_spmm_blocked_adam_f32': (C.c_int, [C.POINTER(arl_blocked), _vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),
+    'arl_lpt_deal': (C.c_int, [_i64, _vp, _i64, _i64, _vp, _vp]),
     'arl_spmm_tiled_f32': (C.c_int, [C.POINTER(arl_tiled), _vp, _i64, _f, _f, _vp, _vp, _vp, _vp]),
     'arl_spmm_tiled_adam_f32': (C.c_int, [C.POINTER(arl_tiled), _vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),
     'arl_spmm_csr_flagged_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _vp, _f, _f, _vp, _vp, _vp, _vp]),

@@ -8,6 +8,9 @@
 // buffers; it costs ~10 ns per draw versus ~2.5 us per sample in the reference's Python loop.
 #include <cstdint>
 #include <cstddef>
+#include <queue>
+#include <utility>
+#include <vector>
 #include "arlib_amd.h"
 
 namespace {
@@ -85,7 +88,7 @@ inline bool user_has_item(const int64_t *rowptr, const int32_t *items, int64_t r
 
 extern "C" {
 
-int arl_abi_version(void) { return 9; }
+int arl_abi_version(void) { return 10; }
 
 int arl_mt_seed(uint32_t *mt_state, const uint32_t *key, int64_t key_len) {
     if (!mt_state || !key) return ARL_E_NULL;
@@ -154,6 +157,28 @@ int arl_sampler_next_batch(uint32_t *mt_state, const int32_t *pairs, int64_t beg
         do { neg = (int32_t)rng.below((uint32_t)n_items); }
         while (user_has_item(memb_rowptr, memb_items, memb_rows, user, neg));
         out_u[b] = user; out_p[b] = pos; out_n[b] = neg;
+    }
+    return ARL_OK;
+}
+
+// Plan helper of the register-blocked SpMM: longest-processing-time dealing.  Rows arrive sorted by weight (edge count),
+// heaviest first; each goes to the least loaded bin (wave) that still has a free slot; ties go to the lowest bin id, so the
+// plan is reproducible.  n_bins * cap >= n is required.
+int arl_lpt_deal(int64_t n, const int32_t *weight_desc, int64_t n_bins, int64_t cap, int32_t *bin_out, int32_t *slot_out) {
+    if (n < 0 || n_bins < 0 || cap < 1 || n_bins > 0x7fffffffll || n_bins * cap < n) return ARL_E_ARG;
+    if (n == 0) return ARL_OK;
+    if (!weight_desc || !bin_out || !slot_out) return ARL_E_NULL;
+    typedef std::pair<int64_t, int32_t> Load;                      // (edges so far, bin)
+    std::priority_queue<Load, std::vector<Load>, std::greater<Load>> open;
+    std::vector<int32_t> fill((size_t)n_bins, 0);
+    for (int64_t b = 0; b < n_bins; ++b) open.push(Load(0, (int32_t)b));
+    for (int64_t r = 0; r < n; ++r) {
+        if (weight_desc[r] < 0 || (r > 0 && weight_desc[r] > weight_desc[r - 1])) return ARL_E_ARG;
+        const Load top = open.top();
+        open.pop();
+        bin_out[r] = top.second;
+        slot_out[r] = fill[top.second]++;
+        if (fill[top.second] < cap) open.push(Load(top.first + weight_desc[r], top.second));
     }
     return ARL_OK;
 }

@@ -476,6 +476,104 @@ int launch_spmm(const arl_csr *A, const float *X, int64_t d, const Epi &ep, hipS
 }
 
 // ================================================================================================
+// Register-blocked SpMM (d = 64): a wave owns up to RPW output rows for the whole kernel, their accumulators in registers
+// (lane = column), and consumes one flat record stream sorted by (column block, row slot).  All waves of a launch are resident
+// together, carry the same number of edges (the plan deals rows longest-first to the least loaded wave) and sweep the column
+// blocks in the same order, so the operand rows a wave gathers were usually just brought into the L2 by its neighbours.
+// A record = (col | slot << 24, val), fetched 64 at a time by one coalesced load and broadcast with v_readlane; the accumulator
+// is selected with the wave-uniform slot (M0-relative register addressing): two vector instructions per edge, no LDS, no
+// atomics, deterministic.  Rows longer than the plan's hub threshold are not in the plan (chunked CSR kernel).
+// ================================================================================================
+typedef float f32x32v __attribute__((ext_vector_type(32)));
+
+struct BlockedDev {
+    int n_waves;
+    const int32_t *wave_ptr;      // [n_waves + 1] record offsets (multiples of 64)
+    const int32_t *wave_rows;     // [n_waves][RPW] output row or -1
+    const int32_t *rec_col;       // col | slot << 24
+    const float *rec_val;
+};
+
+// spmm_epilogue for one column per lane (d = 64); same arithmetic, scalar accesses (a wave writes one 256-B row at a time)
+template <int MODE>
+__device__ __forceinline__ void spmm_epilogue1(const Epi &ep, int row, int c, float a) {
+    const size_t o = (size_t)row * 64 + c;
+    if (MODE == EPI_AXPBY) {
+        float y = ep.alpha * a;
+        if (ep.Z && (!ep.zflags || ep.zflags[row])) y = fmaf(ep.beta, ep.Z[o], y);
+        ep.Y[o] = y;
+    } else if (MODE == EPI_LAYERSUM) {
+        const float sv = ep.S_in[o];
+        if (ep.Y) ep.Y[o] = a;
+        ep.S[o] = sv + a;
+    } else {
+        float g = ep.alpha * a;
+        if (ep.Z && (!ep.zflags || ep.zflags[row])) g = fmaf(ep.beta, ep.Z[o], g);
+        float p = ep.P[o], m = ep.M[o], v = ep.V[o];
+        m = m + (g - m) * (1.0f - ep.b1);
+        v = v * ep.b2 + (1.0f - ep.b2) * g * g;
+        const float denom = sqrtf(v) * ep.inv_bc2_sqrt + ep.eps;
+        p = p - ep.step_size * (m / denom);
+        ep.P[o] = p; ep.M[o] = m; ep.V[o] = v;
+    }
+}
+
+template <int RPW, int MODE>
+__global__ __launch_bounds__(kBlock) void spmm_blocked64_kernel(BlockedDev P, const float *__restrict__ X, Epi ep) {
+    static_assert(RPW == 16 || RPW == 32, "accumulators are one 32-register vector");
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (w >= P.n_waves) return;
+    f32x32v acc;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) acc[r] = 0.f;
+    const int begin = P.wave_ptr[w], end = P.wave_ptr[w + 1];
+    const float *xl = X + lane;
+    int rc = 0; float rv = 0.f;
+    if (begin < end) { rc = P.rec_col[begin + lane]; rv = P.rec_val[begin + lane]; }
+    for (int base = begin; base < end; base += 64) {
+        const int c_cur = rc; const float v_cur = rv;
+        if (base + 64 < end) { rc = P.rec_col[base + 64 + lane]; rv = P.rec_val[base + 64 + lane]; }       // next batch in flight
+#pragma unroll
+        for (int j = 0; j < 64; j += 16) {
+            float x[16]; int cs[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                cs[t] = __builtin_amdgcn_readlane(c_cur, j + t);
+                x[t] = xl[(size_t)(cs[t] & 0xffffff) * 64];
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float v = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v_cur), j + t));
+                const int slot = ((unsigned)cs[t] >> 24) & 31;
+                acc[slot] = fmaf(v, x[t], acc[slot]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = P.wave_rows[w * RPW + r];
+        if (row >= 0) spmm_epilogue1<MODE>(ep, row, lane, acc[r]);
+    }
+}
+
+template <int MODE>
+int launch_spmm_blocked(const arl_blocked *P, const float *X, int64_t d, const Epi &ep, hipStream_t st) {
+    if (!P || !X) return ARL_E_NULL;
+    if (d != 64) return ARL_E_DIM;
+    if (P->n_waves < 0 || P->n_waves > 0x7fffffffll / 64) return ARL_E_RANGE;
+    if (P->rows_per_wave != 16 && P->rows_per_wave != 32) return ARL_E_ARG;
+    if (P->n_waves == 0) return ARL_OK;
+    if (!P->wave_ptr || !P->wave_rows || !P->rec_col || !P->rec_val) return ARL_E_NULL;
+    BlockedDev D = {(int)P->n_waves, P->wave_ptr, P->wave_rows, P->rec_col, P->rec_val};
+    const dim3 grid((unsigned)((P->n_waves + kWavesPerBlock - 1) / kWavesPerBlock));
+    if (P->rows_per_wave == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<16, MODE>), grid, dim3(kBlock), 0, st, D, X, ep);
+    else hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE>), grid, dim3(kBlock), 0, st, D, X, ep);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+// ================================================================================================
 // Degree normalisation (util/DataLoader.py:73-87, recommender/LightGCN.py:212-215)
 // ================================================================================================
 __global__ __launch_bounds__(kBlock) void row_dinv_kernel(int n_rows, const int32_t *__restrict__ rowptr,
@@ -1494,6 +1592,36 @@ int arl_spmm_csr_layersum_f32(const arl_csr *A, const float *X, int64_t d, const
     Epi ep = {};
     ep.S_in = S_in; ep.S = S; ep.Y = Y;
     return launch_spmm<EPI_LAYERSUM>(A, X, d, ep, (hipStream_t)stream);
+}
+
+int arl_spmm_blocked_f32(const arl_blocked *P, const float *X, int64_t d, float alpha, float beta, const float *Z, const uint8_t *zflags, float *Y,
+                         arl_stream_t stream) {
+    if (!Y) return ARL_E_NULL;
+    if (beta != 0.f && !Z) return ARL_E_NULL;
+    if (Y == X) return ARL_E_ARG;
+    Epi ep = {};
+    ep.alpha = alpha; ep.beta = beta; ep.Z = (beta != 0.f) ? Z : nullptr; ep.zflags = zflags; ep.Y = Y;
+    return launch_spmm_blocked<EPI_AXPBY>(P, X, d, ep, (hipStream_t)stream);
+}
+
+int arl_spmm_blocked_layersum_f32(const arl_blocked *P, const float *X, int64_t d, const float *S_in, float *S, float *Y, arl_stream_t stream) {
+    if (!S_in || !S) return ARL_E_NULL;
+    if (Y == X) return ARL_E_ARG;
+    Epi ep = {};
+    ep.S_in = S_in; ep.S = S; ep.Y = Y;
+    return launch_spmm_blocked<EPI_LAYERSUM>(P, X, d, ep, (hipStream_t)stream);
+}
+
+int arl_spmm_blocked_adam_f32(const arl_blocked *P, const float *X, int64_t d, float alpha, float beta, const float *Z, const uint8_t *zflags,
+                              float *Pm, float *M, float *V, float lr, float beta1, float beta2, float eps, int64_t step, arl_stream_t stream) {
+    if (!Pm || !M || !V) return ARL_E_NULL;
+    if (beta != 0.f && !Z) return ARL_E_NULL;
+    if (step < 1 || Pm == X) return ARL_E_ARG;
+    Epi ep = {};
+    ep.alpha = alpha; ep.beta = beta; ep.Z = (beta != 0.f) ? Z : nullptr; ep.zflags = zflags; ep.P = Pm; ep.M = M; ep.V = V;
+    ep.b1 = beta1; ep.b2 = beta2; ep.eps = eps;
+    adam_scalars(lr, beta1, beta2, step, &ep.step_size, &ep.inv_bc2_sqrt);
+    return launch_spmm_blocked<EPI_ADAM>(P, X, d, ep, (hipStream_t)stream);
 }
 
 int arl_spmm_tiled_f32(const arl_tiled *T, const float *X, int64_t d, float alpha, float beta, const float *Z, const uint8_t *zflags, float *Y,

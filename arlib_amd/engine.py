@@ -20,8 +20,10 @@ from . import ops
 
 
 class PropagationEngine:
+    BLOCKED_MIN_NNZ = 4_000_000      # below this the whole operand table sits in the L2 / Infinity Cache and the CSR kernel is as fast
+
     def __init__(self, graph, n_users, n_items, emb_size, n_layers, reg, lr, device, skip_layer0=False,
-                 optimizer='adam', betas=(0.9, 0.999), eps=1e-8, table=None):
+                 optimizer='adam', betas=(0.9, 0.999), eps=1e-8, table=None, schedule='auto'):
         self.A = graph
         self.U, self.I, self.d, self.L = int(n_users), int(n_items), int(emb_size), int(n_layers)
         self.N = self.U + self.I
@@ -37,6 +39,12 @@ class PropagationEngine:
             raise ValueError('graph has %d rows, expected U+I=%d' % (graph.n_rows, self.N))
         if self.skip0 and self.L < 1:
             raise ValueError('skip_layer0 needs n_layers >= 1')
+        if schedule not in ('auto', 'csr', 'blocked'):
+            raise ValueError("schedule must be 'auto', 'csr' or 'blocked'")
+        # full-table hops: register-blocked schedule (ops.BlockedPlan) for large graphs at d = 64, row-per-group CSR kernel otherwise
+        if graph is not None and graph.blocked is None and int(emb_size) == 64 and graph.n_cols < (1 << 24) and (
+                schedule == 'blocked' or (schedule == 'auto' and graph.nnz >= self.BLOCKED_MIN_NNZ)):
+            graph.enable_blocked(split=self.U)
         z = lambda: torch.zeros(self.N, self.d, dtype=torch.float32, device=self.device)
         self.E0 = z() if table is None else table
         if self.E0.shape != (self.N, self.d) or self.E0.dtype != torch.float32 or not self.E0.is_contiguous():

@@ -95,6 +95,15 @@ class CSRGraph:
             self.n_chunks = self.n_long = 0
         self._partial = None
         self.dinv = None
+        self.blocked = None
+
+    def enable_blocked(self, split=None, rows_per_wave=32, hub=1024, col_block=4096):
+        """Attach a register-blocked plan (BlockedPlan): full-table SpMMs at d = 64 then run through arl_spmm_blocked_*.
+        `split` = number of users of a bipartite adjacency: user rows and item rows get separate launches (they gather from
+        different tables).  Returns self."""
+        sets = [(0, self.n_rows)] if not split or split >= self.n_rows else [(0, int(split)), (int(split), self.n_rows)]
+        self.blocked = BlockedPlan(self, sets, rows_per_wave, hub, col_block)
+        return self
 
     def chunks_only(self, rows, chunk=None):
         """View that computes ONLY the given rows, all of them through the chunk plan (row tasks disabled: n_rows = 0)."""
@@ -117,6 +126,7 @@ class CSRGraph:
         g.n_chunks, g.n_long = int(nch.sum()), len(rows_h)
         g._partial = None
         g._rows_disabled = True
+        g.blocked = None
         return g
 
     def with_values(self, val):
@@ -126,6 +136,8 @@ class CSRGraph:
         g.val = _dev(val, torch.float32, 'val', 1)
         if g.val.numel() != self.nnz:
             raise ValueError('with_values: wrong length')
+        if self.blocked is not None:
+            g.blocked = self.blocked.with_values(g)
         return g
 
     def _struct(self, d):
@@ -144,6 +156,108 @@ class CSRGraph:
     def spmm_bytes(self, d):
         """Algorithmic (compulsory) bytes of one SpMM, SURVEY 8d: 8E + 4(N+1) + 8Nd."""
         return 8 * self.nnz + 4 * (self.n_rows + 1) + 8 * self.n_rows * d
+
+
+class BlockedPlan:
+    """Plan of the register-blocked SpMM (include/arlib_amd.h: arl_blocked) for a CSRGraph, built on the device once per graph.
+
+    Per row set (one launch each): rows with at most `hub` edges are sorted by edge count and dealt longest-first to the least
+    loaded of ceil(n / rows_per_wave) waves (arl_lpt_deal), so that every wave carries the same number of edges; a wave's edges
+    are sorted by (column block of `col_block` rows, slot) and padded to a multiple of 64 records.  Rows above `hub` edges stay
+    with the chunked CSR kernel (`self.hub`: a chunks_only view of the graph)."""
+
+    def __init__(self, A, row_sets, rows_per_wave=32, hub=1024, col_block=4096):
+        if rows_per_wave not in (16, 32):
+            raise ValueError('BlockedPlan: rows_per_wave must be 16 or 32')
+        if A.n_cols >= 1 << 24:
+            raise ValueError('BlockedPlan: columns must fit 24 bits')
+        if hub < 1 or col_block < 1:
+            raise ValueError('BlockedPlan: hub and col_block must be positive')
+        self.rpw, self.hub_threshold, self.col_block = int(rows_per_wave), int(hub), int(col_block)
+        dev = A.device
+        rp_all = A.rowptr.long()
+        n_cb = (A.n_cols + self.col_block - 1) // self.col_block
+        self.sets, hub_rows = [], []
+        for lo, hi in row_sets:
+            if not (0 <= lo <= hi <= A.n_rows):
+                raise ValueError('BlockedPlan: bad row set')
+            rp = rp_all[lo:hi + 1]
+            deg = rp[1:] - rp[:-1]
+            planned = deg <= self.hub_threshold
+            hub_rows.append(lo + torch.nonzero(~planned).flatten())
+            local = torch.nonzero(planned).flatten()
+            n = local.numel()
+            if n == 0:
+                continue
+            w_desc, o = torch.sort(deg[local], descending=True, stable=True)
+            local = local[o]
+            n_waves = (n + self.rpw - 1) // self.rpw
+            w_host = w_desc.to(torch.int32).cpu().contiguous()
+            bin_h = torch.empty(n, dtype=torch.int32); slot_h = torch.empty(n, dtype=torch.int32)
+            check(_lib.lib().arl_lpt_deal(n, w_host.data_ptr(), n_waves, self.rpw, bin_h.data_ptr(), slot_h.data_ptr()), 'arl_lpt_deal')
+            wave_of, slot_of = bin_h.to(dev).long(), slot_h.to(dev).long()
+            wave_rows = torch.full((n_waves, self.rpw), -1, dtype=torch.int32, device=dev)
+            wave_rows[wave_of, slot_of] = (lo + local).to(torch.int32)
+            row_wave = torch.full((hi - lo,), -1, dtype=torch.int64, device=dev); row_slot = torch.zeros(hi - lo, dtype=torch.int64, device=dev)
+            row_wave[local] = wave_of; row_slot[local] = slot_of
+            e0, e1 = int(rp[0]), int(rp[-1])
+            erow = torch.repeat_interleave(torch.arange(hi - lo, device=dev), deg, output_size=e1 - e0)
+            ew = row_wave[erow]
+            keep = torch.nonzero(ew >= 0).flatten()
+            ew = ew[keep]; es = row_slot[erow[keep]]; del erow
+            eid = keep + e0; del keep
+            ec = A.col[eid].long()
+            key = (ew * n_cb + ec // self.col_block) * self.rpw + es
+            o = torch.sort(key, stable=True)[1]; del key
+            ew, es, ec, eid = ew[o], es[o], ec[o], eid[o]; del o
+            cnt = torch.bincount(ew, minlength=n_waves)
+            wave_ptr = torch.zeros(n_waves + 1, dtype=torch.int64, device=dev)
+            torch.cumsum((cnt + 63) // 64 * 64, 0, out=wave_ptr[1:])
+            total = int(wave_ptr[-1])
+            if total >= 2 ** 31:
+                raise ValueError('BlockedPlan: too many records for int32 offsets')
+            start = torch.zeros(n_waves + 1, dtype=torch.int64, device=dev); torch.cumsum(cnt, 0, out=start[1:])
+            dst = wave_ptr[ew] + (torch.arange(ew.numel(), device=dev) - start[ew])
+            rec_col = torch.zeros(total, dtype=torch.int32, device=dev)
+            rec_src = torch.full((total,), A.nnz, dtype=torch.int64, device=dev)       # padding -> the appended zero
+            rec_col[dst] = (ec | (es << 24)).to(torch.int32)
+            rec_src[dst] = eid
+            self.sets.append({'n_waves': n_waves, 'wave_ptr': wave_ptr.to(torch.int32), 'wave_rows': wave_rows, 'rec_col': rec_col, 'rec_src': rec_src,
+                              'n_rows': n, 'n_edges': int(ew.numel())})
+        hub_rows = torch.cat(hub_rows) if hub_rows else torch.zeros(0, dtype=torch.int64, device=dev)
+        self.n_hub = int(hub_rows.numel())
+        self._hub_rows = hub_rows
+        self._bind(A)
+
+    def _bind(self, A):
+        vz = torch.cat([A.val, torch.zeros(1, dtype=torch.float32, device=A.device)])
+        self.structs = []
+        for st in self.sets:
+            st['rec_val'] = vz[st['rec_src']]
+            self.structs.append(_lib.arl_blocked(st['n_waves'], self.rpw, st['wave_ptr'].data_ptr(), st['wave_rows'].data_ptr(), st['rec_col'].data_ptr(),
+                                                 st['rec_val'].data_ptr()))
+        self.hub = A.chunks_only(self._hub_rows) if self.n_hub else None
+
+    def with_values(self, A):
+        """The same plan over a graph with the same pattern and new edge values."""
+        p = object.__new__(BlockedPlan)
+        p.__dict__.update(self.__dict__)
+        p.sets = [dict(st) for st in self.sets]
+        p._bind(A)
+        return p
+
+
+def _spmm_dispatch(A, d, blocked_call, csr_call):
+    """Run one full-table SpMM: through the blocked plan (+ its hub rows through the chunked CSR kernel) when the graph has one
+    and d = 64, else through the CSR kernel.  The callables take the ctypes struct pointer."""
+    bp = A.blocked
+    if bp is None or d != 64:
+        csr_call(C.byref(A._struct(d)))
+        return
+    for st in bp.structs:
+        blocked_call(C.byref(st))
+    if bp.hub is not None:
+        csr_call(C.byref(bp.hub._struct(d)))
 
 
 def norm_adj_values(rowptr, col, w, n_rows):
@@ -200,9 +314,10 @@ def spmm(A, X, alpha=1.0, beta=0.0, Z=None, out=None):
     if beta != 0.0:
         if Z is None or _check_xy(A, Z, 'Z') != d:
             raise ValueError('spmm: Z [n_rows, d] required when beta != 0')
-    s = A._struct(d)
+    L, zp, st = _lib.lib(), (_ptr(Z) if beta != 0.0 else None), _stream()
     tok = EVENT_HOOK.begin('axpby') if EVENT_HOOK is not None else None
-    check(_lib.lib().arl_spmm_csr_f32(C.byref(s), _ptr(X), d, alpha, beta, _ptr(Z) if beta != 0.0 else None, _ptr(Y), _stream()), 'arl_spmm_csr_f32')
+    _spmm_dispatch(A, d, lambda p: check(L.arl_spmm_blocked_f32(p, _ptr(X), d, alpha, beta, zp, None, _ptr(Y), st), 'arl_spmm_blocked_f32'),
+                   lambda p: check(L.arl_spmm_csr_f32(p, _ptr(X), d, alpha, beta, zp, _ptr(Y), st), 'arl_spmm_csr_f32'))
     if tok is not None:
         EVENT_HOOK.end(tok)
     return Y
@@ -221,9 +336,10 @@ def spmm_layersum(A, X, S_in, S, Y=None):
             raise ValueError('spmm_layersum: Y must not alias X')
     if S.data_ptr() == X.data_ptr():
         raise ValueError('spmm_layersum: S must not alias X')
-    s = A._struct(d)
+    L, st = _lib.lib(), _stream()
     tok = EVENT_HOOK.begin('layersum') if EVENT_HOOK is not None else None
-    check(_lib.lib().arl_spmm_csr_layersum_f32(C.byref(s), _ptr(X), d, _ptr(S_in), _ptr(S), _ptr(Y), _stream()), 'arl_spmm_csr_layersum_f32')
+    _spmm_dispatch(A, d, lambda p: check(L.arl_spmm_blocked_layersum_f32(p, _ptr(X), d, _ptr(S_in), _ptr(S), _ptr(Y), st), 'arl_spmm_blocked_layersum_f32'),
+                   lambda p: check(L.arl_spmm_csr_layersum_f32(p, _ptr(X), d, _ptr(S_in), _ptr(S), _ptr(Y), st), 'arl_spmm_csr_layersum_f32'))
     if tok is not None:
         EVENT_HOOK.end(tok)
     return S
@@ -248,10 +364,12 @@ def spmm_adam(A, X, alpha, beta, Z, P, M, V, lr, step, betas=(0.9, 0.999), eps=1
             raise ValueError('spmm_adam: Z shape mismatch')
     if zflags is not None:
         _check_flags(zflags, A.n_rows, 'zflags')
-    s = A._struct(d)
+    L, zp, st = _lib.lib(), (_ptr(Z) if beta != 0.0 else None), _stream()
     tok = EVENT_HOOK.begin('adam') if EVENT_HOOK is not None else None
-    check(_lib.lib().arl_spmm_csr_adam_f32(C.byref(s), _ptr(X), d, alpha, beta, _ptr(Z) if beta != 0.0 else None, _ptr(zflags), _ptr(P), _ptr(M), _ptr(V),
-                                           lr, betas[0], betas[1], eps, int(step), _stream()), 'arl_spmm_csr_adam_f32')
+    _spmm_dispatch(A, d, lambda p: check(L.arl_spmm_blocked_adam_f32(p, _ptr(X), d, alpha, beta, zp, _ptr(zflags), _ptr(P), _ptr(M), _ptr(V), lr, betas[0],
+                                                                     betas[1], eps, int(step), st), 'arl_spmm_blocked_adam_f32'),
+                   lambda p: check(L.arl_spmm_csr_adam_f32(p, _ptr(X), d, alpha, beta, zp, _ptr(zflags), _ptr(P), _ptr(M), _ptr(V), lr, betas[0], betas[1], eps,
+                                                           int(step), st), 'arl_spmm_csr_adam_f32'))
     if tok is not None:
         EVENT_HOOK.end(tok)
 
@@ -271,10 +389,13 @@ def spmm_flagged(A, X, xflags=None, alpha=1.0, beta=0.0, Z=None, zflags=None, ou
             raise ValueError('spmm_flagged: bitmap needs ceil(n_cols/32) int32 words')
     if zflags is not None:
         _check_flags(zflags, A.n_rows, 'zflags')
-    s = A._struct(d)
+    L, zp, st = _lib.lib(), (_ptr(Z) if beta != 0.0 else None), _stream()
     tok = EVENT_HOOK.begin('masked' if xflags is not None else 'axpby') if EVENT_HOOK is not None else None
-    check(_lib.lib().arl_spmm_csr_flagged_f32(C.byref(s), _ptr(X), d, _ptr(xflags), alpha, beta, _ptr(Z) if beta != 0.0 else None, _ptr(zflags), _ptr(Y),
-                                              _stream()), 'arl_spmm_csr_flagged_f32')
+    csr = lambda p: check(L.arl_spmm_csr_flagged_f32(p, _ptr(X), d, _ptr(xflags), alpha, beta, zp, _ptr(zflags), _ptr(Y), st), 'arl_spmm_csr_flagged_f32')
+    if xflags is not None:              # the masked hop skips most edges: row-per-group kernel
+        csr(C.byref(A._struct(d)))
+    else:
+        _spmm_dispatch(A, d, lambda p: check(L.arl_spmm_blocked_f32(p, _ptr(X), d, alpha, beta, zp, _ptr(zflags), _ptr(Y), st), 'arl_spmm_blocked_f32'), csr)
     if tok is not None:
         EVENT_HOOK.end(tok)
     return Y

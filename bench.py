@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--no-kernel-events', action='store_true', help='do not bracket SpMM launches with HIP events')
     ap.add_argument('--attack-steps', type=int, default=5, help='PGA gradient steps to time at N=1 (0 disables the attack leg)')
     ap.add_argument('--fake-users', type=int, default=64)
+    ap.add_argument('--schedule', default='auto', choices=['auto', 'csr', 'blocked'], help='full-graph hop schedule (engine.PropagationEngine)')
     ap.add_argument('--dense-step', action='store_true', help='time the reference-shaped step (all 2L hops on the full graph) as the main number')
     return ap.parse_args()
 
@@ -320,7 +321,7 @@ def main():
         val, _ = ops.norm_adj_values(torch.from_numpy(rowptr.astype(np.int32)).to(dev), col_d, w, N)
         del w
         A = ops.CSRGraph(rowptr, col_d, val, dev, chunk=args.chunk, validate=True)
-        eng = engine.PropagationEngine(A, U, I, d, L, 1e-4, 0.005, dev, table=E0.to(dev))
+        eng = engine.PropagationEngine(A, U, I, d, L, 1e-4, 0.005, dev, table=E0.to(dev), schedule=args.schedule)
         dev_rows = torch.cat([dev_batches[:, 0], dev_batches[:, 1] + U, dev_batches[:, 2] + U], 1).contiguous()     # packed row ids [u, U+p, U+n]
         if args.dense_step:
             step = lambda k: eng.step_dense(dev_batches[k, 0], dev_batches[k, 1], dev_batches[k, 2])
@@ -387,7 +388,7 @@ def main():
             # under sharding a launch covers this rank's rows only; report the single-GPU figure only for N=1
             traffic = None
             try:        # HBM-side traffic per launch from the committed PMC passes (profiles/), only for the workload they were taken on
-                pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+                pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_blocked.json' if (not sharded and A.blocked is not None) else 'r01_pmc_traffic.json')))
                 if (U, I, d, args.mean_deg, args.seed, args.chunk) == (1_000_000, 100_000, 64, 32.0, 2018, 512):
                     traffic = pm['traffic_corrected_bytes']
             except Exception:
@@ -395,7 +396,10 @@ def main():
             if not sharded:
                 res['roofline'] = {'bound': 'hbm', 'achieved': spmm_bytes / (avg_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                    'frac': spmm_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': traffic,
-                                   'kernel': 'spmm_rows_kernel<LPR=%d> (+spmm_long_rows_kernel), avg over %d launches' % (max(4, d // 4), len(allv)),
+                                   'kernel': ('one full-graph hop = spmm_blocked64_kernel<%d,*> x%d (user rows, item rows) + spmm_rows_kernel/spmm_long_rows_kernel on '
+                                              '%d hub rows; avg over %d hops' % (A.blocked.rpw, len(A.blocked.structs), A.blocked.n_hub, len(allv))) if A.blocked is not None
+                                   else 'spmm_rows_kernel<LPR=%d> (+spmm_long_rows_kernel), avg over %d launches' % (max(4, d // 4), len(allv)),
+                                   'schedule': 'blocked' if A.blocked is not None else 'csr',
                                    'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': spmm_bytes,
                                    'per_variant_ms': {k: v[0] for k, v in evs.items()},
                                    'gather_model_bytes_per_launch': E * (8 + 4 * d) + 4 * N * d}

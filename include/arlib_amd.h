@@ -130,6 +130,30 @@ int arl_mark_rows_u8(uint8_t *flags, const int32_t *idx, int64_t n, int32_t valu
 int arl_mark_rows_bits_u32(uint32_t *bits, const int32_t *idx, int64_t n, int32_t set, arl_stream_t stream);
 int arl_zero_rows_f32(float *dst, const int32_t *idx, int64_t n, int64_t d, arl_stream_t stream);
 
+/* Register-blocked SpMM (d = 64 only): the same three operations as arl_spmm_csr_f32 / _layersum_f32 / _adam_f32, for the rows
+ * of a PLAN.  A wave owns up to rows_per_wave (16 or 32) output rows with register accumulators and consumes one record stream
+ * sorted by (column block, row slot); waves carry equal edge counts (arl_lpt_deal) and are all resident, so they sweep X in step
+ * and share the gathered rows through the L2.  Rows absent from the plan (longer than its hub threshold) are not written: the
+ * caller runs them through the chunked CSR kernel.  Plans are built by arlib_amd/ops.py:BlockedPlan.
+ * Summation order differs from the CSR kernel: results agree to fp32 rounding, not bitwise; each is deterministic. */
+typedef struct arl_blocked {
+    int64_t n_waves, rows_per_wave;
+    const int32_t *wave_ptr;    /* [n_waves + 1] record offsets, multiples of 64                          */
+    const int32_t *wave_rows;   /* [n_waves][rows_per_wave] output row id, -1 = unused slot               */
+    const int32_t *rec_col;     /* column | slot << 24 (columns < 2^24); padding records have val 0       */
+    const float *rec_val;
+} arl_blocked;
+int arl_spmm_blocked_f32(const arl_blocked *P, const float *X, int64_t d, float alpha, float beta, const float *Z,
+                         const uint8_t *zflags, float *Y, arl_stream_t stream);
+int arl_spmm_blocked_layersum_f32(const arl_blocked *P, const float *X, int64_t d, const float *S_in, float *S, float *Y,
+                                  arl_stream_t stream);
+int arl_spmm_blocked_adam_f32(const arl_blocked *P, const float *X, int64_t d, float alpha, float beta, const float *Z,
+                              const uint8_t *zflags, float *Pm, float *M, float *V, float lr, float beta1, float beta2,
+                              float eps, int64_t step, arl_stream_t stream);
+/* Host helper of the plan: rows sorted by edge count (descending) are dealt to the least loaded of n_bins waves with a free
+ * slot (cap slots each); bin_out / slot_out receive the placement. */
+int arl_lpt_deal(int64_t n, const int32_t *weight_desc, int64_t n_bins, int64_t cap, int32_t *bin_out, int32_t *slot_out);
+
 /* L2-blocked ("tiled") SpMM: same results as arl_spmm_csr_f32 / _adam_f32 on the same adjacency, different schedule.
  * Output rows are dealt into BINS of <= cap rows with equal edge counts; one persistent workgroup per CU keeps a bin's fp32
  * accumulators in LDS for a sweep and walks column blocks of `col_block` rows in ascending order, so the gathered rows of X

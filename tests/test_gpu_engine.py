@@ -100,8 +100,10 @@ def test_simgcl_forward_and_backward_golden(mods, ml100k):
     assert rel_err(got, ref) < RTOL
 
 
-def test_engine_vs_oracle_synthetic_long_rows(mods):
-    """Synthetic power-law graph with rows far longer than the chunk size, 5 Adam steps vs the oracle."""
+@pytest.mark.parametrize('schedule', ['csr', 'blocked'])
+def test_engine_vs_oracle_synthetic_long_rows(mods, schedule):
+    """Synthetic power-law graph with rows far longer than the chunk size, 5 Adam steps vs the oracle; full hops through the
+    row-per-group CSR kernel or the register-blocked schedule (with hub rows above its threshold)."""
     ops, engine = mods
     rng = np.random.default_rng(42)
     U, I, d, L, B = 20000, 2000, 64, 3, 2048
@@ -117,7 +119,8 @@ def test_engine_vs_oracle_synthetic_long_rows(mods):
     bound = np.sqrt(6.0 / (U + d))
     E0 = ((rng.random((U + I, d)) * 2 - 1) * bound).astype(np.float32)
     st = O.TrainState(E0[:U], E0[U:], (rowptr, col, val), L, 1e-4, 0.005)
-    eng = engine.PropagationEngine(A, U, I, d, L, 1e-4, 0.005, DEV, table=T(E0))
+    eng = engine.PropagationEngine(A, U, I, d, L, 1e-4, 0.005, DEV, table=T(E0), schedule=schedule)
+    assert (A.blocked is not None) == (schedule == 'blocked') and (schedule == 'csr' or A.blocked.n_hub > 0)
     pairs = np.stack([us, its], 1)
     for k in range(5):
         sel = rng.integers(0, len(pairs), B)
@@ -145,8 +148,9 @@ def test_sparse_step_equals_dense_step(mods):
     E0 = ((rng.random((U + I, d)) * 2 - 1) * 0.05).astype(np.float32)
     for L in (1, 2, 3, 4):
         A = ops.CSRGraph(rowptr, col, val, DEV)
-        ea = engine.PropagationEngine(A, U, I, d, L, 1e-4, 0.005, DEV, table=T(E0))
+        ea = engine.PropagationEngine(ops.CSRGraph(rowptr, col, val, DEV), U, I, d, L, 1e-4, 0.005, DEV, table=T(E0), schedule='blocked' if L % 2 else 'csr')
         eb = engine.PropagationEngine(A, U, I, d, L, 1e-4, 0.005, DEV, table=T(E0))
+        assert A.blocked is None and (ea.A.blocked is not None) == bool(L % 2)
         for k in range(4):
             sel = rng.integers(0, len(us), B)
             bu, bp, bn = T(us[sel].copy()), T(its[sel].copy()), T(rng.integers(0, I, B).astype(np.int32))

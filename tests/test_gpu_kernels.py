@@ -81,6 +81,74 @@ def test_spmm_all_epilogues(ops, d):
     assert rel_err(Pt.cpu().numpy(), Pr) < RTOL and rel_err(Mt.cpu().numpy(), Mr) < RTOL and rel_err(Vt.cpu().numpy(), Vr) < RTOL
 
 
+@pytest.mark.parametrize('rpw,split,hub', [(32, True, 64), (16, True, 24), (32, False, 100000)])
+def test_spmm_blocked_schedule_all_epilogues(ops, rpw, split, hub):
+    """Register-blocked schedule (arl_spmm_blocked_*: plan rows + hub rows through the chunked kernel) against the oracle: every
+    epilogue, empty rows, rows above the hub threshold, ragged last wave, and edge values replaced through with_values."""
+    rng = np.random.default_rng(rpw + hub)
+    U, I, d = 3001, 703, 64
+    u, i = random_graph(rng, U, I, 12, hot_items=3, hot_deg=2500, empty_users=(5, 77))
+    rowptr, col, w, val = make_csr(u, i, U, I)
+    N = U + I
+    A = ops.CSRGraph(rowptr, col, val, DEV, chunk=512).enable_blocked(split=U if split else None, rows_per_wave=rpw, hub=hub, col_block=256)
+    bp = A.blocked
+    assert len(bp.sets) == (2 if split else 1) and (bp.n_hub > 0) == (hub < 2500)
+    assert sum(s['n_rows'] for s in bp.sets) + bp.n_hub == N
+    X = rng.standard_normal((N, d)).astype(np.float32)
+    Z = rng.standard_normal((N, d)).astype(np.float32)
+    csr = (rowptr, col, val)
+    ref = O.spmm(csr, X)
+    y = ops.spmm(A, T(X))
+    assert rel_err(y.cpu().numpy(), ref) < RTOL
+    assert torch.equal(y, ops.spmm(A, T(X)))                                    # deterministic
+    assert rel_err(ops.spmm(A, T(X), 0.25, 0.25, T(Z)).cpu().numpy(), O.spmm(csr, X, 0.25, 0.25, Z)) < RTOL
+    zf = (rng.random(N) < 0.3).astype(np.uint8)
+    Zs = Z * zf[:, None]
+    assert rel_err(ops.spmm_flagged(A, T(X), None, 0.5, 2.0, T(Zs), T(zf)).cpu().numpy(), O.spmm(csr, X, 0.5, 2.0, Zs)) < RTOL
+    S = T(Z.copy()); Y = torch.empty_like(S)
+    ops.spmm_layersum(A, T(X), S, S, Y)
+    assert rel_err(Y.cpu().numpy(), ref) < RTOL and rel_err(S.cpu().numpy(), Z + ref) < RTOL
+    P = rng.standard_normal((N, d)).astype(np.float32) * 0.1
+    M = rng.standard_normal((N, d)).astype(np.float32) * 0.01
+    V = (rng.random((N, d)).astype(np.float32)) * 1e-4
+    g = O.spmm(csr, X, 0.25, 0.25, Zs)
+    Pr, Mr, Vr = P.copy(), M.copy(), V.copy()
+    O.adam_step(Pr, g, Mr, Vr, 0.005, 7)
+    Pt, Mt, Vt = T(P), T(M), T(V)
+    ops.spmm_adam(A, T(X), 0.25, 0.25, T(Zs), Pt, Mt, Vt, 0.005, 7, zflags=T(zf))
+    assert rel_err(Pt.cpu().numpy(), Pr) < RTOL and rel_err(Mt.cpu().numpy(), Mr) < RTOL and rel_err(Vt.cpu().numpy(), Vr) < RTOL
+    # other widths keep the CSR kernel on the same graph object
+    X32 = rng.standard_normal((N, 32)).astype(np.float32)
+    assert rel_err(ops.spmm(A, T(X32)).cpu().numpy(), O.spmm(csr, X32)) < RTOL
+    # same pattern, new edge values
+    val2 = (val * rng.random(len(val))).astype(np.float32)
+    A2 = A.with_values(T(val2))
+    assert A2.blocked is not None and A2.blocked is not A.blocked
+    assert rel_err(ops.spmm(A2, T(X)).cpu().numpy(), O.spmm((rowptr, col, val2), X)) < RTOL
+    assert rel_err(ops.spmm(A, T(X)).cpu().numpy(), ref) < RTOL
+
+
+def test_spmm_blocked_rejects_bad_plans(ops):
+    import ctypes as C
+    from arlib_amd import _lib
+    rng = np.random.default_rng(0)
+    u, i = random_graph(rng, 200, 50, 5)
+    rowptr, col, w, val = make_csr(u, i, 200, 50)
+    A = ops.CSRGraph(rowptr, col, val, DEV)
+    with pytest.raises(ValueError):
+        A.enable_blocked(rows_per_wave=64)
+    A.enable_blocked(split=200)
+    st = A.blocked.structs[0]
+    X = torch.randn(250, 32, device=DEV); Y = torch.empty_like(X)
+    L = _lib.lib()
+    assert L.arl_spmm_blocked_f32(C.byref(st), X.data_ptr(), 32, 1.0, 0.0, None, None, Y.data_ptr(), None) == -2
+    X = torch.randn(250, 64, device=DEV)
+    assert L.arl_spmm_blocked_f32(C.byref(st), X.data_ptr(), 64, 1.0, 0.0, None, None, X.data_ptr(), None) == -4
+    bad = _lib.arl_blocked(st.n_waves, 48, st.wave_ptr, st.wave_rows, st.rec_col, st.rec_val)
+    Y = torch.empty_like(X)
+    assert L.arl_spmm_blocked_f32(C.byref(bad), X.data_ptr(), 64, 1.0, 0.0, None, None, Y.data_ptr(), None) == -4
+
+
 def test_spmm_deterministic_and_linear(ops):
     rng = np.random.default_rng(3)
     U, I, d = 5000, 900, 64

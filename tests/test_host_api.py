@@ -217,3 +217,29 @@ def test_native_sample_range_is_pythons(n, k):
     assert got.tolist() == want and random.random() == after
     with pytest.raises(ValueError):
         sample_range(3, 4)
+
+
+def test_lpt_deal_balances_and_respects_capacity():
+    """Plan helper of the register-blocked SpMM (include/arlib_amd.h: arl_lpt_deal): against a direct Python restatement."""
+    import ctypes as C, heapq
+    from arlib_amd import _lib
+    rng = np.random.default_rng(5)
+    L = _lib.lib()
+    for n, cap in ((1, 16), (100, 16), (1000, 32), (33, 32), (0, 32)):
+        w = np.sort(rng.integers(0, 500, n)).astype(np.int32)[::-1].copy()
+        n_bins = (n + cap - 1) // cap
+        b = np.full(max(n, 1), -1, np.int32); s = np.full(max(n, 1), -1, np.int32)
+        assert L.arl_lpt_deal(n, w.ctypes.data, n_bins, cap, b.ctypes.data, s.ctypes.data) == 0
+        heap = [(0, k) for k in range(n_bins)]; fill = [0] * n_bins
+        for r in range(n):
+            load, k = heapq.heappop(heap)
+            assert (b[r], s[r]) == (k, fill[k])
+            fill[k] += 1
+            if fill[k] < cap:
+                heapq.heappush(heap, (load + int(w[r]), k))
+        if n:
+            assert np.bincount(b[:n], minlength=n_bins).max() <= cap
+            assert len({(x, y) for x, y in zip(b[:n], s[:n])}) == n
+    w = np.array([1, 5], np.int32); b = np.zeros(2, np.int32); s = np.zeros(2, np.int32)
+    assert L.arl_lpt_deal(2, w.ctypes.data, 1, 16, b.ctypes.data, s.ctypes.data) == -4      # not sorted descending
+    assert L.arl_lpt_deal(40, w.ctypes.data, 1, 16, b.ctypes.data, s.ctypes.data) == -4     # does not fit
