@@ -79,7 +79,7 @@ class ShardedPropagationEngine:
     """Rank-local state + step() of the user-sharded LightGCN (mean of L+1 layers) + BPR/L2 + dense Adam."""
 
     def __init__(self, blocks, n_users, n_items, emb_size, n_layers, reg, lr, device, rank, world, table, chunk=512,
-                 comm=None, kernels=None, betas=(0.9, 0.999), eps=1e-8, skip_layer0=False):
+                 comm=None, kernels=None, betas=(0.9, 0.999), eps=1e-8, skip_layer0=False, schedule='auto'):
         if kernels is None:
             from . import ops as kernels         # the HIP kernels; fails loudly if libarlib_amd.so is missing
         self.k = kernels
@@ -98,6 +98,13 @@ class ShardedPropagationEngine:
         self.Au = kernels.CSRGraph(rp, col, val, self.device, chunk=chunk, n_cols=self.Nl)
         rp, col, val = blocks['Ai']
         self.Ai = kernels.CSRGraph(rp, col, val, self.device, chunk=chunk, n_cols=self.Nl)
+        # full hops of large shards at d = 64: register-blocked schedule (ops.BlockedPlan), as in engine.PropagationEngine
+        if schedule not in ('auto', 'csr', 'blocked'):
+            raise ValueError("schedule must be 'auto', 'csr' or 'blocked'")
+        if self.d == 64 and hasattr(self.Au, 'enable_blocked') and self.Nl < (1 << 24) and (
+                schedule == 'blocked' or (schedule == 'auto' and self.Au.nnz + self.Ai.nnz >= 6_000_000)):
+            mw = 0 if schedule == 'blocked' else 1024
+            self.Au.enable_blocked(min_waves=mw); self.Ai.enable_blocked(min_waves=mw)
         table = torch.as_tensor(table, dtype=torch.float32)
         if table.shape != (self.U + self.I, self.d):
             raise ValueError('table must be the full [U+I, d] initial table (every rank slices its own rows)')

@@ -97,12 +97,12 @@ class CSRGraph:
         self.dinv = None
         self.blocked = None
 
-    def enable_blocked(self, split=None, rows_per_wave=32, hub=1024, col_block=4096):
+    def enable_blocked(self, split=None, rows_per_wave=32, hub=1024, col_block=4096, min_waves=0):
         """Attach a register-blocked plan (BlockedPlan): full-table SpMMs at d = 64 then run through arl_spmm_blocked_*.
         `split` = number of users of a bipartite adjacency: user rows and item rows get separate launches (they gather from
         different tables).  Returns self."""
         sets = [(0, self.n_rows)] if not split or split >= self.n_rows else [(0, int(split)), (int(split), self.n_rows)]
-        self.blocked = BlockedPlan(self, sets, rows_per_wave, hub, col_block)
+        self.blocked = BlockedPlan(self, sets, rows_per_wave, hub, col_block, min_waves)
         return self
 
     def chunks_only(self, rows, chunk=None):
@@ -164,9 +164,10 @@ class BlockedPlan:
     Per row set (one launch each): rows with at most `hub` edges are sorted by edge count and dealt longest-first to the least
     loaded of ceil(n / rows_per_wave) waves (arl_lpt_deal), so that every wave carries the same number of edges; a wave's edges
     are sorted by (column block of `col_block` rows, slot) and padded to a multiple of 64 records.  Rows above `hub` edges stay
-    with the chunked CSR kernel (`self.hub`: a chunks_only view of the graph)."""
+    with the chunked CSR kernel (`self.hub`: a chunks_only view of the graph), and so does a whole row set that would fill fewer
+    than `min_waves` waves (too few streams to cover the memory latency: measured 3x slower at 311 waves)."""
 
-    def __init__(self, A, row_sets, rows_per_wave=32, hub=1024, col_block=4096):
+    def __init__(self, A, row_sets, rows_per_wave=32, hub=1024, col_block=4096, min_waves=0):
         if rows_per_wave not in (16, 32):
             raise ValueError('BlockedPlan: rows_per_wave must be 16 or 32')
         if A.n_cols >= 1 << 24:
@@ -184,6 +185,8 @@ class BlockedPlan:
             rp = rp_all[lo:hi + 1]
             deg = rp[1:] - rp[:-1]
             planned = deg <= self.hub_threshold
+            if (int(planned.sum()) + self.rpw - 1) // self.rpw < min_waves:
+                planned = torch.zeros_like(planned)
             hub_rows.append(lo + torch.nonzero(~planned).flatten())
             local = torch.nonzero(planned).flatten()
             n = local.numel()

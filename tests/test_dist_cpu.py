@@ -10,9 +10,9 @@ from conftest import rel_err, RTOL, ROOT
 from oracle import oracle as O
 
 
-def small_problem():
+def small_problem(d=16):
     from arlib_amd.util import synthetic as S
-    U, I, d, L, B = 600, 90, 16, 3, 256
+    U, I, L, B = 600, 90, 3, 256
     pairs = S.syn_v1_pairs(U, I, mean_deg=10, seed=7)
     rng = np.random.default_rng(1)
     E0 = ((rng.random((U + I, d)) * 2 - 1) * 0.1).astype(np.float32)

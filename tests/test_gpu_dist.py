@@ -33,15 +33,16 @@ class HostStagedComm:
         return self._Done()
 
 
-def _worker(rank, world, port, ret, sparse):
+def _worker(rank, world, port, ret, sparse, d=16, schedule='auto'):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import torch.distributed as dist
     from arlib_amd.dist_engine import ShardedPropagationEngine
     os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    U, I, d, L, pairs, E0, batches = small_problem()
-    eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cuda:0', rank, world, torch.from_numpy(E0), comm=HostStagedComm())
+    U, I, d, L, pairs, E0, batches = small_problem(d)
+    eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cuda:0', rank, world, torch.from_numpy(E0), comm=HostStagedComm(), schedule=schedule)
+    assert (eng.Au.blocked is not None) == (schedule == 'blocked')
     losses = []
     for u, p, n in batches:
         lo = (eng.step_sparse if sparse else eng.step)(torch.from_numpy(u).cuda(), torch.from_numpy(p).cuda(), torch.from_numpy(n).cuda())
@@ -52,17 +53,17 @@ def _worker(rank, world, port, ret, sparse):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('sparse', [False, True])
-def test_sharded_engine_two_ranks_hip_kernels(sparse):
+@pytest.mark.parametrize('sparse,d,schedule', [(False, 16, 'auto'), (True, 16, 'auto'), (True, 64, 'blocked'), (False, 64, 'blocked')])
+def test_sharded_engine_two_ranks_hip_kernels(sparse, d, schedule):
     if not torch.cuda.is_available():
         pytest.fail('GPU tests need a GPU')
-    U, I, d, L, pairs, E0, batches = small_problem()
+    U, I, d, L, pairs, E0, batches = small_problem(d)
     ref_table, ref_losses = oracle_run(U, I, d, L, pairs, E0, batches)
     ctx = mp.get_context('spawn')
     mgr = ctx.Manager()
     ret = mgr.dict()
     port = 29500 + os.getpid() % 2000
-    mp.spawn(_worker, args=(2, port, ret, sparse), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, ret, sparse, d, schedule), nprocs=2, join=True)
     assert np.allclose(ret['losses'], ref_losses, rtol=RTOL, atol=0)
     assert rel_err(ret['table'], ref_table) < RTOL
 

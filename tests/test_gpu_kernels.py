@@ -128,6 +128,19 @@ def test_spmm_blocked_schedule_all_epilogues(ops, rpw, split, hub):
     assert rel_err(ops.spmm(A, T(X)).cpu().numpy(), ref) < RTOL
 
 
+def test_spmm_blocked_small_row_set_stays_with_csr_kernel(ops):
+    """A row set that would fill fewer than min_waves waves is left to the chunked CSR kernel as a whole (BlockedPlan)."""
+    rng = np.random.default_rng(11)
+    U, I, d = 3001, 703, 64
+    u, i = random_graph(rng, U, I, 12, hot_items=2, hot_deg=2000, empty_users=(9,))
+    rowptr, col, w, val = make_csr(u, i, U, I)
+    A = ops.CSRGraph(rowptr, col, val, DEV).enable_blocked(split=U, min_waves=50)
+    assert len(A.blocked.sets) == 1 and A.blocked.sets[0]['n_rows'] == U and A.blocked.n_hub == I
+    X = rng.standard_normal((U + I, d)).astype(np.float32)
+    Z = rng.standard_normal((U + I, d)).astype(np.float32)
+    assert rel_err(ops.spmm(A, T(X), 0.5, -1.0, T(Z)).cpu().numpy(), O.spmm((rowptr, col, val), X, 0.5, -1.0, Z)) < RTOL
+
+
 def test_spmm_blocked_rejects_bad_plans(ops):
     import ctypes as C
     from arlib_amd import _lib
