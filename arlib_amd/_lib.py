@@ -24,7 +24,7 @@ class arl_csr(C.Structure):
 
 
 class arl_blocked(C.Structure):
-    _fields_ = [('n_waves', C.c_int64), ('rows_per_wave', C.c_int64), ('wave_ptr', C.c_void_p), ('wave_rows', C.c_void_p), ('rec_col', C.c_void_p),
+    _fields_ = [('n_waves', C.c_int64), ('rows_per_wave', C.c_int64), ('loads_in_flight', C.c_int64), ('wave_ptr', C.c_void_p), ('wave_rows', C.c_void_p), ('rec_col', C.c_void_p),
                 ('rec_val', C.c_void_p)]
 
 

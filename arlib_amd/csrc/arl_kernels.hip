@@ -518,7 +518,7 @@ __device__ __forceinline__ void spmm_epilogue1(const Epi &ep, int row, int c, fl
     }
 }
 
-template <int RPW, int MODE>
+template <int RPW, int MODE, int UNR>
 __global__ __launch_bounds__(kBlock) void spmm_blocked64_kernel(BlockedDev P, const float *__restrict__ X, Epi ep) {
     static_assert(RPW == 16 || RPW == 32, "accumulators are one 32-register vector");
     const int lane = threadIdx.x & 63;
@@ -535,15 +535,15 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked64_kernel(BlockedDev P, co
         const int c_cur = rc; const float v_cur = rv;
         if (base + 64 < end) { rc = P.rec_col[base + 64 + lane]; rv = P.rec_val[base + 64 + lane]; }       // next batch in flight
 #pragma unroll
-        for (int j = 0; j < 64; j += 16) {
-            float x[16]; int cs[16];
+        for (int j = 0; j < 64; j += UNR) {
+            float x[UNR]; int cs[UNR];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
+            for (int t = 0; t < UNR; ++t) {
                 cs[t] = __builtin_amdgcn_readlane(c_cur, j + t);
                 x[t] = xl[(size_t)(cs[t] & 0xffffff) * 64];
             }
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
+            for (int t = 0; t < UNR; ++t) {
                 const float v = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v_cur), j + t));
                 const int slot = ((unsigned)cs[t] >> 24) & 31;
                 acc[slot] = fmaf(v, x[t], acc[slot]);
@@ -567,8 +567,10 @@ int launch_spmm_blocked(const arl_blocked *P, const float *X, int64_t d, const E
     if (!P->wave_ptr || !P->wave_rows || !P->rec_col || !P->rec_val) return ARL_E_NULL;
     BlockedDev D = {(int)P->n_waves, P->wave_ptr, P->wave_rows, P->rec_col, P->rec_val};
     const dim3 grid((unsigned)((P->n_waves + kWavesPerBlock - 1) / kWavesPerBlock));
-    if (P->rows_per_wave == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<16, MODE>), grid, dim3(kBlock), 0, st, D, X, ep);
-    else hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE>), grid, dim3(kBlock), 0, st, D, X, ep);
+    if (P->loads_in_flight != 16 && P->loads_in_flight != 32) return ARL_E_ARG;
+    if (P->rows_per_wave == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<16, MODE, 16>), grid, dim3(kBlock), 0, st, D, X, ep);
+    else if (P->loads_in_flight == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE, 16>), grid, dim3(kBlock), 0, st, D, X, ep);
+    else hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE, 32>), grid, dim3(kBlock), 0, st, D, X, ep);
     ARL_LAUNCH_CHECK();
     return ARL_OK;
 }

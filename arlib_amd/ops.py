@@ -97,12 +97,12 @@ class CSRGraph:
         self.dinv = None
         self.blocked = None
 
-    def enable_blocked(self, split=None, rows_per_wave=32, hub=1024, col_block=4096, min_waves=0):
+    def enable_blocked(self, split=None, rows_per_wave=32, hub=1024, col_block=1024, min_waves=0, unroll=None):
         """Attach a register-blocked plan (BlockedPlan): full-table SpMMs at d = 64 then run through arl_spmm_blocked_*.
         `split` = number of users of a bipartite adjacency: user rows and item rows get separate launches (they gather from
         different tables).  Returns self."""
         sets = [(0, self.n_rows)] if not split or split >= self.n_rows else [(0, int(split)), (int(split), self.n_rows)]
-        self.blocked = BlockedPlan(self, sets, rows_per_wave, hub, col_block, min_waves)
+        self.blocked = BlockedPlan(self, sets, rows_per_wave, hub, col_block, min_waves, unroll)
         return self
 
     def chunks_only(self, rows, chunk=None):
@@ -167,7 +167,7 @@ class BlockedPlan:
     with the chunked CSR kernel (`self.hub`: a chunks_only view of the graph), and so does a whole row set that would fill fewer
     than `min_waves` waves (too few streams to cover the memory latency: measured 3x slower at 311 waves)."""
 
-    def __init__(self, A, row_sets, rows_per_wave=32, hub=1024, col_block=4096, min_waves=0):
+    def __init__(self, A, row_sets, rows_per_wave=32, hub=1024, col_block=1024, min_waves=0, unroll=None):
         if rows_per_wave not in (16, 32):
             raise ValueError('BlockedPlan: rows_per_wave must be 16 or 32')
         if A.n_cols >= 1 << 24:
@@ -226,7 +226,9 @@ class BlockedPlan:
             rec_col[dst] = (ec | (es << 24)).to(torch.int32)
             rec_src[dst] = eid
             self.sets.append({'n_waves': n_waves, 'wave_ptr': wave_ptr.to(torch.int32), 'wave_rows': wave_rows, 'rec_col': rec_col, 'rec_src': rec_src,
-                              'n_rows': n, 'n_edges': int(ew.numel())})
+                              'n_rows': n, 'n_edges': int(ew.numel()),
+                              # short streams: more loads per wave; long streams (many edges per wave) run better with 16 (measured, cfg2)
+                              'unroll': (16 if self.rpw == 16 or ew.numel() > 4096 * n_waves else 32) if unroll is None else int(unroll)})
         hub_rows = torch.cat(hub_rows) if hub_rows else torch.zeros(0, dtype=torch.int64, device=dev)
         self.n_hub = int(hub_rows.numel())
         self._hub_rows = hub_rows
@@ -237,7 +239,7 @@ class BlockedPlan:
         self.structs = []
         for st in self.sets:
             st['rec_val'] = vz[st['rec_src']]
-            self.structs.append(_lib.arl_blocked(st['n_waves'], self.rpw, st['wave_ptr'].data_ptr(), st['wave_rows'].data_ptr(), st['rec_col'].data_ptr(),
+            self.structs.append(_lib.arl_blocked(st['n_waves'], self.rpw, st['unroll'], st['wave_ptr'].data_ptr(), st['wave_rows'].data_ptr(), st['rec_col'].data_ptr(),
                                                  st['rec_val'].data_ptr()))
         self.hub = A.chunks_only(self._hub_rows) if self.n_hub else None
 

@@ -331,7 +331,8 @@ def main():
         parallelism = 'single'
     else:
         from arlib_amd import dist_engine
-        eng = dist_engine.ShardedPropagationEngine.from_pairs(data.pairs0, U, I, d, L, 1e-4, 0.005, dev, rank, world, table=E0, chunk=args.chunk)
+        eng = dist_engine.ShardedPropagationEngine.from_pairs(data.pairs0, U, I, d, L, 1e-4, 0.005, dev, rank, world, table=E0, chunk=args.chunk,
+                                                               schedule=args.schedule)
         step = (lambda k: eng.step(dev_batches[k, 0], dev_batches[k, 1], dev_batches[k, 2])) if args.dense_step else \
                (lambda k: eng.step_sparse(dev_batches[k, 0], dev_batches[k, 1], dev_batches[k, 2]))
         import torch.distributed as dist

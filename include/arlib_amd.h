@@ -138,6 +138,7 @@ int arl_zero_rows_f32(float *dst, const int32_t *idx, int64_t n, int64_t d, arl_
  * Summation order differs from the CSR kernel: results agree to fp32 rounding, not bitwise; each is deterministic. */
 typedef struct arl_blocked {
     int64_t n_waves, rows_per_wave;
+    int64_t loads_in_flight;    /* 16 or 32 operand rows requested per wave before the first is consumed            */
     const int32_t *wave_ptr;    /* [n_waves + 1] record offsets, multiples of 64                          */
     const int32_t *wave_rows;   /* [n_waves][rows_per_wave] output row id, -1 = unused slot               */
     const int32_t *rec_col;     /* column | slot << 24 (columns < 2^24); padding records have val 0       */

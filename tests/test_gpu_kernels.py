@@ -157,7 +157,7 @@ def test_spmm_blocked_rejects_bad_plans(ops):
     assert L.arl_spmm_blocked_f32(C.byref(st), X.data_ptr(), 32, 1.0, 0.0, None, None, Y.data_ptr(), None) == -2
     X = torch.randn(250, 64, device=DEV)
     assert L.arl_spmm_blocked_f32(C.byref(st), X.data_ptr(), 64, 1.0, 0.0, None, None, X.data_ptr(), None) == -4
-    bad = _lib.arl_blocked(st.n_waves, 48, st.wave_ptr, st.wave_rows, st.rec_col, st.rec_val)
+    bad = _lib.arl_blocked(st.n_waves, 48, 16, st.wave_ptr, st.wave_rows, st.rec_col, st.rec_val)
     Y = torch.empty_like(X)
     assert L.arl_spmm_blocked_f32(C.byref(bad), X.data_ptr(), 64, 1.0, 0.0, None, None, Y.data_ptr(), None) == -4
 

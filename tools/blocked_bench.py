@@ -8,7 +8,8 @@ from arlib_amd import ops
 from arlib_amd.util import synthetic
 
 U, I, d = int(os.environ.get('U', 1_000_000)), int(os.environ.get('I', 100_000)), 64
-RPW, HUB, UB = int(os.environ.get('RPW', 32)), int(os.environ.get('HUB', 1024)), int(os.environ.get('UB', 4096))
+RPW, HUB, UB = int(os.environ.get('RPW', 32)), int(os.environ.get('HUB', 1024)), int(os.environ.get('UB', 1024))
+UNR = int(os.environ['UNR']) if os.environ.get('UNR') else None
 dev = 'cuda:0'
 data = synthetic.syn_v1(U, I)
 import numpy as np
@@ -32,7 +33,7 @@ def t(fn, n=10):
 
 print('CSR hop (row-per-group + chunked long rows): %.3f ms' % t(lambda: ops.spmm(A, X, out=Yr)))
 torch.cuda.synchronize(); t0 = time.perf_counter()
-A.enable_blocked(split=U, rows_per_wave=RPW, hub=HUB, col_block=UB)
+A.enable_blocked(split=U, rows_per_wave=RPW, hub=HUB, col_block=UB, unroll=UNR)
 torch.cuda.synchronize()
 bp = A.blocked
 print('plan built in %.2f s: %s; %d hub rows' % (time.perf_counter() - t0, ', '.join('%d rows / %d waves / %d edges' % (s['n_rows'], s['n_waves'], s['n_edges']) for s in bp.sets),
