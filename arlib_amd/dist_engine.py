@@ -101,10 +101,8 @@ class ShardedPropagationEngine:
         # full hops of large shards at d = 64: register-blocked schedule (ops.BlockedPlan), as in engine.PropagationEngine
         if schedule not in ('auto', 'csr', 'blocked'):
             raise ValueError("schedule must be 'auto', 'csr' or 'blocked'")
-        if self.d == 64 and hasattr(self.Au, 'enable_blocked') and self.Nl < (1 << 24) and (
-                schedule == 'blocked' or (schedule == 'auto' and self.Au.nnz + self.Ai.nnz >= 6_000_000)):
-            mw = 0 if schedule == 'blocked' else 1024
-            self.Au.enable_blocked(min_waves=mw); self.Ai.enable_blocked(min_waves=mw)
+        if schedule != 'csr' and hasattr(kernels, 'auto_blocked') and (schedule == 'blocked' or self.Au.nnz + self.Ai.nnz >= kernels.BLOCKED_MIN_NNZ):
+            kernels.auto_blocked(self.Au, self.d, force=True); kernels.auto_blocked(self.Ai, self.d, force=True)
         table = torch.as_tensor(table, dtype=torch.float32)
         if table.shape != (self.U + self.I, self.d):
             raise ValueError('table must be the full [U+I, d] initial table (every rank slices its own rows)')

@@ -20,9 +20,6 @@ from . import ops
 
 
 class PropagationEngine:
-    BLOCKED_MIN_NNZ = 6_000_000      # measured cross-over (tools/blocked_bench.py): 8M edges 0.284 -> 0.238 ms, 3.4M edges 0.141 -> 0.167 ms
-    BLOCKED_MIN_WAVES = 1024         # a row set with fewer waves stays with the CSR kernel
-
     def __init__(self, graph, n_users, n_items, emb_size, n_layers, reg, lr, device, skip_layer0=False,
                  optimizer='adam', betas=(0.9, 0.999), eps=1e-8, table=None, schedule='auto'):
         self.A = graph
@@ -43,9 +40,8 @@ class PropagationEngine:
         if schedule not in ('auto', 'csr', 'blocked'):
             raise ValueError("schedule must be 'auto', 'csr' or 'blocked'")
         # full-table hops: register-blocked schedule (ops.BlockedPlan) for large graphs at d = 64, row-per-group CSR kernel otherwise
-        if graph is not None and graph.blocked is None and int(emb_size) == 64 and graph.n_cols < (1 << 24) and (
-                schedule == 'blocked' or (schedule == 'auto' and graph.nnz >= self.BLOCKED_MIN_NNZ)):
-            graph.enable_blocked(split=self.U, min_waves=0 if schedule == 'blocked' else self.BLOCKED_MIN_WAVES)
+        if schedule != 'csr':
+            ops.auto_blocked(graph, emb_size, split=self.U, force=(schedule == 'blocked'))
         z = lambda: torch.zeros(self.N, self.d, dtype=torch.float32, device=self.device)
         self.E0 = z() if table is None else table
         if self.E0.shape != (self.N, self.d) or self.E0.dtype != torch.float32 or not self.E0.is_contiguous():

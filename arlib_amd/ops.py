@@ -234,22 +234,39 @@ class BlockedPlan:
         self._hub_rows = hub_rows
         self._bind(A)
 
-    def _bind(self, A):
+    def _bind(self, A, hub=None):
         vz = torch.cat([A.val, torch.zeros(1, dtype=torch.float32, device=A.device)])
         self.structs = []
         for st in self.sets:
             st['rec_val'] = vz[st['rec_src']]
             self.structs.append(_lib.arl_blocked(st['n_waves'], self.rpw, st['unroll'], st['wave_ptr'].data_ptr(), st['wave_rows'].data_ptr(), st['rec_col'].data_ptr(),
                                                  st['rec_val'].data_ptr()))
-        self.hub = A.chunks_only(self._hub_rows) if self.n_hub else None
+        if hub is not None:                       # same chunk plan, new values (no host work)
+            self.hub = hub.with_values(A.val)
+        else:
+            self.hub = A.chunks_only(self._hub_rows) if self.n_hub else None
 
     def with_values(self, A):
         """The same plan over a graph with the same pattern and new edge values."""
         p = object.__new__(BlockedPlan)
         p.__dict__.update(self.__dict__)
         p.sets = [dict(st) for st in self.sets]
-        p._bind(A)
+        p._bind(A, self.hub)
         return p
+
+
+BLOCKED_MIN_NNZ = 6_000_000      # measured cross-over (tools/blocked_bench.py): 8M edges 0.284 -> 0.238 ms, 3.4M edges 0.141 -> 0.167 ms
+BLOCKED_MIN_WAVES = 1024         # a row set with fewer waves stays with the CSR kernel
+
+
+def auto_blocked(graph, d, split=None, force=False):
+    """Attach the register-blocked plan to `graph` when it pays (d = 64, >= BLOCKED_MIN_NNZ edges) or when forced; no-op if the
+    graph already has one or cannot take one (d != 64, 2^24 columns or more).  Returns the graph."""
+    if graph is None or graph.blocked is not None or int(d) != 64 or graph.n_cols >= (1 << 24):
+        return graph
+    if force or graph.nnz >= BLOCKED_MIN_NNZ:
+        graph.enable_blocked(split=split, min_waves=0 if force else BLOCKED_MIN_WAVES)
+    return graph
 
 
 def _spmm_dispatch(A, d, blocked_call, csr_call):

@@ -98,7 +98,7 @@ class SGL_Encoder(GraphEncoder):
         key = np.sort(u * mat.shape[1] + i)                                   # csr_matrix((1, (u, i))) order
         ut = torch.from_numpy(key // mat.shape[1]).to(DEVICE)
         it = torch.from_numpy(key % mat.shape[1]).to(DEVICE)
-        return ops.bipartite_graph(ut, it, self.data.user_num, self.data.item_num)
+        return ops.auto_blocked(ops.bipartite_graph(ut, it, self.data.user_num, self.data.item_num), self.latent_size, split=self.data.user_num)
 
     def forward(self, perturbed_adj=None):
         if perturbed_adj is None:

@@ -182,7 +182,7 @@ class GraphEncoder(nn.Module):
     def _graph(self):
         if self.n_prop_layers == 0:
             return None
-        return self.sparse_norm_adj.graph()
+        return ops.auto_blocked(self.sparse_norm_adj.graph(), self.latent_size, split=self.data.user_num)
 
     def _engine(self, reg=0.0, lr=0.0, optimizer='adam'):
         base = self._pack()
