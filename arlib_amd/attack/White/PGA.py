@@ -24,7 +24,7 @@ class FakeBlockGraph:
     """Device CSR of the (U'+I)^2 adjacency (U' = U + F) whose F fake-user rows (and the matching F columns of every item
     row) are dense, so the fake block S [F, I] maps to two fixed index sets of the edge-weight array."""
 
-    def __init__(self, ui_real, n_real, n_fake, n_items, device=DEVICE):
+    def __init__(self, ui_real, n_real, n_fake, n_items, device=DEVICE, emb_size=None):
         U, F, I = int(n_real), int(n_fake), int(n_items)
         Up = U + F
         R = sp.csr_matrix(ui_real, dtype=np.float32)[:U]
@@ -54,6 +54,8 @@ class FakeBlockGraph:
         self.fwd_lo = fb
         self.bwd_idx = torch.from_numpy(fake_pos.reshape(-1)).to(self.device)
         self.graph = ops.CSRGraph(rowptr, self.col_d, torch.zeros(nnz, device=self.device), self.device)
+        if emb_size is not None:            # the pattern never changes: large graphs get the register-blocked hop plan once (the fake rows are its hub rows)
+            ops.auto_blocked(self.graph, emb_size, split=Up)
         self.fake_rows = torch.arange(U, Up, dtype=torch.int32, device=self.device)
         self.dinv = None
 
@@ -209,7 +211,7 @@ class PGA(AttackBase):
         recommender = deepcopy(originRecommender)
         optimizer = torch.optim.Adam(recommender.model.parameters(), lr=recommender.args.lRate / 10)
         real = sp.csr_matrix(newAdj[:U])
-        fg = FakeBlockGraph(real, U, F, I)
+        fg = FakeBlockGraph(real, U, F, I, emb_size=getattr(recommender.model, 'latent_size', None))
         L = getattr(recommender.model, 'n_prop_layers', 0)
         for epoch in range(self.outerEpoch):
             # outer optimisation: victim retrain on the current poisoned graph

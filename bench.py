@@ -151,7 +151,7 @@ def attack_leg(torch, ops, data, E0_dev, args):
     deg_i = np.bincount(data.pairs0[:, 1], minlength=I)
     targets = [int(t) for t in np.argsort(deg_i, kind='stable')[:5]]
     popular = np.argsort(-deg_i, kind='stable')[:int(0.05 * I)]
-    fg = FakeBlockGraph(real, U, F, I, device=E0_dev.device)
+    fg = FakeBlockGraph(real, U, F, I, device=E0_dev.device, emb_size=None if args.schedule == 'csr' else d)
     del real
     S = torch.zeros(F, I, device=E0_dev.device)
     S[:, targets] = 1.0

@@ -70,6 +70,30 @@ def test_pga_gradient_steps_match_reference_trace():
         assert rel_err(S.cpu().numpy(), g['pga_S'][s + 1]) < 1e-6, s
 
 
+def test_pga_step_on_blocked_hop_schedule_equals_csr_schedule():
+    """FakeBlockGraph with the register-blocked hop plan (fake-user rows = hub rows of the plan, values re-bound per step) gives the
+    same PGA block gradient and loss as the CSR schedule (d = 64)."""
+    from arlib_amd import ops
+    from arlib_amd.attack.White.PGA import FakeBlockGraph, cw_operator, pga_step_block
+    rng = np.random.default_rng(4)
+    U, I, F, L, d = 1500, 400, 4, 2, 64
+    real = sp.random(U, I, density=0.03, random_state=5, format='csr', dtype=np.float32)
+    real.data[:] = 1.0
+    fa, fb = FakeBlockGraph(real, U, F, I), FakeBlockGraph(real, U, F, I)
+    fb.graph.enable_blocked(split=U + F, hub=200)
+    assert fb.graph.blocked.n_hub >= F
+    E0 = T((rng.standard_normal((U + F + I, d)) * 0.1).astype(np.float32))
+    users = torch.from_numpy(rng.integers(0, U, 300)).to(DEV); pos = torch.from_numpy(rng.integers(0, I, 300)).to(DEV); neg = torch.from_numpy(rng.integers(0, I, 300)).to(DEV)
+    M = cw_operator(U + F + I, U + F, users, pos, neg, device=E0.device)
+    for step in range(2):
+        S = T(rng.random((F, I)).astype(np.float32) * (rng.random((F, I)) < 0.3))
+        ga, gb = fa.set_block(S), fb.set_block(S)
+        assert gb.blocked is not None and ga.blocked is None
+        ba, la = pga_step_block(ga, fa.fake_rows, U + F, I, E0, L, M)
+        bb, lb = pga_step_block(gb, fb.fake_rows, U + F, I, E0, L, M)
+        assert rel_err(bb.cpu().numpy(), ba.cpu().numpy()) < RTOL and abs(la.item() - lb.item()) <= RTOL * abs(la.item())
+
+
 def test_dlattack_masked_topk_and_project_match_reference_trace():
     from arlib_amd.attack.White.DLAttack import masked_topk, DLAttack
     g = golden('g7_attacks.npz')
