@@ -11,15 +11,18 @@ T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 bad = 0
 for case in range(n_cases):
-    d = int(rng.choice([4, 8, 32, 64, 128, 256])); L = int(rng.integers(1, 5))
+    d = 64 if rng.random() < 0.5 else int(rng.choice([4, 8, 32, 64, 128, 256])); L = int(rng.integers(1, 5))
     U, I = int(rng.integers(5, 3000)), int(rng.integers(3, 600)); B = int(rng.integers(1, 1500))
     deg = np.clip(rng.poisson(rng.choice([2, 8, 40]), U), 1, I)
     us = np.repeat(np.arange(U), deg); its = np.floor(I * rng.random(len(us)) ** 2).astype(np.int64)
     key = np.unique(us * I + its); us, its = key // I, key % I
     g = ops.bipartite_graph(T(us), T(its), U, I)
+    g2 = ops.bipartite_graph(T(us), T(its), U, I)            # sparse step on the register-blocked hop schedule (d = 64), dense step on the CSR kernels
+    if rng.random() < 0.7:
+        g2.enable_blocked(split=U, rows_per_wave=int(rng.choice([16, 32])), hub=int(rng.choice([5, 50, 100000])), col_block=int(rng.choice([16, 1024])))
     E0 = T(((rng.random((U + I, d)) * 2 - 1) * 0.1).astype(np.float32))
-    ea = engine.PropagationEngine(g, U, I, d, L, 1e-4, 0.005, dev, table=E0.clone())
-    eb = engine.PropagationEngine(g, U, I, d, L, 1e-4, 0.005, dev, table=E0.clone())
+    ea = engine.PropagationEngine(g2, U, I, d, L, 1e-4, 0.005, dev, table=E0.clone(), schedule='csr')
+    eb = engine.PropagationEngine(g, U, I, d, L, 1e-4, 0.005, dev, table=E0.clone(), schedule='csr')
     ok = True
     for k in range(3):
         sel = rng.integers(0, len(us), B)

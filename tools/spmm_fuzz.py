@@ -1,4 +1,5 @@
-"""Randomised cross-check of the SpMM family (plain/AXPBY, layer-sum, Adam epilogue, flag-masked, row-subset; square and
+"""Randomised cross-check of the SpMM family (plain/AXPBY, layer-sum, Adam epilogue, flag-masked, row-subset; CSR and register-blocked
+schedules with random plan parameters; square and
 rectangular CSR; empty rows; rows far longer than the chunk size; d = 4..256) against float64 torch on many small random cases.
     python3 tools/spmm_fuzz.py [n_cases]"""
 import os, sys
@@ -12,7 +13,7 @@ T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 bad = 0
 for case in range(n_cases):
-    d = int(rng.choice([4, 8, 16, 24, 32, 64, 100, 128, 256]))
+    d = 64 if rng.random() < 0.4 else int(rng.choice([4, 8, 16, 24, 32, 64, 100, 128, 256]))
     n_rows = int(rng.integers(1, 3000)); n_cols = n_rows if rng.random() < 0.5 else int(rng.integers(1, 3000))
     chunk = int(rng.choice([32, 64, 512]))
     deg = rng.poisson(rng.choice([0.5, 4, 30]), n_rows)
@@ -24,6 +25,12 @@ for case in range(n_cases):
     col = rng.integers(0, n_cols, max(nnz, 1)).astype(np.int32)[:nnz] if nnz else np.zeros(0, np.int32)      # duplicates allowed
     val = rng.standard_normal(nnz).astype(np.float32)
     A = ops.CSRGraph(rowptr, col if nnz else np.zeros(0, np.int32), val if nnz else np.zeros(0, np.float32), dev, chunk=chunk, n_cols=n_cols)
+    sched = 'csr'
+    if rng.random() < 0.6:           # register-blocked hop schedule (only taken at d = 64) with random plan parameters
+        kw = dict(split=int(rng.integers(0, n_rows + 1)) if rng.random() < 0.5 else None, rows_per_wave=int(rng.choice([16, 32])), hub=int(rng.choice([3, 40, 100000])),
+                  col_block=int(rng.choice([1, 64, 4096])), min_waves=int(rng.choice([0, 0, 8])), unroll=[None, 16, 32][int(rng.integers(0, 3))])
+        A.enable_blocked(**kw)
+        sched = 'blocked %s' % kw
     Ad = torch.zeros(n_rows, n_cols, dtype=torch.float64, device=dev)
     if nnz:
         Ad.index_put_((T(np.repeat(np.arange(n_rows), deg)), T(col.astype(np.int64))), T(val.astype(np.float64)), accumulate=True)
@@ -64,6 +71,6 @@ for case in range(n_cases):
     worst = max(errs.values())
     if not worst < 2e-5:
         bad += 1
-        print('MISMATCH case %d: rows=%d cols=%d d=%d chunk=%d nnz=%d -> %s' % (case, n_rows, n_cols, d, chunk, nnz, {k: '%.2e' % v for k, v in errs.items()}), flush=True)
+        print('MISMATCH case %d: rows=%d cols=%d d=%d chunk=%d nnz=%d %s -> %s' % (case, n_rows, n_cols, d, chunk, nnz, sched, {k: '%.2e' % v for k, v in errs.items()}), flush=True)
 print('%d cases: %d mismatches' % (n_cases, bad))
 sys.exit(1 if bad else 0)
