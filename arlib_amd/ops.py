@@ -221,8 +221,8 @@ class BlockedPlan:
                 raise ValueError('BlockedPlan: too many records for int32 offsets')
             start = torch.zeros(n_waves + 1, dtype=torch.int64, device=dev); torch.cumsum(cnt, 0, out=start[1:])
             dst = wave_ptr[ew] + (torch.arange(ew.numel(), device=dev) - start[ew])
-            rec_col = torch.zeros(total, dtype=torch.int32, device=dev)
-            rec_src = torch.full((total,), A.nnz, dtype=torch.int64, device=dev)       # padding -> the appended zero
+            rec_col = torch.zeros(max(total, 64), dtype=torch.int32, device=dev)        # never empty: the C ABI wants real pointers
+            rec_src = torch.full((max(total, 64),), A.nnz, dtype=torch.int64, device=dev)       # padding -> the appended zero
             rec_col[dst] = (ec | (es << 24)).to(torch.int32)
             rec_src[dst] = eid
             self.sets.append({'n_waves': n_waves, 'wave_ptr': wave_ptr.to(torch.int32), 'wave_rows': wave_rows, 'rec_col': rec_col, 'rec_src': rec_src,

@@ -141,6 +141,15 @@ def test_spmm_blocked_small_row_set_stays_with_csr_kernel(ops):
     assert rel_err(ops.spmm(A, T(X), 0.5, -1.0, T(Z)).cpu().numpy(), O.spmm((rowptr, col, val), X, 0.5, -1.0, Z)) < RTOL
 
 
+def test_spmm_blocked_graph_without_edges(ops):
+    """All rows empty: the blocked plan has waves but no records; epilogues still run on every row."""
+    n, d = 100, 64
+    A = ops.CSRGraph(np.zeros(n + 1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32), DEV).enable_blocked(split=60)
+    X = torch.randn(n, d, device=DEV); Z = torch.randn(n, d, device=DEV)
+    assert torch.equal(ops.spmm(A, X, 2.0, -0.5, Z), -0.5 * Z)
+    assert float(ops.spmm(A, X).abs().max()) == 0.0
+
+
 def test_spmm_blocked_rejects_bad_plans(ops):
     import ctypes as C
     from arlib_amd import _lib
