@@ -50,6 +50,7 @@ class FakeBlockGraph:
         self.device = torch.device(device)
         self.rowptr_d = torch.from_numpy(rowptr.astype(np.int32)).to(self.device)
         self.col_d = torch.from_numpy(col).to(self.device)
+        self.erow_d = torch.repeat_interleave(torch.arange(Up + I, dtype=torch.int32, device=self.device), (self.rowptr_d[1:] - self.rowptr_d[:-1]).long(), output_size=nnz)
         self.w = torch.from_numpy(w).to(self.device)
         self.fwd_lo = fb
         self.bwd_idx = torch.from_numpy(fake_pos.reshape(-1)).to(self.device)
@@ -64,7 +65,7 @@ class FakeBlockGraph:
         flat = S.reshape(-1)
         self.w[self.fwd_lo:self.fwd_lo + flat.numel()] = flat
         self.w[self.bwd_idx] = flat
-        val, self.dinv = ops.norm_adj_values(self.rowptr_d, self.col_d, self.w, self.N)
+        val, self.dinv = ops.norm_adj_values(self.rowptr_d, self.col_d, self.w, self.N, erow=self.erow_d)
         self.graph = self.graph.with_values(val)
         return self.graph
 

@@ -282,13 +282,21 @@ def _spmm_dispatch(A, d, blocked_call, csr_call):
         csr_call(C.byref(bp.hub._struct(d)))
 
 
-def norm_adj_values(rowptr, col, w, n_rows):
-    """val[e] = (dinv[row]*w[e])*dinv[col[e]] on device; returns (val, dinv)."""
+def norm_adj_values(rowptr, col, w, n_rows, erow=None):
+    """val[e] = (dinv[row]*w[e])*dinv[col[e]] on device; returns (val, dinv).  `erow` (int32 row id per edge, optional) selects the
+    edge-parallel form for callers that re-normalise the same pattern many times (PGA)."""
     _dev(rowptr, torch.int32, 'rowptr', 1); _dev(col, torch.int32, 'col', 1); _dev(w, torch.float32, 'w', 1)
     if rowptr.numel() != n_rows + 1 or col.numel() != w.numel():
         raise ValueError('norm_adj_values: shape mismatch')
     dinv = torch.empty(n_rows, dtype=torch.float32, device=w.device)
     val = torch.empty_like(w)
+    if erow is not None:
+        _dev(erow, torch.int32, 'erow', 1)
+        if erow.numel() != w.numel():
+            raise ValueError('norm_adj_values: erow length')
+        check(_lib.lib().arl_norm_adj_values_coo_f32(n_rows, _ptr(rowptr), _ptr(erow), _ptr(col), _ptr(w), w.numel(), _ptr(dinv), _ptr(val), _stream()),
+              'arl_norm_adj_values_coo_f32')
+        return val, dinv
     check(_lib.lib().arl_norm_adj_values_f32(n_rows, _ptr(rowptr), _ptr(col), _ptr(w), _ptr(dinv), _ptr(val), _stream()), 'arl_norm_adj_values_f32')
     return val, dinv
 

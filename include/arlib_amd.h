@@ -88,6 +88,10 @@ typedef struct arl_csr {
  * (0 for an empty row).  dinv: [n_rows] device workspace (kept: PGA re-uses it, attack/White/PGA.py:118-126). */
 int arl_norm_adj_values_f32(int64_t n_rows, const int32_t *rowptr, const int32_t *col, const float *w,
                             float *dinv, float *val, arl_stream_t stream);
+/* Same result for callers that keep the row id of every edge (erow[e], CSR order): the edge values are computed edge-parallel
+ * (no wave per row).  All arrays 16-byte aligned. */
+int arl_norm_adj_values_coo_f32(int64_t n_rows, const int32_t *rowptr, const int32_t *erow, const int32_t *col,
+                                const float *w, int64_t nnz, float *dinv, float *val, arl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SpMM family -- replaces torch.sparse.mm(sparse_norm_adj, ego) and its autograd
