@@ -535,6 +535,80 @@ def gen_attacks():
         undo_shim()
     save('g7_attacks.npz', **out)
 
+# --------------------------------------------------------------------------- BiLevelAttackBatch: CW step, relaxProject
+def gen_bilevel():
+    import io, contextlib
+    from copy import deepcopy
+    import recommender.LightGCN as RL
+    from attack.White.BiLevelAttackBatch import BiLevelAttackBatch
+    os.makedirs('data/clean/ml-100k', exist_ok=True)
+    undo_shim = _scipy_torch_index_shim()
+    rargs = rec_args(emb_size=16, n_layers=2, maxEpoch=1)
+    seedSet(2018)
+    data = DataLoader(rargs)
+    rec = LightGCN(rargs, data)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rec.train(Epoch=1, evalNum=5)
+    atk = BiLevelAttackBatch(_attack_args(attackModelName='BiLevelAttackBatch', maliciousUserSize=3, Epoch=2, outerEpoch=2, innerEpoch=1), data)
+    trace, cap, relax = {}, {}, []
+    orig_init = RL.LGCN_Encoder._init_uiAdj
+    orig_backward, orig_adam_step = torch.Tensor.backward, torch.optim.Adam.step
+    orig_relax = BiLevelAttackBatch.relaxProject
+
+    def init_wrap(self, ui_adj):
+        trace.setdefault('init', []).append((sp.csr_matrix(ui_adj).copy(), self.embedding_dict['user_emb'].detach().numpy().copy(),
+                                             self.embedding_dict['item_emb'].detach().numpy().copy()))
+        return orig_init(self, ui_adj)
+
+    def backward_wrap(self, *a, **k):
+        if 'loss' not in cap and self.dim() == 0 and len(trace.get('init', [])) > 0:
+            cap['loss'] = float(self.item())
+        return orig_backward(self, *a, **k)
+
+    def adam_step_wrap(self, *a, **k):
+        if 'grads' not in cap and 'loss' in cap:
+            ps = self.param_groups[0]['params']
+            cap['grads'] = [p.grad.detach().numpy().copy() for p in ps]
+            cap['n_init'] = len(trace['init'])
+        return orig_adam_step(self, *a, **k)
+
+    def relax_wrap(self, mat, n):
+        st = random.getstate()
+        inp = np.asarray(mat[:, :].todense(), np.float32).copy()
+        m, ind = orig_relax(self, mat, n)
+        relax.append((inp, int(n), np.array(st[1], np.int64), np.asarray(m[:, :].todense(), np.float32).copy(), ind.numpy().copy(),
+                      np.array(random.getstate()[1], np.int64)))
+        return m, ind
+    RL.LGCN_Encoder._init_uiAdj = init_wrap
+    torch.Tensor.backward, torch.optim.Adam.step = backward_wrap, adam_step_wrap
+    BiLevelAttackBatch.relaxProject = relax_wrap
+    out = {}
+    try:
+        random.seed(777)
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = atk.posionDataAttack(deepcopy(rec))
+    finally:
+        RL.LGCN_Encoder._init_uiAdj = orig_init
+        torch.Tensor.backward, torch.optim.Adam.step = orig_backward, orig_adam_step
+        BiLevelAttackBatch.relaxProject = orig_relax
+        undo_shim()
+    U, I, F = atk.userNum, atk.itemNum, atk.fakeUserNum
+    adj, utab, itab = trace['init'][cap['n_init'] - 1]
+    blk = adj[:U + F, U + F:]
+    out['bl_sizes'] = np.array([U, I, F, rargs.n_layers, rargs.emb_size, atk.maliciousFeedbackNum, atk.Epoch], np.int64)
+    out['bl_targets'] = np.array(atk.targetItem, np.int32)
+    out['bl_user_tab'], out['bl_item_tab'] = utab, itab
+    out['bl_ui_indptr'], out['bl_ui_indices'], out['bl_ui_data'] = blk.indptr.astype(np.int64), blk.indices.astype(np.int32), blk.data.astype(np.float32)
+    out['bl_loss'] = np.array([cap['loss']], np.float32)
+    for gr in cap['grads']:                                            # parameter order of the deep-copied ParameterDict: tell by shape
+        out['bl_grad_user' if gr.shape[0] == U + F else 'bl_grad_item'] = gr
+    for k, (inp, n, st0, m, ind, st1) in enumerate(relax):
+        out['bl_relax%d_in' % k], out['bl_relax%d_n' % k], out['bl_relax%d_state' % k] = inp, np.array([n], np.int64), st0
+        out['bl_relax%d_out' % k], out['bl_relax%d_ind' % k], out['bl_relax%d_state_after' % k] = m, ind.astype(np.float32), st1
+    out['bl_result_fake_rows'] = np.asarray(res[U:U + F, :].todense(), np.float32)
+    save('g13_bilevel.npz', **out)
+
+
 # --------------------------------------------------------------------------- NGCF (a9): forward + 3 Adam steps
 def gen_ngcf():
     from recommender.NGCF import NGCF
@@ -679,6 +753,8 @@ if __name__ == '__main__':
             gen_xsimgcl(data)
         if 'sgl' in only:
             gen_sgl(data)
+        if 'bilevel' in only:
+            gen_bilevel()
         sys.exit(0)
     gen_dataset()
     data = gen_sampler()
@@ -695,4 +771,5 @@ if __name__ == '__main__':
     gen_ngcf()
     gen_xsimgcl(data)
     gen_sgl(data)
+    gen_bilevel()
     print('done; scratch dir', SCRATCH)

@@ -168,6 +168,89 @@ def test_posion_data_attack_end_to_end(name, tmp_path, monkeypatch):
         assert sums == [float(x) for x in g['cl_result_fake_rowsums']]
 
 
+def test_bilevel_batch_outer_step_and_relax_project_match_reference_trace():
+    """BiLevelAttackBatch: surrogate loss + parameter gradients at the reference's first outer step, and relaxProject
+    on the reference's own inputs from the reference's RNG state: same matrix (second draw), same returned indices (first draw,
+    the reference's float-index fallback quirk), same RNG state afterwards."""
+    import random
+    from arlib_amd.recommender.LightGCN import LGCN_Encoder
+    from arlib_amd.attack.White.BiLevelAttackBatch import BiLevelAttackBatch
+    from arlib_amd.attack._common import symmetric_adjacency
+    g = golden('g13_bilevel.npz')
+    U, I, F, L, d, m, E = (int(x) for x in g['bl_sizes'])
+    Up = U + F
+    data = SimpleNamespace(user_num=Up, item_num=I, norm_adj=sp.identity(Up + I, dtype=np.float32, format='csr'))
+    model = LGCN_Encoder(data, d, L).cuda()
+    with torch.no_grad():
+        model.embedding_dict['user_emb'][:] = T(g['bl_user_tab']); model.embedding_dict['item_emb'][:] = T(g['bl_item_tab'])
+    ui = sp.csr_matrix((g['bl_ui_data'], g['bl_ui_indices'], g['bl_ui_indptr']), shape=(Up, I))
+    model._init_uiAdj(symmetric_adjacency(ui, Up, I))
+    atk = object.__new__(BiLevelAttackBatch)
+    atk.userNum, atk.itemNum, atk.fakeUserNum, atk.targetItem = U, I, F, [int(t) for t in g['bl_targets']]
+    atk.maliciousFeedbackNum, atk.Epoch = m, E
+    assert [atk.budget(e) for e in range(E)] == [int(g['bl_relax%d_n' % e][0]) for e in range(E)]
+    loss, Pu, Pi = atk.outer_loss(model, None, 50)
+    assert abs(loss.item() - g['bl_loss'][0]) <= RTOL * abs(g['bl_loss'][0])
+    loss.backward()
+    assert rel_err(model.embedding_dict['user_emb'].grad.cpu().numpy(), g['bl_grad_user']) < RTOL
+    assert rel_err(model.embedding_dict['item_emb'].grad.cpu().numpy(), g['bl_grad_item']) < RTOL
+    for e in range(E):
+        st = random.getstate()
+        random.setstate((st[0], tuple(int(x) for x in g['bl_relax%d_state' % e]), None))
+        out, ind = atk.relaxProject(g['bl_relax%d_in' % e], int(g['bl_relax%d_n' % e][0]))
+        assert np.array_equal(out.cpu().numpy(), g['bl_relax%d_out' % e])
+        assert np.array_equal(ind.cpu().numpy().astype(np.float32), g['bl_relax%d_ind' % e])
+        assert list(random.getstate()[1]) == [int(x) for x in g['bl_relax%d_state_after' % e]]
+
+
+def test_bilevel_by_batch_inject_cw_loss_equals_pairwise_form():
+    """BiLevelAttackByBatchInject's surrogate loss (operator form) against the literal pairwise CW loss of the reference
+    (BiLevelAttackByBatchInject.py:80-92) with autograd, on random tables."""
+    from arlib_amd.attack.White.BiLevelAttackByBatchInject import _CwLoss
+    from arlib_amd.attack._common import cw_pairs
+    gen = torch.Generator().manual_seed(11)
+    U, F, I, k, d = 700, 4, 300, 50, 16
+    targets = [3, 77, 150, 299, 8]
+    top_idx = torch.stack([torch.randperm(I, generator=gen)[:k] for _ in range(U + F)]).to(torch.int32).cuda()
+    Pu = torch.randn(U + F, d, generator=gen).cuda().requires_grad_(True); Pi = torch.randn(I, d, generator=gen).cuda().requires_grad_(True)
+    loss = _CwLoss.apply(Pu, Pi, top_idx, U, targets)
+    gu, gi = torch.autograd.grad(loss, (Pu, Pi))
+    users, pos, neg = cw_pairs(top_idx, U, targets, pop=True)
+    ref = ((Pu[users] * Pi[neg]).sum(1) - (Pu[users] * Pi[pos]).sum(1)).mean()
+    ru, ri = torch.autograd.grad(ref, (Pu, Pi))
+    assert abs(loss.item() - ref.item()) <= RTOL * abs(ref.item())
+    assert rel_err(gu.cpu().numpy(), ru.cpu().numpy()) < RTOL and rel_err(gi.cpu().numpy(), ri.cpu().numpy()) < RTOL
+
+
+@pytest.mark.parametrize('name', ['BiLevelAttackBatch', 'BiLevelAttackByBatchInject'])
+def test_scheduled_bilevel_attacks_end_to_end(name, tmp_path, monkeypatch):
+    """Whole posionDataAttack() with two outer epochs: the filler budget is spread over the epochs and the fake profiles satisfy the
+    structure of the reference run (g13: 23 fillers + 5 targets when the first epoch's graph is kept; at most 46 + 5 otherwise)."""
+    import importlib
+    from copy import deepcopy
+    from arlib_amd.util.tool import seedSet
+    from arlib_amd.recommender.LightGCN import LightGCN
+    monkeypatch.chdir(tmp_path)
+    g = golden('g13_bilevel.npz')
+    seedSet(2018)
+    data = make_data()
+    rec = LightGCN(rec_args(emb_size=16, n_layers=2, maxEpoch=1), data)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rec.train(Epoch=1, evalNum=5)
+    cls = getattr(importlib.import_module('arlib_amd.attack.White.' + name), name)
+    atk = cls(attack_args(maliciousUserSize=3, Epoch=2, outerEpoch=2), data)
+    assert sorted(atk.targetItem) == sorted(int(t) for t in g['bl_targets']) and atk.maliciousFeedbackNum == int(g['bl_sizes'][5])
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = sp.csr_matrix(atk.posionDataAttack(deepcopy(rec)))
+    U, I, F = 942, 1412, 3
+    assert res.shape == (U + F, I) and (res[:U] != data.matrix()).nnz == 0
+    fake = np.asarray(res[U:].todense())
+    assert np.all(fake[:, atk.targetItem] == 1) and set(np.unique(fake)) <= {0.0, 1.0}
+    n0, n1 = atk.budget(0), atk.budget(1)
+    for s in fake.sum(1):
+        assert n0 <= s <= n0 + n1 + 5
+
+
 def test_cw_operator_structured_build_equals_sorted_build():
     """CLeaR's per-step CW operator (built from its structure, no 4UT-entry sort/histogram) against the generic builder PGA
     uses once per inner epoch: same SpMM result and loss; negative counts = histogram of the negatives."""
