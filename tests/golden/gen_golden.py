@@ -609,6 +609,85 @@ def gen_bilevel():
     save('g13_bilevel.npz', **out)
 
 
+# --------------------------------------------------------------------------- InfoAttack: a*CW + b*Info step, relaxProject
+def gen_infoattack():
+    import io, contextlib
+    from copy import deepcopy
+    import recommender.LightGCN as RL
+    from attack.White.InfoAttack import InfoAttack
+    os.makedirs('data/clean/ml-100k', exist_ok=True)
+    undo_shim = _scipy_torch_index_shim()
+    rargs = rec_args(emb_size=16, n_layers=2, maxEpoch=1)
+    seedSet(2018)
+    data = DataLoader(rargs)
+    rec = LightGCN(rargs, data)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rec.train(Epoch=1, evalNum=5)
+    atk = InfoAttack(_attack_args(attackModelName='InfoAttack', maliciousUserSize=3, Epoch=1, outerEpoch=2, innerEpoch=1), data)
+    trace, cap, relax = {}, {}, []
+    orig_init, orig_fwd = RL.LGCN_Encoder._init_uiAdj, RL.LGCN_Encoder.forward
+    orig_backward, orig_adam_step = torch.Tensor.backward, torch.optim.Adam.step
+    orig_relax = InfoAttack.relaxProject
+
+    def init_wrap(self, ui_adj):
+        trace.setdefault('init', []).append((sp.csr_matrix(ui_adj).copy(), self.embedding_dict['user_emb'].detach().numpy().copy(),
+                                             self.embedding_dict['item_emb'].detach().numpy().copy()))
+        return orig_init(self, ui_adj)
+
+    def fwd_wrap(self, *a, **k):
+        out = orig_fwd(self, *a, **k)
+        if 'view1' not in cap:
+            cap['view1'] = out[1].detach().numpy().copy()          # first forward of posionDataAttack: the fixed view
+        return out
+
+    def backward_wrap(self, *a, **k):
+        if 'loss' not in cap and self.dim() == 0 and len(trace.get('init', [])) > 0:
+            cap['loss'] = float(self.item()); cap['a'] = float(atk.a); cap['b'] = float(atk.b)
+        return orig_backward(self, *a, **k)
+
+    def adam_step_wrap(self, *a, **k):
+        if 'grads' not in cap and 'loss' in cap:
+            cap['grads'] = [p.grad.detach().numpy().copy() for p in self.param_groups[0]['params']]
+            cap['n_init'] = len(trace['init'])
+        return orig_adam_step(self, *a, **k)
+
+    def relax_wrap(self, mat, n):
+        st = random.getstate()
+        inp = np.asarray(mat[:, :].todense(), np.float32).copy()
+        m, ind = orig_relax(self, mat, n)
+        relax.append((inp, int(n), np.array(st[1], np.int64), np.asarray(m[:, :].todense(), np.float32).copy(), ind.numpy().copy(),
+                      np.array(random.getstate()[1], np.int64)))
+        return m, ind
+    RL.LGCN_Encoder._init_uiAdj, RL.LGCN_Encoder.forward = init_wrap, fwd_wrap
+    torch.Tensor.backward, torch.optim.Adam.step = backward_wrap, adam_step_wrap
+    InfoAttack.relaxProject = relax_wrap
+    out = {}
+    try:
+        random.seed(31337)
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = atk.posionDataAttack(deepcopy(rec))
+    finally:
+        RL.LGCN_Encoder._init_uiAdj, RL.LGCN_Encoder.forward = orig_init, orig_fwd
+        torch.Tensor.backward, torch.optim.Adam.step = orig_backward, orig_adam_step
+        InfoAttack.relaxProject = orig_relax
+        undo_shim()
+    U, I, F = atk.userNum, atk.itemNum, atk.fakeUserNum
+    adj, utab, itab = trace['init'][cap['n_init'] - 1]
+    blk = adj[:U + F, U + F:]
+    out['ia_sizes'] = np.array([U, I, F, rargs.n_layers, rargs.emb_size, atk.maliciousFeedbackNum, min(rec.topN)], np.int64)
+    out['ia_targets'] = np.array(atk.targetItem, np.int32)
+    out['ia_user_tab'], out['ia_item_tab'], out['ia_view1'] = utab, itab, cap['view1']
+    out['ia_ui_indptr'], out['ia_ui_indices'], out['ia_ui_data'] = blk.indptr.astype(np.int64), blk.indices.astype(np.int32), blk.data.astype(np.float32)
+    out['ia_loss'] = np.array([cap['loss'], cap['a'], cap['b']], np.float32)
+    for gr in cap['grads']:
+        out['ia_grad_user' if gr.shape[0] == U + F else 'ia_grad_item'] = gr
+    inp, n, st0, m, ind, st1 = relax[0]
+    out['ia_relax_in'], out['ia_relax_n'], out['ia_relax_state'] = inp, np.array([n], np.int64), st0
+    out['ia_relax_out'], out['ia_relax_ind'], out['ia_relax_state_after'] = m, ind.astype(np.float32), st1
+    out['ia_result_fake_rowsums'] = np.asarray(res[U:U + F, :].sum(1)).ravel().astype(np.float32)
+    save('g14_infoattack.npz', **out)
+
+
 # --------------------------------------------------------------------------- NGCF (a9): forward + 3 Adam steps
 def gen_ngcf():
     from recommender.NGCF import NGCF
@@ -755,6 +834,8 @@ if __name__ == '__main__':
             gen_sgl(data)
         if 'bilevel' in only:
             gen_bilevel()
+        if 'infoattack' in only:
+            gen_infoattack()
         sys.exit(0)
     gen_dataset()
     data = gen_sampler()
@@ -772,4 +853,5 @@ if __name__ == '__main__':
     gen_xsimgcl(data)
     gen_sgl(data)
     gen_bilevel()
+    gen_infoattack()
     print('done; scratch dir', SCRATCH)

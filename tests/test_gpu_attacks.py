@@ -222,7 +222,7 @@ def test_bilevel_by_batch_inject_cw_loss_equals_pairwise_form():
     assert rel_err(gu.cpu().numpy(), ru.cpu().numpy()) < RTOL and rel_err(gi.cpu().numpy(), ri.cpu().numpy()) < RTOL
 
 
-@pytest.mark.parametrize('name', ['BiLevelAttackBatch', 'BiLevelAttackByBatchInject'])
+@pytest.mark.parametrize('name', ['BiLevelAttackBatch', 'BiLevelAttackByBatchInject', 'InfoAttack'])
 def test_scheduled_bilevel_attacks_end_to_end(name, tmp_path, monkeypatch):
     """Whole posionDataAttack() with two outer epochs: the filler budget is spread over the epochs and the fake profiles satisfy the
     structure of the reference run (g13: 23 fillers + 5 targets when the first epoch's graph is kept; at most 46 + 5 otherwise)."""
@@ -246,9 +246,71 @@ def test_scheduled_bilevel_attacks_end_to_end(name, tmp_path, monkeypatch):
     assert res.shape == (U + F, I) and (res[:U] != data.matrix()).nnz == 0
     fake = np.asarray(res[U:].todense())
     assert np.all(fake[:, atk.targetItem] == 1) and set(np.unique(fake)) <= {0.0, 1.0}
+    if name == 'InfoAttack':                                  # whole budget every epoch (g14: 46 fillers + 5 targets when they do not overlap)
+        assert all(atk.maliciousFeedbackNum <= s <= atk.maliciousFeedbackNum + 5 for s in fake.sum(1))
+        assert sorted(golden('g14_infoattack.npz')['ia_result_fake_rowsums'].tolist())[-1] <= atk.maliciousFeedbackNum + 5
+        return
     n0, n1 = atk.budget(0), atk.budget(1)
     for s in fake.sum(1):
         assert n0 <= s <= n0 + n1 + 5
+
+
+def test_infoattack_surrogate_step_and_relax_project_match_reference_trace():
+    """InfoAttack: Loss = a*CW + b*Info with the reference's one-element mask and its item-item InfoNCE against the
+    pre-injection item table; loss, mixing weights and parameter gradients of the reference's first outer step; relaxProject on the
+    reference's inputs and RNG state."""
+    import random
+    from arlib_amd.recommender.LightGCN import LGCN_Encoder
+    from arlib_amd.attack.White.InfoAttack import InfoAttack
+    from arlib_amd.attack._common import symmetric_adjacency
+    g = golden('g14_infoattack.npz')
+    U, I, F, L, d, m, topk = (int(x) for x in g['ia_sizes'])
+    Up = U + F
+    data = SimpleNamespace(user_num=Up, item_num=I, norm_adj=sp.identity(Up + I, dtype=np.float32, format='csr'))
+    model = LGCN_Encoder(data, d, L).cuda()
+    with torch.no_grad():
+        model.embedding_dict['user_emb'][:] = T(g['ia_user_tab']); model.embedding_dict['item_emb'][:] = T(g['ia_item_tab'])
+    ui = sp.csr_matrix((g['ia_ui_data'], g['ia_ui_indices'], g['ia_ui_indptr']), shape=(Up, I))
+    model._init_uiAdj(symmetric_adjacency(ui, Up, I))
+    atk = object.__new__(InfoAttack)
+    atk.userNum, atk.itemNum, atk.fakeUserNum, atk.targetItem, atk.batchSize = U, I, F, [int(t) for t in g['ia_targets']], 256
+    loss, cw, info = atk.surrogate_loss(model, atk.single_element_mask(ui, DEV), topk, T(g['ia_view1']))
+    ref_loss, ref_a, ref_b = (float(x) for x in g['ia_loss'])
+    assert abs(loss.item() - ref_loss) <= RTOL * abs(ref_loss)
+    assert abs(float(atk.a) - ref_a) <= 1e-4 * max(abs(ref_a), 1e-3) and abs(float(atk.b) - ref_b) <= 1e-4 * abs(ref_b)
+    loss.backward()
+    assert rel_err(model.embedding_dict['user_emb'].grad.cpu().numpy(), g['ia_grad_user']) < RTOL
+    assert rel_err(model.embedding_dict['item_emb'].grad.cpu().numpy(), g['ia_grad_item']) < RTOL
+    st = random.getstate()
+    random.setstate((st[0], tuple(int(x) for x in g['ia_relax_state']), None))
+    out, ind = atk.relaxProject(g['ia_relax_in'], int(g['ia_relax_n'][0]))
+    assert np.array_equal(out.cpu().numpy(), g['ia_relax_out'])
+    assert np.array_equal(ind.cpu().numpy().astype(np.float32), g['ia_relax_ind'])
+    assert list(random.getstate()[1]) == [int(x) for x in g['ia_relax_state_after']]
+
+
+def test_item_infonce_panels_equal_literal_autograd_form():
+    """_ItemInfoNCE (panel-wise, gradient accumulated in the forward pass) against the literal loop of InfoAttack.py:96-101 with autograd,
+    ragged last panel."""
+    import torch.nn.functional as F
+    from arlib_amd.attack.White.InfoAttack import _ItemInfoNCE
+    gen = torch.Generator().manual_seed(2)
+    I, d, bs = 700, 16, 256
+    view1 = torch.randn(I, d, generator=gen).cuda()
+    Pi = (view1.cpu() + 0.3 * torch.randn(I, d, generator=gen)).cuda().requires_grad_(True)
+    got = _ItemInfoNCE.apply(Pi, view1, 0.2, bs)
+    gg, = torch.autograd.grad(got, Pi)
+    ref, k = 0, 0
+    for b in range(0, I, bs):
+        k += 1
+        v1, v2 = F.normalize(view1, dim=1), F.normalize(Pi[b:b + bs], dim=1)
+        pos = torch.exp((v1[b:b + bs] * v2).sum(-1) / 0.2)
+        ttl = torch.exp(v1 @ v2.T / 0.2).sum(0)
+        ref = ref + (-torch.log(pos / ttl)).mean()
+    ref = ref / k
+    rg, = torch.autograd.grad(ref, Pi)
+    assert abs(got.item() - ref.item()) <= RTOL * abs(ref.item())
+    assert rel_err(gg.cpu().numpy(), rg.cpu().numpy()) < RTOL
 
 
 def test_cw_operator_structured_build_equals_sorted_build():
