@@ -688,6 +688,69 @@ def gen_infoattack():
     save('g14_infoattack.npz', **out)
 
 
+# --------------------------------------------------------------------------- PipAttack: RNG use of the constructor, first step
+def gen_pipattack():
+    import io, contextlib
+    from copy import deepcopy
+    import recommender.LightGCN as RL
+    from attack.White.PipAttack import PipAttack
+    os.makedirs('data/clean/ml-100k', exist_ok=True)
+    undo_shim = _scipy_torch_index_shim()
+    rargs = rec_args(emb_size=16, n_layers=2, maxEpoch=1)
+    seedSet(2018)
+    data = DataLoader(rargs)
+    rec = LightGCN(rargs, data)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rec.train(Epoch=1, evalNum=5)
+    torch.manual_seed(4321)
+    with contextlib.redirect_stdout(io.StringIO()):
+        atk = PipAttack(_attack_args(attackModelName='PipAttack', maliciousUserSize=3, Epoch=1, outerEpoch=2, innerEpoch=1), data)
+    out = {'pip_rng_probe': torch.rand(4).numpy()}                     # the global torch stream right after the constructor
+    out['pip_mlp_w0'] = atk.popularity_model.layers[0].weight.detach().numpy()[:8].copy()
+    out['pip_mlp_b2'] = atk.popularity_model.layers[4].bias.detach().numpy().copy()
+    trace, cap = {}, {}
+    orig_init = RL.LGCN_Encoder._init_uiAdj
+    orig_backward, orig_adam_step = torch.Tensor.backward, torch.optim.Adam.step
+
+    def init_wrap(self, ui_adj):
+        trace.setdefault('init', []).append((sp.csr_matrix(ui_adj).copy(), self.embedding_dict['user_emb'].detach().numpy().copy(),
+                                             self.embedding_dict['item_emb'].detach().numpy().copy()))
+        return orig_init(self, ui_adj)
+
+    def backward_wrap(self, *a, **k):
+        if 'loss' not in cap and self.dim() == 0 and len(trace.get('init', [])) > 0:
+            cap['loss'] = float(self.item())
+        return orig_backward(self, *a, **k)
+
+    def adam_step_wrap(self, *a, **k):
+        if 'grads' not in cap and 'loss' in cap:
+            cap['grads'] = [p.grad.detach().numpy().copy() for p in self.param_groups[0]['params']]
+            cap['n_init'] = len(trace['init'])
+        return orig_adam_step(self, *a, **k)
+    RL.LGCN_Encoder._init_uiAdj = init_wrap
+    torch.Tensor.backward, torch.optim.Adam.step = backward_wrap, adam_step_wrap
+    try:
+        random.seed(99)
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = atk.posionDataAttack(deepcopy(rec))
+    finally:
+        RL.LGCN_Encoder._init_uiAdj = orig_init
+        torch.Tensor.backward, torch.optim.Adam.step = orig_backward, orig_adam_step
+        undo_shim()
+    U, I, F = atk.userNum, atk.itemNum, atk.fakeUserNum
+    adj, utab, itab = trace['init'][cap['n_init'] - 1]
+    blk = adj[:U + F, U + F:]
+    out['pip_sizes'] = np.array([U, I, F, rargs.n_layers, rargs.emb_size, atk.maliciousFeedbackNum], np.int64)
+    out['pip_targets'] = np.array(atk.targetItem, np.int32)
+    out['pip_user_tab'], out['pip_item_tab'] = utab, itab
+    out['pip_ui_indptr'], out['pip_ui_indices'], out['pip_ui_data'] = blk.indptr.astype(np.int64), blk.indices.astype(np.int32), blk.data.astype(np.float32)
+    out['pip_loss'] = np.array([cap['loss']], np.float32)
+    for gr in cap['grads']:
+        out['pip_grad_user' if gr.shape[0] == U + F else 'pip_grad_item'] = gr
+    out['pip_result_fake_rowsums'] = np.asarray(res[U:U + F, :].sum(1)).ravel().astype(np.float32)
+    save('g15_pipattack.npz', **out)
+
+
 # --------------------------------------------------------------------------- NGCF (a9): forward + 3 Adam steps
 def gen_ngcf():
     from recommender.NGCF import NGCF
@@ -836,6 +899,8 @@ if __name__ == '__main__':
             gen_bilevel()
         if 'infoattack' in only:
             gen_infoattack()
+        if 'pipattack' in only:
+            gen_pipattack()
         sys.exit(0)
     gen_dataset()
     data = gen_sampler()
@@ -854,4 +919,5 @@ if __name__ == '__main__':
     gen_sgl(data)
     gen_bilevel()
     gen_infoattack()
+    gen_pipattack()
     print('done; scratch dir', SCRATCH)

@@ -222,7 +222,7 @@ def test_bilevel_by_batch_inject_cw_loss_equals_pairwise_form():
     assert rel_err(gu.cpu().numpy(), ru.cpu().numpy()) < RTOL and rel_err(gi.cpu().numpy(), ri.cpu().numpy()) < RTOL
 
 
-@pytest.mark.parametrize('name', ['BiLevelAttackBatch', 'BiLevelAttackByBatchInject', 'InfoAttack'])
+@pytest.mark.parametrize('name', ['BiLevelAttackBatch', 'BiLevelAttackByBatchInject', 'InfoAttack', 'PipAttack'])
 def test_scheduled_bilevel_attacks_end_to_end(name, tmp_path, monkeypatch):
     """Whole posionDataAttack() with two outer epochs: the filler budget is spread over the epochs and the fake profiles satisfy the
     structure of the reference run (g13: 23 fillers + 5 targets when the first epoch's graph is kept; at most 46 + 5 otherwise)."""
@@ -246,7 +246,7 @@ def test_scheduled_bilevel_attacks_end_to_end(name, tmp_path, monkeypatch):
     assert res.shape == (U + F, I) and (res[:U] != data.matrix()).nnz == 0
     fake = np.asarray(res[U:].todense())
     assert np.all(fake[:, atk.targetItem] == 1) and set(np.unique(fake)) <= {0.0, 1.0}
-    if name == 'InfoAttack':                                  # whole budget every epoch (g14: 46 fillers + 5 targets when they do not overlap)
+    if name in ('InfoAttack', 'PipAttack'):                   # whole budget every epoch (g14: 46 fillers + 5 targets when they do not overlap)
         assert all(atk.maliciousFeedbackNum <= s <= atk.maliciousFeedbackNum + 5 for s in fake.sum(1))
         assert sorted(golden('g14_infoattack.npz')['ia_result_fake_rowsums'].tolist())[-1] <= atk.maliciousFeedbackNum + 5
         return
@@ -311,6 +311,40 @@ def test_item_infonce_panels_equal_literal_autograd_form():
     rg, = torch.autograd.grad(ref, Pi)
     assert abs(got.item() - ref.item()) <= RTOL * abs(ref.item())
     assert rel_err(gg.cpu().numpy(), rg.cpu().numpy()) < RTOL
+
+
+def test_pipattack_constructor_rng_stream_and_first_step_match_reference_trace(tmp_path, monkeypatch):
+    """PipAttack: constructing the attack trains the popularity classifier with the reference's torch calls, so the global
+    torch RNG stream afterwards is the reference's (probe drawn right after the constructor) and so are the classifier's weights; the
+    first surrogate step reproduces lossall (explicit promotion + 0.1 * constant popularity term) and the parameter gradients."""
+    from arlib_amd.recommender.LightGCN import LGCN_Encoder
+    from arlib_amd.attack.White.PipAttack import PipAttack
+    from arlib_amd.attack._common import symmetric_adjacency
+    from arlib_amd.util.tool import seedSet
+    monkeypatch.chdir(tmp_path)
+    g = golden('g15_pipattack.npz')
+    U, I, F, L, d, m = (int(x) for x in g['pip_sizes'])
+    seedSet(2018)
+    data = make_data()
+    torch.manual_seed(4321)
+    with contextlib.redirect_stdout(io.StringIO()):
+        atk = PipAttack(attack_args(maliciousUserSize=3, Epoch=1, outerEpoch=2), data)
+    assert np.array_equal(torch.rand(4).numpy(), g['pip_rng_probe'])                 # same number of draws from the global stream
+    assert rel_err(atk.popularity_model.layers[0].weight.detach().numpy()[:8], g['pip_mlp_w0']) < 1e-3      # CPU BLAS of another host
+    assert rel_err(atk.popularity_model.layers[4].bias.detach().numpy(), g['pip_mlp_b2']) < 1e-3
+    Up = U + F
+    enc_data = SimpleNamespace(user_num=Up, item_num=I, norm_adj=sp.identity(Up + I, dtype=np.float32, format='csr'))
+    model = LGCN_Encoder(enc_data, d, L).cuda()
+    with torch.no_grad():
+        model.embedding_dict['user_emb'][:] = T(g['pip_user_tab']); model.embedding_dict['item_emb'][:] = T(g['pip_item_tab'])
+    ui = sp.csr_matrix((g['pip_ui_data'], g['pip_ui_indices'], g['pip_ui_indptr']), shape=(Up, I))
+    model._init_uiAdj(symmetric_adjacency(ui, Up, I))
+    atk.targetItem = [int(t) for t in g['pip_targets']]
+    lossall, Pu, Pi, explicit, pop = atk.surrogate_loss(model, ui, 50)
+    assert abs(lossall.item() - g['pip_loss'][0]) <= 1e-3 * abs(g['pip_loss'][0]) + 1e-7      # the constant comes from a CPU-trained classifier
+    lossall.backward()
+    assert rel_err(model.embedding_dict['user_emb'].grad.cpu().numpy(), g['pip_grad_user']) < RTOL
+    assert rel_err(model.embedding_dict['item_emb'].grad.cpu().numpy(), g['pip_grad_item']) < RTOL
 
 
 def test_cw_operator_structured_build_equals_sorted_build():
