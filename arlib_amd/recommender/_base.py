@@ -18,7 +18,7 @@ import torch.nn as nn
 from .. import ops
 from ..engine import PropagationEngine
 from ..util.sampler import next_batch_pairwise, device_epoch
-from ..util.loss import bpr_l2_loss, InfoNCE
+from ..util.loss import bpr_l2_loss, l2_reg_loss, InfoNCE
 from ..util.metrics import ranking_evaluation, ranking_evaluation_topk
 
 DEVICE = 'cuda'
@@ -272,6 +272,9 @@ class Recommender:
                 optimizer.state[p]['step'] = torch.tensor(float(eng.t))
 
     # ---- training ------------------------------------------------------------------------------------------------
+    l2_scale = 1.0          # NCL divides its L2 term by the batch size (NCL.py:147) ...
+    l2_on_negatives = False # ... and also regularises the negative items' rows
+
     def _extra_loss(self, model, user_idx, pos_idx):
         return None
 
@@ -330,7 +333,9 @@ class Recommender:
                 rec_user_emb, rec_item_emb = outs[0], outs[1]
                 ul, pl, nl = u.long(), p.long(), ng.long()
                 user_emb, pos_item_emb, neg_item_emb = rec_user_emb[ul], rec_item_emb[pl], rec_item_emb[nl]
-                batch_loss = bpr_l2_loss(user_emb, pos_item_emb, neg_item_emb, self.args.reg)
+                batch_loss = bpr_l2_loss(user_emb, pos_item_emb, neg_item_emb, self.args.reg * self.l2_scale)
+                if self.l2_on_negatives:
+                    batch_loss = batch_loss + l2_reg_loss(self.args.reg * self.l2_scale, neg_item_emb)
                 if self.has_extra_loss:
                     batch_loss = batch_loss + (self._extra_loss(model, ul, pl, *outs) if self.train_forward_perturbed else self._extra_loss(model, ul, pl))
                 optimizer.zero_grad()
@@ -376,7 +381,9 @@ class Recommender:
                 continue
             outs = model(True) if self.train_forward_perturbed else model()
             rec_user_emb, rec_item_emb = outs[0], outs[1]
-            loss = bpr_l2_loss(rec_user_emb[u.long()], rec_item_emb[p.long()], rec_item_emb[ng.long()], self.args.reg)
+            loss = bpr_l2_loss(rec_user_emb[u.long()], rec_item_emb[p.long()], rec_item_emb[ng.long()], self.args.reg * self.l2_scale)
+            if self.l2_on_negatives:
+                loss = loss + l2_reg_loss(self.args.reg * self.l2_scale, rec_item_emb[ng.long()])
             if self.has_extra_loss:
                 loss = loss + (self._extra_loss(model, u.long(), p.long(), *outs) if self.train_forward_perturbed else self._extra_loss(model, u.long(), p.long()))
             optimizer.zero_grad()

@@ -836,6 +836,55 @@ def gen_xsimgcl(data):
     save('g11_xsimgcl.npz', **o)
 
 
+# --------------------------------------------------------------------------- G16: NCL (structure + prototype contrast)
+def gen_ncl(data):
+    """One reference NCL iteration of the prototype phase (recommender/NCL.py:131-166): BPR + L2/batch_size + ssl_layer_loss (2-hop
+    context against ALL initial rows) + ProtoNCE_loss (k-means centroids of e_step, k lowered from 2000 to 30: ml-100k has 942 users)."""
+    import io, contextlib
+    from recommender.NCL import NCL, TorchGraphInterface
+    args = rec_args(emb_size=16, n_layers=2, model_name='NCL')
+    seedSet(2018)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rec = NCL(args, data)
+    rec.k = 30
+    model = rec.model
+    o = {'user0': model.embedding_dict['user_emb'].detach().numpy().copy(), 'item0': model.embedding_dict['item_emb'].detach().numpy().copy(),
+         'hyper': np.array([rec.n_layers, rec.hyper_layers, rec.ssl_temp, rec.ssl_reg, rec.alpha, rec.proto_reg, rec.k, rec.batch_size], np.float64)}
+    np.random.seed(515)
+    rec.e_step()
+    o['user_centroids'], o['user_2cluster'] = rec.user_centroids.numpy().copy(), rec.user_2cluster.numpy().astype(np.int32)
+    o['item_centroids'], o['item_2cluster'] = rec.item_centroids.numpy().copy(), rec.item_2cluster.numpy().astype(np.int32)
+    random.seed(2018)
+    d2 = copy.copy(data); d2.training_data = [list(r) for r in data_training0]
+    user_idx, pos_idx, neg_idx = next(iter(ref_sampler.next_batch_pairwise(d2, 2048)))
+    optim = torch.optim.Adam(model.parameters(), lr=args.lRate)
+    ru, ri = model()
+    A = TorchGraphInterface.convert_sparse_mat_to_tensor(data.norm_adj)
+    ego = torch.cat([model.embedding_dict['user_emb'], model.embedding_dict['item_emb']], 0)
+    emb_list = [ego]
+    for k in range(rec.n_layers):
+        ego = torch.sparse.mm(A, ego)
+        emb_list.append(ego)
+    user_emb, pos_item_emb, neg_item_emb = ru[user_idx], ri[pos_idx], ri[neg_idx]
+    rec_loss = ref_loss.bpr_loss(user_emb, pos_item_emb, neg_item_emb)
+    ssl = rec.ssl_layer_loss(emb_list[rec.hyper_layers * 2], emb_list[0], user_idx, pos_idx)
+    proto = rec.ProtoNCE_loss(emb_list[0], user_idx, pos_idx)
+    ps = [model.embedding_dict['user_emb'], model.embedding_dict['item_emb']]
+    gs = torch.autograd.grad(ssl, ps, retain_graph=True)
+    gp = torch.autograd.grad(proto, ps, retain_graph=True)
+    o['ssl_grad_user'], o['ssl_grad_item'] = gs[0].numpy().copy(), gs[1].numpy().copy()
+    o['proto_grad_user'], o['proto_grad_item'] = gp[0].numpy().copy(), gp[1].numpy().copy()
+    batch_loss = rec_loss + ref_loss.l2_reg_loss(args.reg, user_emb, pos_item_emb, neg_item_emb) / rec.batch_size + ssl + proto
+    optim.zero_grad()
+    batch_loss.backward()
+    o['grad_user'] = model.embedding_dict['user_emb'].grad.numpy().copy(); o['grad_item'] = model.embedding_dict['item_emb'].grad.numpy().copy()
+    optim.step()
+    o['losses'] = np.array([rec_loss.item(), ssl.item(), proto.item(), batch_loss.item()], np.float64)
+    o['user_k1'] = model.embedding_dict['user_emb'].detach().numpy().copy(); o['item_k1'] = model.embedding_dict['item_emb'].detach().numpy().copy()
+    o['batch_u'] = np.asarray(user_idx, np.int32); o['batch_p'] = np.asarray(pos_idx, np.int32); o['batch_n'] = np.asarray(neg_idx, np.int32)
+    save('g16_ncl.npz', **o)
+
+
 # --------------------------------------------------------------------------- G12: SGL (edge-dropout views, SURVEY 8f-4)
 def gen_sgl(data):
     """Reference SGL (recommender/SGL.py): the two edge-dropped graphs of an epoch (Python `random.sample` over the edges) and one
@@ -895,6 +944,8 @@ if __name__ == '__main__':
             gen_xsimgcl(data)
         if 'sgl' in only:
             gen_sgl(data)
+        if 'ncl' in only:
+            gen_ncl(data)
         if 'bilevel' in only:
             gen_bilevel()
         if 'infoattack' in only:
@@ -917,6 +968,7 @@ if __name__ == '__main__':
     gen_ngcf()
     gen_xsimgcl(data)
     gen_sgl(data)
+    gen_ncl(data)
     gen_bilevel()
     gen_infoattack()
     gen_pipattack()
