@@ -751,6 +751,72 @@ def gen_pipattack():
     save('g15_pipattack.npz', **out)
 
 
+# --------------------------------------------------------------------------- gray-box siblings: A_ra loss step, result structure
+def gen_gray():
+    import io, contextlib
+    from copy import deepcopy
+    import recommender.LightGCN as RL
+    from attack.Gray.A_ra import A_ra
+    from attack.Gray.FedRecAttack import FedRecAttack
+    os.makedirs('data/clean/ml-100k', exist_ok=True)
+    undo_shim = _scipy_torch_index_shim()
+    rargs = rec_args(emb_size=16, n_layers=2, maxEpoch=1)
+    out = {}
+    for cls, tag in ((A_ra, 'ara'), (FedRecAttack, 'fed')):
+        seedSet(2018)
+        data = DataLoader(rargs)
+        rec = LightGCN(rargs, data)
+        with contextlib.redirect_stdout(io.StringIO()):
+            rec.train(Epoch=1, evalNum=5)
+        atk = cls(_attack_args(attackCategory='Gray', attackModelName=cls.__name__, maliciousUserSize=3, Epoch=1, outerEpoch=1, innerEpoch=1), data)
+        cap = {}
+        orig_fwd, orig_randn = RL.LGCN_Encoder.forward, torch.randn
+        orig_backward, orig_adam_step = torch.Tensor.backward, torch.optim.Adam.step
+        a_fixed = orig_randn(100, rargs.emb_size, generator=torch.Generator().manual_seed(7))
+
+        def randn_wrap(*a, **k):
+            if len(a) == 1 and isinstance(a[0], tuple) and a[0] == (100, rargs.emb_size):
+                cap['armed'] = True                      # the attack loss of this outer step follows
+                return a_fixed.clone()
+            return orig_randn(*a, **k)
+
+        def fwd_wrap(self, *a, **k):
+            o = orig_fwd(self, *a, **k)
+            cap['last_tabs'] = (self.embedding_dict['user_emb'].detach().numpy().copy(), self.embedding_dict['item_emb'].detach().numpy().copy(),
+                                o[1].detach().numpy().copy())
+            return o
+
+        def backward_wrap(self, *a, **k):
+            if cap.get('armed') and 'loss' not in cap:
+                cap['loss'] = float(self.item()); cap['tabs'] = cap['last_tabs']
+            return orig_backward(self, *a, **k)
+
+        def adam_step_wrap(self, *a, **k):
+            if 'loss' in cap and 'grads' not in cap:
+                cap['grads'] = [p.grad.detach().numpy().copy() for p in self.param_groups[0]['params']]
+            return orig_adam_step(self, *a, **k)
+        if tag == 'ara':
+            RL.LGCN_Encoder.forward, torch.randn = fwd_wrap, randn_wrap
+            torch.Tensor.backward, torch.optim.Adam.step = backward_wrap, adam_step_wrap
+        try:
+            random.seed(11)
+            with contextlib.redirect_stdout(io.StringIO()):
+                res = atk.posionDataAttack(deepcopy(rec))
+        finally:
+            RL.LGCN_Encoder.forward, torch.randn = orig_fwd, orig_randn
+            torch.Tensor.backward, torch.optim.Adam.step = orig_backward, orig_adam_step
+        U, F = atk.userNum, atk.fakeUserNum
+        out[tag + '_result_fake_rowsums'] = np.asarray(res[U:U + F, :].sum(1)).ravel().astype(np.float32)
+        out[tag + '_targets'] = np.array(atk.targetItem, np.int32)
+        if tag == 'ara':
+            out['ara_a'] = a_fixed.numpy()
+            out['ara_item_prop'] = cap['tabs'][2]                     # propagated item table the loss was computed on
+            out['ara_loss'] = np.array([cap['loss']], np.float32)
+            out['ara_sizes'] = np.array([U, atk.itemNum, F, atk.n], np.int64)
+    undo_shim()
+    save('g17_gray.npz', **out)
+
+
 # --------------------------------------------------------------------------- NGCF (a9): forward + 3 Adam steps
 def gen_ngcf():
     from recommender.NGCF import NGCF
@@ -952,6 +1018,8 @@ if __name__ == '__main__':
             gen_infoattack()
         if 'pipattack' in only:
             gen_pipattack()
+        if 'gray' in only:
+            gen_gray()
         sys.exit(0)
     gen_dataset()
     data = gen_sampler()
@@ -972,4 +1040,5 @@ if __name__ == '__main__':
     gen_bilevel()
     gen_infoattack()
     gen_pipattack()
+    gen_gray()
     print('done; scratch dir', SCRATCH)

@@ -347,6 +347,52 @@ def test_pipattack_constructor_rng_stream_and_first_step_match_reference_trace(t
     assert rel_err(model.embedding_dict['item_emb'].grad.cpu().numpy(), g['pip_grad_item']) < RTOL
 
 
+def test_a_ra_loss_matches_reference_value(monkeypatch):
+    """A_ra's attack loss on the reference's own propagated item table and random user vectors (g17)."""
+    from arlib_amd.attack.Gray.A_ra import A_ra
+    g = golden('g17_gray.npz')
+    atk = object.__new__(A_ra)
+    atk.n, atk.sigma, atk.targetItem = int(g['ara_sizes'][3]), 1, [int(t) for t in g['ara_targets']]
+    a = torch.from_numpy(g['ara_a'])
+    monkeypatch.setattr(torch, 'randn', lambda *args, **kw: a.clone())
+    Pi = T(g['ara_item_prop']).requires_grad_(True)
+    loss, _, _ = atk.outer_loss(lambda: (None, Pi), None, 50)
+    assert abs(loss.item() - g['ara_loss'][0]) <= RTOL * abs(g['ara_loss'][0])
+    gi, = torch.autograd.grad(loss, Pi)
+    assert float(gi.abs().sum()) > 0 and float(gi[[i for i in range(Pi.shape[0]) if i not in atk.targetItem]].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('name', ['FedRecAttack', 'A_ra'])
+def test_gray_box_attacks_end_to_end(name, tmp_path, monkeypatch):
+    """Whole posionDataAttack() of the gray-box siblings (user table re-learnt with a user-only Adam before every attack step; the victim's
+    retraining then runs on that foreign optimiser, i.e. inert): structure of the reference run (g17: 46 fillers + 5 targets, overlaps
+    allowed)."""
+    import importlib
+    from copy import deepcopy
+    from arlib_amd.util.tool import seedSet
+    from arlib_amd.recommender.LightGCN import LightGCN
+    monkeypatch.chdir(tmp_path)
+    g = golden('g17_gray.npz')
+    seedSet(2018)
+    data = make_data()
+    rec = LightGCN(rec_args(emb_size=16, n_layers=2, maxEpoch=1), data)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rec.train(Epoch=1, evalNum=5)
+    cls = getattr(importlib.import_module('arlib_amd.attack.Gray.' + name), name)
+    atk = cls(attack_args(maliciousUserSize=3, Epoch=1, outerEpoch=1), data)
+    assert sorted(atk.targetItem) == sorted(int(t) for t in g['ara_targets' if name == 'A_ra' else 'fed_targets'])
+    victim = deepcopy(rec)
+    before = None
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = sp.csr_matrix(atk.posionDataAttack(victim))
+    U, I, F = 942, 1412, 3
+    assert res.shape == (U + F, I) and (res[:U] != data.matrix()).nnz == 0
+    fake = np.asarray(res[U:].todense())
+    assert np.all(fake[:, atk.targetItem] == 1) and set(np.unique(fake)) <= {0.0, 1.0}
+    ref = g['ara_result_fake_rowsums' if name == 'A_ra' else 'fed_result_fake_rowsums']
+    assert all(atk.maliciousFeedbackNum <= s <= atk.maliciousFeedbackNum + 5 for s in fake.sum(1)) and all(46 <= s <= 51 for s in ref)
+
+
 def test_cw_operator_structured_build_equals_sorted_build():
     """CLeaR's per-step CW operator (built from its structure, no 4UT-entry sort/histogram) against the generic builder PGA
     uses once per inner epoch: same SpMM result and loss; negative counts = histogram of the negatives."""
