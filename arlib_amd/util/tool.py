@@ -42,11 +42,26 @@ def targetItemSelect(data, arg, popularThreshold=0.1):
     return targetItem
 
 
-def dataSave(ratings, fileName, id2user, id2item):
-    """util/tool.py:23-49: one `user item rating` line per stored interaction, CSR order."""
-    coo = ratings.tocoo() if hasattr(ratings, 'tocoo') else None
-    rows, cols = ratings.nonzero()
+def dataSave(ratings, fileName, id2user, id2item, chunk=4_000_000):
+    """util/tool.py:23-49: one `user item rating` line per non-zero interaction in `ratings.nonzero()` order, users missing from
+    id2user written as fakeUser<row>, the value formatted as the matrix's scalar type formats itself (`1.0`, `0.5`).
+    The reference builds the text with one sparse `ratings[i, j]` lookup per entry; here the triples come from the COO arrays
+    and the lines are written chunk-wise through pandas' C writer (poisoned cfg2-size outputs have ~10^8 rows)."""
+    import pandas as pd
+    import scipy.sparse as sp
+    m = sp.csr_matrix(ratings)
+    m.sum_duplicates()
+    coo = m.tocoo()
+    keep = coo.data != 0
+    rows, cols, data = coo.row[keep], coo.col[keep], coo.data[keep]
+    n_u, n_i = m.shape
+    users = np.array([id2user[i] if i in id2user else 'fakeUser' + str(i) for i in range(n_u)], dtype=object)
+    items = np.array([id2item.get(j, '') for j in range(n_i)], dtype=object)
+    if len(cols) and any(int(j) not in id2item for j in np.unique(cols)):
+        raise KeyError('dataSave: an interacted item has no external id')
+    uniq, inv = np.unique(data, return_inverse=True)
+    vals = np.array(['{}'.format(v) for v in uniq], dtype=object)          # numpy scalar formatting, as '{}'.format(ratings[i, j])
     with open(fileName, 'w') as f:
-        for i, j in zip(rows.tolist(), cols.tolist()):
-            user = id2user[i] if i in id2user else 'fakeUser' + str(i)
-            f.write('{} {} {}\n'.format(user, id2item[j], ratings[i, j]))
+        for lo in range(0, len(rows), chunk):
+            hi = min(lo + chunk, len(rows))
+            pd.DataFrame({'u': users[rows[lo:hi]], 'i': items[cols[lo:hi]], 'v': vals[inv[lo:hi]]}).to_csv(f, sep=' ', header=False, index=False, lineterminator='\n')

@@ -243,3 +243,28 @@ def test_lpt_deal_balances_and_respects_capacity():
     w = np.array([1, 5], np.int32); b = np.zeros(2, np.int32); s = np.zeros(2, np.int32)
     assert L.arl_lpt_deal(2, w.ctypes.data, 1, 16, b.ctypes.data, s.ctypes.data) == -4      # not sorted descending
     assert L.arl_lpt_deal(40, w.ctypes.data, 1, 16, b.ctypes.data, s.ctypes.data) == -4     # does not fit
+
+
+def test_datasave_matches_per_entry_formatting(tmp_path):
+    """util/tool.py:dataSave: the chunked writer against the reference's per-entry construction (restated here), with fake users
+    missing from id2user, non-unit weights, an explicit zero and an empty row."""
+    import scipy.sparse as sp
+    from arlib_amd.util.tool import dataSave
+    rng = np.random.default_rng(8)
+    U, I = 37, 23
+    dense = (rng.random((U, I)) < 0.2).astype(np.float32)
+    dense[5] = 0; dense[U - 1, :4] = [0.5, 0.25, 1, 0.125]; dense[U - 2, 7] = 3
+    m = sp.csr_matrix(dense)
+    m.data[0] = 0.0                                      # stored zero: nonzero() skips it
+    id2user = {u: 'u%d' % (u * 7) for u in range(U - 2)}
+    id2item = {i: 'item_%d' % i for i in range(I)}
+    want = []
+    ind = m.nonzero()
+    for i, j in zip(ind[0].tolist(), ind[1].tolist()):
+        user = id2user[i] if i in id2user.keys() else 'fakeUser' + str(i)
+        want.append('{} {} {}'.format(user, id2item[j], m[i, j]) + '\n')
+    for chunk in (4_000_000, 7):
+        path = tmp_path / ('out%d.txt' % chunk)
+        dataSave(m, str(path), id2user, id2item, chunk=chunk)
+        assert open(path).readlines() == want
+    assert any(l.startswith('fakeUser%d ' % (U - 1)) and l.endswith(' 0.125\n') for l in want) and any(l.endswith(' 3.0\n') for l in want)
