@@ -274,6 +274,7 @@ class Recommender:
     # ---- training ------------------------------------------------------------------------------------------------
     l2_scale = 1.0          # NCL divides its L2 term by the batch size (NCL.py:147) ...
     l2_on_negatives = False # ... and also regularises the negative items' rows
+    extra_loss_takes_outputs = False   # proxyLG's extra term is computed from the step's own forward outputs
 
     def _extra_loss(self, model, user_idx, pos_idx):
         return None
@@ -337,7 +338,8 @@ class Recommender:
                 if self.l2_on_negatives:
                     batch_loss = batch_loss + l2_reg_loss(self.args.reg * self.l2_scale, neg_item_emb)
                 if self.has_extra_loss:
-                    batch_loss = batch_loss + (self._extra_loss(model, ul, pl, *outs) if self.train_forward_perturbed else self._extra_loss(model, ul, pl))
+                    batch_loss = batch_loss + (self._extra_loss(model, ul, pl, *outs) if (self.train_forward_perturbed or self.extra_loss_takes_outputs)
+                                               else self._extra_loss(model, ul, pl))
                 optimizer.zero_grad()
                 batch_loss.backward()
                 if requires_embgrad and maxEpoch - epoch < gradIterationNum:
@@ -385,7 +387,8 @@ class Recommender:
             if self.l2_on_negatives:
                 loss = loss + l2_reg_loss(self.args.reg * self.l2_scale, rec_item_emb[ng.long()])
             if self.has_extra_loss:
-                loss = loss + (self._extra_loss(model, u.long(), p.long(), *outs) if self.train_forward_perturbed else self._extra_loss(model, u.long(), p.long()))
+                loss = loss + (self._extra_loss(model, u.long(), p.long(), *outs) if (self.train_forward_perturbed or self.extra_loss_takes_outputs)
+                               else self._extra_loss(model, u.long(), p.long()))
             optimizer.zero_grad()
             loss.backward()
             optimizer.step()

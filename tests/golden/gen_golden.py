@@ -817,6 +817,71 @@ def gen_gray():
     save('g17_gray.npz', **out)
 
 
+# --------------------------------------------------------------------------- GTA: proxyLG's first training step, result structure
+def gen_gta():
+    import io, contextlib
+    from copy import deepcopy
+    import attack.Black.GTA as G
+    os.makedirs('data/clean/ml-100k', exist_ok=True)
+    undo_shim = _scipy_torch_index_shim()
+    rargs = rec_args(emb_size=16, n_layers=2, maxEpoch=1)
+    out = {}
+    # (1) one proxyLG training step from fresh tables: loss and parameter gradients of the first batch
+    seedSet(2018)
+    data = DataLoader(rargs)
+    with contextlib.redirect_stdout(io.StringIO()):
+        proxy = G.proxyLG(rargs, data, [3, 77, 500, 1000, 1411])
+    out['gta_user0'] = proxy.model.embedding_dict['user_emb'].detach().numpy().copy()
+    out['gta_item0'] = proxy.model.embedding_dict['item_emb'].detach().numpy().copy()
+    cap = {}
+    orig_backward, orig_adam_step, orig_nbp = torch.Tensor.backward, torch.optim.Adam.step, G.next_batch_pairwise
+
+    def nbp_wrap(d, bs):
+        for b in orig_nbp(d, bs):
+            if 'batch' not in cap:
+                cap['batch'] = [np.asarray(x, np.int32) for x in b]
+            yield b
+
+    def backward_wrap(self, *a, **k):
+        if 'loss' not in cap:
+            cap['loss'] = float(self.item())
+        return orig_backward(self, *a, **k)
+
+    def adam_step_wrap(self, *a, **k):
+        if 'grads' not in cap:
+            cap['grads'] = [p.grad.detach().numpy().copy() for p in self.param_groups[0]['params']]
+        return orig_adam_step(self, *a, **k)
+    G.next_batch_pairwise = nbp_wrap
+    torch.Tensor.backward, torch.optim.Adam.step = backward_wrap, adam_step_wrap
+    try:
+        random.seed(2018)
+        with contextlib.redirect_stdout(io.StringIO()):
+            proxy.train(Epoch=1, evalNum=5)
+    finally:
+        G.next_batch_pairwise = orig_nbp
+        torch.Tensor.backward, torch.optim.Adam.step = orig_backward, orig_adam_step
+    out['gta_targets0'] = np.array([3, 77, 500, 1000, 1411], np.int32)
+    out['gta_batch_u'], out['gta_batch_p'], out['gta_batch_n'] = cap['batch']
+    out['gta_loss'] = np.array([cap['loss']], np.float32)
+    for gr in cap['grads']:
+        out['gta_grad_user' if gr.shape[0] == data.user_num else 'gta_grad_item'] = gr
+    # (2) the whole attack: structure of the result
+    seedSet(2018)
+    data = DataLoader(rargs)
+    rec = LightGCN(rargs, data)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rec.train(Epoch=1, evalNum=5)
+    atk = G.GTA(_attack_args(attackCategory='Black', attackModelName='GTA', maliciousUserSize=3, Epoch=2, outerEpoch=1, innerEpoch=1), data)
+    random.seed(5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = atk.posionDataAttack(rec)
+    U, F = atk.userNum, atk.fakeUserNum
+    out['gta_result_fake_rowsums'] = np.asarray(res[U:U + F, :].sum(1)).ravel().astype(np.float32)
+    out['gta_targets'] = np.array(atk.targetItem, np.int32)
+    undo_shim()
+    save('g18_gta.npz', **out)
+
+
 # --------------------------------------------------------------------------- NGCF (a9): forward + 3 Adam steps
 def gen_ngcf():
     from recommender.NGCF import NGCF
@@ -1020,6 +1085,8 @@ if __name__ == '__main__':
             gen_pipattack()
         if 'gray' in only:
             gen_gray()
+        if 'gta' in only:
+            gen_gta()
         sys.exit(0)
     gen_dataset()
     data = gen_sampler()
@@ -1041,4 +1108,5 @@ if __name__ == '__main__':
     gen_infoattack()
     gen_pipattack()
     gen_gray()
+    gen_gta()
     print('done; scratch dir', SCRATCH)

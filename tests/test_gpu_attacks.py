@@ -393,6 +393,56 @@ def test_gray_box_attacks_end_to_end(name, tmp_path, monkeypatch):
     assert all(atk.maliciousFeedbackNum <= s <= atk.maliciousFeedbackNum + 5 for s in fake.sum(1)) and all(46 <= s <= 51 for s in ref)
 
 
+def test_gta_proxy_training_step_matches_reference(tmp_path, monkeypatch):
+    """GTA's proxyLG: loss and parameter gradients of the reference's first training batch (0.01 * CW/d over all
+    (user, target) pairs with negatives from the masked top-k of the step's own forward + BPR + L2), from the same tables and batch."""
+    from arlib_amd.attack.Black.GTA import proxyLG
+    from arlib_amd.util.loss import bpr_l2_loss
+    monkeypatch.chdir(tmp_path)
+    g = golden('g18_gta.npz')
+    data = make_data()
+    with contextlib.redirect_stdout(io.StringIO()):
+        proxy = proxyLG(rec_args(emb_size=16, n_layers=2, maxEpoch=1), data, [int(t) for t in g['gta_targets0']])
+    model = proxy.model.cuda()
+    with torch.no_grad():
+        model.embedding_dict['user_emb'][:] = T(g['gta_user0']); model.embedding_dict['item_emb'][:] = T(g['gta_item0'])
+    u, p, n = (torch.from_numpy(g[x].astype(np.int64)).cuda() for x in ('gta_batch_u', 'gta_batch_p', 'gta_batch_n'))
+    ru, ri = model()
+    loss = bpr_l2_loss(ru[u], ri[p], ri[n], 1e-4) + proxy._extra_loss(model, u, p, ru, ri)
+    assert abs(loss.item() - g['gta_loss'][0]) <= RTOL * abs(g['gta_loss'][0])
+    loss.backward()
+    assert rel_err(model.embedding_dict['user_emb'].grad.cpu().numpy(), g['gta_grad_user']) < RTOL
+    assert rel_err(model.embedding_dict['item_emb'].grad.cpu().numpy(), g['gta_grad_item']) < RTOL
+
+
+def test_gta_end_to_end(tmp_path, monkeypatch):
+    """Whole GTA.posionDataAttack(): proxy on the victim's DataLoader, 30 + inner epochs of proxy training, seed items drawn from ALL items
+    (np.matrix slicing quirk), best EVALUATED graph returned (g18: the reference run kept the initial random profiles, 46 fillers)."""
+    from arlib_amd.util.tool import seedSet
+    from arlib_amd.recommender.LightGCN import LightGCN
+    from arlib_amd.attack.Black.GTA import GTA
+    monkeypatch.chdir(tmp_path)
+    g = golden('g18_gta.npz')
+    seedSet(2018)
+    data = make_data()
+    rec = LightGCN(rec_args(emb_size=16, n_layers=2, maxEpoch=1), data)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rec.train(Epoch=1, evalNum=5)
+    clean = sp.csr_matrix(data.matrix()).copy()
+    atk = GTA(attack_args(maliciousUserSize=3, Epoch=2, outerEpoch=1), data)
+    assert sorted(atk.targetItem) == sorted(int(t) for t in g['gta_targets'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = sp.csr_matrix(atk.posionDataAttack(rec))
+    U, I, F = 942, 1412, 3
+    assert res.shape == (U + F, I) and (res[:U] != clean).nnz == 0 and data.user_num == U + F          # the victim's DataLoader was extended
+    fake = np.asarray(res[U:].todense())
+    assert set(np.unique(fake)) <= {0.0, 1.0}
+    m = atk.maliciousFeedbackNum
+    for s_, ref in zip(fake.sum(1), g['gta_result_fake_rowsums']):
+        assert s_ == m or (m // 2 <= s_ <= 2 * (m // 2) + 5)       # initial random profile, or seeds + projection + targets
+        assert ref == m or (m // 2 <= ref <= 2 * (m // 2) + 5)
+
+
 def test_cw_operator_structured_build_equals_sorted_build():
     """CLeaR's per-step CW operator (built from its structure, no 4UT-entry sort/histogram) against the generic builder PGA
     uses once per inner epoch: same SpMM result and loss; negative counts = histogram of the negatives."""
