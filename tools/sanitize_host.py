@@ -72,6 +72,18 @@ O.orc_num_threads.restype = C.c_int
 OR._LIB = O
 U, I, d = 30, 12, 8
 u = rng.integers(0, U - 3, 200); it = rng.integers(0, I - 2, 200)                 # 3 users and 2 items stay isolated
+# plan helper of the register-blocked SpMM: exact fill (n == n_bins * cap), ragged, empty, rejected inputs
+H.arl_lpt_deal.argtypes = [i64, C.c_void_p, i64, i64, C.c_void_p, C.c_void_p]
+for n, cap in ((64, 16), (65, 16), (1, 32), (0, 16), (5000, 32)):
+    wts = np.sort(rng.integers(0, 1000, n)).astype(np.int32)[::-1].copy()
+    nb = (n + cap - 1) // cap
+    b = np.zeros(max(n, 1), np.int32); sl = np.zeros(max(n, 1), np.int32)
+    assert H.arl_lpt_deal(n, vp(wts), nb, cap, vp(b), vp(sl)) == 0
+    if n:
+        assert b[:n].max() < nb and sl[:n].max() < cap and np.bincount(b[:n]).max() <= cap
+assert H.arl_lpt_deal(10, vp(np.arange(10, dtype=np.int32)), 1, 16, vp(np.zeros(10, np.int32)), vp(np.zeros(10, np.int32))) == -4     # ascending weights
+assert H.arl_lpt_deal(40, vp(np.zeros(40, np.int32)), 2, 16, vp(np.zeros(40, np.int32)), vp(np.zeros(40, np.int32))) == -4            # does not fit
+print('arl_lpt_deal: ok')
 rowptr, col, w = OR.bipartite_csr(u, it, U, I)
 val = OR.norm_adj_values(rowptr, col, w)
 assert np.isfinite(val).all()
