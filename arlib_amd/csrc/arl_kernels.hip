@@ -501,7 +501,7 @@ __device__ __forceinline__ void spmm_epilogue1(const Epi &ep, int row, int c, fl
     if (MODE == EPI_AXPBY) {
         float y = ep.alpha * a;
         if (ep.Z && (!ep.zflags || ep.zflags[row])) y = fmaf(ep.beta, ep.Z[o], y);
-        ep.Y[o] = y;
+        __builtin_nontemporal_store(y, ep.Y + o);
     } else if (MODE == EPI_LAYERSUM) {
         const float sv = ep.S_in[o];
         if (ep.Y) ep.Y[o] = a;
@@ -530,10 +530,10 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked64_kernel(BlockedDev P, co
     const int begin = P.wave_ptr[w], end = P.wave_ptr[w + 1];
     const float *xl = X + lane;
     int rc = 0; float rv = 0.f;
-    if (begin < end) { rc = P.rec_col[begin + lane]; rv = P.rec_val[begin + lane]; }
+    if (begin < end) { rc = __builtin_nontemporal_load(P.rec_col + begin + lane); rv = __builtin_nontemporal_load(P.rec_val + begin + lane); }
     for (int base = begin; base < end; base += 64) {
         const int c_cur = rc; const float v_cur = rv;
-        if (base + 64 < end) { rc = P.rec_col[base + 64 + lane]; rv = P.rec_val[base + 64 + lane]; }       // next batch in flight
+        if (base + 64 < end) { rc = __builtin_nontemporal_load(P.rec_col + base + 64 + lane); rv = __builtin_nontemporal_load(P.rec_val + base + 64 + lane); }       // next batch in flight
 #pragma unroll
         for (int j = 0; j < 64; j += UNR) {
             float x[UNR]; int cs[UNR];
