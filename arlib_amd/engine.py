@@ -417,20 +417,28 @@ class PropagationEngine:
         return self.loss_out, cl_loss
 
     def _sparse_buffers(self, B):
+        """Buffers of the sparse-batch step.  The node-sized ones exist once; the batch-sized ones are kept per batch size (an epoch has two:
+        the full batches and the last one), so that the last batch of every epoch does not re-allocate them."""
         if getattr(self, '_sparse_B', None) == B:
             return
         dev, d = self.device, self.d
-        self.flags = torch.zeros(self.N, dtype=torch.uint8, device=dev)          # byte per row: read once per OUTPUT row (epilogue)
-        self.bits = torch.zeros((self.N + 31) // 32, dtype=torch.int32, device=dev)   # bit per node: read once per EDGE (masked hop)
-        self.Gc = torch.zeros(3 * B, d, dtype=torch.float32, device=dev)
-        self.out_c = torch.empty(3 * B, d, dtype=torch.float32, device=dev)
-        self.nsplit = 32            # edge ranges per batch row in the row-subset hop (cfg2 sweep: 8: 0.56 ms, 16: 0.33, 32/64: 0.21, 128: 0.36)
-        self.rows_ws = torch.empty(3 * B * self.nsplit * d, dtype=torch.float32, device=dev)
-        self.ar = torch.arange(B, dtype=torch.int32, device=dev)
-        self.arB = self.ar + B
-        self._ws = torch.empty(4 * B, dtype=torch.float32, device=dev)
-        # forward needs E_1..E_{L-1} alive at the same time; Ea/Eb cover L <= 3
-        self.hops = [self.Ea, self.Eb] + [torch.empty_like(self.Ea) for _ in range(max(0, self.L - 3))]
+        if not hasattr(self, '_sb_cache'):
+            self._sb_cache = {}
+            self.flags = torch.zeros(self.N, dtype=torch.uint8, device=dev)          # byte per row: read once per OUTPUT row (epilogue)
+            self.bits = torch.zeros((self.N + 31) // 32, dtype=torch.int32, device=dev)   # bit per node: read once per EDGE (masked hop)
+            self.nsplit = 32            # edge ranges per batch row in the row-subset hop (cfg2 sweep: 8: 0.56 ms, 16: 0.33, 32/64: 0.21, 128: 0.36)
+            # forward needs E_1..E_{L-1} alive at the same time; Ea/Eb cover L <= 3
+            self.hops = [self.Ea, self.Eb] + [torch.empty_like(self.Ea) for _ in range(max(0, self.L - 3))]
+        sb = self._sb_cache.get(B)
+        if sb is None:
+            ar = torch.arange(B, dtype=torch.int32, device=dev)
+            sb = {'Gc': torch.zeros(3 * B, d, dtype=torch.float32, device=dev), 'out_c': torch.empty(3 * B, d, dtype=torch.float32, device=dev),
+                  'rows_ws': torch.empty(3 * B * self.nsplit * d, dtype=torch.float32, device=dev), 'ar': ar, 'arB': ar + B,
+                  '_ws': torch.empty(4 * B, dtype=torch.float32, device=dev)}
+            if len(self._sb_cache) >= 8:                   # unusual callers with many batch sizes: drop the oldest set
+                del self._sb_cache[next(iter(self._sb_cache))]
+            self._sb_cache[B] = sb
+        self.Gc, self.out_c, self.rows_ws, self.ar, self.arB, self._ws = sb['Gc'], sb['out_c'], sb['rows_ws'], sb['ar'], sb['arB'], sb['_ws']
         self._sparse_B = B
 
     def step_dense(self, u, p, n):
