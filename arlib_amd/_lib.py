@@ -58,6 +58,8 @@ _SIGS = {
     'arl_mark_rows_u8': (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     'arl_mark_rows_bits_u32': (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     'arl_zero_rows_f32': (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
+    'arl_batch_rows_set_f32': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _f, _vp]),
+    'arl_batch_rows_clear_f32': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     'arl_bpr_l2_workspace_bytes': (_i64, [_i64]),
     'arl_bpr_l2_fwd_bwd_f32': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _f, _f, _vp, _vp, _vp, _vp]),
     'arl_bpr_l2_partial_f32': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),

@@ -311,6 +311,36 @@ __global__ __launch_bounds__(kBlock) void zero_rows_kernel(float *__restrict__ d
     for (int k = lane; k < d; k += kWave) o[k] = 0.f;
 }
 
+// The sparse-batch step touches <= 3B rows of three node-sized arrays (gradient table, byte flags, bitmap) with the same index list:
+// once to add the batch gradients and mark the rows, once to clear everything again.  One launch each instead of three (at ml-100k
+// size a launch is a measurable part of the step).  Duplicate indices are fine: the adds accumulate, the marks are idempotent.
+__global__ __launch_bounds__(kBlock) void batch_rows_set_kernel(float *__restrict__ G, uint8_t *__restrict__ flags, uint32_t *__restrict__ bits,
+                                                                 const int32_t *__restrict__ idx, int n, int d, const float *__restrict__ src, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (t >= n) return;
+    const int row = idx[t];
+    float *o = G + (size_t)row * d;
+    for (int k = lane; k < d; k += kWave) atomicAdd(o + k, scale * src[(size_t)t * d + k]);
+    if (lane == 0) {
+        flags[row] = 1;
+        atomicOr(bits + (row >> 5), 1u << (row & 31));
+    }
+}
+__global__ __launch_bounds__(kBlock) void batch_rows_clear_kernel(float *__restrict__ G, uint8_t *__restrict__ flags, uint32_t *__restrict__ bits,
+                                                                   const int32_t *__restrict__ idx, int n, int d) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (t >= n) return;
+    const int row = idx[t];
+    float *o = G + (size_t)row * d;
+    for (int k = lane; k < d; k += kWave) o[k] = 0.f;
+    if (lane == 0) {
+        flags[row] = 0;
+        atomicAnd(bits + (row >> 5), ~(1u << (row & 31)));
+    }
+}
+
 // ================================================================================================
 // L2-blocked ("tiled") SpMM.  The row-per-wave kernel above moves one 256-B row per edge through the Infinity-Cache fabric
 // (~8 TB/s).  Gathers that hit the XCD's 4 MB L2 run 2.2x faster (tools/l2_gather_bench.py: 15.8 TB/s from a 2 MB table), so
@@ -1759,6 +1789,27 @@ int arl_mark_rows_bits_u32(uint32_t *bits, const int32_t *idx, int64_t n, int32_
     if (n < 0 || n > 0x7fffffffll) return ARL_E_ARG;
     if (n == 0) return ARL_OK;
     hipLaunchKernelGGL(mark_bits_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, bits, idx, (int)n, (int)set);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_batch_rows_set_f32(float *G, uint8_t *flags, uint32_t *bits, const int32_t *idx, int64_t n, int64_t d, const float *src, float scale,
+                           arl_stream_t stream) {
+    if (!G || !flags || !bits || !idx || !src) return ARL_E_NULL;
+    if (n < 0 || n > 0x7fffffffll || d <= 0 || d > 0x7fffffffll) return ARL_E_ARG;
+    if (n == 0) return ARL_OK;
+    hipLaunchKernelGGL(batch_rows_set_kernel, dim3((unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, G, flags,
+                       bits, idx, (int)n, (int)d, src, scale);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_batch_rows_clear_f32(float *G, uint8_t *flags, uint32_t *bits, const int32_t *idx, int64_t n, int64_t d, arl_stream_t stream) {
+    if (!G || !flags || !bits || !idx) return ARL_E_NULL;
+    if (n < 0 || n > 0x7fffffffll || d <= 0 || d > 0x7fffffffll) return ARL_E_ARG;
+    if (n == 0) return ARL_OK;
+    hipLaunchKernelGGL(batch_rows_clear_kernel, dim3((unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, G, flags,
+                       bits, idx, (int)n, (int)d);
     ARL_LAUNCH_CHECK();
     return ARL_OK;
 }

@@ -169,9 +169,7 @@ class PropagationEngine:
         # loss + compact per-sample gradients (rows [0,B) users, [B,2B) positives, [2B,3B) negatives of out_c)
         self.Gc.zero_()
         ops.bpr_l2_fwd_bwd(self.out_c, B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self._ws, loss_out=self.loss_out, check_range=False)
-        ops.scatter_add_rows(self.G, rows, self.Gc, 1.0, check_range=False)          # duplicates accumulate
-        ops.mark_rows_(self.flags, rows, 1, check_range=False)
-        ops.mark_bits_(self.bits, rows, True, self.N, check_range=False)
+        ops.batch_rows_set_(self.G, self.flags, self.bits, rows, self.Gc, 1.0, check_range=False)      # duplicates accumulate; rows marked
         # backward (Horner): first hop gathers flagged rows only; G is read through the flags everywhere
         self.t += 1
         if L == 1:
@@ -182,9 +180,7 @@ class PropagationEngine:
             for k in range(1, L - 1):
                 acc = ops.spmm_flagged(A, acc, None, 1.0, 1.0, self.G, self.flags, out=self.hops[k % 2 if len(self.hops) == 2 else k])
             ops.spmm_adam(A, acc, s, s, self.G, self.E0, self.m, self.v, self.lr, self.t, self.betas, self.eps, zflags=self.flags)
-        ops.zero_rows_(self.G, rows, check_range=False)
-        ops.mark_rows_(self.flags, rows, 0, check_range=False)
-        ops.mark_bits_(self.bits, rows, False, self.N, check_range=False)
+        ops.batch_rows_clear_(self.G, self.flags, self.bits, rows, check_range=False)
         return self.loss_out
 
     def step_simgcl(self, u, p, n, cl_rate=0.2, tau=0.2, eps=0.1, noises=None):
@@ -263,9 +259,7 @@ class PropagationEngine:
             ops.adam_dense(self.E0, tmp, self.m, self.v, self.lr, self.t, self.betas, self.eps)
         else:
             ops.spmm_adam(A, acc, inv, 0.0, None, self.E0, self.m, self.v, self.lr, self.t, self.betas, self.eps)
-        ops.zero_rows_(self.G, allrows, check_range=False)
-        ops.mark_rows_(self.flags, allrows, 0, check_range=False)
-        ops.mark_bits_(self.bits, allrows, False, N, check_range=False)
+        ops.batch_rows_clear_(self.G, self.flags, self.bits, allrows, check_range=False)
         return self.loss_out, cl_loss
 
     def step_xsimgcl(self, u, p, n, cl_rate=0.2, tau=0.1, eps=0.1, layer_cl=1, noises=None):
@@ -348,9 +342,7 @@ class PropagationEngine:
                 acc = ops.spmm_flagged(A, acc, None, 1.0, 1.0, self.G, self.flags, out=dst)
                 level -= 1
             ops.spmm_adam(A, acc, 1.0, 0.0, None, self.E0, self.m, self.v, self.lr, self.t, self.betas, self.eps)
-        ops.zero_rows_(self.G, allrows, check_range=False)
-        ops.mark_rows_(self.flags, allrows, 0, check_range=False)
-        ops.mark_bits_(self.bits, allrows, False, N, check_range=False)
+        ops.batch_rows_clear_(self.G, self.flags, self.bits, allrows, check_range=False)
         return self.loss_out, cl_loss
 
     def step_sgl(self, u, p, n, view1, view2, cl_rate=0.2, tau=0.2):
@@ -380,9 +372,7 @@ class PropagationEngine:
             return ops.spmm_rows(graph, layers[-1], sel, layers, s, nsplit=self.nsplit, check_range=False)
 
         def backward_into(graph, sel, grad_c, dst, accumulate):             # dst (+)= dL/dE0 of a pass whose output gradient is grad_c at rows sel
-            ops.scatter_add_rows(self.G, sel, grad_c, 1.0, check_range=False)
-            ops.mark_rows_(self.flags, sel, 1, check_range=False)
-            ops.mark_bits_(self.bits, sel, True, N, check_range=False)
+            ops.batch_rows_set_(self.G, self.flags, self.bits, sel, grad_c, 1.0, check_range=False)
             beta, Z = (1.0, dst) if accumulate else (0.0, None)
             if L == 1:
                 tmp = ops.spmm_flagged(graph, self.G, self.bits, s, s, self.G, self.flags, out=self._sgl_hops[0])
@@ -395,9 +385,7 @@ class PropagationEngine:
                 dst.add_(tmp)
             else:
                 dst.copy_(tmp)
-            ops.zero_rows_(self.G, sel, check_range=False)
-            ops.mark_rows_(self.flags, sel, 0, check_range=False)
-            ops.mark_bits_(self.bits, sel, False, N, check_range=False)
+            ops.batch_rows_clear_(self.G, self.flags, self.bits, sel, check_range=False)
 
         # clean pass: BPR + L2 on the batch rows
         out_c = forward_rows(self.A, rows)

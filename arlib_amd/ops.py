@@ -469,6 +469,28 @@ def mark_rows_(flags, idx, value, check_range=True):
     return flags
 
 
+def batch_rows_set_(G, flags, bits, idx, src, scale=1.0, check_range=True):
+    """G[idx[t]] += scale * src[t] (duplicates accumulate), flags[idx[t]] = 1, bit idx[t] of `bits` set: one launch."""
+    _dev(G, torch.float32, 'G', 2); _dev(flags, torch.uint8, 'flags', 1); _dev(bits, torch.int32, 'bits', 1); _dev(idx, torch.int32, 'idx', 1)
+    _dev(src, torch.float32, 'src', 2)
+    N, d = G.shape
+    if flags.numel() != N or bits.numel() != (N + 31) // 32 or src.shape != (idx.numel(), d):
+        raise ValueError('batch_rows_set_: shape mismatch')
+    if check_range and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= N):
+        raise IndexError('batch_rows_set_: index out of range')
+    check(_lib.lib().arl_batch_rows_set_f32(_ptr(G), _ptr(flags), _ptr(bits), _ptr(idx), idx.numel(), d, _ptr(src), scale, _stream()), 'arl_batch_rows_set_f32')
+
+
+def batch_rows_clear_(G, flags, bits, idx, check_range=True):
+    """Rows idx of G zeroed, their byte flags and bitmap bits cleared: one launch."""
+    _dev(G, torch.float32, 'G', 2); _dev(flags, torch.uint8, 'flags', 1); _dev(bits, torch.int32, 'bits', 1); _dev(idx, torch.int32, 'idx', 1)
+    N, d = G.shape
+    if flags.numel() != N or bits.numel() != (N + 31) // 32:
+        raise ValueError('batch_rows_clear_: shape mismatch')
+    if check_range and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= N):
+        raise IndexError('batch_rows_clear_: index out of range')
+    check(_lib.lib().arl_batch_rows_clear_f32(_ptr(G), _ptr(flags), _ptr(bits), _ptr(idx), idx.numel(), d, _stream()), 'arl_batch_rows_clear_f32')
+
 def mark_bits_(bits, idx, set_, n_nodes, check_range=True):
     """Set / clear bits idx[t] of a node bitmap (int32 words)."""
     _dev(bits, torch.int32, 'bits', 1); _dev(idx, torch.int32, 'idx', 1)

@@ -133,6 +133,12 @@ int arl_mark_rows_u8(uint8_t *flags, const int32_t *idx, int64_t n, int32_t valu
 /* set (set != 0) or clear the bits idx[t] of a bitmap with atomic OR / AND (duplicates allowed) */
 int arl_mark_rows_bits_u32(uint32_t *bits, const int32_t *idx, int64_t n, int32_t set, arl_stream_t stream);
 int arl_zero_rows_f32(float *dst, const int32_t *idx, int64_t n, int64_t d, arl_stream_t stream);
+/* The three per-batch updates of the sparse-batch step on one index list, fused: G[idx[t]] += scale * src[t] (accumulating over
+ * duplicates), flags[idx[t]] = 1, bit idx[t] of `bits` set -- and the clearing counterpart (rows zeroed, flag and bit cleared). */
+int arl_batch_rows_set_f32(float *G, uint8_t *flags, uint32_t *bits, const int32_t *idx, int64_t n, int64_t d,
+                           const float *src, float scale, arl_stream_t stream);
+int arl_batch_rows_clear_f32(float *G, uint8_t *flags, uint32_t *bits, const int32_t *idx, int64_t n, int64_t d,
+                             arl_stream_t stream);
 
 /* Register-blocked SpMM (d = 64 only): the same three operations as arl_spmm_csr_f32 / _layersum_f32 / _adam_f32, for the rows
  * of a PLAN.  A wave owns up to rows_per_wave (16 or 32) output rows with register accumulators and consumes one record stream

@@ -171,6 +171,30 @@ def test_spmm_blocked_rejects_bad_plans(ops):
     assert L.arl_spmm_blocked_f32(C.byref(bad), X.data_ptr(), 64, 1.0, 0.0, None, None, Y.data_ptr(), None) == -4
 
 
+def test_batch_rows_set_and_clear(ops):
+    """Fused per-batch updates of the sparse-batch step (gradient rows += with duplicates, byte flags, bitmap) against torch."""
+    rng = np.random.default_rng(12)
+    N, d, n = 1000, 48, 400
+    idx = rng.integers(0, N, n).astype(np.int32); idx[:50] = 7; idx[50:60] = N - 1
+    src = rng.standard_normal((n, d)).astype(np.float32)
+    G = torch.zeros(N, d, device=DEV); G[3] = 1.0
+    flags = torch.zeros(N, dtype=torch.uint8, device=DEV); bits = torch.zeros((N + 31) // 32, dtype=torch.int32, device=DEV)
+    ops.batch_rows_set_(G, flags, bits, T(idx), T(src), 0.5)
+    ref = np.zeros((N, d), np.float64); ref[3] = 1.0
+    np.add.at(ref, idx.astype(np.int64), 0.5 * src.astype(np.float64))
+    assert rel_err(G.cpu().numpy(), ref.astype(np.float32)) < 1e-5
+    want = np.zeros(N, np.uint8); want[idx] = 1
+    assert np.array_equal(flags.cpu().numpy(), want)
+    bn = bits.cpu().numpy().view(np.uint32)
+    assert np.array_equal(((bn[np.arange(N) >> 5] >> (np.arange(N) & 31)) & 1).astype(np.uint8), want)
+    ops.batch_rows_clear_(G, flags, bits, T(idx))
+    assert int(flags.max()) == 0 and int(bits.abs().max()) == 0
+    g = G.cpu().numpy()
+    assert np.all(g[3] == 1.0) and float(np.abs(np.delete(g, 3, axis=0)).max()) == 0.0
+    with pytest.raises(IndexError):
+        ops.batch_rows_set_(G, flags, bits, T(np.array([N], np.int32)), T(src[:1]))
+
+
 def test_spmm_deterministic_and_linear(ops):
     rng = np.random.default_rng(3)
     U, I, d = 5000, 900, 64
