@@ -43,6 +43,7 @@ _SIGS = {
     'arl_sampler_next_batch': (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp]),
     'arl_norm_adj_values_f32': (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     'arl_norm_adj_values_coo_f32': (C.c_int, [_i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    'arl_norm_vals_coo_f32': (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     'arl_spmm_csr_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _f, _f, _vp, _vp, _vp]),
     'arl_spmm_csr_layersum_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _vp, _vp, _vp, _vp]),
     'arl_spmm_csr_adam_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),

@@ -54,6 +54,8 @@ class FakeBlockGraph:
         self.w = torch.from_numpy(w).to(self.device)
         self.fwd_lo = fb
         self.bwd_idx = torch.from_numpy(fake_pos.reshape(-1)).to(self.device)
+        base = np.zeros(Up + I, np.float32); base[:U] = np.asarray(R.sum(1)).ravel(); base[Up:] = np.asarray(R.sum(0)).ravel()
+        self.base_rowsum = torch.from_numpy(base).to(self.device)          # weighted degrees of the real interactions
         self.graph = ops.CSRGraph(rowptr, self.col_d, torch.zeros(nnz, device=self.device), self.device)
         if emb_size is not None:            # the pattern never changes: large graphs get the register-blocked hop plan once (the fake rows are its hub rows)
             ops.auto_blocked(self.graph, emb_size, split=Up)
@@ -65,7 +67,13 @@ class FakeBlockGraph:
         flat = S.reshape(-1)
         self.w[self.fwd_lo:self.fwd_lo + flat.numel()] = flat
         self.w[self.bwd_idx] = flat
-        val, self.dinv = ops.norm_adj_values(self.rowptr_d, self.col_d, self.w, self.N, erow=self.erow_d)
+        # row sums of the fixed pattern: real users keep their degree, a fake user has its S row, an item its real degree + its S column
+        # (PGA.py:93-97 recomputes all 77 M-edge sums with scipy); then the edge-parallel value pass
+        rs = self.base_rowsum.clone()
+        rs[self.U:self.Up] = S.sum(1)
+        rs[self.Up:] += S.sum(0)
+        self.dinv = torch.where(rs > 0, 1.0 / torch.sqrt(rs), torch.zeros_like(rs))
+        val = ops.norm_vals_coo(self.erow_d, self.col_d, self.w, self.dinv)
         self.graph = self.graph.with_values(val)
         return self.graph
 

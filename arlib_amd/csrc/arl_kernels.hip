@@ -1626,6 +1626,18 @@ int arl_norm_adj_values_f32(int64_t n_rows, const int32_t *rowptr, const int32_t
     return ARL_OK;
 }
 
+int arl_norm_vals_coo_f32(const int32_t *erow, const int32_t *col, const float *w, int64_t nnz, const float *dinv, float *val, arl_stream_t stream) {
+    if (nnz < 0 || nnz > 0x7fffffffll) return ARL_E_RANGE;
+    if (nnz == 0) return ARL_OK;
+    if (!erow || !col || !w || !dinv || !val) return ARL_E_NULL;
+    if (((uintptr_t)erow | (uintptr_t)col | (uintptr_t)w | (uintptr_t)val) & 15) return ARL_E_ARG;      // 16-B vector accesses
+    const long long quads = (nnz + 3) / 4;
+    hipLaunchKernelGGL(norm_vals_coo_kernel, dim3((unsigned)((quads + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, (long long)nnz, erow, col, w,
+                       dinv, val);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
 int arl_norm_adj_values_coo_f32(int64_t n_rows, const int32_t *rowptr, const int32_t *erow, const int32_t *col, const float *w, int64_t nnz,
                                 float *dinv, float *val, arl_stream_t stream) {
     if (!rowptr || !dinv || !val) return ARL_E_NULL;

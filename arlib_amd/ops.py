@@ -282,6 +282,16 @@ def _spmm_dispatch(A, d, blocked_call, csr_call):
         csr_call(C.byref(bp.hub._struct(d)))
 
 
+def norm_vals_coo(erow, col, w, dinv):
+    """val[e] = (dinv[erow[e]] * w[e]) * dinv[col[e]] for a caller that already has dinv (edge-parallel)."""
+    _dev(erow, torch.int32, 'erow', 1); _dev(col, torch.int32, 'col', 1); _dev(w, torch.float32, 'w', 1); _dev(dinv, torch.float32, 'dinv', 1)
+    if erow.numel() != w.numel() or col.numel() != w.numel():
+        raise ValueError('norm_vals_coo: length mismatch')
+    val = torch.empty_like(w)
+    check(_lib.lib().arl_norm_vals_coo_f32(_ptr(erow), _ptr(col), _ptr(w), w.numel(), _ptr(dinv), _ptr(val), _stream()), 'arl_norm_vals_coo_f32')
+    return val
+
+
 def norm_adj_values(rowptr, col, w, n_rows, erow=None):
     """val[e] = (dinv[row]*w[e])*dinv[col[e]] on device; returns (val, dinv).  `erow` (int32 row id per edge, optional) selects the
     edge-parallel form for callers that re-normalise the same pattern many times (PGA)."""

@@ -92,6 +92,10 @@ int arl_norm_adj_values_f32(int64_t n_rows, const int32_t *rowptr, const int32_t
  * (no wave per row).  All arrays 16-byte aligned. */
 int arl_norm_adj_values_coo_f32(int64_t n_rows, const int32_t *rowptr, const int32_t *erow, const int32_t *col,
                                 const float *w, int64_t nnz, float *dinv, float *val, arl_stream_t stream);
+/* The value pass alone, for a caller that already has dinv (PGA: the row sums of its fixed-pattern graph follow from the F x I fake
+ * block in O(F I), so the 77 M-edge row-sum pass is not needed): val[e] = (dinv[erow[e]] * w[e]) * dinv[col[e]]. */
+int arl_norm_vals_coo_f32(const int32_t *erow, const int32_t *col, const float *w, int64_t nnz, const float *dinv, float *val,
+                          arl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SpMM family -- replaces torch.sparse.mm(sparse_norm_adj, ego) and its autograd
