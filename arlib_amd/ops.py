@@ -222,10 +222,11 @@ class BlockedPlan:
             start = torch.zeros(n_waves + 1, dtype=torch.int64, device=dev); torch.cumsum(cnt, 0, out=start[1:])
             dst = wave_ptr[ew] + (torch.arange(ew.numel(), device=dev) - start[ew])
             rec_col = torch.zeros(max(total, 64), dtype=torch.int32, device=dev)        # never empty: the C ABI wants real pointers
-            rec_src = torch.full((max(total, 64),), A.nnz, dtype=torch.int64, device=dev)       # padding -> the appended zero
+            rec_src = torch.zeros(max(total, 64), dtype=torch.int32, device=dev)                # edge id of every record (padding: 0, zeroed in _bind)
             rec_col[dst] = (ec | (es << 24)).to(torch.int32)
-            rec_src[dst] = eid
-            self.sets.append({'n_waves': n_waves, 'wave_ptr': wave_ptr.to(torch.int32), 'wave_rows': wave_rows, 'rec_col': rec_col, 'rec_src': rec_src,
+            rec_src[dst] = eid.to(torch.int32)
+            pad = torch.ones(max(total, 64), dtype=torch.bool, device=dev); pad[dst] = False
+            self.sets.append({'n_waves': n_waves, 'wave_ptr': wave_ptr.to(torch.int32), 'wave_rows': wave_rows, 'rec_col': rec_col, 'rec_src': rec_src, 'pad_pos': torch.nonzero(pad).flatten(),
                               'n_rows': n, 'n_edges': int(ew.numel()),
                               # short streams: more loads per wave; long streams (many edges per wave) run better with 16 (measured, cfg2)
                               'unroll': (16 if self.rpw == 16 or ew.numel() > 4096 * n_waves else 32) if unroll is None else int(unroll)})
@@ -235,10 +236,13 @@ class BlockedPlan:
         self._bind(A)
 
     def _bind(self, A, hub=None):
-        vz = torch.cat([A.val, torch.zeros(1, dtype=torch.float32, device=A.device)])
         self.structs = []
         for st in self.sets:
-            st['rec_val'] = vz[st['rec_src']]
+            if A.nnz:
+                st['rec_val'] = A.val[st['rec_src']]
+                st['rec_val'][st['pad_pos']] = 0.0
+            else:
+                st['rec_val'] = torch.zeros(st['rec_src'].numel(), dtype=torch.float32, device=A.device)
             self.structs.append(_lib.arl_blocked(st['n_waves'], self.rpw, st['unroll'], st['wave_ptr'].data_ptr(), st['wave_rows'].data_ptr(), st['rec_col'].data_ptr(),
                                                  st['rec_val'].data_ptr()))
         if hub is not None:                       # same chunk plan, new values (no host work)
