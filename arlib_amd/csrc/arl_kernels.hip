@@ -524,41 +524,48 @@ struct BlockedDev {
     const float *rec_val;
 };
 
-// spmm_epilogue for one column per lane (d = 64); same arithmetic, scalar accesses (a wave writes one 256-B row at a time)
-template <int MODE>
-__device__ __forceinline__ void spmm_epilogue1(const Epi &ep, int row, int c, float a) {
-    const size_t o = (size_t)row * 64 + c;
-    if (MODE == EPI_AXPBY) {
-        float y = ep.alpha * a;
-        if (ep.Z && (!ep.zflags || ep.zflags[row])) y = fmaf(ep.beta, ep.Z[o], y);
-        __builtin_nontemporal_store(y, ep.Y + o);
-    } else if (MODE == EPI_LAYERSUM) {
-        const float sv = ep.S_in[o];
-        if (ep.Y) ep.Y[o] = a;
-        ep.S[o] = sv + a;
-    } else {
-        float g = ep.alpha * a;
-        if (ep.Z && (!ep.zflags || ep.zflags[row])) g = fmaf(ep.beta, ep.Z[o], g);
-        float p = ep.P[o], m = ep.M[o], v = ep.V[o];
-        m = m + (g - m) * (1.0f - ep.b1);
-        v = v * ep.b2 + (1.0f - ep.b2) * g * g;
-        const float denom = sqrtf(v) * ep.inv_bc2_sqrt + ep.eps;
-        p = p - ep.step_size * (m / denom);
-        ep.P[o] = p; ep.M[o] = m; ep.V[o] = v;
+// spmm_epilogue for CPL adjacent columns per lane (d = 64 * CPL); same arithmetic (a wave writes one 256-B / 512-B row at a time)
+template <int MODE, int CPL>
+__device__ __forceinline__ void spmm_epilogue1(const Epi &ep, int row, int lane, const float *a) {
+    const size_t o = ((size_t)row * 64 + lane) * CPL;
+    const bool zr = ep.Z && (!ep.zflags || ep.zflags[row]);
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        if (MODE == EPI_AXPBY) {
+            float y = ep.alpha * a[c];
+            if (zr) y = fmaf(ep.beta, ep.Z[o + c], y);
+            __builtin_nontemporal_store(y, ep.Y + o + c);
+        } else if (MODE == EPI_LAYERSUM) {
+            const float sv = ep.S_in[o + c];
+            if (ep.Y) ep.Y[o + c] = a[c];
+            ep.S[o + c] = sv + a[c];
+        } else {
+            float g = ep.alpha * a[c];
+            if (zr) g = fmaf(ep.beta, ep.Z[o + c], g);
+            float p = ep.P[o + c], m = ep.M[o + c], v = ep.V[o + c];
+            m = m + (g - m) * (1.0f - ep.b1);
+            v = v * ep.b2 + (1.0f - ep.b2) * g * g;
+            const float denom = sqrtf(v) * ep.inv_bc2_sqrt + ep.eps;
+            p = p - ep.step_size * (m / denom);
+            ep.P[o + c] = p; ep.M[o + c] = m; ep.V[o + c] = v;
+        }
     }
 }
 
-template <int RPW, int MODE, int UNR>
+template <int RPW, int MODE, int UNR, int CPL>
 __global__ __launch_bounds__(kBlock) void spmm_blocked64_kernel(BlockedDev P, const float *__restrict__ X, Epi ep) {
-    static_assert(RPW == 16 || RPW == 32, "accumulators are one 32-register vector");
+    static_assert(RPW == 16 || RPW == 32, "accumulators are 32-register vectors");
+    static_assert(CPL == 1 || CPL == 2, "d = 64 (one column per lane) or d = 128 (two adjacent columns per lane)");
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (w >= P.n_waves) return;
-    f32x32v acc;
+    f32x32v acc[CPL];
 #pragma unroll
-    for (int r = 0; r < 32; ++r) acc[r] = 0.f;
+    for (int c = 0; c < CPL; ++c)
+#pragma unroll
+        for (int r = 0; r < 32; ++r) acc[c][r] = 0.f;
     const int begin = P.wave_ptr[w], end = P.wave_ptr[w + 1];
-    const float *xl = X + lane;
+    const float *xl = X + lane * CPL;
     int rc = 0; float rv = 0.f;
     if (begin < end) { rc = __builtin_nontemporal_load(P.rec_col + begin + lane); rv = __builtin_nontemporal_load(P.rec_val + begin + lane); }
     for (int base = begin; base < end; base += 64) {
@@ -566,31 +573,37 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked64_kernel(BlockedDev P, co
         if (base + 64 < end) { rc = __builtin_nontemporal_load(P.rec_col + base + 64 + lane); rv = __builtin_nontemporal_load(P.rec_val + base + 64 + lane); }       // next batch in flight
 #pragma unroll
         for (int j = 0; j < 64; j += UNR) {
-            float x[UNR]; int cs[UNR];
+            float x[UNR][CPL]; int cs[UNR];
 #pragma unroll
             for (int t = 0; t < UNR; ++t) {
                 cs[t] = __builtin_amdgcn_readlane(c_cur, j + t);
-                x[t] = xl[(size_t)(cs[t] & 0xffffff) * 64];
+                const float *src = xl + (size_t)(cs[t] & 0xffffff) * (64 * CPL);
+                if (CPL == 2) { const float2 v2 = *reinterpret_cast<const float2 *>(src); x[t][0] = v2.x; x[t][CPL - 1] = v2.y; }
+                else x[t][0] = src[0];
             }
 #pragma unroll
             for (int t = 0; t < UNR; ++t) {
                 const float v = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v_cur), j + t));
                 const int slot = ((unsigned)cs[t] >> 24) & 31;
-                acc[slot] = fmaf(v, x[t], acc[slot]);
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) acc[c][slot] = fmaf(v, x[t][c], acc[c][slot]);
             }
         }
     }
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int row = P.wave_rows[w * RPW + r];
-        if (row >= 0) spmm_epilogue1<MODE>(ep, row, lane, acc[r]);
+        float a[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) a[c] = acc[c][r];
+        if (row >= 0) spmm_epilogue1<MODE, CPL>(ep, row, lane, a);
     }
 }
 
 template <int MODE>
 int launch_spmm_blocked(const arl_blocked *P, const float *X, int64_t d, const Epi &ep, hipStream_t st) {
     if (!P || !X) return ARL_E_NULL;
-    if (d != 64) return ARL_E_DIM;
+    if (d != 64 && d != 128) return ARL_E_DIM;
     if (P->n_waves < 0 || P->n_waves > 0x7fffffffll / 64) return ARL_E_RANGE;
     if (P->rows_per_wave != 16 && P->rows_per_wave != 32) return ARL_E_ARG;
     if (P->n_waves == 0) return ARL_OK;
@@ -598,9 +611,12 @@ int launch_spmm_blocked(const arl_blocked *P, const float *X, int64_t d, const E
     BlockedDev D = {(int)P->n_waves, P->wave_ptr, P->wave_rows, P->rec_col, P->rec_val};
     const dim3 grid((unsigned)((P->n_waves + kWavesPerBlock - 1) / kWavesPerBlock));
     if (P->loads_in_flight != 16 && P->loads_in_flight != 32) return ARL_E_ARG;
-    if (P->rows_per_wave == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<16, MODE, 16>), grid, dim3(kBlock), 0, st, D, X, ep);
-    else if (P->loads_in_flight == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE, 16>), grid, dim3(kBlock), 0, st, D, X, ep);
-    else hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE, 32>), grid, dim3(kBlock), 0, st, D, X, ep);
+    if (d == 128) {                                      // two columns per lane: 64 accumulator registers, 16 rows in flight
+        if (P->rows_per_wave == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<16, MODE, 16, 2>), grid, dim3(kBlock), 0, st, D, X, ep);
+        else hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE, 16, 2>), grid, dim3(kBlock), 0, st, D, X, ep);
+    } else if (P->rows_per_wave == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<16, MODE, 16, 1>), grid, dim3(kBlock), 0, st, D, X, ep);
+    else if (P->loads_in_flight == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE, 16, 1>), grid, dim3(kBlock), 0, st, D, X, ep);
+    else hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE, 32, 1>), grid, dim3(kBlock), 0, st, D, X, ep);
     ARL_LAUNCH_CHECK();
     return ARL_OK;
 }

@@ -264,9 +264,9 @@ BLOCKED_MIN_WAVES = 1024         # a row set with fewer waves stays with the CSR
 
 
 def auto_blocked(graph, d, split=None, force=False):
-    """Attach the register-blocked plan to `graph` when it pays (d = 64, >= BLOCKED_MIN_NNZ edges) or when forced; no-op if the
-    graph already has one or cannot take one (d != 64, 2^24 columns or more).  Returns the graph."""
-    if graph is None or graph.blocked is not None or int(d) != 64 or graph.n_cols >= (1 << 24):
+    """Attach the register-blocked plan to `graph` when it pays (d = 64 or 128, >= BLOCKED_MIN_NNZ edges) or when forced; no-op if the
+    graph already has one or cannot take one (other widths, 2^24 columns or more).  Returns the graph."""
+    if graph is None or graph.blocked is not None or int(d) not in (64, 128) or graph.n_cols >= (1 << 24):
         return graph
     if force or graph.nnz >= BLOCKED_MIN_NNZ:
         graph.enable_blocked(split=split, min_waves=0 if force else BLOCKED_MIN_WAVES)
@@ -275,9 +275,9 @@ def auto_blocked(graph, d, split=None, force=False):
 
 def _spmm_dispatch(A, d, blocked_call, csr_call):
     """Run one full-table SpMM: through the blocked plan (+ its hub rows through the chunked CSR kernel) when the graph has one
-    and d = 64, else through the CSR kernel.  The callables take the ctypes struct pointer."""
+    and d = 64 or 128, else through the CSR kernel.  The callables take the ctypes struct pointer."""
     bp = A.blocked
-    if bp is None or d != 64:
+    if bp is None or d not in (64, 128):
         csr_call(C.byref(A._struct(d)))
         return
     for st in bp.structs:

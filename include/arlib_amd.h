@@ -144,7 +144,7 @@ int arl_batch_rows_set_f32(float *G, uint8_t *flags, uint32_t *bits, const int32
 int arl_batch_rows_clear_f32(float *G, uint8_t *flags, uint32_t *bits, const int32_t *idx, int64_t n, int64_t d,
                              arl_stream_t stream);
 
-/* Register-blocked SpMM (d = 64 only): the same three operations as arl_spmm_csr_f32 / _layersum_f32 / _adam_f32, for the rows
+/* Register-blocked SpMM (d = 64: one column per lane; d = 128: two adjacent columns per lane, 16 operand rows in flight): the same three operations as arl_spmm_csr_f32 / _layersum_f32 / _adam_f32, for the rows
  * of a PLAN.  A wave owns up to rows_per_wave (16 or 32) output rows with register accumulators and consumes one record stream
  * sorted by (column block, row slot); waves carry equal edge counts (arl_lpt_deal) and are all resident, so they sweep X in step
  * and share the gathered rows through the L2.  Rows absent from the plan (longer than its hub threshold) are not written: the

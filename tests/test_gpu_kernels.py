@@ -81,12 +81,12 @@ def test_spmm_all_epilogues(ops, d):
     assert rel_err(Pt.cpu().numpy(), Pr) < RTOL and rel_err(Mt.cpu().numpy(), Mr) < RTOL and rel_err(Vt.cpu().numpy(), Vr) < RTOL
 
 
-@pytest.mark.parametrize('rpw,split,hub', [(32, True, 64), (16, True, 24), (32, False, 100000)])
-def test_spmm_blocked_schedule_all_epilogues(ops, rpw, split, hub):
+@pytest.mark.parametrize('rpw,split,hub,d', [(32, True, 64, 64), (16, True, 24, 64), (32, False, 100000, 64), (32, True, 64, 128), (16, False, 300, 128)])
+def test_spmm_blocked_schedule_all_epilogues(ops, rpw, split, hub, d):
     """Register-blocked schedule (arl_spmm_blocked_*: plan rows + hub rows through the chunked kernel) against the oracle: every
     epilogue, empty rows, rows above the hub threshold, ragged last wave, and edge values replaced through with_values."""
-    rng = np.random.default_rng(rpw + hub)
-    U, I, d = 3001, 703, 64
+    rng = np.random.default_rng(rpw + hub + d)
+    U, I = 3001, 703
     u, i = random_graph(rng, U, I, 12, hot_items=3, hot_deg=2500, empty_users=(5, 77))
     rowptr, col, w, val = make_csr(u, i, U, I)
     N = U + I

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from arlib_amd import ops
 from arlib_amd.util import synthetic
 
-U, I, d = int(os.environ.get('U', 1_000_000)), int(os.environ.get('I', 100_000)), 64
+U, I, d = int(os.environ.get('U', 1_000_000)), int(os.environ.get('I', 100_000)), int(os.environ.get('D', 64))
 RPW, HUB, UB = int(os.environ.get('RPW', 32)), int(os.environ.get('HUB', 1024)), int(os.environ.get('UB', 1024))
 UNR = int(os.environ['UNR']) if os.environ.get('UNR') else None
 dev = 'cuda:0'

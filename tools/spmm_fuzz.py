@@ -13,7 +13,7 @@ T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 bad = 0
 for case in range(n_cases):
-    d = 64 if rng.random() < 0.4 else int(rng.choice([4, 8, 16, 24, 32, 64, 100, 128, 256]))
+    d = int(rng.choice([64, 128])) if rng.random() < 0.5 else int(rng.choice([4, 8, 16, 24, 32, 64, 100, 128, 256]))
     n_rows = int(rng.integers(1, 3000)); n_cols = n_rows if rng.random() < 0.5 else int(rng.integers(1, 3000))
     chunk = int(rng.choice([32, 64, 512]))
     deg = rng.poisson(rng.choice([0.5, 4, 30]), n_rows)
@@ -26,7 +26,7 @@ for case in range(n_cases):
     val = rng.standard_normal(nnz).astype(np.float32)
     A = ops.CSRGraph(rowptr, col if nnz else np.zeros(0, np.int32), val if nnz else np.zeros(0, np.float32), dev, chunk=chunk, n_cols=n_cols)
     sched = 'csr'
-    if rng.random() < 0.6:           # register-blocked hop schedule (only taken at d = 64) with random plan parameters
+    if rng.random() < 0.6:           # register-blocked hop schedule (only taken at d = 64 and 128) with random plan parameters
         kw = dict(split=int(rng.integers(0, n_rows + 1)) if rng.random() < 0.5 else None, rows_per_wave=int(rng.choice([16, 32])), hub=int(rng.choice([3, 40, 100000])),
                   col_block=int(rng.choice([1, 64, 4096])), min_waves=int(rng.choice([0, 0, 8])), unroll=[None, 16, 32][int(rng.integers(0, 3))])
         A.enable_blocked(**kw)
