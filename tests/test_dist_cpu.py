@@ -1,6 +1,7 @@
 """CPU tests of the N>1 path: block construction ("virtual ranks" in one process) and the user-sharded engine under
 world_size-2 gloo with the oracle-backed kernel shim.  The result must equal the single-process oracle run."""
 import os
+import socket
 import sys
 import numpy as np
 import pytest
@@ -8,6 +9,13 @@ import torch
 import torch.multiprocessing as mp
 from conftest import rel_err, RTOL, ROOT
 from oracle import oracle as O
+
+
+def free_port():
+    """A rendezvous port nobody listens on right now (consecutive tests of one pytest process used to share a pid-derived port)."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
 
 
 def small_problem(d=16):
@@ -88,7 +96,7 @@ def test_sharded_engine_gloo_matches_single_process_oracle(world, sparse):
     ref_table, ref_losses = oracle_run(U, I, d, L, pairs, E0, batches)
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 29500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_worker, args=(world, port, ret, sparse), nprocs=world, join=True)
     assert np.allclose(ret['losses'], ref_losses, rtol=RTOL, atol=0)
     assert rel_err(ret['table'], ref_table) < RTOL
@@ -153,7 +161,7 @@ def test_sharded_simgcl_step_gloo_matches_single_process_oracle(world):
     ref_table, ref_rec, ref_cl = oracle_simgcl_step(*simgcl_problem())
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 31500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_simgcl_worker, args=(world, port, ret), nprocs=world, join=True)
     assert abs(ret['rec'] - ref_rec) <= RTOL * abs(ref_rec)
     assert abs(ret['cl'] - ref_cl) <= RTOL * abs(ref_cl)

@@ -2,6 +2,7 @@
 refuses two ranks on one device, so the collective is gloo staged through host memory here; the RCCL path itself is the
 driver's multi-GPU bench).  Result must equal the single-GPU engine and the oracle."""
 import os
+import socket
 import sys
 import numpy as np
 import pytest
@@ -11,6 +12,25 @@ from conftest import rel_err, RTOL, ROOT
 from test_dist_cpu import small_problem, oracle_run
 
 pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def _spawn(worker, args_after_port, nprocs=2):
+    """mp.spawn with a fresh rendezvous port; one retry if the processes could not be brought up (port race, slow first CUDA init)."""
+    ctx = mp.get_context('spawn')
+    for attempt in range(2):
+        ret = ctx.Manager().dict()
+        try:
+            mp.spawn(worker, args=(nprocs, _free_port(), ret) + tuple(args_after_port), nprocs=nprocs, join=True)
+            return ret
+        except Exception:
+            if attempt == 1:
+                raise
 
 
 class HostStagedComm:
@@ -59,11 +79,7 @@ def test_sharded_engine_two_ranks_hip_kernels(sparse, d, schedule):
         pytest.fail('GPU tests need a GPU')
     U, I, d, L, pairs, E0, batches = small_problem(d)
     ref_table, ref_losses = oracle_run(U, I, d, L, pairs, E0, batches)
-    ctx = mp.get_context('spawn')
-    mgr = ctx.Manager()
-    ret = mgr.dict()
-    port = 29500 + os.getpid() % 2000
-    mp.spawn(_worker, args=(2, port, ret, sparse, d, schedule), nprocs=2, join=True)
+    ret = _spawn(_worker, (sparse, d, schedule))
     assert np.allclose(ret['losses'], ref_losses, rtol=RTOL, atol=0)
     assert rel_err(ret['table'], ref_table) < RTOL
 
@@ -98,10 +114,7 @@ def test_sharded_simgcl_two_ranks_hip_kernels():
         pytest.fail('GPU tests need a GPU')
     from test_dist_cpu import simgcl_problem, oracle_simgcl_step
     ref_table, ref_rec, ref_cl = oracle_simgcl_step(*simgcl_problem())
-    ctx = mp.get_context('spawn')
-    ret = ctx.Manager().dict()
-    port = 33500 + os.getpid() % 2000
-    mp.spawn(_simgcl_worker, args=(2, port, ret), nprocs=2, join=True)
+    ret = _spawn(_simgcl_worker, ())
     assert abs(ret['rec'] - ref_rec) <= RTOL * abs(ref_rec)
     assert abs(ret['cl'] - ref_cl) <= RTOL * abs(ref_cl)
     assert rel_err(ret['table'], ref_table) < RTOL
