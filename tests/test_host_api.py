@@ -268,3 +268,21 @@ def test_datasave_matches_per_entry_formatting(tmp_path):
         dataSave(m, str(path), id2user, id2item, chunk=chunk)
         assert open(path).readlines() == want
     assert any(l.startswith('fakeUser%d ' % (U - 1)) and l.endswith(' 0.125\n') for l in want) and any(l.endswith(' 3.0\n') for l in want)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/arlib_amd.h is the FFI contract: it must compile as C99 (and as C++) on its own, and its two structs must have the layout
+    the ctypes mirror in arlib_amd/_lib.py assumes."""
+    import shutil, subprocess
+    from arlib_amd import _lib
+    hdr = os.path.join(ROOT, 'include', 'arlib_amd.h')
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    subprocess.run(['gcc', '-x', 'c', '-std=c99', '-fsyntax-only', '-Wall', '-Werror', hdr], check=True)
+    subprocess.run(['g++', '-x', 'c++', '-std=c++17', '-fsyntax-only', '-Wall', '-Werror', hdr], check=True)
+    src = tmp_path / 'sz.c'
+    src.write_text('#include <stdio.h>\n#include "arlib_amd.h"\nint main(void) { printf("%zu %zu %zu\\n", sizeof(arl_csr), sizeof(arl_blocked), sizeof(arl_tiled)); return 0; }\n')
+    exe = tmp_path / 'sz'
+    subprocess.run(['gcc', '-std=c99', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    sizes = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert sizes == [ctypes.sizeof(_lib.arl_csr), ctypes.sizeof(_lib.arl_blocked), ctypes.sizeof(_lib.arl_tiled)]
