@@ -286,3 +286,60 @@ def test_header_is_plain_c(tmp_path):
     subprocess.run(['gcc', '-std=c99', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
     sizes = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     assert sizes == [ctypes.sizeof(_lib.arl_csr), ctypes.sizeof(_lib.arl_blocked), ctypes.sizeof(_lib.arl_tiled)]
+
+
+@pytest.mark.parametrize('rpw,hub,split', [(32, 40, True), (16, 100000, False), (32, 7, True)])
+def test_blocked_plan_invariants_and_numpy_emulation(rpw, hub, split):
+    """ops.BlockedPlan built on the CPU (torch ops + the host dealing helper; no kernel runs): every planned row sits in exactly one
+    wave slot, every edge of a planned row is exactly one record of that wave with that slot, streams are padded to 64 with zero values
+    and sorted by (column block, slot), waves of a set carry (nearly) equal edge counts -- and a numpy emulation of the kernel's
+    arithmetic on the plan, plus the hub rows, reproduces A @ X."""
+    import torch
+    import scipy.sparse as sp
+    from arlib_amd import ops
+    rng = np.random.default_rng(rpw + hub)
+    U, I, d = 700, 150, 64
+    deg = np.clip(rng.poisson(6, U), 0, I)
+    us = np.repeat(np.arange(U), deg); its = np.floor(I * rng.random(len(us)) ** 2).astype(np.int64)
+    key = np.unique(us * I + its); us, its = key // I, key % I
+    R = sp.csr_matrix((rng.random(len(us)).astype(np.float32) + 0.5, (us, its)), shape=(U, I))
+    Adj = sp.bmat([[None, R], [R.T, None]], format='csr').astype(np.float32)
+    Adj.sort_indices()
+    N = U + I
+    A = ops.CSRGraph(Adj.indptr.astype(np.int64), Adj.indices.astype(np.int32), Adj.data, 'cpu', chunk=64)
+    A.enable_blocked(split=U if split else None, rows_per_wave=rpw, hub=hub, col_block=32)
+    bp = A.blocked
+    X = rng.standard_normal((N, d)).astype(np.float32)
+    Y = np.full((N, d), np.nan, np.float32)
+    seen_rows, seen_edges = [], 0
+    rowdeg = np.diff(Adj.indptr)
+    for st in bp.sets:
+        wp, wr = st['wave_ptr'].numpy(), st['wave_rows'].numpy()
+        rc, rv = st['rec_col'].numpy(), st['rec_val'].numpy()
+        assert np.all(wp % 64 == 0) and wp[0] == 0 and np.all(np.diff(wp) >= 0)
+        loads = []
+        for w in range(st['n_waves']):
+            c, v = rc[wp[w]:wp[w + 1]], rv[wp[w]:wp[w + 1]]
+            slot, colid = (c.astype(np.uint32) >> 24).astype(np.int64), (c & 0xffffff).astype(np.int64)
+            real = v != 0
+            keyw = (colid[real] // 32) * rpw + slot[real]
+            assert np.all(np.diff(keyw) >= 0) and slot.max(initial=0) < rpw       # sorted by (column block, slot)
+            acc = np.zeros((rpw, d), np.float64)
+            np.add.at(acc, slot, v[:, None].astype(np.float64) * X[colid])
+            rows = wr[w]
+            for sl, r in enumerate(rows):
+                if r >= 0:
+                    Y[r] = acc[sl]; seen_rows.append(int(r))
+                    assert int((slot[real] == sl).sum()) == rowdeg[r]              # all of the row's edges are here, under its slot
+                else:
+                    assert not np.any(slot[real] == sl)
+            loads.append(int(real.sum()))
+            seen_edges += int(real.sum())
+        if st['n_waves'] > 1 and hub >= 40:
+            assert max(loads) - min(loads) <= max(rowdeg[rowdeg <= hub].max(), 1)                # longest-first dealing balances the waves
+    hub_rows = bp._hub_rows.numpy()
+    assert sorted(seen_rows + hub_rows.tolist()) == list(range(N))                     # every row exactly once
+    assert seen_edges + int(rowdeg[hub_rows].sum()) == Adj.nnz
+    Y[hub_rows] = (Adj[hub_rows] @ X)
+    ref = Adj @ X
+    assert np.abs(Y - ref).max() <= 1e-4 * np.abs(ref).max()
