@@ -167,6 +167,8 @@ class BlockedPlan:
     with the chunked CSR kernel (`self.hub`: a chunks_only view of the graph), and so does a whole row set that would fill fewer
     than `min_waves` waves (too few streams to cover the memory latency: measured 3x slower at 311 waves)."""
 
+    LONG_WAVES = 3072
+
     def __init__(self, A, row_sets, rows_per_wave=32, hub=1024, col_block=1024, min_waves=0, unroll=None):
         if rows_per_wave not in (16, 32):
             raise ValueError('BlockedPlan: rows_per_wave must be 16 or 32')
@@ -179,6 +181,18 @@ class BlockedPlan:
         rp_all = A.rowptr.long()
         n_cb = (A.n_cols + self.col_block - 1) // self.col_block
         self.sets, hub_rows = [], []
+        # a set of LONG rows (thousands of edges per wave) runs best with ~3 000 waves per launch -- all resident, 12 per CU, sweeping together
+        # (cfg2's item rows: 3 049); larger sets are cut into contiguous row ranges of that many waves (4 M x 400 K: one launch of 12 194
+        # waves 3.56 ms, four launches 3.10 ms; cutting cfg2's own 3 049 waves in two costs 0.85 vs 0.54 ms, hence only from 2 x 3 072 on)
+        cut = []
+        for lo, hi in row_sets:
+            if not (0 <= lo <= hi <= A.n_rows):
+                raise ValueError('BlockedPlan: bad row set')
+            waves = (hi - lo + self.rpw - 1) // self.rpw
+            edges = int(rp_all[hi] - rp_all[lo])
+            k = waves // self.LONG_WAVES if (waves >= 2 * self.LONG_WAVES and edges >= 4096 * waves) else 1
+            cut += [(lo + ((hi - lo) * j) // k, lo + ((hi - lo) * (j + 1)) // k) for j in range(k)]
+        row_sets = cut
         for lo, hi in row_sets:
             if not (0 <= lo <= hi <= A.n_rows):
                 raise ValueError('BlockedPlan: bad row set')

@@ -33,7 +33,14 @@ def t(fn, n=10):
 
 print('CSR hop (row-per-group + chunked long rows): %.3f ms' % t(lambda: ops.spmm(A, X, out=Yr)))
 torch.cuda.synchronize(); t0 = time.perf_counter()
-A.enable_blocked(split=U, rows_per_wave=RPW, hub=HUB, col_block=UB, unroll=UNR)
+if os.environ.get('ISPLIT'):                 # experiment: the item rows in k separate launches (each launch's waves resident together)
+    k = int(os.environ['ISPLIT'])
+    cuts = [U + (I * j) // k for j in range(k + 1)]
+    ku = int(os.environ.get('USPLIT', 1))
+    ucuts = [(U * j) // ku for j in range(ku + 1)]
+    A.blocked = ops.BlockedPlan(A, [(ucuts[j], ucuts[j + 1]) for j in range(ku)] + [(cuts[j], cuts[j + 1]) for j in range(k)], RPW, HUB, UB, 0, UNR)
+else:
+    A.enable_blocked(split=U, rows_per_wave=RPW, hub=HUB, col_block=UB, unroll=UNR)
 torch.cuda.synchronize()
 bp = A.blocked
 print('plan built in %.2f s: %s; %d hub rows' % (time.perf_counter() - t0, ', '.join('%d rows / %d waves / %d edges' % (s['n_rows'], s['n_waves'], s['n_edges']) for s in bp.sets),
