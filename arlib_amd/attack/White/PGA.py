@@ -9,6 +9,9 @@ Same protocol and numbers (posionDataAttack(recommender) -> scipy (U+F) x I matr
     (PGA.py:117-134).  Here only the F x I block is ever computed: sum over layers of two row-restricted SDDMMs,
       grad[f,j] = dinv[f] dinv[U'+j] ( sum_k <dE_{k+1}[f], E_k[U'+j]> + <dE_{k+1}[U'+j], E_k[f]> ),
     with dE_k = G/(L+1) + A dE_{k+1} (adjacency symmetric) and G the gradient of the CW loss w.r.t. the output.
+  * posionDataAttack applies the poisoned operator in factors (FactoredFakeGraph): the real edges keep fixed values and a fixed hop plan,
+    the fake block is dense algebra, so a step rewrites nothing of size nnz.  FakeBlockGraph (all edges in one re-normalised CSR) is the
+    form the reference-trace test drives; both are tested against each other.
 """
 from copy import deepcopy
 
@@ -76,6 +79,71 @@ class FakeBlockGraph:
         val = ops.norm_vals_coo(self.erow_d, self.col_d, self.w, self.dinv)
         self.graph = self.graph.with_values(val)
         return self.graph
+
+
+class FactoredFakeGraph:
+    """The same operator as FakeBlockGraph.set_block(S).graph, applied in factors:  A_hat X = D^-1/2 ( W_real (D^-1/2 X) + fake block ).
+    W_real is the un-normalised adjacency of the REAL interactions only (fixed: its blocked hop plan and its values are built once), the
+    F x I fake block enters as two small dense products (S (D^-1/2 X)_items for the fake users' rows, S^T (D^-1/2 X)_fake for the items'),
+    and the degrees follow from S in O(F I).  Nothing of size nnz is touched when S changes: no 77 M-edge renormalisation, no
+    re-binding of the plan's values, and the hops do not carry the 2 F I fake edges through the sparse kernels.  Row-scalings are
+    element-wise passes over the [N, d] operand.  Results agree with FakeBlockGraph to fp32 rounding (different association)."""
+
+    def __init__(self, ui_real, n_real, n_fake, n_items, device=DEVICE, emb_size=None):
+        U, F, I = int(n_real), int(n_fake), int(n_items)
+        Up = U + F
+        R = sp.csr_matrix(ui_real, dtype=np.float32)[:U]
+        R.eliminate_zeros(); R.sort_indices()
+        Rt = R.T.tocsr(); Rt.sort_indices()
+        rowptr = np.zeros(Up + I + 1, np.int64)
+        np.cumsum(np.concatenate([np.diff(R.indptr), np.zeros(F, np.int64), np.diff(Rt.indptr)]), out=rowptr[1:])
+        col = np.concatenate([R.indices.astype(np.int32) + Up, Rt.indices.astype(np.int32)])
+        val = np.concatenate([R.data, Rt.data]).astype(np.float32)
+        self.U, self.F, self.I, self.Up, self.N = U, F, I, Up, Up + I
+        self.device = torch.device(device)
+        self.W = ops.CSRGraph(rowptr, col, val, self.device, validate=False)
+        if emb_size is not None:
+            ops.auto_blocked(self.W, emb_size, split=Up)
+        base = np.zeros(Up + I, np.float32); base[:U] = np.asarray(R.sum(1)).ravel(); base[Up:] = np.asarray(R.sum(0)).ravel()
+        self.base_rowsum = torch.from_numpy(base).to(self.device)
+        self.fake_rows = torch.arange(U, Up, dtype=torch.int32, device=self.device)
+        self.S = self.dinv = None
+
+    def set_block(self, S):
+        self.S = S
+        rs = self.base_rowsum.clone()
+        rs[self.U:self.Up] = S.sum(1)
+        rs[self.Up:] += S.sum(0)
+        self.dinv = torch.where(rs > 0, 1.0 / torch.sqrt(rs), torch.zeros_like(rs))
+        self._dcol = self.dinv[:, None].contiguous()
+        return self
+
+    def _fake_rows_product(self, Xi):
+        """S [F, I] @ Xi [I, d]: a skinny product with a 10^5-long reduction, for which the BLAS library picks a slow kernel (0.2 ms at
+        F = 64, I = 100 K, d = 64); cut the reduction into panels (batched product + sum: 0.03 ms) when I has a suitable divisor."""
+        I = self.I
+        c = next((c for c in range(max(1, I // 2048), min(I, I // 512) + 1) if I % c == 0), 0) if I >= 8192 else 0
+        if not c:
+            return self.S @ Xi
+        return torch.bmm(self.S.view(self.F, c, I // c).permute(1, 0, 2), Xi.view(c, I // c, Xi.shape[1])).sum(0)
+
+    def hop(self, X, alpha=1.0, beta=0.0, Z=None):
+        """alpha * (A_hat @ X) + beta * Z."""
+        Xs = X * self._dcol
+        Y = ops.spmm(self.W, Xs)
+        Y[self.U:self.Up].add_(self._fake_rows_product(Xs[self.Up:]))
+        Y[self.Up:].addmm_(self.S.t(), Xs[self.U:self.Up])
+        Y.mul_(self._dcol if alpha == 1.0 else self._dcol * alpha)
+        if beta != 0.0:
+            Y.add_(Z, alpha=beta)
+        return Y
+
+
+def _hop(graph, X, alpha=1.0, beta=0.0, Z=None):
+    """One application of the poisoned normalised adjacency: a CSRGraph (FakeBlockGraph) or a FactoredFakeGraph."""
+    if hasattr(graph, 'hop'):
+        return graph.hop(X, alpha, beta, Z)
+    return ops.spmm(graph, X, alpha, beta, Z)
 
 
 def cw_loss_and_grad(out, Up, users, pos, neg):
@@ -154,13 +222,13 @@ def pga_block_gradient(graph, fake_rows, Up, I, E0, L, G):
     """Returns the un-normalised F x I block sum_k <dE_{k+1}[f], E_k[U'+j]> + <E_k[f], dE_{k+1}[U'+j]> for the LightGCN mean."""
     E = [E0]
     for k in range(L):
-        E.append(ops.spmm(graph, E[k]))
+        E.append(_hop(graph, E[k]))
     s = 1.0 / (L + 1)
     Gs = G * s
     dE = [None] * (L + 1)
     dE[L] = Gs
     for k in range(L - 1, 0, -1):
-        dE[k] = ops.spmm(graph, dE[k + 1], 1.0, 1.0, Gs)
+        dE[k] = _hop(graph, dE[k + 1], 1.0, 1.0, Gs)
     block = torch.zeros(fake_rows.numel(), I, dtype=torch.float32, device=E0.device)
     for k in range(L):
         ops.sddmm_rows_dense(dE[k + 1], E[k], fake_rows, Up, I, out=block)
@@ -174,7 +242,7 @@ def pga_step_block(graph, fake_rows, Up, I, E0, L, M):
     E = [E0]
     out = E0.clone()
     for k in range(L):
-        E.append(ops.spmm(graph, E[k]))
+        E.append(_hop(graph, E[k]))
         out += E[-1]
     out /= (L + 1)
     loss, G = cw_loss_and_grad_op(M, out)
@@ -183,7 +251,7 @@ def pga_step_block(graph, fake_rows, Up, I, E0, L, M):
     dE = [None] * (L + 1)
     dE[L] = Gs
     for k in range(L - 1, 0, -1):
-        dE[k] = ops.spmm(graph, dE[k + 1], 1.0, 1.0, Gs)
+        dE[k] = _hop(graph, dE[k + 1], 1.0, 1.0, Gs)
     block = torch.zeros(fake_rows.numel(), I, dtype=torch.float32, device=E0.device)
     for k in range(L):
         ops.sddmm_rows_dense(dE[k + 1], E[k], fake_rows, Up, I, out=block)
@@ -220,7 +288,7 @@ class PGA(AttackBase):
         recommender = deepcopy(originRecommender)
         optimizer = torch.optim.Adam(recommender.model.parameters(), lr=recommender.args.lRate / 10)
         real = sp.csr_matrix(newAdj[:U])
-        fg = FakeBlockGraph(real, U, F, I, emb_size=getattr(recommender.model, 'latent_size', None))
+        fg = FactoredFakeGraph(real, U, F, I, emb_size=getattr(recommender.model, 'latent_size', None))
         L = getattr(recommender.model, 'n_prop_layers', 0)
         for epoch in range(self.outerEpoch):
             # outer optimisation: victim retrain on the current poisoned graph
@@ -240,7 +308,7 @@ class PGA(AttackBase):
                         out = E0.clone()
                         E = E0
                         for k in range(L):
-                            E = ops.spmm(graph, E)
+                            E = _hop(graph, E)
                             out += E
                         out /= (L + 1)
                         top_idx, _ = ops.score_mask_topk(out[:U + F].contiguous(), out[U + F:].contiguous(), min(50, I))     # no interacted mask (PGA.py:101-102)

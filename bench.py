@@ -142,7 +142,7 @@ def attack_leg(torch, ops, data, E0_dev, args):
     (attack/White/PGA.py:92-142): device re-normalisation of the poisoned graph, L-hop forward, CW gradient (one SpMM with the
     bilinear operator), L-1 hop backward, 2L row-restricted SDDMMs, tanh/clamp update.  F fake users, T=5 unpopular targets."""
     import scipy.sparse as sp
-    from arlib_amd.attack.White.PGA import FakeBlockGraph, cw_operator, pga_step_block
+    from arlib_amd.attack.White.PGA import FactoredFakeGraph, _hop, cw_operator, pga_step_block
     from arlib_amd.attack._common import cw_pairs
     U, I, nnz = data.training_size()
     F, L, d = args.fake_users, args.layers, args.emb
@@ -151,7 +151,7 @@ def attack_leg(torch, ops, data, E0_dev, args):
     deg_i = np.bincount(data.pairs0[:, 1], minlength=I)
     targets = [int(t) for t in np.argsort(deg_i, kind='stable')[:5]]
     popular = np.argsort(-deg_i, kind='stable')[:int(0.05 * I)]
-    fg = FakeBlockGraph(real, U, F, I, device=E0_dev.device, emb_size=None if args.schedule == 'csr' else d)
+    fg = FactoredFakeGraph(real, U, F, I, device=E0_dev.device, emb_size=None if args.schedule == 'csr' else d)
     del real
     S = torch.zeros(F, I, device=E0_dev.device)
     S[:, targets] = 1.0
@@ -163,7 +163,7 @@ def attack_leg(torch, ops, data, E0_dev, args):
     graph = fg.set_block(S)
     out = E0.clone(); E = E0
     for k in range(L):
-        E = ops.spmm(graph, E); out += E
+        E = _hop(graph, E); out += E
     out /= (L + 1)
     torch.cuda.synchronize(); t1 = time.perf_counter()
     top_idx, _ = ops.score_mask_topk(out[:U + F].contiguous(), out[U + F:].contiguous(), 50)

@@ -94,6 +94,38 @@ def test_pga_step_on_blocked_hop_schedule_equals_csr_schedule():
         assert rel_err(bb.cpu().numpy(), ba.cpu().numpy()) < RTOL and abs(la.item() - lb.item()) <= RTOL * abs(la.item())
 
 
+@pytest.mark.parametrize('d,blocked', [(16, False), (64, True)])
+def test_pga_factored_graph_equals_fake_block_graph(d, blocked):
+    """FactoredFakeGraph (real edges through the sparse kernels with fixed values, the F x I fake block as two dense products, degrees from
+    S in O(F I)) applies the same operator as FakeBlockGraph (all edges in one re-normalised CSR): single hops with alpha/beta, the PGA
+    block gradient, the loss and dinv, for two successive blocks S."""
+    from arlib_amd import ops
+    from arlib_amd.attack.White.PGA import FakeBlockGraph, FactoredFakeGraph, _hop, cw_operator, pga_step_block
+    rng = np.random.default_rng(d)
+    U, I, F, L = 1500, 400, 4, 2
+    real = sp.random(U, I, density=0.03, random_state=5, format='csr', dtype=np.float32)
+    real.data[:] = 1.0
+    fa, fb = FakeBlockGraph(real, U, F, I), FactoredFakeGraph(real, U, F, I)
+    if blocked:
+        fb.W.enable_blocked(split=U + F, hub=60)
+    N = U + F + I
+    E0 = T((rng.standard_normal((N, d)) * 0.1).astype(np.float32))
+    Z = T(rng.standard_normal((N, d)).astype(np.float32))
+    users = torch.from_numpy(rng.integers(0, U, 300)).to(DEV); pos = torch.from_numpy(rng.integers(0, I, 300)).to(DEV); neg = torch.from_numpy(rng.integers(0, I, 300)).to(DEV)
+    M = cw_operator(N, U + F, users, pos, neg, device=E0.device)
+    for step in range(2):
+        S = T(rng.random((F, I)).astype(np.float32) * (rng.random((F, I)) < 0.3))
+        if step == 1:
+            S[2] = 0                                              # a fake user without interactions: degree 0 -> dinv 0
+        ga, gb = fa.set_block(S), fb.set_block(S)
+        assert rel_err(fb.dinv.cpu().numpy(), fa.dinv.cpu().numpy()) < 1e-6
+        assert rel_err(_hop(gb, E0).cpu().numpy(), _hop(ga, E0).cpu().numpy()) < 1e-5
+        assert rel_err(_hop(gb, E0, 0.5, -2.0, Z).cpu().numpy(), _hop(ga, E0, 0.5, -2.0, Z).cpu().numpy()) < 1e-5
+        ba, la = pga_step_block(ga, fa.fake_rows, U + F, I, E0, L, M)
+        bb, lb = pga_step_block(gb, fb.fake_rows, U + F, I, E0, L, M)
+        assert rel_err(bb.cpu().numpy(), ba.cpu().numpy()) < RTOL and abs(la.item() - lb.item()) <= RTOL * abs(la.item())
+
+
 def test_dlattack_masked_topk_and_project_match_reference_trace():
     from arlib_amd.attack.White.DLAttack import masked_topk, DLAttack
     g = golden('g7_attacks.npz')
