@@ -48,6 +48,8 @@ _SIGS = {
     'arl_spmm_csr_layersum_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _vp, _vp, _vp, _vp]),
     'arl_spmm_csr_adam_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),
     'arl_spmm_blocked_f32': (C.c_int, [C.POINTER(arl_blocked), _vp, _i64, _f, _f, _vp, _vp, _vp, _vp]),
+    'arl_spmm_csr_rscale_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _vp, _f, _f, _vp, _vp, _vp]),
+    'arl_spmm_blocked_rscale_f32': (C.c_int, [C.POINTER(arl_blocked), _vp, _i64, _vp, _f, _f, _vp, _vp, _vp]),
     'arl_spmm_blocked_layersum_f32': (C.c_int, [C.POINTER(arl_blocked), _vp, _i64, _vp, _vp, _vp, _vp]),
     'arl_spmm_blocked_adam_f32': (C.c_int, [C.POINTER(arl_blocked), _vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),
     'arl_lpt_deal': (C.c_int, [_i64, _vp, _i64, _i64, _vp, _vp]),

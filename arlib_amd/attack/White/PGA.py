@@ -130,12 +130,10 @@ class FactoredFakeGraph:
     def hop(self, X, alpha=1.0, beta=0.0, Z=None):
         """alpha * (A_hat @ X) + beta * Z."""
         Xs = X * self._dcol
-        Y = ops.spmm(self.W, Xs)
-        Y[self.U:self.Up].add_(self._fake_rows_product(Xs[self.Up:]))
-        Y[self.Up:].addmm_(self.S.t(), Xs[self.U:self.Up])
-        Y.mul_(self._dcol if alpha == 1.0 else self._dcol * alpha)
-        if beta != 0.0:
-            Y.add_(Z, alpha=beta)
+        Y = ops.spmm(self.W, Xs, alpha, beta, Z, row_scale=self.dinv)          # alpha D^-1/2 (W Xs) + beta Z in the SpMM epilogue
+        U, Up = self.U, self.Up
+        Y[U:Up].addcmul_(self._fake_rows_product(Xs[Up:]), self._dcol[U:Up], value=alpha)
+        Y[Up:].addcmul_(self.S.t() @ Xs[U:Up], self._dcol[Up:], value=alpha)
         return Y
 
 

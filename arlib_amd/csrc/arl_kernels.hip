@@ -64,6 +64,7 @@ struct Epi {
     float *S;
     float *P, *M, *V;        // ADAM
     float step_size, inv_bc2_sqrt, b1, b2, eps;
+    const float *rscale;     // AXPBY, optional: y = alpha * rscale[row] * (A x)[row] + beta * z (a diagonal factor applied to the product)
 };
 
 // Accumulate sum_e val[e] * X[col[e], 4q..4q+3] over edges [begin,end) for this lane's column quad.
@@ -127,7 +128,8 @@ template <int MODE>
 __device__ __forceinline__ void spmm_epilogue(const Epi &ep, int row, int d, int q, float4 a) {
     const size_t o = (size_t)row * d + q * 4;
     if (MODE == EPI_AXPBY) {
-        float4 y = make_float4(ep.alpha * a.x, ep.alpha * a.y, ep.alpha * a.z, ep.alpha * a.w);
+        const float al = ep.rscale ? ep.alpha * ep.rscale[row] : ep.alpha;
+        float4 y = make_float4(al * a.x, al * a.y, al * a.z, al * a.w);
         if (ep.Z && (!ep.zflags || ep.zflags[row])) {
             const float4 z = *reinterpret_cast<const float4 *>(ep.Z + o);
             y.x = fmaf(ep.beta, z.x, y.x); y.y = fmaf(ep.beta, z.y, y.y); y.z = fmaf(ep.beta, z.z, y.z); y.w = fmaf(ep.beta, z.w, y.w);
@@ -532,7 +534,7 @@ __device__ __forceinline__ void spmm_epilogue1(const Epi &ep, int row, int lane,
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
         if (MODE == EPI_AXPBY) {
-            float y = ep.alpha * a[c];
+            float y = (ep.rscale ? ep.alpha * ep.rscale[row] : ep.alpha) * a[c];
             if (zr) y = fmaf(ep.beta, ep.Z[o + c], y);
             __builtin_nontemporal_store(y, ep.Y + o + c);
         } else if (MODE == EPI_LAYERSUM) {
@@ -1681,6 +1683,16 @@ int arl_spmm_csr_f32(const arl_csr *A, const float *X, int64_t d, float alpha, f
     return launch_spmm<EPI_AXPBY>(A, X, d, ep, (hipStream_t)stream);
 }
 
+int arl_spmm_csr_rscale_f32(const arl_csr *A, const float *X, int64_t d, const float *row_scale, float alpha, float beta, const float *Z, float *Y,
+                            arl_stream_t stream) {
+    if (!Y || !row_scale) return ARL_E_NULL;
+    if (beta != 0.f && !Z) return ARL_E_NULL;
+    if (Y == X) return ARL_E_ARG;
+    Epi ep = {};
+    ep.alpha = alpha; ep.beta = beta; ep.Z = (beta != 0.f) ? Z : nullptr; ep.Y = Y; ep.rscale = row_scale;
+    return launch_spmm<EPI_AXPBY>(A, X, d, ep, (hipStream_t)stream);
+}
+
 int arl_spmm_csr_layersum_f32(const arl_csr *A, const float *X, int64_t d, const float *S_in, float *S, float *Y, arl_stream_t stream) {
     if (!S_in || !S) return ARL_E_NULL;
     if (Y == X) return ARL_E_ARG;
@@ -1696,6 +1708,16 @@ int arl_spmm_blocked_f32(const arl_blocked *P, const float *X, int64_t d, float 
     if (Y == X) return ARL_E_ARG;
     Epi ep = {};
     ep.alpha = alpha; ep.beta = beta; ep.Z = (beta != 0.f) ? Z : nullptr; ep.zflags = zflags; ep.Y = Y;
+    return launch_spmm_blocked<EPI_AXPBY>(P, X, d, ep, (hipStream_t)stream);
+}
+
+int arl_spmm_blocked_rscale_f32(const arl_blocked *P, const float *X, int64_t d, const float *row_scale, float alpha, float beta, const float *Z,
+                                float *Y, arl_stream_t stream) {
+    if (!Y || !row_scale) return ARL_E_NULL;
+    if (beta != 0.f && !Z) return ARL_E_NULL;
+    if (Y == X) return ARL_E_ARG;
+    Epi ep = {};
+    ep.alpha = alpha; ep.beta = beta; ep.Z = (beta != 0.f) ? Z : nullptr; ep.Y = Y; ep.rscale = row_scale;
     return launch_spmm_blocked<EPI_AXPBY>(P, X, d, ep, (hipStream_t)stream);
 }
 

@@ -363,8 +363,9 @@ def _check_xy(A, X, name='X', rows=None):
     return d
 
 
-def spmm(A, X, alpha=1.0, beta=0.0, Z=None, out=None):
-    """out = alpha * (A @ X) + beta * Z.   X: [A.n_cols, d]; out, Z: [A.n_rows, d]."""
+def spmm(A, X, alpha=1.0, beta=0.0, Z=None, out=None, row_scale=None):
+    """out = alpha * (A @ X) + beta * Z.   X: [A.n_cols, d]; out, Z: [A.n_rows, d].   row_scale [n_rows] (optional): the product's rows are
+    multiplied by it in the epilogue, out = alpha * diag(row_scale) (A @ X) + beta * Z."""
     d = _check_xy(A, X, 'X', A.n_cols)
     Y = torch.empty(A.n_rows, d, dtype=torch.float32, device=X.device) if out is None else out
     if _check_xy(A, Y, 'out') != d or Y.data_ptr() == X.data_ptr():
@@ -374,8 +375,15 @@ def spmm(A, X, alpha=1.0, beta=0.0, Z=None, out=None):
             raise ValueError('spmm: Z [n_rows, d] required when beta != 0')
     L, zp, st = _lib.lib(), (_ptr(Z) if beta != 0.0 else None), _stream()
     tok = EVENT_HOOK.begin('axpby') if EVENT_HOOK is not None else None
-    _spmm_dispatch(A, d, lambda p: check(L.arl_spmm_blocked_f32(p, _ptr(X), d, alpha, beta, zp, None, _ptr(Y), st), 'arl_spmm_blocked_f32'),
-                   lambda p: check(L.arl_spmm_csr_f32(p, _ptr(X), d, alpha, beta, zp, _ptr(Y), st), 'arl_spmm_csr_f32'))
+    if row_scale is not None:
+        _dev(row_scale, torch.float32, 'row_scale', 1)
+        if row_scale.numel() != A.n_rows:
+            raise ValueError('spmm: row_scale needs one entry per output row')
+        _spmm_dispatch(A, d, lambda p: check(L.arl_spmm_blocked_rscale_f32(p, _ptr(X), d, _ptr(row_scale), alpha, beta, zp, _ptr(Y), st), 'arl_spmm_blocked_rscale_f32'),
+                       lambda p: check(L.arl_spmm_csr_rscale_f32(p, _ptr(X), d, _ptr(row_scale), alpha, beta, zp, _ptr(Y), st), 'arl_spmm_csr_rscale_f32'))
+    else:
+        _spmm_dispatch(A, d, lambda p: check(L.arl_spmm_blocked_f32(p, _ptr(X), d, alpha, beta, zp, None, _ptr(Y), st), 'arl_spmm_blocked_f32'),
+                       lambda p: check(L.arl_spmm_csr_f32(p, _ptr(X), d, alpha, beta, zp, _ptr(Y), st), 'arl_spmm_csr_f32'))
     if tok is not None:
         EVENT_HOOK.end(tok)
     return Y

@@ -160,6 +160,12 @@ typedef struct arl_blocked {
 } arl_blocked;
 int arl_spmm_blocked_f32(const arl_blocked *P, const float *X, int64_t d, float alpha, float beta, const float *Z,
                          const uint8_t *zflags, float *Y, arl_stream_t stream);
+/* Y = alpha * diag(row_scale) (A X) + beta * Z: the product with a diagonal factor in the epilogue (PGA applies D^-1/2 W D^-1/2 in
+ * factors and keeps W's values fixed); CSR and blocked schedules. */
+int arl_spmm_csr_rscale_f32(const arl_csr *A, const float *X, int64_t d, const float *row_scale, float alpha, float beta,
+                            const float *Z, float *Y, arl_stream_t stream);
+int arl_spmm_blocked_rscale_f32(const arl_blocked *P, const float *X, int64_t d, const float *row_scale, float alpha,
+                                float beta, const float *Z, float *Y, arl_stream_t stream);
 int arl_spmm_blocked_layersum_f32(const arl_blocked *P, const float *X, int64_t d, const float *S_in, float *S, float *Y,
                                   arl_stream_t stream);
 int arl_spmm_blocked_adam_f32(const arl_blocked *P, const float *X, int64_t d, float alpha, float beta, const float *Z,

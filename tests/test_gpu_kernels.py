@@ -195,6 +195,25 @@ def test_batch_rows_set_and_clear(ops):
         ops.batch_rows_set_(G, flags, bits, T(np.array([N], np.int32)), T(src[:1]))
 
 
+@pytest.mark.parametrize('blocked', [False, True])
+def test_spmm_row_scale_epilogue(ops, blocked):
+    """out = alpha * diag(row_scale) (A X) + beta * Z on both schedules (PGA's factored operator)."""
+    rng = np.random.default_rng(31)
+    U, I, d = 2001, 503, 64
+    u, i = random_graph(rng, U, I, 10, hot_items=2, hot_deg=1500, empty_users=(3,))
+    rowptr, col, w, val = make_csr(u, i, U, I)
+    N = U + I
+    A = ops.CSRGraph(rowptr, col, val, DEV, chunk=512)
+    if blocked:
+        A.enable_blocked(split=U, hub=100)
+    X = rng.standard_normal((N, d)).astype(np.float32); Z = rng.standard_normal((N, d)).astype(np.float32)
+    rs = rng.random(N).astype(np.float32); rs[7] = 0
+    ref = O.spmm((rowptr, col, val), X)
+    got = ops.spmm(A, T(X), 0.5, -1.5, T(Z), row_scale=T(rs))
+    assert rel_err(got.cpu().numpy(), 0.5 * rs[:, None] * ref - 1.5 * Z) < RTOL
+    assert rel_err(ops.spmm(A, T(X), row_scale=T(rs)).cpu().numpy(), rs[:, None] * ref) < RTOL
+
+
 def test_spmm_deterministic_and_linear(ops):
     rng = np.random.default_rng(3)
     U, I, d = 5000, 900, 64
