@@ -40,6 +40,39 @@ class _Layer(torch.autograd.Function):
         return g_ego, gW[:d], gW[d:], None, None
 
 
+class _LastLayerRows(torch.autograd.Function):
+    """The LAST NGCF layer evaluated on the listed rows only (the training loss reads the mean over layers on <= 3B batch rows): the hop is
+    the row-subset SpMM, the dense part runs on [3B, 2d]; backward scatters the rows' gP into an otherwise zero table and propagates it with
+    the flag-masked hop (A symmetric), then adds the rows' gE.  Duplicate row ids are fine: their gradients accumulate."""
+
+    @staticmethod
+    def forward(ctx, ego, W1, W2, graph, slope, rows):
+        ego = ego.contiguous()
+        P = ops.spmm_rows(graph, ego, rows, (), 1.0, check_range=False)
+        E = ops.gather_rows(ego, rows, check_range=False)
+        ST = ops.ngcf_combine(P, E)
+        Wcat = torch.cat([W1, W2], 0)
+        out = ops.ngcf_act_(torch.mm(ST, Wcat), None, slope)
+        ctx.save_for_backward(P, E, ST, out, Wcat, rows)
+        ctx.graph, ctx.slope, ctx.shape = graph, slope, tuple(ego.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        P, E, ST, out, Wcat, rows = ctx.saved_tensors
+        N, d = ctx.shape
+        gZ = ops.ngcf_act_bwd(g_out.contiguous(), out, ctx.slope)
+        gW = torch.mm(ST.t(), gZ)
+        gP, gE = ops.ngcf_combine_bwd(torch.mm(gZ, Wcat.t()), P, E)
+        Gp = torch.zeros(N, d, dtype=torch.float32, device=gP.device)
+        ops.scatter_add_rows(Gp, rows, gP, 1.0, check_range=False)
+        bits = torch.zeros((N + 31) // 32, dtype=torch.int32, device=gP.device)
+        ops.mark_bits_(bits, rows, True, N, check_range=False)
+        g_ego = ops.spmm_flagged(ctx.graph, Gp, bits)
+        ops.scatter_add_rows(g_ego, rows, gE, 1.0, check_range=False)
+        return g_ego, gW[:d], gW[d:], None, None, None
+
+
 class NGCF_Encoder(GraphEncoder):
     def __init__(self, data, emb_size, n_layers):
         super().__init__(data, emb_size)
@@ -73,6 +106,22 @@ class NGCF_Encoder(GraphEncoder):
         out = acc / (self.layers + 1)
         U = self.data.user_num
         return out[:U], out[U:]
+
+    def forward_rows(self, rows):
+        """Rows `rows` (int32 node ids, users then U + items) of the mean over layers -- what a training step reads.  The first L-1 layers
+        are full-table passes; the last one is evaluated on those rows alone (_LastLayerRows): one full hop, one dense [N, 2d] product and
+        their backward counterparts less per step."""
+        self.cuda()
+        graph = self._graph()
+        ego = torch.cat([self.embedding_dict['user_emb'], self.embedding_dict['item_emb']], 0)
+        idx = rows.long()
+        acc = ego[idx]
+        for k in range(self.layers - 1):
+            ego = _Layer.apply(ego, self.W['w1_' + str(k)], self.W['w2_' + str(k)], graph, 0.01)
+            acc = acc + ego[idx]
+        k = self.layers - 1
+        acc = acc + _LastLayerRows.apply(ego, self.W['w1_' + str(k)], self.W['w2_' + str(k)], graph, 0.01, rows.contiguous())
+        return acc / (self.layers + 1)
 
 
 class NGCF(Recommender):

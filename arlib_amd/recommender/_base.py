@@ -275,6 +275,7 @@ class Recommender:
     l2_scale = 1.0          # NCL divides its L2 term by the batch size (NCL.py:147) ...
     l2_on_negatives = False # ... and also regularises the negative items' rows
     extra_loss_takes_outputs = False   # proxyLG's extra term is computed from the step's own forward outputs
+    rows_forward = True                # use model.forward_rows(batch rows) in the training loop when the encoder offers it
 
     def _extra_loss(self, model, user_idx, pos_idx):
         return None
@@ -330,10 +331,16 @@ class Recommender:
                         print('training:', epoch + 1, 'batch', n, 'batch_loss:', float(lo[0] + lo[1]))
                     continue
                 model.train()
-                outs = model(True) if self.train_forward_perturbed else model()
-                rec_user_emb, rec_item_emb = outs[0], outs[1]
                 ul, pl, nl = u.long(), p.long(), ng.long()
-                user_emb, pos_item_emb, neg_item_emb = rec_user_emb[ul], rec_item_emb[pl], rec_item_emb[nl]
+                if self.rows_forward and hasattr(model, 'forward_rows') and not self.train_forward_perturbed and not self.has_extra_loss:
+                    # the loss reads the output on the batch rows only: encoders that can evaluate just those rows do (NGCF's last layer)
+                    B = u.numel()
+                    out_r = model.forward_rows(torch.cat([u, p + U, ng + U]).to(torch.int32))
+                    user_emb, pos_item_emb, neg_item_emb = out_r[:B], out_r[B:2 * B], out_r[2 * B:]
+                else:
+                    outs = model(True) if self.train_forward_perturbed else model()
+                    rec_user_emb, rec_item_emb = outs[0], outs[1]
+                    user_emb, pos_item_emb, neg_item_emb = rec_user_emb[ul], rec_item_emb[pl], rec_item_emb[nl]
                 batch_loss = bpr_l2_loss(user_emb, pos_item_emb, neg_item_emb, self.args.reg * self.l2_scale)
                 if self.l2_on_negatives:
                     batch_loss = batch_loss + l2_reg_loss(self.args.reg * self.l2_scale, neg_item_emb)

@@ -147,6 +147,29 @@ def test_ngcf_forward_and_steps_match_reference():
     assert rel_err(model.embedding_dict['user_emb'].detach().cpu().numpy(), g['user_k3']) < RTOL
     assert rel_err(model.embedding_dict['item_emb'].detach().cpu().numpy(), g['item_k3']) < RTOL
     assert rel_err(model.W['w1_0'].detach().cpu().numpy(), g['w1_0_k3']) < RTOL
+    # the training loop's form: last layer on the batch rows only (forward_rows) -- same three steps, same golden
+    rec2 = NGCF(rec_args(emb_size=32, n_layers=2, model_name='NGCF'), data)
+    m2 = rec2.model.cuda()
+    with torch.no_grad():
+        m2.embedding_dict['user_emb'][:] = torch.from_numpy(g['user0']).cuda(); m2.embedding_dict['item_emb'][:] = torch.from_numpy(g['item0']).cuda()
+        for k in range(2):
+            m2.W['w1_%d' % k][:] = torch.from_numpy(g['w1_%d' % k]).cuda(); m2.W['w2_%d' % k][:] = torch.from_numpy(g['w2_%d' % k]).cuda()
+    opt2 = torch.optim.Adam(m2.parameters(), lr=0.005)
+    U = data.user_num
+    for k in range(3):
+        bu, bp, bn = (torch.from_numpy(g[x][k].astype(np.int32)).cuda() for x in ('batch_u', 'batch_p', 'batch_n'))
+        B = bu.numel()
+        out_r = m2.forward_rows(torch.cat([bu, bp + U, bn + U]))
+        loss = bpr_loss(out_r[:B], out_r[B:2 * B], out_r[2 * B:]) + l2_reg_loss(1e-4, out_r[:B], out_r[B:2 * B])
+        opt2.zero_grad(); loss.backward()
+        if k == 0:
+            assert rel_err(m2.embedding_dict['user_emb'].grad.cpu().numpy(), g['grad_user']) < RTOL
+            assert rel_err(m2.W['w1_0'].grad.cpu().numpy(), g['grad_w1_0']) < RTOL and rel_err(m2.W['w2_1'].grad.cpu().numpy(), g['grad_w2_1']) < RTOL
+        opt2.step()
+        assert abs(loss.item() - g['losses'][k]) <= RTOL * abs(g['losses'][k])
+    assert rel_err(m2.embedding_dict['user_emb'].detach().cpu().numpy(), g['user_k3']) < RTOL
+    assert rel_err(m2.embedding_dict['item_emb'].detach().cpu().numpy(), g['item_k3']) < RTOL
+    assert rel_err(m2.W['w1_0'].detach().cpu().numpy(), g['w1_0_k3']) < RTOL
 
 
 def test_ncl_prototype_phase_step_matches_reference(tmp_path, monkeypatch):

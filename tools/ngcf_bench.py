@@ -18,7 +18,7 @@ nnz = data.training_size()[2]
 rowptr, col = data.adjacency_pattern()
 col_d = torch.from_numpy(col).to(dev)
 val, _ = ops.norm_adj_values(torch.from_numpy(rowptr.astype(np.int32)).to(dev), col_d, torch.ones(2 * nnz, device=dev), U + I)
-A = ops.CSRGraph(rowptr, col_d, val, dev)
+A = ops.auto_blocked(ops.CSRGraph(rowptr, col_d, val, dev), d, split=U)
 torch.manual_seed(2018)
 enc = NGCF_Encoder.__new__(NGCF_Encoder)
 torch.nn.Module.__init__(enc)
@@ -37,9 +37,17 @@ g = torch.Generator().manual_seed(1)
 u = torch.randint(0, U, (B,), generator=g).to(dev); p = torch.randint(0, I, (B,), generator=g).to(dev); n = torch.randint(0, I, (B,), generator=g).to(dev)
 
 
+ROWS = not os.environ.get('FULL')            # the training loop's form: last layer on the batch rows only
+rows = torch.cat([u, p + U, n + U]).to(torch.int32)
+
+
 def step():
-    ue, ie = enc()
-    loss = bpr_loss(ue[u], ie[p], ie[n]) + l2_reg_loss(1e-4, ue[u], ie[p])
+    if ROWS:
+        o = enc.forward_rows(rows)
+        loss = bpr_loss(o[:B], o[B:2 * B], o[2 * B:]) + l2_reg_loss(1e-4, o[:B], o[B:2 * B])
+    else:
+        ue, ie = enc()
+        loss = bpr_loss(ue[u], ie[p], ie[n]) + l2_reg_loss(1e-4, ue[u], ie[p])
     opt.zero_grad()
     loss.backward()
     opt.step()
@@ -55,5 +63,5 @@ for _ in range(K):
     loss = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
-print('NGCF d=%d L=%d on %dx%d (nnz %d): %.1f ms/step = %.0f interactions/s, loss %.5f, peak mem %.1f GB'
+print(('rows-form ' if ROWS else 'full-table ') + 'NGCF d=%d L=%d on %dx%d (nnz %d): %.1f ms/step = %.0f interactions/s, loss %.5f, peak mem %.1f GB'
       % (d, L, U, I, nnz, 1e3 * dt, B / dt, float(loss.detach()), torch.cuda.max_memory_allocated() / 1e9))
