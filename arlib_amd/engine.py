@@ -123,6 +123,40 @@ class PropagationEngine:
             acc = dst
         return acc
 
+    # ---- the propagated mean on a row subset, with its backward: the sparse-batch schedule of step() for callers that keep autograd and
+    # their own optimiser (an extra loss term, an optimiser over one table only, gradient capture)
+    def forward_rows(self, rows):
+        """mean(E_0 .. E_L)[rows] (LightGCN): L-1 full hops and the last hop on the listed rows only.  rows: int32 node ids, duplicates allowed."""
+        L, A = self.L, self.A
+        if L == 0 or self.skip0 or L > 8:
+            raise ValueError('forward_rows: LightGCN mean over layers 0..L with 1 <= L <= 8')
+        n = rows.numel()
+        self._sparse_buffers(max(n // 3, 1) if n % 3 == 0 else n)          # node-sized buffers (flags, bits, hops); batch-sized ones are not used here
+        layers = [self.E0]
+        for k in range(L - 1):
+            ops.spmm(A, layers[-1], out=self.hops[k])
+            layers.append(self.hops[k])
+        return ops.spmm_rows(A, layers[-1], rows, layers, 1.0 / (L + 1), nsplit=self.nsplit, check_range=False)
+
+    def backward_rows(self, rows, g_rows):
+        """dL/dE0 [N, d] from dL/d(forward_rows(rows)) = g_rows: scatter into the (all-zero) gradient table, flag-masked first hop, Horner
+        over the remaining hops; the sparse state is cleared again before returning."""
+        L, A = self.L, self.A
+        s = 1.0 / (L + 1)
+        if getattr(self, '_G_dirty', True):
+            self.G.zero_()
+            self._G_dirty = False
+        ops.batch_rows_set_(self.G, self.flags, self.bits, rows, g_rows.contiguous(), 1.0, check_range=False)
+        if L == 1:
+            out = ops.spmm_flagged(A, self.G, self.bits, s, s, self.G, self.flags)
+        else:
+            acc = ops.spmm_flagged(A, self.G, self.bits, 1.0, 1.0, self.G, self.flags, out=self.hops[0])
+            for k in range(1, L - 1):
+                acc = ops.spmm_flagged(A, acc, None, 1.0, 1.0, self.G, self.flags, out=self.hops[k % 2 if len(self.hops) == 2 else k])
+            out = ops.spmm_flagged(A, acc, None, s, s, self.G, self.flags)
+        ops.batch_rows_clear_(self.G, self.flags, self.bits, rows, check_range=False)
+        return out
+
     def loss_and_grad_out(self, out, u, p, n):
         self.G.zero_()
         self._G_dirty = True          # the sparse step keeps G all-zero between calls; dense users leave it dirty

@@ -102,6 +102,22 @@ class _Propagate(torch.autograd.Function):
         return dE0[:U], dE0[U:], None, None
 
 
+class _PropagateRows(torch.autograd.Function):
+    """(user_emb, item_emb, rows) -> the propagated LightGCN mean on the listed rows only, [len(rows), d]; forward and backward on the
+    sparse-batch schedule of the fused step (engine.forward_rows / backward_rows): 2L-2 full hops instead of 2L."""
+
+    @staticmethod
+    def forward(ctx, user_emb, item_emb, enc, rows):
+        eng = enc._engine()
+        ctx.enc, ctx.rows, ctx.U = enc, rows, user_emb.shape[0]
+        return eng.forward_rows(rows)
+
+    @staticmethod
+    def backward(ctx, g_rows):
+        dE0 = ctx.enc._engine().backward_rows(ctx.rows, g_rows)
+        return dE0[:ctx.U], dE0[ctx.U:], None, None
+
+
 class GraphEncoder(nn.Module):
     n_prop_layers = 0          # 0 = plain matrix factorisation
     skip_layer0 = False
@@ -204,6 +220,15 @@ class GraphEncoder(nn.Module):
             noises = [torch.rand(N, self.latent_size, device=u.device) for _ in range(self.n_prop_layers)]      # SimGCL.py:204
         return _Propagate.apply(u, i, self, noises)
 
+    def forward_rows(self, rows):
+        """Rows `rows` (int32 node ids: users, then U + items) of forward()'s output -- what a training step reads -- on the sparse-batch
+        schedule.  Plain LightGCN mean (layers 0..L) only; other encoders do not define this."""
+        u, i = self.embedding_dict['user_emb'], self.embedding_dict['item_emb']
+        if self.n_prop_layers == 0:
+            return torch.cat([u, i], 0)[rows.long()]
+        self._pack()
+        return _PropagateRows.apply(u, i, self, rows.contiguous())
+
     def __getstate__(self):
         st = dict(self.__dict__)
         st['_eng'] = None
@@ -216,6 +241,15 @@ class Recommender:
     has_extra_loss = False
     fused_extra_loss = False      # the model's extra loss has a fused engine step (SimGCL)
     train_forward_perturbed = False   # the training forward is model(True) and hands extra outputs to _extra_loss (XSimGCL)
+
+    @staticmethod
+    def _rows_capable(model):
+        """Encoders whose training forward can be evaluated on the batch rows alone: NGCF (own forward_rows) and the plain LightGCN mean
+        (GraphEncoder.forward_rows; not the SimGCL family, whose mean skips layer 0 and whose views are perturbed)."""
+        if not hasattr(model, 'forward_rows'):
+            return False
+        return type(model).forward_rows is not GraphEncoder.forward_rows or (not getattr(model, 'skip_layer0', False) and getattr(model, 'n_prop_layers', 0) <= 8
+                                                                             and type(model).forward is GraphEncoder.forward)
 
     def _fused_step(self, eng, u, p, n):
         return eng.step(u, p, n)
@@ -332,7 +366,8 @@ class Recommender:
                     continue
                 model.train()
                 ul, pl, nl = u.long(), p.long(), ng.long()
-                if self.rows_forward and hasattr(model, 'forward_rows') and not self.train_forward_perturbed and not self.has_extra_loss:
+                if (self.rows_forward and self._rows_capable(model) and not self.train_forward_perturbed
+                        and not (self.has_extra_loss and self.extra_loss_takes_outputs)):
                     # the loss reads the output on the batch rows only: encoders that can evaluate just those rows do (NGCF's last layer)
                     B = u.numel()
                     out_r = model.forward_rows(torch.cat([u, p + U, ng + U]).to(torch.int32))

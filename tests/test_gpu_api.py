@@ -172,6 +172,39 @@ def test_ngcf_forward_and_steps_match_reference():
     assert rel_err(m2.W['w1_0'].detach().cpu().numpy(), g['w1_0_k3']) < RTOL
 
 
+@pytest.mark.parametrize('L', [0, 1, 2, 3])
+def test_encoder_forward_rows_equals_full_forward_with_autograd(L):
+    """GraphEncoder.forward_rows (sparse-batch schedule under autograd: last hop on the batch rows, flag-masked first backward hop) against
+    the full-table forward + indexing: same batch-row outputs and the same parameter gradients, duplicates in the batch included."""
+    from arlib_amd.recommender.LightGCN import LGCN_Encoder
+    from arlib_amd.recommender.GMF import GMF
+    from arlib_amd.util.loss import bpr_loss, l2_reg_loss
+    data = make_data()
+    torch.manual_seed(3)
+    rng = np.random.default_rng(L)
+    U, I, B = data.user_num, data.item_num, 700
+    u = torch.from_numpy(rng.integers(0, U, B)).cuda(); p = torch.from_numpy(rng.integers(0, I, B)).cuda(); n = torch.from_numpy(rng.integers(0, I, B)).cuda()
+    u[:40] = u[0]; p[:25] = p[1]; n[:10] = p[1]
+    grads = []
+    for rows_form in (False, True):
+        torch.manual_seed(3)
+        model = (LGCN_Encoder(data, 32, L) if L else GMF(rec_args(emb_size=32, model_name='GMF'), data).model).cuda()
+        if rows_form:
+            out = model.forward_rows(torch.cat([u, p + U, n + U]).to(torch.int32))
+            ue, pe, ne = out[:B], out[B:2 * B], out[2 * B:]
+        else:
+            fu, fi = model()
+            ue, pe, ne = fu[u], fi[p], fi[n]
+        loss = bpr_loss(ue, pe, ne) + l2_reg_loss(1e-4, ue, pe)
+        loss.backward()
+        grads.append((loss.item(), model.embedding_dict['user_emb'].grad.cpu().numpy().copy(), model.embedding_dict['item_emb'].grad.cpu().numpy().copy()))
+        if rows_form and L:
+            eng = model._engine()
+            assert float(eng.G.abs().max()) == 0.0 and int(eng.flags.max()) == 0 and int(eng.bits.abs().max()) == 0
+    assert abs(grads[0][0] - grads[1][0]) <= RTOL * abs(grads[0][0])
+    assert rel_err(grads[1][1], grads[0][1]) < RTOL and rel_err(grads[1][2], grads[0][2]) < RTOL
+
+
 def test_ncl_prototype_phase_step_matches_reference(tmp_path, monkeypatch):
     """NCL: one iteration of the prototype phase against the reference's own (g16): BPR + L2/batch_size over (u, p, n) rows +
     structure loss against ALL rows (panel-wise) + ProtoNCE on the reference's centroids; separate gradients of the two contrastive terms,
