@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ARLIB_AMD_LIB') or os.path.join(_HERE, 'lib', 'libarlib_amd.so')      # override: developer builds (e.g. `make prof`)
-ABI_VERSION = 10
+ABI_VERSION = 11
 _lib = None
 
 
@@ -25,7 +25,8 @@ class arl_csr(C.Structure):
 
 class arl_blocked(C.Structure):
     _fields_ = [('n_waves', C.c_int64), ('rows_per_wave', C.c_int64), ('loads_in_flight', C.c_int64), ('wave_ptr', C.c_void_p), ('wave_rows', C.c_void_p), ('rec_col', C.c_void_p),
-                ('rec_val', C.c_void_p)]
+                ('rec_val', C.c_void_p), ('n_split', C.c_int64), ('split_row', C.c_void_p), ('split_first', C.c_void_p), ('split_count', C.c_void_p),
+                ('partial', C.c_void_p), ('waves_per_group', C.c_int64)]
 
 
 class arl_tiled(C.Structure):

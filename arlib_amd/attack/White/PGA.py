@@ -60,7 +60,7 @@ class FakeBlockGraph:
         base = np.zeros(Up + I, np.float32); base[:U] = np.asarray(R.sum(1)).ravel(); base[Up:] = np.asarray(R.sum(0)).ravel()
         self.base_rowsum = torch.from_numpy(base).to(self.device)          # weighted degrees of the real interactions
         self.graph = ops.CSRGraph(rowptr, self.col_d, torch.zeros(nnz, device=self.device), self.device)
-        if emb_size is not None:            # the pattern never changes: large graphs get the register-blocked hop plan once (the fake rows are its hub rows)
+        if emb_size is not None:            # the pattern never changes: large graphs get the register-blocked hop plan once (the dense fake rows are dealt as strided pieces)
             ops.auto_blocked(self.graph, emb_size, split=Up)
         self.fake_rows = torch.arange(U, Up, dtype=torch.int32, device=self.device)
         self.dinv = None

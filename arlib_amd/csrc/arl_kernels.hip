@@ -524,6 +524,7 @@ struct BlockedDev {
     const int32_t *wave_rows;     // [n_waves][RPW] output row or -1
     const int32_t *rec_col;       // col | slot << 24
     const float *rec_val;
+    float *partial;               // [n_pieces][d] raw sums of split-row pieces (wave_rows entry -(2 + t))
 };
 
 // spmm_epilogue for CPL adjacent columns per lane (d = 64 * CPL); same arithmetic (a wave writes one 256-B / 512-B row at a time)
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked64_kernel(BlockedDev P, co
     static_assert(RPW == 16 || RPW == 32, "accumulators are 32-register vectors");
     static_assert(CPL == 1 || CPL == 2, "d = 64 (one column per lane) or d = 128 (two adjacent columns per lane)");
     const int lane = threadIdx.x & 63;
-    const int w = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (w >= P.n_waves) return;
     f32x32v acc[CPL];
 #pragma unroll
@@ -599,6 +600,11 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked64_kernel(BlockedDev P, co
 #pragma unroll
         for (int c = 0; c < CPL; ++c) a[c] = acc[c][r];
         if (row >= 0) spmm_epilogue1<MODE, CPL>(ep, row, lane, a);
+        else if (row < -1) {                                     // piece of a split (hub) row: raw sum, combined by spmm_long_rows_kernel
+            float *dst = P.partial + ((size_t)(-row - 2) * 64 + lane) * CPL;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) dst[c] = a[c];
+        }
     }
 }
 
@@ -610,16 +616,28 @@ int launch_spmm_blocked(const arl_blocked *P, const float *X, int64_t d, const E
     if (P->rows_per_wave != 16 && P->rows_per_wave != 32) return ARL_E_ARG;
     if (P->n_waves == 0) return ARL_OK;
     if (!P->wave_ptr || !P->wave_rows || !P->rec_col || !P->rec_val) return ARL_E_NULL;
-    BlockedDev D = {(int)P->n_waves, P->wave_ptr, P->wave_rows, P->rec_col, P->rec_val};
-    const dim3 grid((unsigned)((P->n_waves + kWavesPerBlock - 1) / kWavesPerBlock));
+    if (P->n_split < 0 || P->n_split > 0x7fffffffll) return ARL_E_RANGE;
+    if (P->n_split > 0 && (!P->split_row || !P->split_first || !P->split_count || !P->partial)) return ARL_E_NULL;
+    BlockedDev D = {(int)P->n_waves, P->wave_ptr, P->wave_rows, P->rec_col, P->rec_val, P->partial};
+    const int64_t wpg = P->waves_per_group ? P->waves_per_group : kWavesPerBlock;
+    if (wpg != 1 && wpg != 2 && wpg != 4) return ARL_E_ARG;
+    const dim3 grid((unsigned)((P->n_waves + wpg - 1) / wpg)), block((unsigned)(wpg * kWave));
     if (P->loads_in_flight != 16 && P->loads_in_flight != 32) return ARL_E_ARG;
     if (d == 128) {                                      // two columns per lane: 64 accumulator registers, 16 rows in flight
-        if (P->rows_per_wave == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<16, MODE, 16, 2>), grid, dim3(kBlock), 0, st, D, X, ep);
-        else hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE, 16, 2>), grid, dim3(kBlock), 0, st, D, X, ep);
-    } else if (P->rows_per_wave == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<16, MODE, 16, 1>), grid, dim3(kBlock), 0, st, D, X, ep);
-    else if (P->loads_in_flight == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE, 16, 1>), grid, dim3(kBlock), 0, st, D, X, ep);
-    else hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE, 32, 1>), grid, dim3(kBlock), 0, st, D, X, ep);
+        if (P->rows_per_wave == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<16, MODE, 16, 2>), grid, block, 0, st, D, X, ep);
+        else hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE, 16, 2>), grid, block, 0, st, D, X, ep);
+    } else if (P->rows_per_wave == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<16, MODE, 16, 1>), grid, block, 0, st, D, X, ep);
+    else if (P->loads_in_flight == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE, 16, 1>), grid, block, 0, st, D, X, ep);
+    else hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE, 32, 1>), grid, block, 0, st, D, X, ep);
     ARL_LAUNCH_CHECK();
+    if (P->n_split > 0) {                                // split rows: add the pieces in piece order and run the epilogue
+        CsrDev C = {};
+        C.n_long = (int)P->n_split; C.long_row = P->split_row; C.long_first = P->split_first; C.long_count = P->split_count; C.partial = P->partial;
+        const unsigned grid_long = (unsigned)((C.n_long + kWavesPerBlock - 1) / kWavesPerBlock);
+        if (d == 128) hipLaunchKernelGGL((spmm_long_rows_kernel<32, MODE>), dim3(grid_long), dim3(kBlock), 0, st, C, 128, ep);
+        else hipLaunchKernelGGL((spmm_long_rows_kernel<16, MODE>), dim3(grid_long), dim3(kBlock), 0, st, C, 64, ep);
+        ARL_LAUNCH_CHECK();
+    }
     return ARL_OK;
 }
 

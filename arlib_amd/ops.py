@@ -97,12 +97,12 @@ class CSRGraph:
         self.dinv = None
         self.blocked = None
 
-    def enable_blocked(self, split=None, rows_per_wave=32, hub=1024, col_block=1024, min_waves=0, unroll=None):
+    def enable_blocked(self, split=None, rows_per_wave=32, hub=None, col_block=1024, min_waves=0, unroll=None, split_hubs=True, piece=None, wpg=None, wave_multiple=None, col_order=None):
         """Attach a register-blocked plan (BlockedPlan): full-table SpMMs at d = 64 then run through arl_spmm_blocked_*.
         `split` = number of users of a bipartite adjacency: user rows and item rows get separate launches (they gather from
         different tables).  Returns self."""
         sets = [(0, self.n_rows)] if not split or split >= self.n_rows else [(0, int(split)), (int(split), self.n_rows)]
-        self.blocked = BlockedPlan(self, sets, rows_per_wave, hub, col_block, min_waves, unroll)
+        self.blocked = BlockedPlan(self, sets, rows_per_wave, hub, col_block, min_waves, unroll, split_hubs, piece, wpg, wave_multiple, col_order)
         return self
 
     def chunks_only(self, rows, chunk=None):
@@ -169,17 +169,31 @@ class BlockedPlan:
 
     LONG_WAVES = 3072
 
-    def __init__(self, A, row_sets, rows_per_wave=32, hub=1024, col_block=1024, min_waves=0, unroll=None):
+    def __init__(self, A, row_sets, rows_per_wave=32, hub=None, col_block=1024, min_waves=0, unroll=None, split_hubs=True, piece=None, wpg=None, wave_multiple=None, col_order=None):
         if rows_per_wave not in (16, 32):
             raise ValueError('BlockedPlan: rows_per_wave must be 16 or 32')
         if A.n_cols >= 1 << 24:
             raise ValueError('BlockedPlan: columns must fit 24 bits')
-        if hub < 1 or col_block < 1:
-            raise ValueError('BlockedPlan: hub and col_block must be positive')
-        self.rpw, self.hub_threshold, self.col_block = int(rows_per_wave), int(hub), int(col_block)
+        if (hub is not None and hub < 1) or col_block < 1 or (piece is not None and piece < 1):
+            raise ValueError('BlockedPlan: hub, piece and col_block must be positive')
+        self.rpw, self.col_block = int(rows_per_wave), int(col_block)
+        # hub / piece / wpg / wave_multiple = None: chosen per row set from its edges per wave (measured on cfg2, tools/hop_experiments.py):
+        #   a row longer than the average wave load cannot be balanced, so the threshold is the largest power of two below that load
+        #   (capped at 4096: user rows 1024, item rows 4096); a set of long streams (> 4096 edges per wave: ~12 waves per CU, all resident)
+        #   is dealt over a multiple of 256 waves and launched one wave per workgroup, so every CU carries the same number of streams
+        self._hub_arg, self._piece_arg, self._wpg_arg, self._wm_arg = hub, piece, wpg, wave_multiple
+        self.split_hubs = bool(split_hubs)
+        self.col_order = col_order
         dev = A.device
         rp_all = A.rowptr.long()
         n_cb = (A.n_cols + self.col_block - 1) // self.col_block
+        col_pos = None
+        if col_order == 'degree':                 # sweep the operand rows hottest-first: position of a column = its rank by in-plan edge count
+            cdeg = torch.bincount(A.col.long(), minlength=A.n_cols)
+            col_pos = torch.empty(A.n_cols, dtype=torch.int64, device=dev)
+            col_pos[torch.sort(cdeg, descending=True, stable=True)[1]] = torch.arange(A.n_cols, device=dev)
+        elif col_order is not None:
+            raise ValueError('BlockedPlan: col_order must be None or "degree"')
         self.sets, hub_rows = [], []
         # a set of LONG rows (thousands of edges per wave) runs best with ~3 000 waves per launch -- all resident, 12 per CU, sweeping together
         # (cfg2's item rows: 3 049); larger sets are cut into contiguous row ranges of that many waves (4 M x 400 K: one launch of 12 194
@@ -198,33 +212,64 @@ class BlockedPlan:
                 raise ValueError('BlockedPlan: bad row set')
             rp = rp_all[lo:hi + 1]
             deg = rp[1:] - rp[:-1]
-            planned = deg <= self.hub_threshold
-            if (int(planned.sum()) + self.rpw - 1) // self.rpw < min_waves:
-                planned = torch.zeros_like(planned)
+            load = int(rp[-1] - rp[0]) / max(1, (hi - lo + self.rpw - 1) // self.rpw)          # edges per wave
+            long_streams = load > 4096
+            hub_t = int(self._hub_arg) if self._hub_arg is not None else min(4096, max(256, 1 << max(0, int(load).bit_length() - 1)))
+            piece_t = int(self._piece_arg) if self._piece_arg is not None else hub_t
+            wpg_t = int(self._wpg_arg) if self._wpg_arg is not None else (1 if long_streams and self.split_hubs else 4)
+            wm_t = int(self._wm_arg) if self._wm_arg is not None else (256 if long_streams and self.split_hubs else 1)
+            long_ = deg > hub_t
+            if self.split_hubs:
+                planned = torch.ones_like(long_)
+            else:
+                planned = ~long_
+            n_pl = int(planned.sum())
+            # pieces per planned row: 1, or ceil(deg / piece) for a split (hub) row
+            npc = torch.where(long_ & planned, (deg + piece_t - 1) // piece_t, torch.ones_like(deg)) * planned.long()
+            n_virtual = int(npc.sum())
+            if (n_virtual + self.rpw - 1) // self.rpw < min_waves:
+                planned = torch.zeros_like(planned); npc = torch.zeros_like(npc); n_virtual = 0
             hub_rows.append(lo + torch.nonzero(~planned).flatten())
-            local = torch.nonzero(planned).flatten()
-            n = local.numel()
-            if n == 0:
+            if n_virtual == 0:
                 continue
-            w_desc, o = torch.sort(deg[local], descending=True, stable=True)
-            local = local[o]
-            n_waves = (n + self.rpw - 1) // self.rpw
+            vfirst = torch.cumsum(npc, 0) - npc                               # first virtual row of every local row
+            vrow = torch.repeat_interleave(torch.arange(hi - lo, device=dev), npc, output_size=n_virtual)     # local row of a virtual row
+            vk = torch.arange(n_virtual, device=dev) - vfirst[vrow]           # piece number inside its row
+            vdeg = (deg[vrow] - vk + npc[vrow] - 1) // npc[vrow]              # piece p of P takes edges p, p + P, ...
+            w_desc, o = torch.sort(vdeg, descending=True, stable=True)
+            n_waves = (n_virtual + self.rpw - 1) // self.rpw
+            if wm_t > 1 and int(deg.sum()) > 4096 * n_waves:
+                n_waves = (n_waves + wm_t - 1) // wm_t * wm_t
             w_host = w_desc.to(torch.int32).cpu().contiguous()
-            bin_h = torch.empty(n, dtype=torch.int32); slot_h = torch.empty(n, dtype=torch.int32)
-            check(_lib.lib().arl_lpt_deal(n, w_host.data_ptr(), n_waves, self.rpw, bin_h.data_ptr(), slot_h.data_ptr()), 'arl_lpt_deal')
-            wave_of, slot_of = bin_h.to(dev).long(), slot_h.to(dev).long()
+            bin_h = torch.empty(n_virtual, dtype=torch.int32); slot_h = torch.empty(n_virtual, dtype=torch.int32)
+            check(_lib.lib().arl_lpt_deal(n_virtual, w_host.data_ptr(), n_waves, self.rpw, bin_h.data_ptr(), slot_h.data_ptr()), 'arl_lpt_deal')
+            v_wave = torch.empty(n_virtual, dtype=torch.int64, device=dev); v_slot = torch.empty(n_virtual, dtype=torch.int64, device=dev)
+            v_wave[o] = bin_h.to(dev).long(); v_slot[o] = slot_h.to(dev).long()
+            # split rows: their pieces are numbered in (row, piece) order; a piece's slot entry is -(2 + piece index)
+            is_split = (npc > 1)
+            split_local = torch.nonzero(is_split).flatten()
+            n_split = int(split_local.numel())
+            split_cnt = npc[split_local]
+            split_first = torch.cumsum(split_cnt, 0) - split_cnt
+            piece_base = torch.zeros(hi - lo, dtype=torch.int64, device=dev)
+            piece_base[split_local] = split_first
+            v_entry = torch.where(is_split[vrow], -(2 + piece_base[vrow] + vk), lo + vrow)
             wave_rows = torch.full((n_waves, self.rpw), -1, dtype=torch.int32, device=dev)
-            wave_rows[wave_of, slot_of] = (lo + local).to(torch.int32)
-            row_wave = torch.full((hi - lo,), -1, dtype=torch.int64, device=dev); row_slot = torch.zeros(hi - lo, dtype=torch.int64, device=dev)
-            row_wave[local] = wave_of; row_slot[local] = slot_of
+            wave_rows[v_wave, v_slot] = v_entry.to(torch.int32)
             e0, e1 = int(rp[0]), int(rp[-1])
             erow = torch.repeat_interleave(torch.arange(hi - lo, device=dev), deg, output_size=e1 - e0)
-            ew = row_wave[erow]
-            keep = torch.nonzero(ew >= 0).flatten()
-            ew = ew[keep]; es = row_slot[erow[keep]]; del erow
-            eid = keep + e0; del keep
+            keep = torch.nonzero(planned[erow]).flatten() if n_pl < hi - lo else None
+            if keep is not None:
+                erow = erow[keep]
+                eid = keep + e0
+            else:
+                eid = torch.arange(e0, e1, device=dev)
+            del keep
+            ev = vfirst[erow] + (eid - rp[erow]) % npc[erow]                  # virtual row of every edge
+            del erow
+            ew, es = v_wave[ev], v_slot[ev]; del ev
             ec = A.col[eid].long()
-            key = (ew * n_cb + ec // self.col_block) * self.rpw + es
+            key = (ew * n_cb + (ec if col_pos is None else col_pos[ec]) // self.col_block) * self.rpw + es
             o = torch.sort(key, stable=True)[1]; del key
             ew, es, ec, eid = ew[o], es[o], ec[o], eid[o]; del o
             cnt = torch.bincount(ew, minlength=n_waves)
@@ -240,8 +285,17 @@ class BlockedPlan:
             rec_col[dst] = (ec | (es << 24)).to(torch.int32)
             rec_src[dst] = eid.to(torch.int32)
             pad = torch.ones(max(total, 64), dtype=torch.bool, device=dev); pad[dst] = False
-            self.sets.append({'n_waves': n_waves, 'wave_ptr': wave_ptr.to(torch.int32), 'wave_rows': wave_rows, 'rec_col': rec_col, 'rec_src': rec_src, 'pad_pos': torch.nonzero(pad).flatten(),
-                              'n_rows': n, 'n_edges': int(ew.numel()),
+            pad_pos = torch.nonzero(pad).flatten()
+            # a padding record repeats its wave's last real record with value 0: whatever 0 * X[col] gives (NaN for a non-finite
+            # operand row) lands on a row that already takes that operand row, never on an unrelated one
+            if pad_pos.numel() and total:
+                pw = torch.searchsorted(wave_ptr[1:].contiguous(), pad_pos, right=True).clamp_(max=n_waves - 1)
+                last = wave_ptr[pw] + cnt[pw] - 1
+                ok = cnt[pw] > 0
+                rec_col[pad_pos[ok]] = rec_col[last[ok]]
+            self.sets.append({'n_waves': n_waves, 'wave_ptr': wave_ptr.to(torch.int32), 'wave_rows': wave_rows, 'rec_col': rec_col, 'rec_src': rec_src, 'pad_pos': pad_pos,
+                              'n_rows': n_pl, 'n_edges': int(ew.numel()), 'hub': hub_t, 'piece': piece_t, 'wpg': wpg_t, 'n_split': n_split, 'n_pieces': int(split_cnt.sum()) if n_split else 0,
+                              'split_row': (lo + split_local).to(torch.int32), 'split_first': split_first.to(torch.int32), 'split_count': split_cnt.to(torch.int32),
                               # short streams: more loads per wave; long streams (many edges per wave) run better with 16 (measured, cfg2)
                               'unroll': (16 if self.rpw == 16 or ew.numel() > 4096 * n_waves else 32) if unroll is None else int(unroll)})
         hub_rows = torch.cat(hub_rows) if hub_rows else torch.zeros(0, dtype=torch.int64, device=dev)
@@ -257,12 +311,21 @@ class BlockedPlan:
                 st['rec_val'][st['pad_pos']] = 0.0
             else:
                 st['rec_val'] = torch.zeros(st['rec_src'].numel(), dtype=torch.float32, device=A.device)
-            self.structs.append(_lib.arl_blocked(st['n_waves'], self.rpw, st['unroll'], st['wave_ptr'].data_ptr(), st['wave_rows'].data_ptr(), st['rec_col'].data_ptr(),
-                                                 st['rec_val'].data_ptr()))
+            self.structs.append(None)
         if hub is not None:                       # same chunk plan, new values (no host work)
             self.hub = hub.with_values(A.val)
         else:
             self.hub = A.chunks_only(self._hub_rows) if self.n_hub else None
+
+    def struct(self, k, d):
+        """ctypes image of row set k for an operand of width d (the split rows' [n_pieces, d] workspace is sized here)."""
+        st = self.sets[k]
+        n_sp = st.get('n_split', 0)
+        if n_sp and (st.get('partial') is None or st['partial'].numel() < st['n_pieces'] * d):
+            st['partial'] = torch.empty(st['n_pieces'] * d, dtype=torch.float32, device=st['rec_col'].device)
+        return _lib.arl_blocked(st['n_waves'], self.rpw, st['unroll'], st['wave_ptr'].data_ptr(), st['wave_rows'].data_ptr(), st['rec_col'].data_ptr(),
+                                st['rec_val'].data_ptr(), n_sp, st['split_row'].data_ptr() if n_sp else None, st['split_first'].data_ptr() if n_sp else None,
+                                st['split_count'].data_ptr() if n_sp else None, st['partial'].data_ptr() if n_sp else None, int(st['wpg']))
 
     def with_values(self, A):
         """The same plan over a graph with the same pattern and new edge values."""
@@ -294,8 +357,8 @@ def _spmm_dispatch(A, d, blocked_call, csr_call):
     if bp is None or d not in (64, 128):
         csr_call(C.byref(A._struct(d)))
         return
-    for st in bp.structs:
-        blocked_call(C.byref(st))
+    for k in range(len(bp.sets)):
+        blocked_call(C.byref(bp.struct(k, d)))
     if bp.hub is not None:
         csr_call(C.byref(bp.hub._struct(d)))
 

@@ -116,6 +116,8 @@ class NGCF_Encoder(GraphEncoder):
         ego = torch.cat([self.embedding_dict['user_emb'], self.embedding_dict['item_emb']], 0)
         idx = rows.long()
         acc = ego[idx]
+        if self.layers == 0:                              # no propagation layer: the plain rows of the ego table (as forward() and the reference)
+            return acc
         for k in range(self.layers - 1):
             ego = _Layer.apply(ego, self.W['w1_' + str(k)], self.W['w2_' + str(k)], graph, 0.01)
             acc = acc + ego[idx]

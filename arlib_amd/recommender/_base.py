@@ -225,7 +225,13 @@ class GraphEncoder(nn.Module):
         schedule.  Plain LightGCN mean (layers 0..L) only; other encoders do not define this."""
         u, i = self.embedding_dict['user_emb'], self.embedding_dict['item_emb']
         if self.n_prop_layers == 0:
-            return torch.cat([u, i], 0)[rows.long()]
+            # index the two Parameters directly (as the reference does): no [U+I, d] copy, no dense gradient through a cat
+            r = rows.long()
+            U = u.shape[0]
+            isu = r < U
+            out = torch.empty(r.numel(), u.shape[1], dtype=u.dtype, device=u.device)
+            ku, ki = torch.nonzero(isu).flatten(), torch.nonzero(~isu).flatten()
+            return out.index_copy(0, ku, u[r[ku]]).index_copy(0, ki, i[r[ki] - U])
         self._pack()
         return _PropagateRows.apply(u, i, self, rows.contiguous())
 
@@ -292,7 +298,12 @@ class Recommender:
             return
         eng.betas, eng.eps = tuple(g['betas']), float(g['eps'])
         U = self.data.user_num
-        for p, sl in zip(self._params(), (slice(0, U), slice(U, None))):
+        params = self._params()
+        if not any('exp_avg' in optimizer.state[p] for p in params):
+            # a fresh optimizer (what the reference builds per train(optimizer=None) call, LightGCN.py:31) starts from zero moments and
+            # step 0, whatever an earlier run left in the cached engine
+            eng.m.zero_(); eng.v.zero_(); eng.t = 0
+        for p, sl in zip(params, (slice(0, U), slice(U, None))):
             st = optimizer.state[p]
             if 'exp_avg' in st and st['exp_avg'].data_ptr() != eng.m[sl].data_ptr():
                 eng.m[sl].copy_(st['exp_avg']); eng.v[sl].copy_(st['exp_avg_sq'])

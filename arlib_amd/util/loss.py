@@ -62,14 +62,15 @@ class _FrobNorm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         x, out = ctx.saved_tensors
-        return x * (gout / out[2])
+        # torch.norm's backward gives 0 (not NaN) at the origin; bpr_bwd_kernel guards the same way
+        return x * torch.where(out[2] > 0, gout / out[2], torch.zeros_like(gout))
 
 
 def l2_reg_loss(reg, *args):
     """util/loss.py:25-29: reg * sum_k ||emb_k||_F  (un-squared Frobenius norms)."""
     total = 0
     for emb in args:
-        total = total + (_FrobNorm.apply(emb) if emb.dim() == 2 and emb.is_cuda and emb.dtype == torch.float32 else torch.norm(emb, p=2))
+        total = total + (_FrobNorm.apply(emb) if emb.dim() == 2 and emb.is_cuda and emb.dtype == torch.float32 and emb.shape[0] > 0 else torch.norm(emb, p=2))
     return total * reg
 
 

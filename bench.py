@@ -398,7 +398,7 @@ def main():
                 res['roofline'] = {'bound': 'hbm', 'achieved': spmm_bytes / (avg_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                    'frac': spmm_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': traffic,
                                    'kernel': ('one full-graph hop = spmm_blocked64_kernel<%d,*> x%d (user rows, item rows) + spmm_rows_kernel/spmm_long_rows_kernel on '
-                                              '%d hub rows; avg over %d hops' % (A.blocked.rpw, len(A.blocked.structs), A.blocked.n_hub, len(allv))) if A.blocked is not None
+                                              '%d hub rows; avg over %d hops' % (A.blocked.rpw, len(A.blocked.sets), A.blocked.n_hub, len(allv))) if A.blocked is not None
                                    else 'spmm_rows_kernel<LPR=%d> (+spmm_long_rows_kernel), avg over %d launches' % (max(4, d // 4), len(allv)),
                                    'schedule': 'blocked' if A.blocked is not None else 'csr',
                                    'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': spmm_bytes,

@@ -157,6 +157,17 @@ typedef struct arl_blocked {
     const int32_t *wave_rows;   /* [n_waves][rows_per_wave] output row id, -1 = unused slot               */
     const int32_t *rec_col;     /* column | slot << 24 (columns < 2^24); padding records have val 0       */
     const float *rec_val;
+    /* split rows: a row longer than the plan's hub threshold is dealt as several PIECES (piece p of P takes every P-th edge of the
+     * column-sorted row, so each piece sweeps the whole column range like an ordinary row); a piece's slot holds -(2 + t) in
+     * wave_rows and its raw sum goes to partial[t]; after the sweep the n_split rows are combined in piece order (deterministic)
+     * and run the epilogue.  n_split = 0: no split rows (partial and the split_* arrays may be NULL). */
+    int64_t n_split;
+    const int32_t *split_row;   /* [n_split] output row                                                    */
+    const int32_t *split_first; /* [n_split] first piece                                                   */
+    const int32_t *split_count; /* [n_split] number of pieces                                              */
+    float *partial;             /* [n_pieces][d] workspace                                                 */
+    int64_t waves_per_group;    /* 1, 2 or 4 wavefronts per workgroup (0 = 4): the dispatcher balances workgroups, not waves, over
+                                 * the CUs, so a launch of ~12 waves per CU is spread evenly only with small workgroups         */
 } arl_blocked;
 int arl_spmm_blocked_f32(const arl_blocked *P, const float *X, int64_t d, float alpha, float beta, const float *Z,
                          const uint8_t *zflags, float *Y, arl_stream_t stream);

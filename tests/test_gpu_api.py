@@ -380,3 +380,52 @@ def test_sgl_views_and_step_match_reference():
         rec.train(Epoch=1, evalNum=1)
     assert rec.model._eng is not None and rec.model._eng.t >= 22               # the fused step ran
     assert np.isfinite(rec.user_emb.cpu().numpy()).all()
+
+
+def test_second_train_call_starts_a_fresh_adam():
+    """train(optimizer=None) builds a new Adam per call in the reference (LightGCN.py:31): zero moments, step 0.  The fused engine is cached
+    on the encoder across calls, so its moments / step count must be reset when a fresh optimizer is bound -- checked against the
+    autograd route (requires_embgrad=True), which uses a real torch.optim.Adam per call."""
+    from arlib_amd.util.tool import seedSet
+    from arlib_amd.recommender.LightGCN import LightGCN
+    tables = []
+    for fused in (True, False):
+        seedSet(2018)
+        data = make_data()
+        rec = LightGCN(rec_args(emb_size=32, n_layers=2), data)
+        with contextlib.redirect_stdout(io.StringIO()):
+            rec.train(Epoch=1, evalNum=1, requires_embgrad=not fused)
+            if fused:
+                assert rec.model._eng is not None and rec.model._eng.t == 22
+            rec.train(Epoch=1, evalNum=1, requires_embgrad=not fused)
+            if fused:
+                assert rec.model._eng.t == 22                                     # restarted, not 44
+        tables.append((rec.model.embedding_dict['user_emb'].detach().cpu().numpy().copy(), rec.model.embedding_dict['item_emb'].detach().cpu().numpy().copy()))
+    assert rel_err(tables[0][0], tables[1][0]) < RTOL and rel_err(tables[0][1], tables[1][1]) < RTOL
+    # an optimizer that already carries state keeps it (continuing a run is still possible)
+    seedSet(2018)
+    rec = LightGCN(rec_args(emb_size=32, n_layers=2), make_data())
+    opt = torch.optim.Adam(rec.model.cuda().parameters(), lr=0.005)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rec.train(Epoch=1, evalNum=1, optimizer=opt)
+        rec.train(Epoch=1, evalNum=1, optimizer=opt)
+    assert rec.model._eng.t == 44 and int(opt.state[rec.model.embedding_dict['user_emb']]['step']) == 44
+
+
+def test_zero_layer_ngcf_rows_and_zero_norm_gradient():
+    """NGCF.forward_rows with n_layers = 0 is the plain rows of the ego table; l2_reg_loss of an all-zero block has a zero
+    (not NaN) gradient like torch.norm, and an empty block falls back to torch.norm."""
+    from arlib_amd.recommender.NGCF import NGCF
+    from arlib_amd.util.loss import l2_reg_loss
+    data = make_data()
+    rec = NGCF(rec_args(emb_size=16, n_layers=0, model_name='NGCF'), data)
+    model = rec.model.cuda()
+    rows = torch.tensor([0, 5, data.user_num, data.user_num + 7], dtype=torch.int32, device='cuda')
+    out = model.forward_rows(rows)
+    fu, fi = model()
+    assert torch.equal(out[:2], fu[[0, 5]]) and torch.equal(out[2:], fi[[0, 7]])
+    x = torch.zeros(8, 16, device='cuda', requires_grad=True)
+    l2_reg_loss(1e-3, x).backward()
+    assert float(x.grad.abs().max()) == 0.0
+    e = torch.zeros(0, 16, device='cuda', requires_grad=True)
+    assert float(l2_reg_loss(1e-3, e).detach()) == 0.0

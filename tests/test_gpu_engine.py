@@ -103,7 +103,7 @@ def test_simgcl_forward_and_backward_golden(mods, ml100k):
 @pytest.mark.parametrize('schedule', ['csr', 'blocked'])
 def test_engine_vs_oracle_synthetic_long_rows(mods, schedule):
     """Synthetic power-law graph with rows far longer than the chunk size, 5 Adam steps vs the oracle; full hops through the
-    row-per-group CSR kernel or the register-blocked schedule (with hub rows above its threshold)."""
+    row-per-group CSR kernel or the register-blocked schedule (with split rows above its threshold)."""
     ops, engine = mods
     rng = np.random.default_rng(42)
     U, I, d, L, B = 20000, 2000, 64, 3, 2048
@@ -120,7 +120,7 @@ def test_engine_vs_oracle_synthetic_long_rows(mods, schedule):
     E0 = ((rng.random((U + I, d)) * 2 - 1) * bound).astype(np.float32)
     st = O.TrainState(E0[:U], E0[U:], (rowptr, col, val), L, 1e-4, 0.005)
     eng = engine.PropagationEngine(A, U, I, d, L, 1e-4, 0.005, DEV, table=T(E0), schedule=schedule)
-    assert (A.blocked is not None) == (schedule == 'blocked') and (schedule == 'csr' or A.blocked.n_hub > 0)
+    assert (A.blocked is not None) == (schedule == 'blocked') and (schedule == 'csr' or sum(s_['n_split'] for s_ in A.blocked.sets) > 0)
     pairs = np.stack([us, its], 1)
     for k in range(5):
         sel = rng.integers(0, len(pairs), B)

@@ -81,18 +81,21 @@ def test_spmm_all_epilogues(ops, d):
     assert rel_err(Pt.cpu().numpy(), Pr) < RTOL and rel_err(Mt.cpu().numpy(), Mr) < RTOL and rel_err(Vt.cpu().numpy(), Vr) < RTOL
 
 
-@pytest.mark.parametrize('rpw,split,hub,d', [(32, True, 64, 64), (16, True, 24, 64), (32, False, 100000, 64), (32, True, 64, 128), (16, False, 300, 128)])
-def test_spmm_blocked_schedule_all_epilogues(ops, rpw, split, hub, d):
-    """Register-blocked schedule (arl_spmm_blocked_*: plan rows + hub rows through the chunked kernel) against the oracle: every
-    epilogue, empty rows, rows above the hub threshold, ragged last wave, and edge values replaced through with_values."""
+@pytest.mark.parametrize('rpw,split,hub,d,split_hubs', [(32, True, 64, 64, True), (32, True, 64, 64, False), (16, True, 24, 64, True), (32, False, 100000, 64, True),
+                                                        (32, True, 64, 128, True), (16, False, 300, 128, False), (16, False, 300, 128, True)])
+def test_spmm_blocked_schedule_all_epilogues(ops, rpw, split, hub, d, split_hubs):
+    """Register-blocked schedule (arl_spmm_blocked_*) against the oracle: every epilogue, empty rows, rows above the hub threshold (dealt as
+    strided pieces + combine pass with split_hubs, through the chunked kernel without), ragged last wave, and edge values replaced through
+    with_values."""
     rng = np.random.default_rng(rpw + hub + d)
     U, I = 3001, 703
     u, i = random_graph(rng, U, I, 12, hot_items=3, hot_deg=2500, empty_users=(5, 77))
     rowptr, col, w, val = make_csr(u, i, U, I)
     N = U + I
-    A = ops.CSRGraph(rowptr, col, val, DEV, chunk=512).enable_blocked(split=U if split else None, rows_per_wave=rpw, hub=hub, col_block=256)
+    A = ops.CSRGraph(rowptr, col, val, DEV, chunk=512).enable_blocked(split=U if split else None, rows_per_wave=rpw, hub=hub, col_block=256, split_hubs=split_hubs)
     bp = A.blocked
-    assert len(bp.sets) == (2 if split else 1) and (bp.n_hub > 0) == (hub < 2500)
+    assert len(bp.sets) == (2 if split else 1) and (bp.n_hub > 0) == (hub < 2500 and not split_hubs)
+    assert (sum(s['n_split'] for s in bp.sets) > 0) == (hub < 2500 and split_hubs)
     assert sum(s['n_rows'] for s in bp.sets) + bp.n_hub == N
     X = rng.standard_normal((N, d)).astype(np.float32)
     Z = rng.standard_normal((N, d)).astype(np.float32)
@@ -128,6 +131,24 @@ def test_spmm_blocked_schedule_all_epilogues(ops, rpw, split, hub, d):
     assert rel_err(ops.spmm(A, T(X)).cpu().numpy(), ref) < RTOL
 
 
+def test_spmm_blocked_nonfinite_operand_row_stays_on_its_neighbours(ops):
+    """A non-finite operand row reaches exactly the rows adjacent to it, as with the CSR kernel (padding records repeat the wave's last real
+    record with value 0 instead of pointing at row 0)."""
+    rng = np.random.default_rng(5)
+    U, I, d = 2000, 300, 64
+    u, i = random_graph(rng, U, I, 9, hot_items=2, hot_deg=1500)
+    rowptr, col, w, val = make_csr(u, i, U, I)
+    N = U + I
+    X = rng.standard_normal((N, d)).astype(np.float32)
+    X[0] = np.inf                                                               # user 0
+    Ac = ops.CSRGraph(rowptr, col, val, DEV)
+    Ab = ops.CSRGraph(rowptr, col, val, DEV).enable_blocked(split=U, hub=200)
+    yc, yb = ops.spmm(Ac, T(X)), ops.spmm(Ab, T(X))
+    bad_c, bad_b = ~torch.isfinite(yc).all(1), ~torch.isfinite(yb).all(1)
+    nbrs = torch.zeros(N, dtype=torch.bool, device=DEV); nbrs[torch.from_numpy(col[rowptr[0]:rowptr[1]].astype(np.int64)).to(DEV)] = True
+    assert torch.equal(bad_c, nbrs) and torch.equal(bad_b, nbrs)
+
+
 def test_spmm_blocked_small_row_set_stays_with_csr_kernel(ops):
     """A row set that would fill fewer than min_waves waves is left to the chunked CSR kernel as a whole (BlockedPlan)."""
     rng = np.random.default_rng(11)
@@ -160,13 +181,13 @@ def test_spmm_blocked_rejects_bad_plans(ops):
     with pytest.raises(ValueError):
         A.enable_blocked(rows_per_wave=64)
     A.enable_blocked(split=200)
-    st = A.blocked.structs[0]
+    st = A.blocked.struct(0, 64)
     X = torch.randn(250, 32, device=DEV); Y = torch.empty_like(X)
     L = _lib.lib()
     assert L.arl_spmm_blocked_f32(C.byref(st), X.data_ptr(), 32, 1.0, 0.0, None, None, Y.data_ptr(), None) == -2
     X = torch.randn(250, 64, device=DEV)
     assert L.arl_spmm_blocked_f32(C.byref(st), X.data_ptr(), 64, 1.0, 0.0, None, None, X.data_ptr(), None) == -4
-    bad = _lib.arl_blocked(st.n_waves, 48, 16, st.wave_ptr, st.wave_rows, st.rec_col, st.rec_val)
+    bad = _lib.arl_blocked(st.n_waves, 48, 16, st.wave_ptr, st.wave_rows, st.rec_col, st.rec_val, 0, None, None, None, None, 0)
     Y = torch.empty_like(X)
     assert L.arl_spmm_blocked_f32(C.byref(bad), X.data_ptr(), 64, 1.0, 0.0, None, None, Y.data_ptr(), None) == -4
 

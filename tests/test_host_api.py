@@ -288,12 +288,14 @@ def test_header_is_plain_c(tmp_path):
     assert sizes == [ctypes.sizeof(_lib.arl_csr), ctypes.sizeof(_lib.arl_blocked), ctypes.sizeof(_lib.arl_tiled)]
 
 
-@pytest.mark.parametrize('rpw,hub,split', [(32, 40, True), (16, 100000, False), (32, 7, True)])
-def test_blocked_plan_invariants_and_numpy_emulation(rpw, hub, split):
+@pytest.mark.parametrize('rpw,hub,split,split_hubs', [(32, 40, True, True), (32, 40, True, False), (16, 100000, False, True), (32, 7, True, True), (32, 7, True, False),
+                                                    (16, 12, False, True)])
+def test_blocked_plan_invariants_and_numpy_emulation(rpw, hub, split, split_hubs):
     """ops.BlockedPlan built on the CPU (torch ops + the host dealing helper; no kernel runs): every planned row sits in exactly one
     wave slot, every edge of a planned row is exactly one record of that wave with that slot, streams are padded to 64 with zero values
     and sorted by (column block, slot), waves of a set carry (nearly) equal edge counts -- and a numpy emulation of the kernel's
-    arithmetic on the plan, plus the hub rows, reproduces A @ X."""
+    arithmetic on the plan, plus the hub rows, reproduces A @ X.  With split_hubs the rows above the hub threshold are dealt as strided
+    pieces (piece p of P = every P-th edge of the column-sorted row) whose raw sums meet in the split_* combine lists."""
     import torch
     import scipy.sparse as sp
     from arlib_amd import ops
@@ -307,7 +309,7 @@ def test_blocked_plan_invariants_and_numpy_emulation(rpw, hub, split):
     Adj.sort_indices()
     N = U + I
     A = ops.CSRGraph(Adj.indptr.astype(np.int64), Adj.indices.astype(np.int32), Adj.data, 'cpu', chunk=64)
-    A.enable_blocked(split=U if split else None, rows_per_wave=rpw, hub=hub, col_block=32)
+    A.enable_blocked(split=U if split else None, rows_per_wave=rpw, hub=hub, col_block=32, split_hubs=split_hubs)
     bp = A.blocked
     X = rng.standard_normal((N, d)).astype(np.float32)
     Y = np.full((N, d), np.nan, np.float32)
@@ -318,10 +320,15 @@ def test_blocked_plan_invariants_and_numpy_emulation(rpw, hub, split):
         rc, rv = st['rec_col'].numpy(), st['rec_val'].numpy()
         assert np.all(wp % 64 == 0) and wp[0] == 0 and np.all(np.diff(wp) >= 0)
         loads = []
+        partial = np.full((max(st['n_pieces'], 1), d), np.nan, np.float64)
+        piece_edges = np.zeros(max(st['n_pieces'], 1), np.int64)
+        piece_cols = {}
         for w in range(st['n_waves']):
             c, v = rc[wp[w]:wp[w + 1]], rv[wp[w]:wp[w + 1]]
             slot, colid = (c.astype(np.uint32) >> 24).astype(np.int64), (c & 0xffffff).astype(np.int64)
             real = v != 0
+            if (~real).any() and real.any():                                       # padding repeats the wave's last real record
+                assert np.all(c[~real] == c[real][-1])
             keyw = (colid[real] // 32) * rpw + slot[real]
             assert np.all(np.diff(keyw) >= 0) and slot.max(initial=0) < rpw       # sorted by (column block, slot)
             acc = np.zeros((rpw, d), np.float64)
@@ -331,13 +338,28 @@ def test_blocked_plan_invariants_and_numpy_emulation(rpw, hub, split):
                 if r >= 0:
                     Y[r] = acc[sl]; seen_rows.append(int(r))
                     assert int((slot[real] == sl).sum()) == rowdeg[r]              # all of the row's edges are here, under its slot
+                elif r < -1:
+                    assert np.isnan(partial[-r - 2, 0])
+                    partial[-r - 2] = acc[sl]; piece_edges[-r - 2] = int((slot[real] == sl).sum())
+                    piece_cols[-r - 2] = np.sort(colid[real][slot[real] == sl])
                 else:
                     assert not np.any(slot[real] == sl)
             loads.append(int(real.sum()))
             seen_edges += int(real.sum())
         if st['n_waves'] > 1 and hub >= 40:
             assert max(loads) - min(loads) <= max(rowdeg[rowdeg <= hub].max(), 1)                # longest-first dealing balances the waves
+        if st['n_split']:
+            assert split_hubs
+            sr, sf, sc = st['split_row'].numpy(), st['split_first'].numpy(), st['split_count'].numpy()
+            assert sf[0] == 0 and np.all(sf[1:] == np.cumsum(sc)[:-1]) and int(sc.sum()) == st['n_pieces'] and np.all(sc >= 2)
+            for r, f, n in zip(sr, sf, sc):
+                assert rowdeg[r] > hub and piece_edges[f:f + n].sum() == rowdeg[r] and piece_edges[f:f + n].max() <= hub
+                Y[r] = partial[f:f + n].sum(0); seen_rows.append(int(r))
+                rc_ = Adj.indices[Adj.indptr[r]:Adj.indptr[r + 1]]
+                for k in range(n):                                                 # piece k = every n-th edge of the column-sorted row, from k
+                    assert np.array_equal(piece_cols[f + k], rc_[k::n])
     hub_rows = bp._hub_rows.numpy()
+    assert (len(hub_rows) == 0) if split_hubs else np.array_equal(np.sort(hub_rows), np.nonzero(rowdeg > hub)[0])
     assert sorted(seen_rows + hub_rows.tolist()) == list(range(N))                     # every row exactly once
     assert seen_edges + int(rowdeg[hub_rows].sum()) == Adj.nnz
     Y[hub_rows] = (Adj[hub_rows] @ X)
