@@ -918,6 +918,169 @@ def gen_ngcf():
     save('g9_ngcf.npz', **o)
 
 
+
+# --------------------------------------------------------------------------- NGCF at cfg5's width (d = 128, L = 3): forward + 3 Adam steps
+def gen_ngcf128():
+    from recommender.NGCF import NGCF
+    args = rec_args(emb_size=128, n_layers=3, model_name='NGCF')
+    seedSet(2018)
+    data = DataLoader(args)
+    rec = NGCF(args, data)
+    model = rec.model
+    o = {'user0': model.embedding_dict['user_emb'].detach().numpy().copy(), 'item0': model.embedding_dict['item_emb'].detach().numpy().copy()}
+    for k in range(3):
+        o['w1_%d' % k] = model.W['w1_%d' % k].detach().numpy().copy(); o['w2_%d' % k] = model.W['w2_%d' % k].detach().numpy().copy()
+    with torch.no_grad():
+        u, i = model()
+    o['fwd_user'], o['fwd_item'] = u.numpy().copy(), i.numpy().copy()
+    optim = torch.optim.Adam(model.parameters(), lr=args.lRate)
+    random.seed(2018)
+    losses, bu, bp, bn = [], [], [], []
+    for step, batch in enumerate(ref_sampler.next_batch_pairwise(data, args.batch_size)):
+        if step == 3:
+            break
+        user_idx, pos_idx, neg_idx = batch
+        ue, ie = model()
+        loss = ref_loss.bpr_loss(ue[user_idx], ie[pos_idx], ie[neg_idx]) + ref_loss.l2_reg_loss(args.reg, ue[user_idx], ie[pos_idx])
+        optim.zero_grad(); loss.backward()
+        if step == 0:
+            o['grad_user'] = model.embedding_dict['user_emb'].grad.numpy().copy()
+            o['grad_w1_0'] = model.W['w1_0'].grad.numpy().copy(); o['grad_w2_2'] = model.W['w2_2'].grad.numpy().copy()
+        optim.step()
+        losses.append(loss.item()); bu.append(np.asarray(user_idx, np.int32)); bp.append(np.asarray(pos_idx, np.int32)); bn.append(np.asarray(neg_idx, np.int32))
+    o['losses'] = np.array(losses, np.float32)
+    o['batch_u'], o['batch_p'], o['batch_n'] = np.stack(bu), np.stack(bp), np.stack(bn)
+    o['user_k3'] = model.embedding_dict['user_emb'].detach().numpy().copy(); o['item_k3'] = model.embedding_dict['item_emb'].detach().numpy().copy()
+    o['w1_0_k3'] = model.W['w1_0'].detach().numpy().copy()
+    save('g9_ngcf128.npz', **o)
+
+
+# --------------------------------------------------------------------------- G19: DLAttack / CLeaR on NGCF and SimGCL victims; NoneAttack protocol
+def gen_victims():
+    """BASELINE configs 4 and 5 name SimGCL + CLeaR and NGCF + DL_Attack.  The unmodified reference attacks are run end to end on both
+    victims (structure of the returned matrix), and CLeaR's first surrogate step on each victim's encoder is captured (tables, dense
+    weights, poisoned interactions, injected r0 -> loss and parameter gradients).  NoneAttack: the identity protocol of config 1."""
+    import io, contextlib
+    from copy import deepcopy
+    import recommender.NGCF as RN
+    import recommender.SimGCL as RS
+    from attack.White.DLAttack import DLAttack
+    from attack.White.CLeaR import CLeaR
+    from attack.Black.NoneAttack import NoneAttack
+    os.makedirs('data/clean/ml-100k', exist_ok=True)
+    undo_shim = _scipy_torch_index_shim()
+    out = {}
+    orig_randn, orig_backward, orig_adam_step = torch.randn, torch.Tensor.backward, torch.optim.Adam.step
+    try:
+        for tag, mod, cls, enc, kw in (('ngcf', RN, RN.NGCF, RN.NGCF_Encoder, dict(emb_size=16, n_layers=2, model_name='NGCF')),
+                                       ('simgcl', RS, RS.SimGCL, RS.SimGCL_Encoder, dict(emb_size=16, n_layers=2, model_name='SimGCL'))):
+            rargs = rec_args(maxEpoch=1, **kw)
+
+            def fresh():
+                seedSet(2018)
+                data = DataLoader(rargs)
+                rec = cls(rargs, data)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    rec.train(Epoch=1, evalNum=5)
+                return data, rec
+            trace = []
+            orig_init = enc._init_uiAdj
+
+            def init_wrap(self, ui_adj, _orig=orig_init):
+                snap = {'adj': sp.csr_matrix(ui_adj).copy(), 'user': self.embedding_dict['user_emb'].detach().numpy().copy(),
+                        'item': self.embedding_dict['item_emb'].detach().numpy().copy()}
+                if hasattr(self, 'W'):
+                    snap['W'] = {k: v.detach().numpy().copy() for k, v in self.W.items()}
+                trace.append(snap)
+                return _orig(self, ui_adj)
+            enc._init_uiAdj = init_wrap
+            # ---- DLAttack end to end
+            data, rec = fresh()
+            atk = DLAttack(_attack_args(attackModelName='DLAttack', maliciousUserSize=2), data)
+            out[tag + '_dl_targets'] = np.array(atk.targetItem, np.int32)
+            with contextlib.redirect_stdout(io.StringIO()):
+                res = atk.posionDataAttack(deepcopy(rec))
+            res = sp.csr_matrix(res)
+            out[tag + '_dl_result_fake_rowsums'] = np.asarray(res[atk.userNum:, :].sum(1)).ravel().astype(np.float32)
+            out[tag + '_dl_shape'] = np.array(res.shape, np.int64)
+            # ---- CLeaR end to end, first surrogate step captured
+            data, rec = fresh()
+            atk = CLeaR(_attack_args(attackModelName='CLeaR', maliciousUserSize=3), data)
+            r0 = torch.randn(rargs.emb_size, generator=torch.Generator().manual_seed(99))
+            cap = {}
+
+            def randn_wrap(*a, **k):
+                if len(a) == 1 and a[0] == rargs.emb_size:
+                    return r0.clone()
+                return orig_randn(*a, **k)
+
+            def backward_wrap(self, *a, **k):
+                if 'loss' not in cap:
+                    cap['loss'] = float(self.item())
+                return orig_backward(self, *a, **k)
+
+            def adam_step_wrap(self, *a, **k):
+                if 'grads' not in cap and 'loss' in cap:
+                    cap['grads'] = {id(p): p.grad.detach().numpy().copy() for p in self.param_groups[0]['params'] if p.grad is not None}
+                    cap['params'] = list(self.param_groups[0]['params'])
+                    cap['values'] = {id(p): p.detach().numpy().copy() for p in cap['params']}        # before the step: still the snapshot's values
+                    cap['n_init'] = len(trace)
+                return orig_adam_step(self, *a, **k)
+            del trace[:]
+            torch.randn, torch.Tensor.backward, torch.optim.Adam.step = randn_wrap, backward_wrap, adam_step_wrap
+            random.seed(4242)
+            holder = {}
+            orig_deepcopy_target = CLeaR.posionDataAttack
+            with contextlib.redirect_stdout(io.StringIO()):
+                res = atk.posionDataAttack(deepcopy(rec))
+            torch.randn, torch.Tensor.backward, torch.optim.Adam.step = orig_randn, orig_backward, orig_adam_step
+            snap = trace[cap['n_init'] - 1]
+            Un = snap['user'].shape[0]
+            blk = snap['adj'][:Un, Un:]
+            out[tag + '_cl_user_tab'], out[tag + '_cl_item_tab'] = snap['user'], snap['item']
+            for k, v in snap.get('W', {}).items():
+                out[tag + '_cl_' + k] = v
+            out[tag + '_cl_ui_indptr'], out[tag + '_cl_ui_indices'], out[tag + '_cl_ui_data'] = blk.indptr.astype(np.int64), blk.indices.astype(np.int32), blk.data.astype(np.float32)
+            out[tag + '_cl_r0'] = r0.numpy()
+            out[tag + '_cl_loss'] = np.array([cap['loss']], np.float32)
+            # gradients keyed by parameter shape (user table / item table / the d x d weights in creation order)
+            gl = [cap['grads'][id(p)] for p in cap['params'] if id(p) in cap['grads']]
+            for g_ in gl:
+                if g_.shape[0] == Un:
+                    out[tag + '_cl_grad_user'] = g_
+                elif g_.shape[0] == atk.itemNum:
+                    out[tag + '_cl_grad_item'] = g_
+            if tag == 'ngcf':
+                # name each d x d gradient by matching its parameter's pre-step value with the snapshot of W taken at _init_uiAdj
+                for p_ in cap['params']:
+                    if tuple(p_.shape) == (rargs.emb_size, rargs.emb_size) and id(p_) in cap['grads']:
+                        hit = [k for k, v in snap['W'].items() if np.array_equal(v, cap['values'][id(p_)])]
+                        assert len(hit) == 1, hit
+                        out[tag + '_cl_grad_' + hit[0]] = cap['grads'][id(p_)]
+            out[tag + '_cl_targets'] = np.array(atk.targetItem, np.int32)
+            out[tag + '_cl_sizes'] = np.array([atk.userNum, atk.itemNum, atk.fakeUserNum, min(rec.topN)], np.int64)
+            out[tag + '_cl_result_fake_rowsums'] = np.asarray(sp.csr_matrix(res)[atk.userNum:, :].sum(1)).ravel().astype(np.float32)
+            enc._init_uiAdj = orig_init
+        # ---- NoneAttack (config 1's attack leg): constructor contract + identity
+        seedSet(2018)
+        rargs = rec_args(emb_size=16, model_name='GMF', maxEpoch=1)
+        data = DataLoader(rargs)
+        tf = './data/clean/' + data.dataName + '/targetItem_unpopular_5.txt'        # written by the attacks above: NoneAttack must draw its own
+        if os.path.exists(tf):
+            os.remove(tf)
+        atk = NoneAttack(_attack_args(attackCategory='Black', attackModelName='NoneAttack'), data)
+        res = sp.csr_matrix(atk.posionDataAttack())
+        out['none_targets'] = np.array(atk.targetItem, np.int32)
+        out['none_sizes'] = np.array([atk.userNum, atk.itemNum, atk.fakeUserNum, atk.maliciousFeedbackNum, res.nnz], np.int64)
+        out['none_flags'] = np.array([atk.recommenderGradientRequired, atk.recommenderModelRequired], np.int8)
+        out['none_identity'] = np.array([(res != sp.csr_matrix(data.matrix())).nnz], np.int64)
+        out['none_next_random'] = np.array([random.random()])
+    finally:
+        torch.randn, torch.Tensor.backward, torch.optim.Adam.step = orig_randn, orig_backward, orig_adam_step
+        undo_shim()
+    save('g19_victims.npz', **out)
+
+
 # --------------------------------------------------------------------------- G11: XSimGCL (SURVEY 8f-4: LightGCN + one extra term)
 def gen_xsimgcl(data):
     """One reference XSimGCL iteration (recommender/XSimGCL.py:62-75,205-223) with injected noise: ONE perturbed forward whose
@@ -1087,6 +1250,10 @@ if __name__ == '__main__':
             gen_gray()
         if 'gta' in only:
             gen_gta()
+        if 'ngcf128' in only:
+            gen_ngcf128()
+        if 'victims' in only:
+            gen_victims()
         sys.exit(0)
     gen_dataset()
     data = gen_sampler()
@@ -1109,4 +1276,6 @@ if __name__ == '__main__':
     gen_pipattack()
     gen_gray()
     gen_gta()
+    gen_ngcf128()
+    gen_victims()
     print('done; scratch dir', SCRATCH)

@@ -118,19 +118,36 @@ def test_simgcl_step_with_injected_noise_matches_reference():
     assert np.isfinite(rec.user_emb.cpu().numpy()).all()
 
 
-def test_ngcf_forward_and_steps_match_reference():
-    """NGCF (a9): forward and 3 Adam steps vs the reference class; the two sparse hops per layer of the reference are
+@pytest.mark.parametrize('gname,emb,L', [('g9_ngcf.npz', 32, 2), ('g9_ngcf128.npz', 128, 3)])
+def test_ngcf_forward_and_steps_match_reference(gname, emb, L):
+    """NGCF (a9): forward and 3 Adam steps vs the reference class, at d = 32 / L = 2 and at BASELINE cfg5's width d = 128 / L = 3 (the
+    CPL = 2 blocked-hop path when the graph is large; here the CSR kernels at LPR = 32); the two sparse hops per layer of the reference are
     one hop here (A(E W1) = (A E) W1)."""
     from arlib_amd.recommender.NGCF import NGCF
     from arlib_amd.util.loss import bpr_loss, l2_reg_loss
-    g = golden('g9_ngcf.npz')
+    g = golden(gname)
     data = make_data()
-    rec = NGCF(rec_args(emb_size=32, n_layers=2, model_name='NGCF'), data)
-    model = rec.model.cuda()
+    wl = 'w2_%d' % (L - 1)
+
+    def fresh():
+        rec = NGCF(rec_args(emb_size=emb, n_layers=L, model_name='NGCF'), data)
+        model = rec.model.cuda()
+        with torch.no_grad():
+            model.embedding_dict['user_emb'][:] = torch.from_numpy(g['user0']).cuda(); model.embedding_dict['item_emb'][:] = torch.from_numpy(g['item0']).cuda()
+            for k in range(L):
+                model.W['w1_%d' % k][:] = torch.from_numpy(g['w1_%d' % k]).cuda(); model.W['w2_%d' % k][:] = torch.from_numpy(g['w2_%d' % k]).cuda()
+        return model
+
+    def check_end(model):
+        assert rel_err(model.embedding_dict['user_emb'].detach().cpu().numpy(), g['user_k3']) < RTOL
+        assert rel_err(model.embedding_dict['item_emb'].detach().cpu().numpy(), g['item_k3']) < RTOL
+        assert rel_err(model.W['w1_0'].detach().cpu().numpy(), g['w1_0_k3']) < RTOL
+
+    def check_grads(model):
+        assert rel_err(model.embedding_dict['user_emb'].grad.cpu().numpy(), g['grad_user']) < RTOL
+        assert rel_err(model.W['w1_0'].grad.cpu().numpy(), g['grad_w1_0']) < RTOL and rel_err(model.W[wl].grad.cpu().numpy(), g['grad_' + wl]) < RTOL
+    model = fresh()
     with torch.no_grad():
-        model.embedding_dict['user_emb'][:] = torch.from_numpy(g['user0']).cuda(); model.embedding_dict['item_emb'][:] = torch.from_numpy(g['item0']).cuda()
-        for k in range(2):
-            model.W['w1_%d' % k][:] = torch.from_numpy(g['w1_%d' % k]).cuda(); model.W['w2_%d' % k][:] = torch.from_numpy(g['w2_%d' % k]).cuda()
         u, i = model()
     assert rel_err(u.cpu().numpy(), g['fwd_user']) < RTOL and rel_err(i.cpu().numpy(), g['fwd_item']) < RTOL
     opt = torch.optim.Adam(model.parameters(), lr=0.005)
@@ -140,20 +157,12 @@ def test_ngcf_forward_and_steps_match_reference():
         loss = bpr_loss(ue[bu], ie[bp], ie[bn]) + l2_reg_loss(1e-4, ue[bu], ie[bp])
         opt.zero_grad(); loss.backward()
         if k == 0:
-            assert rel_err(model.embedding_dict['user_emb'].grad.cpu().numpy(), g['grad_user']) < RTOL
-            assert rel_err(model.W['w1_0'].grad.cpu().numpy(), g['grad_w1_0']) < RTOL and rel_err(model.W['w2_1'].grad.cpu().numpy(), g['grad_w2_1']) < RTOL
+            check_grads(model)
         opt.step()
         assert abs(loss.item() - g['losses'][k]) <= RTOL * abs(g['losses'][k])
-    assert rel_err(model.embedding_dict['user_emb'].detach().cpu().numpy(), g['user_k3']) < RTOL
-    assert rel_err(model.embedding_dict['item_emb'].detach().cpu().numpy(), g['item_k3']) < RTOL
-    assert rel_err(model.W['w1_0'].detach().cpu().numpy(), g['w1_0_k3']) < RTOL
+    check_end(model)
     # the training loop's form: last layer on the batch rows only (forward_rows) -- same three steps, same golden
-    rec2 = NGCF(rec_args(emb_size=32, n_layers=2, model_name='NGCF'), data)
-    m2 = rec2.model.cuda()
-    with torch.no_grad():
-        m2.embedding_dict['user_emb'][:] = torch.from_numpy(g['user0']).cuda(); m2.embedding_dict['item_emb'][:] = torch.from_numpy(g['item0']).cuda()
-        for k in range(2):
-            m2.W['w1_%d' % k][:] = torch.from_numpy(g['w1_%d' % k]).cuda(); m2.W['w2_%d' % k][:] = torch.from_numpy(g['w2_%d' % k]).cuda()
+    m2 = fresh()
     opt2 = torch.optim.Adam(m2.parameters(), lr=0.005)
     U = data.user_num
     for k in range(3):
@@ -163,13 +172,19 @@ def test_ngcf_forward_and_steps_match_reference():
         loss = bpr_loss(out_r[:B], out_r[B:2 * B], out_r[2 * B:]) + l2_reg_loss(1e-4, out_r[:B], out_r[B:2 * B])
         opt2.zero_grad(); loss.backward()
         if k == 0:
-            assert rel_err(m2.embedding_dict['user_emb'].grad.cpu().numpy(), g['grad_user']) < RTOL
-            assert rel_err(m2.W['w1_0'].grad.cpu().numpy(), g['grad_w1_0']) < RTOL and rel_err(m2.W['w2_1'].grad.cpu().numpy(), g['grad_w2_1']) < RTOL
+            check_grads(m2)
         opt2.step()
         assert abs(loss.item() - g['losses'][k]) <= RTOL * abs(g['losses'][k])
-    assert rel_err(m2.embedding_dict['user_emb'].detach().cpu().numpy(), g['user_k3']) < RTOL
-    assert rel_err(m2.embedding_dict['item_emb'].detach().cpu().numpy(), g['item_k3']) < RTOL
-    assert rel_err(m2.W['w1_0'].detach().cpu().numpy(), g['w1_0_k3']) < RTOL
+    check_end(m2)
+    if emb == 128:
+        # the same forward through the register-blocked plan forced onto this small graph (CPL = 2: two columns per lane, what cfg5-sized
+        # graphs run) -- the d = 128 blocked kernel under an NGCF layer
+        m3 = fresh()
+        m3._graph().enable_blocked(split=U)
+        assert m3._graph().blocked is not None
+        with torch.no_grad():
+            u3, i3 = m3()
+        assert rel_err(u3.cpu().numpy(), g['fwd_user']) < RTOL and rel_err(i3.cpu().numpy(), g['fwd_item']) < RTOL
 
 
 @pytest.mark.parametrize('L', [0, 1, 2, 3])

@@ -498,3 +498,70 @@ def test_cw_operator_structured_build_equals_sorted_build():
     assert rel_err(G.cpu().numpy(), G_ref.cpu().numpy()) < 1e-5
     assert torch.equal(cnt, torch.bincount(neg, minlength=I))
     assert not G[U:Up].any()                                                 # fake users carry no CW gradient
+
+
+@pytest.mark.parametrize('tag', ['ngcf', 'simgcl'])
+def test_clear_surrogate_step_on_ngcf_and_simgcl_victims_matches_reference_trace(tag):
+    """BASELINE configs 4 / 5 name SimGCL + CLeaR and NGCF + DL_Attack: the surrogate of a bi-level attack is a deep copy of the VICTIM, so its
+    CW + SFA loss runs through that victim's encoder.  One CLeaR surrogate step on an NGCF encoder (dense d x d weights, leaky-relu layers) and on
+    a SimGCL encoder (layer 0 skipped) against the reference's own autograd with injected r0 (g19): loss, table gradients, weight gradients."""
+    from arlib_amd.recommender.NGCF import NGCF_Encoder
+    from arlib_amd.recommender.SimGCL import SimGCL_Encoder
+    from arlib_amd.attack.White.CLeaR import CLeaR
+    from arlib_amd.attack._common import init_graph
+    g = golden('g19_victims.npz')
+    U, I, F, topk = (int(x) for x in g[tag + '_cl_sizes'])
+    Up = U + F
+    data = SimpleNamespace(user_num=Up, item_num=I, norm_adj=sp.identity(Up + I, dtype=np.float32, format='csr'))
+    model = (NGCF_Encoder(data, 16, 2) if tag == 'ngcf' else SimGCL_Encoder(data, 16, 0.1, 2)).cuda()
+    with torch.no_grad():
+        model.embedding_dict['user_emb'][:] = T(g[tag + '_cl_user_tab']); model.embedding_dict['item_emb'][:] = T(g[tag + '_cl_item_tab'])
+        if tag == 'ngcf':
+            for k in model.W:
+                model.W[k][:] = T(g['ngcf_cl_' + k])
+    ui = sp.csr_matrix((g[tag + '_cl_ui_data'], g[tag + '_cl_ui_indices'], g[tag + '_cl_ui_indptr']), shape=(Up, I))
+    init_graph(model, ui, Up, I)
+    atk = object.__new__(CLeaR)
+    atk.userNum, atk.itemNum, atk.fakeUserNum, atk.targetItem = U, I, F, [int(t) for t in g[tag + '_cl_targets']]
+    lossall, Pu, Pi, cw, sfa = atk.surrogate_loss(model, ui, topk, r0=T(g[tag + '_cl_r0']))
+    assert abs(lossall.item() - g[tag + '_cl_loss'][0]) <= 2 * RTOL * abs(g[tag + '_cl_loss'][0])
+    lossall.backward()
+    assert rel_err(model.embedding_dict['user_emb'].grad.cpu().numpy(), g[tag + '_cl_grad_user']) < RTOL
+    assert rel_err(model.embedding_dict['item_emb'].grad.cpu().numpy(), g[tag + '_cl_grad_item']) < RTOL
+    if tag == 'ngcf':
+        for k in model.W:
+            assert rel_err(model.W[k].grad.cpu().numpy(), g['ngcf_cl_grad_' + k]) < RTOL, k
+
+
+@pytest.mark.parametrize('victim,name', [('NGCF', 'DLAttack'), ('NGCF', 'CLeaR'), ('SimGCL', 'DLAttack'), ('SimGCL', 'CLeaR')])
+def test_posion_data_attack_end_to_end_on_ngcf_and_simgcl_victims(victim, name, tmp_path, monkeypatch):
+    """Whole posionDataAttack() with an NGCF / a SimGCL victim (BASELINE configs 5 / 4) under the reference's protocol: same target draw, real
+    users untouched, fake rows binary with every target set, and the row sums the reference run recorded (g19: DLAttack [5, 46], CLeaR 51 each)."""
+    import importlib
+    from copy import deepcopy
+    from arlib_amd.util.tool import seedSet
+    monkeypatch.chdir(tmp_path)
+    g = golden('g19_victims.npz')
+    tag = victim.lower()
+    seedSet(2018)
+    data = make_data()
+    vcls = getattr(importlib.import_module('arlib_amd.recommender.' + victim), victim)
+    rec = vcls(rec_args(emb_size=16, n_layers=2, maxEpoch=1, model_name=victim), data)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rec.train(Epoch=1, evalNum=5)
+    cls = getattr(importlib.import_module('arlib_amd.attack.White.' + name), name)
+    F = 2 if name == 'DLAttack' else 3
+    atk = cls(attack_args(maliciousUserSize=F), data)
+    key = tag + ('_dl' if name == 'DLAttack' else '_cl')
+    assert sorted(atk.targetItem) == sorted(int(t) for t in g[key + '_targets'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = sp.csr_matrix(atk.posionDataAttack(deepcopy(rec)))
+    U, I = 942, 1412
+    assert res.shape == (U + F, I)
+    assert (res[:U] != data.matrix()[:U]).nnz == 0
+    fake = np.asarray(res[U:].todense())
+    assert set(np.unique(fake)) <= {0.0, 1.0}
+    # CLeaR sets every target in every fake row (CLeaR.py:136-137); DLAttack's last fake user is the plain top-n of the surrogate's scores
+    # (DLAttack.py:110-113: targets only if they rank there) while earlier ones keep just their injected targets (quirk Q6)
+    assert np.all(fake[:-1 if name == 'DLAttack' else None, atk.targetItem] == 1)
+    assert fake.sum(1).tolist() == [float(x) for x in g[key + '_result_fake_rowsums']]

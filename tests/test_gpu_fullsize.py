@@ -2,7 +2,8 @@
 properties -- the oracle cannot run this size in seconds, so the checks are identities that hold for any graph:
   * A_hat (D^1/2 1) = D^1/2 1            (exact fixed point of the symmetric normalisation, every row incl. 100k-edge rows)
   * <y, A x> = <A y, x>  and linearity   (the backward pass relies on the symmetry)
-  * sparse-batch step == dense 2L-hop step (tables, Adam moments, loss) on real sampler batches
+  * blocked hop == CSR hop (all epilogues); sparse-batch step (blocked) == dense 2L-hop step (CSR) on real sampler batches;
+    three steps against the oracle itself
   * sampler epoch: positives are a permutation of the training pairs (checksum), negatives never interacted, indices in range
 """
 import numpy as np
@@ -24,8 +25,10 @@ def cfg2():
     rowptr, col = data.adjacency_pattern()
     col_d = torch.from_numpy(col).to(DEV)
     val, dinv = ops.norm_adj_values(torch.from_numpy(rowptr.astype(np.int32)).to(DEV), col_d, torch.ones(2 * nnz, device=DEV), U + I)
-    A = ops.CSRGraph(rowptr, col_d, val, DEV)
-    return dict(data=data, U=U, I=I, nnz=nnz, rowptr=rowptr, A=A, dinv=dinv, ops=ops)
+    A = ops.CSRGraph(rowptr, col_d, val, DEV)                                   # CSR schedule only (no blocked plan attached)
+    Ab = ops.CSRGraph(rowptr, col_d, val, DEV, validate=False).enable_blocked(split=U)      # the headline schedule: register-blocked plan, explicit
+    assert A.blocked is None and Ab.blocked is not None and len(Ab.blocked.sets) == 2
+    return dict(data=data, U=U, I=I, nnz=nnz, rowptr=rowptr, col=col, A=A, Ab=Ab, dinv=dinv, ops=ops)
 
 
 def test_normalised_adjacency_fixed_point(cfg2):
@@ -36,6 +39,71 @@ def test_normalised_adjacency_fixed_point(cfg2):
     rel = ((y - x).abs().max() / x.abs().max()).item()
     assert rel < 1e-5, rel
     assert int(deg.max()) > 50_000                                            # a popular-item row with > 50k edges is covered
+
+
+def test_blocked_hop_equals_csr_hop_full_size_all_epilogues(cfg2):
+    """The headline kernel at the headline size against an INDEPENDENT schedule: spmm_blocked64_kernel (+ split rows) vs the CSR row kernel on
+    the same operand, for the three epilogues the step uses (AXPBY with a flagged Z, layer sum, fused Adam), plus the fixed point on the
+    blocked path.  An offset overflow or a lost record at 64 M records shows up here (the two schedules share no index arrays)."""
+    ops, A, Ab, U, I = cfg2['ops'], cfg2['A'], cfg2['Ab'], cfg2['U'], cfg2['I']
+    N = U + I
+    plan = Ab.blocked
+    assert plan.n_hub == 0 and sum(s['n_edges'] for s in plan.sets) == 2 * cfg2['nnz'] and sum(s['n_rows'] for s in plan.sets) == N      # every edge is a record
+    assert sum(s['n_split'] for s in plan.sets) > 100                          # incl. the > 4096-edge item rows, dealt as pieces
+    g = torch.Generator(device=DEV).manual_seed(5)
+    X = torch.randn(N, 64, device=DEV, generator=g); Z = torch.randn(N, 64, device=DEV, generator=g)
+    rel = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()
+    yc, yb = ops.spmm(A, X), ops.spmm(Ab, X)
+    assert rel(yb, yc) < 1e-5
+    assert torch.equal(yb, ops.spmm(Ab, X))                                   # deterministic
+    # row-wise check too: the tensor-level bar could hide a wrong small-magnitude row
+    rown = (yb - yc).norm(dim=1) / yc.norm(dim=1).clamp_min(1e-20)
+    assert float(rown.max()) < 1e-4
+    zf = (torch.rand(N, device=DEV, generator=g) < 0.01).to(torch.uint8)
+    Zs = Z * zf[:, None]
+    assert rel(ops.spmm_flagged(Ab, X, None, 0.25, 0.25, Zs, zf), ops.spmm_flagged(A, X, None, 0.25, 0.25, Zs, zf)) < 1e-5
+    Sc, Sb = Z.clone(), Z.clone()
+    ops.spmm_layersum(A, X, Sc, Sc); ops.spmm_layersum(Ab, X, Sb, Sb)
+    assert rel(Sb, Sc) < 1e-5
+    P = torch.randn(N, 64, device=DEV, generator=g) * 0.1; M = torch.randn(N, 64, device=DEV, generator=g) * 0.01; V = torch.rand(N, 64, device=DEV, generator=g) * 1e-4
+    Pc, Mc, Vc, Pb, Mb, Vb = P.clone(), M.clone(), V.clone(), P.clone(), M.clone(), V.clone()
+    ops.spmm_adam(A, X, 0.25, 0.25, Zs, Pc, Mc, Vc, 0.005, 7, zflags=zf)
+    ops.spmm_adam(Ab, X, 0.25, 0.25, Zs, Pb, Mb, Vb, 0.005, 7, zflags=zf)
+    assert rel(Pb, Pc) < 1e-5 and rel(Mb, Mc) < 1e-5 and rel(Vb, Vc) < 1e-5
+    deg = torch.from_numpy(np.diff(cfg2['rowptr']).astype(np.float32)).to(DEV)
+    x = torch.sqrt(deg)[:, None].repeat(1, 64).contiguous()
+    # A_hat (D^1/2 1) = D^1/2 1 through the blocked plan: an all-positive sum, the worst case for a sequential fp32 chain (a piece of a
+    # 50k-edge row adds up to 4096 terms into one register: 2.4e-5 measured; the CSR kernel's shorter chains give < 1e-5)
+    assert rel(ops.spmm(Ab, x), x) < 1e-4
+
+
+def test_three_steps_at_full_size_match_the_oracle(cfg2):
+    """Product and oracle meeting at cfg2: three Adam steps of the LightGCN d=64 L=3 step (the engine on its default = blocked schedule) from
+    the bench's start state against oracle/arl_oracle.c on the host cores (OpenMP; ~4 s per step on the GPU box) -- updated tables within
+    1e-4 rel, losses within 1e-4."""
+    from arlib_amd import engine
+    from arlib_amd.util.sampler import MTState
+    from oracle import oracle as O
+    O.build()
+    ops, Ab, U, I, nnz = cfg2['ops'], cfg2['Ab'], cfg2['U'], cfg2['I'], cfg2['nnz']
+    torch.manual_seed(2018)
+    E0 = torch.cat([torch.nn.init.xavier_uniform_(torch.empty(U, 64)), torch.nn.init.xavier_uniform_(torch.empty(I, 64))], 0)
+    eng = engine.PropagationEngine(Ab, U, I, 64, 3, 1e-4, 0.005, DEV, table=E0.to(DEV))
+    assert eng.A.blocked is not None
+    st = O.TrainState(E0[:U].numpy(), E0[U:].numpy(), (cfg2['rowptr'], cfg2['col'], Ab.val.cpu().numpy()), 3, 1e-4, 0.005)
+    st.f32acc = True
+    mt = MTState.from_seed(2018)
+    sampler = cfg2['data'].pair_sampler
+    sampler.shuffle(mt)
+    for k in range(3):
+        b = sampler.batch(mt, k * 2048, 2048)
+        ref = st.step(b[0].copy(), b[1].copy(), b[2].copy())
+        lo = eng.step(*(torch.from_numpy(np.ascontiguousarray(x)).to(DEV) for x in b)).cpu().numpy()
+        assert abs(float(lo[0] + lo[1]) - ref) <= 1e-4 * abs(ref)
+    got = eng.E0.cpu().numpy()
+    assert float(np.abs(got - st.E0).max() / np.abs(st.E0).max()) < 1e-4
+    moved = np.abs(st.E0 - E0.numpy()).max()
+    assert float(np.abs(got - st.E0).max()) < 1e-2 * moved                     # error far below what three steps moved the table by
 
 
 def test_spmm_adjoint_symmetry_and_linearity(cfg2):
@@ -51,13 +119,15 @@ def test_spmm_adjoint_symmetry_and_linearity(cfg2):
 
 
 def test_sparse_step_equals_dense_step_full_size(cfg2):
+    """Sparse-batch step on the BLOCKED schedule against the dense 2L-hop step on the CSR schedule (independent kernels and index arrays)."""
     from arlib_amd import engine
     from arlib_amd.util.sampler import MTState
-    ops, A, U, I = cfg2['ops'], cfg2['A'], cfg2['U'], cfg2['I']
+    ops, A, Ab, U, I = cfg2['ops'], cfg2['A'], cfg2['Ab'], cfg2['U'], cfg2['I']
     torch.manual_seed(2018)
     E0 = torch.cat([torch.nn.init.xavier_uniform_(torch.empty(U, 64)), torch.nn.init.xavier_uniform_(torch.empty(I, 64))], 0).to(DEV)
-    ea = engine.PropagationEngine(A, U, I, 64, 3, 1e-4, 0.005, DEV, table=E0.clone())
-    eb = engine.PropagationEngine(A, U, I, 64, 3, 1e-4, 0.005, DEV, table=E0.clone())
+    ea = engine.PropagationEngine(Ab, U, I, 64, 3, 1e-4, 0.005, DEV, table=E0.clone())
+    eb = engine.PropagationEngine(A, U, I, 64, 3, 1e-4, 0.005, DEV, table=E0.clone(), schedule='csr')
+    assert ea.A.blocked is not None and eb.A.blocked is None
     mt = MTState.from_seed(2018)
     sampler = cfg2['data'].pair_sampler
     sampler.shuffle(mt)

@@ -365,3 +365,25 @@ def test_blocked_plan_invariants_and_numpy_emulation(rpw, hub, split, split_hubs
     Y[hub_rows] = (Adj[hub_rows] @ X)
     ref = Adj @ X
     assert np.abs(Y - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+def test_none_attack_protocol_matches_reference_run():
+    """BASELINE config 1's attack leg (attack/Black/NoneAttack.py:7-40): constructor contract (target draw from Python's RNG, budgets, capability
+    flags) and the identity posionDataAttack(), against the reference run recorded in g19 -- incl. the next random() afterwards (nothing else
+    draws).  No GPU involved."""
+    import random
+    from types import SimpleNamespace
+    import scipy.sparse as sp
+    from arlib_amd.util.tool import seedSet
+    from arlib_amd.attack.Black.NoneAttack import NoneAttack
+    g = golden('g19_victims.npz')
+    seedSet(2018)
+    data = make_data()
+    args = SimpleNamespace(maliciousUserSize=3, maliciousFeedbackSize=0, Epoch=1, innerEpoch=1, outerEpoch=1, attackTargetChooseWay='unpopular', targetSize=5)
+    atk = NoneAttack(args, data)
+    res = sp.csr_matrix(atk.posionDataAttack())
+    assert list(atk.targetItem) == [int(t) for t in g['none_targets']]
+    assert [atk.userNum, atk.itemNum, atk.fakeUserNum, atk.maliciousFeedbackNum, res.nnz] == [int(x) for x in g['none_sizes']]
+    assert [int(atk.recommenderGradientRequired), int(atk.recommenderModelRequired)] == [int(x) for x in g['none_flags']]
+    assert (res != sp.csr_matrix(data.matrix())).nnz == 0
+    assert random.random() == float(g['none_next_random'][0])

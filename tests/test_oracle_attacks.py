@@ -80,3 +80,32 @@ def test_sfa_closed_form_equals_literal_restatement():
     G2 = w[:, None] * ((A / (numel * Q)) * np.sign(s)[:, None] * r[None, :] + q[:, None] * g_r[None, :] + (Xd @ g_r)[:, None] * r0[None, :])
     assert abs(S * A / (numel * Q) - loss) < 1e-12 * abs(loss)
     assert rel_err(G2, G) < 1e-10
+
+
+def test_clear_surrogate_step_on_a_simgcl_victim_matches_reference_trace():
+    """BASELINE config 4 (SimGCL + CLeaR): the surrogate is the victim's encoder -- mean of layers 1..L, layer 0 skipped -- so the CW + SFA
+    loss and the table gradients follow the skip0 forward/backward (g19, reference autograd with injected r0)."""
+    g = golden('g19_victims.npz')
+    U, I, F, topk = (int(x) for x in g['simgcl_cl_sizes'])
+    Up, L = U + F, 2
+    E0 = np.concatenate([g['simgcl_cl_user_tab'], g['simgcl_cl_item_tab']])
+    rows = np.repeat(np.arange(Up), np.diff(g['simgcl_cl_ui_indptr']))
+    rowptr, col, w = O.bipartite_csr(rows, g['simgcl_cl_ui_indices'], Up, I, g['simgcl_cl_ui_data'])
+    csr = (rowptr, col, O.norm_adj_values(rowptr, col, w))
+    out = O.lightgcn_forward(csr, E0, L, skip0=True)
+    idx, _ = O.score_mask_topk(out[:Up], out[Up:], topk, (g['simgcl_cl_ui_indptr'], g['simgcl_cl_ui_indices']))
+    users, pos, neg = O.cw_pairs(idx, U, g['simgcl_cl_targets'], pop=True)
+    cw, sfa, G = O.clear_loss_grad(out, Up, users, pos, neg, g['simgcl_cl_r0'])
+    assert abs(cw + sfa - g['simgcl_cl_loss'][0]) <= 2 * RTOL * abs(g['simgcl_cl_loss'][0])
+    dE0 = O.lightgcn_backward(csr, G, L, skip0=True)
+    assert rel_err(dE0[:Up], g['simgcl_cl_grad_user']) < RTOL and rel_err(dE0[Up:], g['simgcl_cl_grad_item']) < RTOL
+
+
+def test_attacks_on_ngcf_and_simgcl_victims_keep_the_reference_structure():
+    """The reference runs recorded in g19: DLAttack's fake rows [5, 46] (quirk Q6) and CLeaR's 51 = 46 fillers + 5 targets hold for NGCF and
+    SimGCL victims alike; NoneAttack returns the clean matrix and draws nothing beyond the target selection."""
+    g = golden('g19_victims.npz')
+    for tag in ('ngcf', 'simgcl'):
+        assert list(g[tag + '_dl_result_fake_rowsums']) == [5.0, 46.0] and list(g[tag + '_dl_shape']) == [944, 1412]
+        assert list(g[tag + '_cl_result_fake_rowsums']) == [51.0, 51.0, 51.0]
+    assert int(g['none_identity'][0]) == 0 and list(g['none_flags']) == [0, 0]

@@ -288,3 +288,13 @@ def test_sgl_views_and_step(ml100k):
     assert rel_err(E[:U], g['user_k1']) < RTOL and rel_err(E[U:], g['item_k1']) < RTOL
     w1 = O.lightgcn_forward(views[0][1], np.concatenate([g['user_k1'], g['item_k1']]), L)
     assert rel_err(w1[:U], g['view1_user']) < RTOL and rel_err(w1[U:], g['view1_item']) < RTOL
+
+
+def test_ngcf_forward_at_cfg5_width(ml100k):
+    """NGCF at BASELINE cfg5's width (d = 128, L = 3) against the reference class (g9_ngcf128)."""
+    g = golden('g9_ngcf128.npz')
+    csr = _ml100k_csr(ml100k)
+    out = O.ngcf_forward(csr, np.concatenate([g['user0'], g['item0']]), [g['w1_%d' % k] for k in range(3)], [g['w2_%d' % k] for k in range(3)])
+    U = ml100k['U']
+    assert g['user0'].shape[1] == 128
+    assert rel_err(out[:U], g['fwd_user']) < RTOL and rel_err(out[U:], g['fwd_item']) < RTOL
