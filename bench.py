@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+TRAFFIC_BLOCKED, TRAFFIC_CSR = 'r01_pmc_traffic_blocked.json', 'r01_pmc_traffic.json'      # PMC passes `roofline.traffic` quotes (tools/pmc_traffic.py)
 
 
 def parse():
@@ -40,11 +41,12 @@ def parse():
     ap.add_argument('--chunk', type=int, default=512)
     ap.add_argument('--cpu-baseline', type=int, default=1, help='0 disables the CPU baseline leg')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target seconds of CPU work for the baseline sample')
-    ap.add_argument('--cpu-torch', type=int, default=0, help='also time N steps of stock PyTorch-CPU running the reference-shaped math (COO sparse.mm + autograd + Adam)')
+    ap.add_argument('--cpu-torch', type=int, default=1, help='also time N steps of stock PyTorch-CPU running the reference-shaped math (COO sparse.mm + autograd + Adam)')
     ap.add_argument('--no-kernel-events', action='store_true', help='do not bracket SpMM launches with HIP events')
     ap.add_argument('--attack-steps', type=int, default=5, help='PGA gradient steps to time at N=1 (0 disables the attack leg)')
     ap.add_argument('--fake-users', type=int, default=64)
     ap.add_argument('--schedule', default='auto', choices=['auto', 'csr', 'blocked'], help='full-graph hop schedule (engine.PropagationEngine)')
+    ap.add_argument('--repeats', type=int, default=3, help='timed regions of K steps each: the first is the contract figure (`value`), all are listed with median and spread')
     ap.add_argument('--dense-step', action='store_true', help='time the reference-shaped step (all 2L hops on the full graph) as the main number')
     return ap.parse_args()
 
@@ -190,11 +192,14 @@ def attack_leg(torch, ops, data, E0_dev, args):
         rowptr, col = data.adjacency_pattern()
         users_h, pos_h, neg_h = (t.cpu().numpy() for t in cw_pairs(top_idx, U, targets, pop=True))
         S_h, E0_h = S.cpu().numpy(), E0.cpu().numpy()
-        tc = time.perf_counter()
-        _, S_next, cw_h = O.pga_step(rowptr[:U + 1].astype(np.int64), (col[:nnz] - U).astype(np.int64), U, F, I, S_h, E0_h, L, users_h, pos_h, neg_h)
-        cpu_s = time.perf_counter() - tc
-        cpu = {'value': 1.0 / cpu_s, 'unit': 'steps/s', 'cores': O.num_threads(), 'kind': 'port', 'seconds_per_step': cpu_s,
-               'sample': '1 PGA step of the same workload (oracle: numpy graph rebuild + OpenMP SpMM + scipy CW product)', 'cw_loss': float(cw_h)}
+        cpu_times = []
+        for _ in range(2):                           # first step warms the OpenMP team / page cache; the second is the figure
+            tc = time.perf_counter()
+            _, S_next, cw_h = O.pga_step(rowptr[:U + 1].astype(np.int64), (col[:nnz] - U).astype(np.int64), U, F, I, S_h, E0_h, L, users_h, pos_h, neg_h)
+            cpu_times.append(time.perf_counter() - tc)
+        cpu_s = cpu_times[-1]
+        cpu = {'value': 1.0 / cpu_s, 'unit': 'steps/s', 'cores': O.num_threads(), 'kind': 'port', 'seconds_per_step': cpu_s, 'first_unwarmed_step_s': cpu_times[0],
+               'sample': '1 PGA step of the same workload after 1 warm-up step (oracle: numpy graph rebuild + OpenMP SpMM + scipy CW product)', 'cw_loss': float(cw_h)}
     Ep, Np = 2 * nnz + 2 * F * I, U + F + I
     step_bytes = L * (8 * Ep + 4 * Np + 16 * Np * d) + (L - 1) * (8 * Ep + 4 * Np + 8 * Np * d) + L * (2 * F * I * 4 + 2 * I * d * 4 + 2 * F * d * 4) + 3 * F * I * 4
     return {'metric': 'attack-grad steps/sec (PGA gradient w.r.t. fake interactions, LightGCN d=%d L=%d surrogate)' % (d, L),
@@ -356,11 +361,22 @@ def main():
     ev.on = False
     ops.EVENT_HOOK = None
     loss = float(lo[0] + lo[1])
+    # further timed regions of the same K steps (same batches again: the step's cost does not depend on the table values), each bracketed
+    # like the first; `value` stays the first region (the contract), the list shows how repeatable it is
+    region_s = [dt]
+    for _ in range(max(0, args.repeats - 1)):
+        barrier(); torch.cuda.synchronize()
+        t0r = time.perf_counter()
+        for k in range(args.warmup, n_batches):
+            step(k)
+        torch.cuda.synchronize(); barrier()
+        region_s.append(time.perf_counter() - t0r)
     if sharded:
         import torch.distributed as dist
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor(region_s, dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        region_s = [float(x) for x in tmax.tolist()]
+        dt = region_s[0]
 
     if rank == 0:
         ms = 1e3 * dt / args.steps
@@ -375,6 +391,8 @@ def main():
             'config': {'workload': 'cfg2: LightGCN d=%d L=%d + BPR/L2 + dense Adam, SYN-v1 %d users x %d items, nnz=%d, B=%d, seed %d'
                                    % (d, L, U, I, nnz, B, args.seed), 'parallelism': parallelism, 'chunk': args.chunk},
             'final_loss': loss,
+            'repeat_ms_per_step': {'regions': [1e3 * x / args.steps for x in region_s], 'median': 1e3 * float(np.median(region_s)) / args.steps,
+                                   'spread': 1e3 * (max(region_s) - min(region_s)) / args.steps, 'note': '`value` / `ms_per_step` = the first region'},
             'step_roofline': {'bound': 'hbm', 'algorithmic_bytes_per_step': step_bytes, 'achieved': step_bytes / (ms * 1e-3) / 1e9 / world,
                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': step_bytes / (ms * 1e-3) / 1e9 / world / HBM_PEAK_GBS,
                               'note': 'whole step, per GPU'},
@@ -387,9 +405,10 @@ def main():
             allv = [s.elapsed_time(e) for tag, s, e in ev.recs if tag in ('axpby', 'layersum', 'adam')]
             avg_ms = float(np.mean(allv))
             # under sharding a launch covers this rank's rows only; report the single-GPU figure only for N=1
-            traffic = None
+            traffic, traffic_src = None, None
             try:        # HBM-side traffic per launch from the committed PMC passes (profiles/), only for the workload they were taken on
-                pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_blocked.json' if (not sharded and A.blocked is not None) else 'r01_pmc_traffic.json')))
+                traffic_src = 'profiles/' + (TRAFFIC_BLOCKED if (not sharded and A.blocked is not None) else TRAFFIC_CSR)
+                pm = json.load(open(os.path.join(ROOT, traffic_src)))
                 if (U, I, d, args.mean_deg, args.seed, args.chunk) == (1_000_000, 100_000, 64, 32.0, 2018, 512):
                     traffic = pm['traffic_corrected_bytes']
             except Exception:
@@ -397,8 +416,10 @@ def main():
             if not sharded:
                 res['roofline'] = {'bound': 'hbm', 'achieved': spmm_bytes / (avg_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                    'frac': spmm_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': traffic,
-                                   'kernel': ('one full-graph hop = spmm_blocked64_kernel<%d,*> x%d (user rows, item rows) + spmm_rows_kernel/spmm_long_rows_kernel on '
-                                              '%d hub rows; avg over %d hops' % (A.blocked.rpw, len(A.blocked.sets), A.blocked.n_hub, len(allv))) if A.blocked is not None
+                                   'traffic_source': (traffic_src + ' (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of this workload, gfx950-corrected; NOT measured in this run)') if traffic is not None else None,
+                                   'kernel': ('one full-graph hop = spmm_blocked64_kernel<%d,*> x%d (user rows, item rows; %d rows above the per-set threshold dealt as strided '
+                                              'pieces + spmm_long_rows_kernel combine, %d rows on the chunked CSR kernel); avg over %d hops'
+                                              % (A.blocked.rpw, len(A.blocked.sets), sum(s_['n_split'] for s_ in A.blocked.sets), A.blocked.n_hub, len(allv))) if A.blocked is not None
                                    else 'spmm_rows_kernel<LPR=%d> (+spmm_long_rows_kernel), avg over %d launches' % (max(4, d // 4), len(allv)),
                                    'schedule': 'blocked' if A.blocked is not None else 'csr',
                                    'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': spmm_bytes,

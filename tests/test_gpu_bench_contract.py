@@ -34,3 +34,7 @@ def test_bench_json_contract_small_instance():
     assert r['attack']['value'] > 0 and r['attack']['cpu_baseline']['value'] > 0
     assert abs(r['attack']['cw_loss'] - r['attack']['cpu_baseline']['cw_loss']) <= 1e-4 * abs(r['attack']['cpu_baseline']['cw_loss'])
     assert r['attack_clear']['value'] > 0 and r['attack_dlattack_inner']['value'] > 0
+    rep = r['repeat_ms_per_step']
+    assert len(rep['regions']) == 3 and abs(rep['regions'][0] - r['ms_per_step']) < 1e-9 and rep['spread'] >= 0
+    assert r['cpu_baseline_torch']['value'] > 0 and r['cpu_baseline_torch']['steps_timed'] >= 1      # reference-shaped stock-PyTorch step, on by default
+    assert 'traffic_source' in roof
