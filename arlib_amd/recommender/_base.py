@@ -8,7 +8,9 @@ recommender/LightGCN.py:17-161,202-252, GMF.py:16-175, SimGCL.py:18-231).
   fused device engine when it owns the optimizer (or is handed a plain torch Adam/SGD over exactly these parameters)
   and otherwise drives the caller's optimizer through autograd with the same kernels.
 """
+import itertools
 import sys
+import time
 
 import numpy as np
 import scipy.sparse as sp
@@ -30,12 +32,40 @@ class SparseNormAdj:
     (attack/White/PGA.py:98,117): the gradient lives on `.values` (one fp32 per stored edge, CSR order)."""
 
     def __init__(self, mat):
+        if hasattr(mat, 'device_graph') and not sp.issparse(mat):
+            # array-native data (util/DataLoader.LazyNormAdj): assembled and normalised on the device, never as a scipy matrix
+            g = mat.device_graph(DEVICE)
+            self.shape = tuple(mat.shape)
+            self._indptr = self._indices = None
+            self.values, self.dinv, self._graph = g.val, g.dinv, g
+            return
         m = sp.csr_matrix(mat, dtype=np.float32)
         m.sort_indices()
         self.shape = m.shape
         self.indptr, self.indices = m.indptr.astype(np.int64), m.indices.astype(np.int32)
         self.values = torch.from_numpy(m.data.astype(np.float32))
         self._graph = None
+
+    # host images of the pattern: numpy arrays, fetched from the device graph the first time somebody reads them
+    @property
+    def indptr(self):
+        if self._indptr is None:
+            self._indptr = self._graph.rowptr.cpu().numpy().astype(np.int64)
+        return self._indptr
+
+    @indptr.setter
+    def indptr(self, a):
+        self._indptr = a
+
+    @property
+    def indices(self):
+        if self._indices is None:
+            self._indices = self._graph.col.cpu().numpy()
+        return self._indices
+
+    @indices.setter
+    def indices(self, a):
+        self._indices = a
 
     @property
     def requires_grad(self):
@@ -69,9 +99,12 @@ class SparseNormAdj:
         return sp.csr_matrix((self.values.detach().cpu().numpy(), self.indices, self.indptr), shape=self.shape)
 
     def __getstate__(self):
+        self.indptr, self.indices                               # host images of the pattern travel, the device graph does not
         st = dict(self.__dict__)
         st['_graph'] = None
         st['values'] = self.values.detach().cpu()
+        if st.get('dinv') is not None:
+            st['dinv'] = st['dinv'].detach().cpu()
         return st
 
 
@@ -167,7 +200,7 @@ class GraphEncoder(nn.Module):
         g = ops.bipartite_graph(u, torch.from_numpy(m.indices.astype(np.int64)).to(DEVICE), U, I, weights=torch.from_numpy(m.data).to(DEVICE))
         adj = SparseNormAdj.__new__(SparseNormAdj)
         adj.shape = (U + I, U + I)
-        adj.indptr, adj.indices = g.rowptr.cpu().numpy().astype(np.int64), g.col.cpu().numpy()
+        adj._indptr = adj._indices = None                   # host images of the pattern are fetched only if somebody reads them
         adj.values, adj.dinv, adj._graph = g.val, g.dinv, g
         self.sparse_norm_adj = adj
         self._eng = None
@@ -321,6 +354,7 @@ class Recommender:
     l2_on_negatives = False # ... and also regularises the negative items' rows
     extra_loss_takes_outputs = False   # proxyLG's extra term is computed from the step's own forward outputs
     rows_forward = True                # use model.forward_rows(batch rows) in the training loop when the encoder offers it
+    max_steps_per_epoch = None         # measurement knob (bench.py's class-API leg): stop an epoch after this many batches
 
     def _extra_loss(self, model, user_idx, pos_idx):
         return None
@@ -369,7 +403,15 @@ class Recommender:
                 batches = ()
             else:
                 batches = device_epoch(self.data, self.args.batch_size, DEVICE, U, I)
-            for n, (u, p, ng) in enumerate(batches):
+            it = iter(batches)
+            first = next(it, None)                                   # the epoch's shuffle + negatives are drawn here (host), before the loop clock starts
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            t_loop, n_done = time.perf_counter(), 0
+            for n, (u, p, ng) in enumerate(itertools.chain(() if first is None else (first,), it)):
+                if self.max_steps_per_epoch is not None and n >= self.max_steps_per_epoch:
+                    break
+                n_done += 1
                 if eng is not None:
                     lo = self._fused_step(eng, u, p, ng)
                     if n % self.print_every == 0:
@@ -401,6 +443,10 @@ class Recommender:
                 optimizer.step()
                 if n % self.print_every == 0:
                     print('training:', epoch + 1, 'batch', n, 'batch_loss:', batch_loss.item())
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            # wall clock of the epoch's batch loop alone (sampler draw, evaluation and the epoch-end forward excluded)
+            self.last_train_stats = {'steps': n_done, 'loop_seconds': time.perf_counter() - t_loop, 'fused': eng is not None}
             if eng is not None:
                 self._sync_optimizer_step(eng, optimizer, fused_kind)
             model.eval()

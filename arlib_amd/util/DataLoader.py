@@ -170,10 +170,19 @@ class DataLoader():
         return vec
 
     # ---- array views used by the device path (no counterpart in the reference) ------------------------------------
+    ARRAY_NATIVE_MIN_NNZ = 2_000_000
+
     @classmethod
-    def from_arrays(cls, train, val=None, test=None, dataName=None):
+    def from_arrays(cls, train, val=None, test=None, dataName=None, array_native=None):
         """Build from integer/float triples (u, i, r) arrays instead of text files; raw ids are stringified exactly like
-        FileIO.load_data_set would read them, so id assignment (first-seen order) is identical to a file round trip."""
+        FileIO.load_data_set would read them, so id assignment (first-seen order) is identical to a file round trip.
+        array_native (default: from ARRAY_NATIVE_MIN_NNZ interactions on) returns an ArrayDataLoader: the same object surface
+        over numpy arrays, its Python containers materialised only when somebody reads them."""
+        if array_native is None:
+            array_native = len(np.asarray(train[0])) >= cls.ARRAY_NATIVE_MIN_NNZ
+        if array_native and cls is DataLoader:
+            return ArrayDataLoader(train, val, test, dataName)
+
         def rows(t):
             if t is None:
                 return []
@@ -246,4 +255,216 @@ class DataLoader():
                 new._arl_memb = v
             else:
                 setattr(new, k, copy.deepcopy(v, memo))
+        return new
+
+
+class _RowDicts:
+    """Read-only mapping  raw id -> {raw id: rating}  over a CSR (the reference's training_set_u / training_set_i dict-of-dicts,
+    util/DataLoader.py:41-42), rows built on demand.  Iteration order = first-seen order of the keys, as a dict filled in file order."""
+
+    def __init__(self, key_names, key_ids, rowptr, cols, vals, col_names):
+        self._names, self._ids, self._rp, self._cols, self._vals, self._colnames = key_names, key_ids, rowptr, cols, vals, col_names
+
+    def __len__(self):
+        return len(self._names)
+
+    def __iter__(self):
+        return iter(self._names)
+
+    def __contains__(self, k):
+        return k in self._ids and self._ids[k] < len(self._rp) - 1
+
+    def keys(self):
+        return list(self._names)
+
+    def __getitem__(self, k):
+        r = self._ids.get(k)
+        if r is None or r >= len(self._rp) - 1:
+            return {}                                              # defaultdict(dict) semantics for an unknown key (read side)
+        b, e = int(self._rp[r]), int(self._rp[r + 1])
+        cn = self._colnames
+        return {cn[c]: v for c, v in zip(self._cols[b:e].tolist(), self._vals[b:e].tolist())}
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        return ((k, self[k]) for k in self._names)
+
+
+class LazyNormAdj:
+    """data.norm_adj of an ArrayDataLoader: the normalised (U+I)^2 adjacency (util/DataLoader.py:57-87) that is only assembled
+    where it is consumed -- on the device by the encoders (`device_graph`), as scipy for anybody who asks (`to_scipy`)."""
+
+    def __init__(self, data):
+        self._data = data
+        n = data.user_num + data.item_num
+        self.shape = (n, n)
+
+    def get_shape(self):
+        return self.shape
+
+    def device_graph(self, device='cuda'):
+        import torch
+        from .. import ops
+        u, i = self._data._sorted_pairs()
+        return ops.bipartite_graph(torch.from_numpy(u).to(device), torch.from_numpy(i).to(device), self._data.user_num, self._data.item_num, device=device)
+
+    def to_scipy(self):
+        return self._data.normalize_graph_mat(self._data.ui_adj)
+
+    def tocsr(self):
+        return self.to_scipy().tocsr()
+
+
+class ArrayDataLoader(DataLoader):
+    """DataLoader with the same attributes and methods, built from (u, i, r) arrays in O(nnz) numpy: at 3.2e7 interactions the
+    reference's list of rows and dict-of-dict sets (util/DataLoader.py:8-55) are ~10^8 Python objects.  The int32 pair array is the
+    primary image (`pair_sampler`, what next_batch_pairwise shuffles in place of the list); `training_data`, `training_set_u/i`,
+    `ui_adj`, `norm_adj`, `interaction_mat` are materialised when read.  Ids are assigned in first-seen order, raw ids stringified,
+    exactly as a file round trip would (tested against the list-based loader)."""
+
+    def __init__(self, train, val=None, test=None, dataName=None):
+        from .sampler import PairSampler, build_membership
+        tu, ti, tr = (np.asarray(a) for a in train)
+        self.dataName = dataName
+
+        def first_seen(raw):
+            uniq, first, inv = np.unique(raw, return_index=True, return_inverse=True)
+            order = np.argsort(first, kind='stable')              # unique values in first-seen order
+            rank = np.empty(len(uniq), np.int64); rank[order] = np.arange(len(uniq))
+            return uniq[order], rank[inv]
+        raw_u, uid = first_seen(tu)
+        raw_i, iid = first_seen(ti)
+        name_u, name_i = [str(x) for x in raw_u.tolist()], [str(x) for x in raw_i.tolist()]
+        self.user, self.item = dict(zip(name_u, range(len(name_u)))), dict(zip(name_i, range(len(name_i))))
+        self.id2user, self.id2item = dict(enumerate(name_u)), dict(enumerate(name_i))
+        self.user_num, self.item_num = len(name_u), len(name_i)
+        pairs = np.stack([uid, iid], 1).astype(np.int32)
+        self._rating = np.asarray(tr, np.float64).copy()           # in the CURRENT order of the pairs (permuted with them)
+        self._uniform_rating = bool(len(self._rating) == 0 or np.all(self._rating == self._rating[0]))
+        memb = build_membership(pairs, self.user_num)
+        self._arl_memb = memb
+        self.pair_sampler = PairSampler(pairs, self.item_num, memb)
+        # training_set_u / training_set_i as CSR (last rating wins for a repeated pair, as dict assignment does)
+        key = uid * self.item_num + iid
+        _, last = np.unique(key[::-1], return_index=True)
+        keep = np.sort(len(key) - 1 - last)
+        ku, ki, kr = uid[keep], iid[keep], self._rating[keep]
+
+        def csr(rows, cols, n_rows):
+            o = np.argsort(rows, kind='stable')                   # columns stay in first-seen (file) order inside a row
+            rp = np.zeros(n_rows + 1, np.int64); np.cumsum(np.bincount(rows, minlength=n_rows), out=rp[1:])
+            return rp, cols[o].astype(np.int32), kr[o]
+        self.training_set_u = _RowDicts(name_u, self.user, *csr(ku, ki, self.user_num), name_i)
+        self.training_set_i = _RowDicts(name_i, self.item, *csr(ki, ku, self.item_num), name_u)
+        self.val_data, self.test_data = [], []
+        self.val_set, self.val_set_item = self._held_out(val)
+        self.test_set, self.test_set_item = self._held_out(test)
+        self._ui_adj = self._norm_adj = self._interaction_mat = None
+
+    def _held_out(self, t):
+        """val/test split as the reference's dict-of-dicts (users unseen in training are skipped, util/DataLoader.py:44-55)."""
+        out, seen = defaultdict(dict), set()
+        if t is None:
+            return out, seen
+        u, i, r = (np.asarray(a).tolist() for a in t)
+        for a, b, c in zip(u, i, r):
+            a, b = str(a), str(b)
+            if a in self.user:
+                out[a][b] = float(c)
+                seen.add(b)
+        return out, seen
+
+    # ---- the list view of the reference (materialised on demand; the pair array stays the primary image)
+    @property
+    def training_data(self):
+        p = self.pair_sampler.pairs
+        iu, ii = self.id2user, self.id2item
+        return [[iu[a], ii[b], c] for (a, b), c in zip(p.tolist(), self._rating.tolist())]
+
+    @training_data.setter
+    def training_data(self, rows):
+        raise AttributeError('ArrayDataLoader: training_data is a view of the pair array; use append_training_rows()')
+
+    def append_training_rows(self, rows):
+        from .sampler import PairSampler
+        tail = np.array([[self.user[r[0]], self.item[r[1]]] for r in rows], np.int32).reshape(-1, 2)
+        sh = self.pair_sampler
+        self.pair_sampler = PairSampler(np.concatenate([sh.pairs, tail]), len(self.item), (sh.memb_rowptr, sh.memb_items))
+        self._rating = np.concatenate([self._rating, np.array([float(r[2]) if len(r) > 2 else 1.0 for r in rows], np.float64)])
+        self._uniform_rating = self._uniform_rating and bool(np.all(self._rating[-len(rows):] == self._rating[0])) if len(rows) else self._uniform_rating
+        self._ui_adj = self._norm_adj = self._interaction_mat = None
+
+    def _permute_ratings(self, order):
+        """Called by the sampler after an epoch shuffle with the permutation it applied to the pairs (skipped while all ratings are equal)."""
+        self._rating = self._rating[order]
+
+    def _ids(self):
+        p = self.pair_sampler.pairs
+        return p[:, 0].astype(np.int64), p[:, 1].astype(np.int64)
+
+    def _sorted_pairs(self):
+        """Unique (user, item) pairs sorted user-major (int64 arrays): the pattern of the interaction matrix."""
+        u, i = self._ids()
+        key = np.unique(u * self.item_num + i)
+        return key // self.item_num, key % self.item_num
+
+    def training_size(self):
+        return len(self.user), len(self.item), self.pair_sampler.nnz
+
+    def membership_csr(self):
+        return self._arl_memb
+
+    def contain(self, u, i):
+        return u in self.user and i in self.training_set_u[u]
+
+    # ---- matrices, built when read (attacks assign ui_adj / norm_adj / interaction_mat: plain setters)
+    @property
+    def ui_adj(self):
+        if self._ui_adj is None:
+            self._ui_adj = self._bipartite_adjacency()
+        return self._ui_adj
+
+    @ui_adj.setter
+    def ui_adj(self, m):
+        self._ui_adj = m
+
+    @property
+    def norm_adj(self):
+        return LazyNormAdj(self) if self._norm_adj is None else self._norm_adj
+
+    @norm_adj.setter
+    def norm_adj(self, m):
+        self._norm_adj = m
+
+    @property
+    def interaction_mat(self):
+        if self._interaction_mat is None:
+            self._interaction_mat = self._interaction_matrix()
+        return self._interaction_mat
+
+    @interaction_mat.setter
+    def interaction_mat(self, m):
+        self._interaction_mat = m
+
+    def __getstate__(self):
+        return dict(self.__dict__)
+
+    def __deepcopy__(self, memo):
+        import copy
+        from .sampler import PairSampler
+        new = object.__new__(type(self))
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k == 'pair_sampler':
+                new.pair_sampler = PairSampler(v.pairs.copy(), v.n_items, (v.memb_rowptr, v.memb_items))
+            elif k in ('training_set_u', 'training_set_i', '_arl_memb', 'val_data', 'test_data'):
+                new.__dict__[k] = v                               # read-only images
+            elif k in ('user', 'item', 'id2user', 'id2item'):
+                new.__dict__[k] = dict(v)
+            elif k == '_rating':
+                new.__dict__[k] = v.copy()
+            else:
+                new.__dict__[k] = copy.deepcopy(v, memo)
         return new

@@ -194,14 +194,19 @@ def next_batch_pairwise(data, batch_size, whole_epoch=False):
     same (the stream is consumed sample by sample either way); what changes is WHEN Python's `random` state advances -- at
     once instead of batch by batch -- so it is only for loops that do not touch `random` between batches (our own training
     loops).  It removes the per-batch getstate/setstate round trip (~0.2 ms per batch)."""
-    if hasattr(data, 'pair_sampler'):               # array-native data (arlib_amd.util.synthetic.InteractionData)
+    track = None
+    if hasattr(data, 'pair_sampler'):               # array-native data (synthetic.InteractionData, DataLoader.ArrayDataLoader)
         sh = data.pair_sampler
         order = None
+        if hasattr(data, '_permute_ratings') and not getattr(data, '_uniform_rating', True):
+            track = np.stack([np.arange(sh.nnz, dtype=np.int32), np.zeros(sh.nnz, np.int32)], 1)      # ratings follow their pairs
     else:
         sh = _shadow(data)
         order = np.stack([np.arange(sh.nnz, dtype=np.int32), np.zeros(sh.nnz, np.int32)], 1)
     mt = MTState.from_python()
-    sh.shuffle(mt, also=order)
+    sh.shuffle(mt, also=order if track is None else track)
+    if track is not None:
+        data._permute_ratings(track[:, 0])
     if whole_epoch and sh.nnz:
         allb = sh.batch(mt, 0, sh.nnz)
     mt.to_python()

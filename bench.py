@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--fake-users', type=int, default=64)
     ap.add_argument('--schedule', default='auto', choices=['auto', 'csr', 'blocked'], help='full-graph hop schedule (engine.PropagationEngine)')
     ap.add_argument('--repeats', type=int, default=3, help='timed regions of K steps each: the first is the contract figure (`value`), all are listed with median and spread')
+    ap.add_argument('--api-steps', type=int, default=200, help='steps of LightGCN(args, DataLoader).train() to time through the class API at N=1 (0 disables)')
     ap.add_argument('--dense-step', action='store_true', help='time the reference-shaped step (all 2L hops on the full graph) as the main number')
     return ap.parse_args()
 
@@ -266,6 +267,43 @@ def clear_leg(torch, ops, data, A, E0_dev, args):
             'note': 'dominated by the U x I scoring pass (compute-bound line item, SURVEY 8d); peak memory %.1f GB' % (torch.cuda.max_memory_allocated() / 1e9)}
 
 
+def class_api_leg(torch, data, args, engine_ms):
+    """The same training step through the reference's class surface: LightGCN(args, DataLoader).train(Epoch=1) on the same graph
+    (recommender/LightGCN.py:17-80), array-native DataLoader, the drop-in sampler drawing the epoch from Python's RNG, the fused engine
+    behind train().  Timed: the batch loop of the epoch (first `api_steps` batches), wall clock between device synchronisations."""
+    import io, contextlib, random
+    from types import SimpleNamespace
+    from arlib_amd.util.DataLoader import DataLoader
+    from arlib_amd.recommender.LightGCN import LightGCN
+    t0 = time.perf_counter()
+    p = data.pairs0
+    # train() evaluates on data.test_set every evalNum epochs (LightGCN.py:71-72; an empty split divides by zero there): a 1 024-row split
+    ts = p[:: max(1, len(p) // 1024)][:1024]
+    dl = DataLoader.from_arrays((p[:, 0], p[:, 1], np.ones(len(p), np.float32)), test=(ts[:, 0], ts[:, 1], np.ones(len(ts), np.float32)), dataName='SYN-v1')
+    build_s = time.perf_counter() - t0
+    a = SimpleNamespace(dataset='SYN-v1', model_name='LightGCN', maxEpoch=1, batch_size=args.batch, emb_size=args.emb, n_layers=args.layers, reg=1e-4,
+                        lRate=0.005, seed=args.seed, topK='50')
+    random.seed(args.seed); torch.manual_seed(args.seed)
+    t1 = time.perf_counter()
+    with contextlib.redirect_stdout(io.StringIO()):          # the classes print like the reference does; stdout is the JSON line's
+        rec = LightGCN(a, dl)
+    init_s = time.perf_counter() - t1
+    with contextlib.redirect_stdout(io.StringIO()):
+        rec.max_steps_per_epoch = 20
+        rec.train(Epoch=1, evalNum=1)                       # warm-up: plan build, first launches
+        rec.max_steps_per_epoch = args.api_steps
+        t2 = time.perf_counter()
+        rec.train(Epoch=1, evalNum=1)
+        epoch_wall = time.perf_counter() - t2
+    st = rec.last_train_stats
+    ms = 1e3 * st['loop_seconds'] / max(1, st['steps'])
+    return {'what': 'LightGCN(args, DataLoader.from_arrays(...)).train(Epoch=1) on the same cfg2 graph, first %d batches of the epoch' % st['steps'],
+            'ms_per_step': ms, 'value': args.batch * st['steps'] / st['loop_seconds'], 'unit': 'interactions/s', 'steps': st['steps'], 'fused_engine': st['fused'],
+            'engine_step_ms': engine_ms, 'gap_vs_engine_step': ms / engine_ms - 1.0,
+            'dataloader_build_seconds': build_s, 'model_init_seconds': init_s,
+            'train_call_wall_seconds': epoch_wall, 'note': 'train() wall also holds the epoch shuffle + all negatives of the epoch (host, one native call) and the epoch-end full forward'}
+
+
 def main():
     args = parse()
     import torch
@@ -448,6 +486,9 @@ def main():
             # DLAttack's inner step (attack/White/DLAttack.py:86-113) is the BPR/Adam step of the headline metric on the
             # surrogate (its CW term is a detached constant); the scoring pass above runs once per outer epoch
             res['attack_dlattack_inner'] = {'value': 1e3 / ms, 'unit': 'steps/s', 'note': 'same fused step as `value` (B=%d)' % B}
+        if not sharded and args.api_steps > 0:
+            torch.cuda.empty_cache()
+            res['class_api'] = class_api_leg(torch, data, args, float(np.median(region_s)) * 1e3 / args.steps)
         if not sharded and args.cpu_baseline:
             val_np = eng.A.val.cpu().numpy()
             batches = [(hb[k, 0].copy(), hb[k, 1].copy(), hb[k, 2].copy()) for k in range(min(n_batches, 8))]

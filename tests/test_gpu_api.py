@@ -29,20 +29,25 @@ def need_gpu():
         pytest.fail('GPU tests need a GPU')
 
 
-@pytest.mark.parametrize('name', ['gmf', 'lgn'])
+@pytest.mark.parametrize('name', ['gmf', 'lgn', 'lgn_array_native'])
 def test_train_two_epochs_matches_reference_run(name):
+    """X(args, data).train(Epoch=2, evalNum=1) + test() + predict() against the reference classes' own run (g10); 'lgn_array_native' feeds the
+    same run from the array-native DataLoader (what 3.2e7-interaction graphs use): lazy norm_adj assembled on the device, pair-array sampler."""
+    array_native = name.endswith('_array_native')
+    name = name.split('_')[0]
     from arlib_amd.util.tool import seedSet
     from arlib_amd.recommender.GMF import GMF
     from arlib_amd.recommender.LightGCN import LightGCN
     g = golden('g10_train_api.npz')
     cls, kw = (GMF, dict(emb_size=64, model_name='GMF')) if name == 'gmf' else (LightGCN, dict(emb_size=64, n_layers=2))
     seedSet(2018)
-    data = make_data()
+    data = make_data(array_native)
     rec = cls(rec_args(**kw), data)
     with contextlib.redirect_stdout(io.StringIO()):
         rec.train(Epoch=2, evalNum=1)
         rec_list, measure = rec.test()
     assert rec.model._eng is not None and rec.model._eng.t == 44            # the fused device engine ran all 2 x 22 steps (not autograd)
+    assert rec.last_train_stats['steps'] == 22 and rec.last_train_stats['fused'] and rec.last_train_stats['loop_seconds'] > 0
     assert random.random() == float(g[name + '_next_random'][0])          # sampler consumed python `random` bit-exactly
     assert rel_err(rec.model.embedding_dict['user_emb'].detach().cpu().numpy(), g[name + '_user']) < RTOL
     assert rel_err(rec.model.embedding_dict['item_emb'].detach().cpu().numpy(), g[name + '_item']) < RTOL

@@ -15,7 +15,7 @@ def test_bench_json_contract_small_instance():
     if not torch.cuda.is_available():
         pytest.fail('GPU tests need a GPU')
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--users', '30000', '--items', '3000', '--steps', '3', '--warmup', '1',
-           '--attack-steps', '2', '--fake-users', '8', '--cpu-seconds', '0.5']
+           '--attack-steps', '2', '--fake-users', '8', '--cpu-seconds', '0.5', '--api-steps', '5']
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
@@ -38,3 +38,4 @@ def test_bench_json_contract_small_instance():
     assert len(rep['regions']) == 3 and abs(rep['regions'][0] - r['ms_per_step']) < 1e-9 and rep['spread'] >= 0
     assert r['cpu_baseline_torch']['value'] > 0 and r['cpu_baseline_torch']['steps_timed'] >= 1      # reference-shaped stock-PyTorch step, on by default
     assert 'traffic_source' in roof
+    assert r['class_api']['steps'] == 5 and r['class_api']['fused_engine'] and r['class_api']['ms_per_step'] > 0

@@ -9,11 +9,11 @@ import pytest
 from conftest import golden, ROOT
 
 
-def make_data():
+def make_data(array_native=False):
     from arlib_amd.util.DataLoader import DataLoader
     g = golden('ml100k_data.npz')
     return DataLoader.from_arrays((g['train_u'], g['train_i'], g['train_r']), (g['val_u'], g['val_i'], g['val_r']),
-                                  (g['test_u'], g['test_i'], g['test_r']), dataName='ml-100k')
+                                  (g['test_u'], g['test_i'], g['test_r']), dataName='ml-100k', array_native=array_native)
 
 
 def test_abi_exports_match_header():
@@ -387,3 +387,63 @@ def test_none_attack_protocol_matches_reference_run():
     assert [int(atk.recommenderGradientRequired), int(atk.recommenderModelRequired)] == [int(x) for x in g['none_flags']]
     assert (res != sp.csr_matrix(data.matrix())).nnz == 0
     assert random.random() == float(g['none_next_random'][0])
+
+
+def test_array_native_dataloader_equals_list_based_loader():
+    """DataLoader.from_arrays(array_native=True) (numpy images, Python containers materialised on demand -- what 3.2e7-interaction graphs
+    use) against the list/dict-based loader that mirrors util/DataLoader.py:8-55 on ml-100k: id maps in first-seen order, the train/val/test
+    sets (key order included), matrices, the sampler's rejection sets, the batch stream drawn from Python's RNG, the in-place shuffle of
+    training_data with ratings following their rows, appends and deepcopy."""
+    import copy
+    import random
+    from arlib_amd.util.DataLoader import DataLoader, ArrayDataLoader
+    from arlib_amd.util.sampler import next_batch_pairwise
+    g = golden('ml100k_data.npz')
+    tr, va, te = ((g[s + '_u'], g[s + '_i'], g[s + '_r']) for s in ('train', 'val', 'test'))
+    a = DataLoader.from_arrays(tr, va, te, dataName='ml-100k', array_native=False)
+    b = DataLoader.from_arrays(tr, va, te, dataName='ml-100k', array_native=True)
+    assert isinstance(b, ArrayDataLoader) and type(a) is DataLoader
+    assert a.user == b.user and a.item == b.item and a.id2user == b.id2user and a.id2item == b.id2item
+    assert (a.user_num, a.item_num) == (b.user_num, b.item_num) and a.training_size() == b.training_size()
+    assert dict(a.test_set) == dict(b.test_set) and list(a.test_set) == list(b.test_set) and a.test_set_item == b.test_set_item and dict(a.val_set) == dict(b.val_set)
+    assert list(a.training_set_u) == list(b.training_set_u) and all(a.training_set_u[u] == b.training_set_u[u] for u in a.training_set_u)
+    assert list(a.training_set_u['1']) == list(b.training_set_u['1'])                      # inner key order = file order
+    assert list(a.training_set_i) == list(b.training_set_i) and all(a.training_set_i[i] == b.training_set_i[i] for i in list(a.training_set_i)[::7])
+    assert a.contain('1', '61') == b.contain('1', '61') and a.contain('1', 'nope') == b.contain('1', 'nope') and a.user_rated('5') == b.user_rated('5')
+    assert a.training_data == b.training_data
+    assert (a.matrix() != b.matrix()).nnz == 0 and (a.ui_adj != b.ui_adj).nnz == 0 and abs(a.norm_adj - b.norm_adj.to_scipy()).max() < 1e-7
+    ma, mb = a.membership_csr(), b.membership_csr()
+    assert np.array_equal(ma[0], mb[0]) and np.array_equal(ma[1], mb[1])
+    outs = []
+    for d in (a, b):
+        random.seed(2018)
+        outs.append(([tuple(x.copy() for x in bt) for bt in next_batch_pairwise(d, 2048)], random.random()))
+    assert outs[0][1] == outs[1][1] and len(outs[0][0]) == len(outs[1][0]) == 22
+    assert all(np.array_equal(x, y) for ba, bb in zip(outs[0][0], outs[1][0]) for x, y in zip(ba, bb))
+    assert a.training_data == b.training_data and a.training_data[0] != [str(g['train_u'][0]), str(g['train_i'][0]), float(g['train_r'][0])]   # shuffled alike
+    # an attack's appends: new user id, rows at the end, matrices follow
+    for d in (a, b):
+        d.user['fakeuser0'] = len(d.user); d.id2user[len(d.user) - 1] = 'fakeuser0'; d.user_num += 1
+        d.append_training_rows([['fakeuser0', d.id2item[3], 1.0], ['fakeuser0', d.id2item[9], 1.0]])
+    assert a.training_data[-2:] == b.training_data[-2:] and (a.matrix() != b.matrix()).nnz == 0 and a.matrix().shape == (a.user_num, a.item_num)
+    c = copy.deepcopy(b)
+    c.append_training_rows([['fakeuser0', c.id2item[11], 1.0]])
+    assert c.training_size()[2] == b.training_size()[2] + 1 and c.user == b.user and c.user is not b.user
+
+
+def test_array_native_dataloader_at_scale_builds_in_seconds():
+    """3.2 M synthetic interactions (a tenth of cfg2): the array-native loader is the default from 2 M interactions on and builds in
+    O(nnz) numpy; spot checks of its lazy views against the arrays."""
+    import time
+    from arlib_amd.util import synthetic
+    from arlib_amd.util.DataLoader import DataLoader, ArrayDataLoader
+    pairs = synthetic.syn_v1_pairs(100_000, 20_000)
+    t0 = time.perf_counter()
+    d = DataLoader.from_arrays((pairs[:, 0], pairs[:, 1], np.ones(len(pairs), np.float32)), dataName='syn')
+    dt = time.perf_counter() - t0
+    assert isinstance(d, ArrayDataLoader) and dt < 60
+    assert d.training_size() == (100_000, 20_000, len(pairs))
+    u0 = d.id2user[0]
+    row = pairs[pairs[:, 0] == int(u0), 1]
+    assert list(d.training_set_u[u0]) == [str(x) for x in row.tolist()]
+    assert d.matrix().nnz == len(pairs) and d.norm_adj.shape == (120_000, 120_000)
