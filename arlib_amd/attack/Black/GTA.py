@@ -73,7 +73,7 @@ class GTA(AttackBase):
         seedItem = random.sample(order.tolist()[0], self.maliciousFeedbackNum // 2)
         Up = self.userNum + self.fakeUserNum
         for epoch in range(self.Epoch):
-            init_graph(recommender.model, uiAdj, Up, self.itemNum)
+            init_graph(recommender.model, uiAdj, Up, self.itemNum, n_real=self.userNum)
             recommender.train(Epoch=self.innerEpoch, optimizer=optimizer, evalNum=5)
             targetHitRate = AttackMetric(recommender, self.targetItem, [topk]).hitRate()[0]
             print(targetHitRate)
@@ -106,5 +106,5 @@ class GTA(AttackBase):
             append_rows(data, [(data.id2user[u], data.id2item[i]) for i in random.sample(tuple(set(range(self.itemNum))), int(self.maliciousFeedbackNum))])
         _, _, data.interaction_mat = rebuild_interaction_matrix(data)
         recommender.__init__(recommender.args, data, self.targetItem)
-        init_graph(recommender.model, sp.csr_matrix(data.matrix()), self.userNum + self.fakeUserNum, self.itemNum)
+        init_graph(recommender.model, sp.csr_matrix(data.matrix()), self.userNum + self.fakeUserNum, self.itemNum, n_real=self.userNum)
         recommender.train(Epoch=30)

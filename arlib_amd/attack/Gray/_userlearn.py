@@ -40,7 +40,7 @@ class UserLearningBiLevel(CLeaR):
         for epoch in range(self.Epoch):
             tmpRecommender = deepcopy(recommender)
             uiAdj2 = uiAdj.copy()
-            init_graph(tmpRecommender.model, uiAdj2, Up, self.itemNum)
+            init_graph(tmpRecommender.model, uiAdj2, Up, self.itemNum, n_real=self.userNum)
             optimizer_attack = torch.optim.Adam(tmpRecommender.model.parameters(), lr=recommender.args.lRate)
             mask = device_mask(uiAdj2)
             Pu = Pi = None
@@ -62,7 +62,7 @@ class UserLearningBiLevel(CLeaR):
             rows[:, self.targetItem] = 1
             uiAdj2 = with_fake_rows(uiAdj2, self.userNum, rows.cpu().numpy())
             uiAdj = uiAdj2.copy()
-            init_graph(recommender.model, uiAdj, Up, self.itemNum)
+            init_graph(recommender.model, uiAdj, Up, self.itemNum, n_real=self.userNum)
             recommender.train(Epoch=self.innerEpoch, optimizer=optimizer, evalNum=5)
             targetHitRate = AttackMetric(recommender, self.targetItem, [topk]).hitRate()[0]
             print(targetHitRate)

@@ -89,7 +89,7 @@ class CLeaR(AttackBase):
         for epoch in range(self.Epoch):
             tmpRecommender = deepcopy(recommender)
             uiAdj2 = uiAdj.copy()
-            init_graph(tmpRecommender.model, uiAdj2, Up, self.itemNum)
+            init_graph(tmpRecommender.model, uiAdj2, Up, self.itemNum, n_real=self.userNum)
             optimizer_attack = torch.optim.Adam(tmpRecommender.model.parameters(), lr=recommender.args.lRate)
             Pu = Pi = None
             mask = device_mask(uiAdj2)          # the poisoned pattern is fixed while the surrogate is trained
@@ -108,7 +108,7 @@ class CLeaR(AttackBase):
             proj[:, self.targetItem] = 1
             uiAdj2 = with_fake_rows(uiAdj2, self.userNum, proj.cpu().numpy())
             uiAdj = uiAdj2.copy()
-            init_graph(recommender.model, uiAdj, Up, self.itemNum)
+            init_graph(recommender.model, uiAdj, Up, self.itemNum, n_real=self.userNum)
             recommender.train(Epoch=self.innerEpoch, optimizer=optimizer, evalNum=5)
             targetHitRate = AttackMetric(recommender, self.targetItem, [topk]).hitRate()[0]
             print(targetHitRate)

@@ -58,7 +58,7 @@ class DLAttack(AttackBase):
             tmpRecommender = deepcopy(recommender)
             uiAdj2 = sp.csr_matrix(uiAdj, copy=True)
             U_now = tmpRecommender.data.user_num
-            init_graph(tmpRecommender.model, uiAdj2, U_now, self.itemNum)
+            init_graph(tmpRecommender.model, uiAdj2, U_now, self.itemNum, n_real=self.userNum)
             tmpRecommender.train(Epoch=self.innerEpoch, optimizer=optimizer, evalNum=5)
             optimizer_attack = torch.optim.Adam(tmpRecommender.model.parameters(), lr=recommender.args.lRate)
             mask = device_mask(uiAdj2)
@@ -79,7 +79,7 @@ class DLAttack(AttackBase):
             p[ind] = p[ind] * sigma
             if p.max() < 1:
                 p = torch.ones(self.itemNum, device=DEVICE)
-            init_graph(recommender.model, uiAdj2, recommender.data.user_num, self.itemNum)
+            init_graph(recommender.model, uiAdj2, recommender.data.user_num, self.itemNum, n_real=self.userNum)
             uiAdj = uiAdj2
         self.interact = uiAdj
         return self.interact

@@ -93,10 +93,12 @@ def append_rows(data, rows):
         data.training_data.extend(rows)
 
 
-def init_graph(model, ui, n_users, n_items):
+def init_graph(model, ui, n_users, n_items, n_real=None):
     """model._init_uiAdj(ui_adj + ui_adj.T) for the U' x I interaction matrix `ui` -- on the device when the model offers it
-    (our encoders), through the (U'+I)^2 scipy matrix otherwise (any model with the reference's interface)."""
-    if hasattr(model, '_init_uiAdj_from_interactions') and sp.csr_matrix(ui).shape == (n_users, n_items):
-        model._init_uiAdj_from_interactions(ui)
+    (our encoders), through the (U'+I)^2 scipy matrix otherwise (any model with the reference's interface).  `n_real` = number of
+    real users (the leading rows, unchanged over an attack's epochs): our encoders then only merge the fake users' rows into the
+    device graph they already hold (ops.IncrementalBipartite)."""
+    if hasattr(model, '_init_uiAdj_from_interactions') and ui.shape == (n_users, n_items):
+        model._init_uiAdj_from_interactions(ui, n_real=n_real)
     else:
         model._init_uiAdj(symmetric_adjacency(ui, n_users, n_items))

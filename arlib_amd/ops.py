@@ -294,7 +294,8 @@ class BlockedPlan:
                 ok = cnt[pw] > 0
                 rec_col[pad_pos[ok]] = rec_col[last[ok]]
             self.sets.append({'n_waves': n_waves, 'wave_ptr': wave_ptr.to(torch.int32), 'wave_rows': wave_rows, 'rec_col': rec_col, 'rec_src': rec_src, 'pad_pos': pad_pos,
-                              'n_rows': n_pl, 'n_edges': int(ew.numel()), 'hub': hub_t, 'piece': piece_t, 'wpg': wpg_t, 'n_split': n_split, 'n_pieces': int(split_cnt.sum()) if n_split else 0,
+                              'n_rows': n_pl, 'n_edges': int(ew.numel()), 'hub': hub_t, 'piece': piece_t, 'wpg': wpg_t, 'n_split': n_split,
+                              'lo': lo, 'hi': hi, 'row_wave': v_wave[vfirst.clamp(max=n_virtual - 1)] * planned.long() - (~planned).long(), 'row_slot': v_slot[vfirst.clamp(max=n_virtual - 1)], 'cnt': cnt, 'n_pieces': int(split_cnt.sum()) if n_split else 0,
                               'split_row': (lo + split_local).to(torch.int32), 'split_first': split_first.to(torch.int32), 'split_count': split_cnt.to(torch.int32),
                               # short streams: more loads per wave; long streams (many edges per wave) run better with 16 (measured, cfg2)
                               'unroll': (16 if self.rpw == 16 or ew.numel() > 4096 * n_waves else 32) if unroll is None else int(unroll)})
@@ -411,6 +412,135 @@ def bipartite_graph(u, i, n_users, n_items, device=None, weights=None):
     g = CSRGraph(rowptr, col, val, dev, validate=False)
     g.dinv = dinv
     return g
+
+
+class IncrementalBipartite:
+    """Normalised symmetric adjacency of the stacked interactions [R; B]: R = the REAL users' U x I block, fixed for the life of the object,
+    B = the F fake users' rows, replaced at every attack epoch (attack/White/CLeaR.py:66-71,130-145, DLAttack.py:57-61,110-121 rebuild the whole
+    (U+F+I)^2 scipy matrix and re-upload it per epoch).  update() assembles the new CSR on the device by MERGING: fake users are the last user
+    rows, and in every item row they sort behind all real users, so the new pattern is the old one with entries appended at row ends --
+    a prefix sum and two scatters --; degrees change on the touched rows only and the values are re-normalised by the same kernel as a fresh
+    build (bit-identical to ops.bipartite_graph on the stacked matrix).  The register-blocked hop plan of R is kept and PATCHED: the new
+    records are appended to their rows' waves (streams are re-laid-out by one gather), values re-gathered; no sort of the 6.4e7 records, no host
+    dealing.  Everything runs on the device; the host sees a handful of scalars."""
+
+    def __init__(self, u, i, n_real, n_fake, n_items, device=None, weights=None, emb_size=None):
+        dev = u.device if device is None else torch.device(device)
+        self.device = dev
+        self.U, self.F, self.I = int(n_real), int(n_fake), int(n_items)
+        U, F, I = self.U, self.F, self.I
+        Up = U + F
+        self.Up, self.N = Up, Up + I
+        u = u.to(dev, torch.int64); i = i.to(dev, torch.int64)
+        nnz = u.numel()
+        self.nnz = nnz
+        w = torch.ones(nnz, dtype=torch.float32, device=dev) if weights is None else weights.to(dev, torch.float32)
+        if nnz and (int(u.max()) >= U or int(i.max()) >= I):
+            raise ValueError('IncrementalBipartite: real interactions out of range')
+        self.rp_u = torch.searchsorted(u, torch.arange(Up + 1, device=dev, dtype=torch.int64))           # fake rows empty
+        it_sorted, order = torch.sort(i, stable=True)
+        self.rp_i = torch.searchsorted(it_sorted, torch.arange(I + 1, device=dev, dtype=torch.int64))
+        self.col_u, self.w_u = (i + Up).to(torch.int32), w
+        self.col_i, self.w_i = u[order].to(torch.int32), w[order]
+        self.item_of_edge = it_sorted                                                                     # item id of every item-half edge
+        self.base = None
+        if emb_size is not None and int(emb_size) in (64, 128) and 2 * nnz >= BLOCKED_MIN_NNZ and self.N < (1 << 24):
+            rowptr0 = torch.cat([self.rp_u, nnz + self.rp_i[1:]])
+            self.base = CSRGraph(rowptr0, torch.cat([self.col_u, self.col_i]), torch.zeros(2 * nnz, dtype=torch.float32, device=dev), dev, validate=False)
+            self.base.enable_blocked(split=Up, min_waves=BLOCKED_MIN_WAVES)
+            if not self.base.blocked.sets or self.base.blocked.n_hub:
+                self.base = None                                                                          # (a set left to the CSR kernel: no plan to patch)
+
+    def __deepcopy__(self, memo):
+        return self                                  # immutable base: surrogates forked with copy.deepcopy share it
+
+    def update(self, fu, fi, fw=None):
+        """CSRGraph of [R; B] for the fake block given as COO sorted by (fake user, item): fu in [0, F), fi in [0, I), optional weights."""
+        dev, U, F, I, Up, N, nnz = self.device, self.U, self.F, self.I, self.Up, self.N, self.nnz
+        fu = fu.to(dev, torch.int64); fi = fi.to(dev, torch.int64)
+        nf = fu.numel()
+        fw = torch.ones(nf, dtype=torch.float32, device=dev) if fw is None else fw.to(dev, torch.float32)
+        if nf:
+            if int(fu.min()) < 0 or int(fu.max()) >= F or int(fi.min()) < 0 or int(fi.max()) >= I:
+                raise ValueError('IncrementalBipartite.update: fake interactions out of range')
+            k = fu * I + fi
+            if bool((k[1:] <= k[:-1]).any()):
+                raise ValueError('IncrementalBipartite.update: fake interactions must be sorted by (user, item) and unique')
+        # user half: real user rows as they are, then the fake rows
+        rp_user = torch.cat([self.rp_u[:U + 1], nnz + torch.searchsorted(fu, torch.arange(1, F + 1, device=dev, dtype=torch.int64))]) if F else self.rp_u
+        col_user = torch.cat([self.col_u, (fi + Up).to(torch.int32)])
+        w_user = torch.cat([self.w_u, fw])
+        # item half: every item row keeps its real users and gains its fake users at the end
+        ins = torch.bincount(fi, minlength=I)
+        cumins = torch.cumsum(ins, 0) - ins
+        rp_item = self.rp_i.clone(); rp_item[1:] += torch.cumsum(ins, 0)
+        new_pos_old = torch.arange(nnz, device=dev, dtype=torch.int64) + cumins[self.item_of_edge]
+        fi_s, o = torch.sort(fi, stable=True)                                   # within an item: fake users ascending
+        rank = torch.arange(nf, device=dev, dtype=torch.int64) - (torch.cumsum(ins, 0) - ins)[fi_s]
+        pos_fake = rp_item[fi_s + 1] - ins[fi_s] + rank
+        col_item = torch.empty(nnz + nf, dtype=torch.int32, device=dev); w_item = torch.empty(nnz + nf, dtype=torch.float32, device=dev)
+        col_item[new_pos_old] = self.col_i; w_item[new_pos_old] = self.w_i
+        col_item[pos_fake] = (U + fu[o]).to(torch.int32); w_item[pos_fake] = fw[o]
+        E_user = nnz + nf
+        rowptr = torch.cat([rp_user, E_user + rp_item[1:]])
+        col = torch.cat([col_user, col_item]); ww = torch.cat([w_user, w_item])
+        val, dinv = norm_adj_values(rowptr.to(torch.int32), col, ww, N)
+        g = CSRGraph(rowptr, col, val, dev, validate=False)
+        g.dinv = dinv
+        if self.base is not None:
+            g.blocked = self._patched_plan(g, nf, fu, fi, o, fi_s, pos_fake, new_pos_old, E_user)
+        return g
+
+    def _patched_plan(self, g, nf, fu, fi, o, fi_s, pos_fake, new_pos_old, E_user):
+        dev, U, Up, nnz = self.device, self.U, self.Up, self.nnz
+        bp0 = self.base.blocked
+        bp = object.__new__(BlockedPlan)
+        bp.__dict__.update(bp0.__dict__)
+        bp.sets = []
+        for st in bp0.sets:
+            user_set = st['lo'] == 0
+            if user_set:       # new records: the fake users' rows; old records keep their edge ids (real user rows do not move)
+                rows = U + fu; cols = fi + Up; eids = nnz + torch.arange(nf, device=dev, dtype=torch.int64)
+                src_old = st['rec_src'].long()
+            else:              # new records: the items' fake neighbours; an old item-half edge e moved to E_user + new_pos_old[e - nnz]
+                rows = Up + fi_s; cols = U + fu[o]; eids = E_user + pos_fake
+                src_old = E_user + new_pos_old[(st['rec_src'].long() - nnz).clamp_(min=0)]
+            local = rows - st['lo']
+            wv, sl = st['row_wave'][local], st['row_slot'][local]
+            cnt0, wp0 = st['cnt'], st['wave_ptr'].long()
+            n_waves = st['n_waves']
+            # new records of a wave keep the (column block, slot) order among themselves; they trail the wave's old records
+            okey = torch.sort((wv * (1 << 22) + cols // bp0.col_block) * bp0.rpw + sl, stable=True)[1] if nf else torch.zeros(0, dtype=torch.int64, device=dev)
+            wv, sl, cols, eids = wv[okey], sl[okey], cols[okey], eids[okey]
+            add = torch.bincount(wv, minlength=n_waves)
+            cnt = cnt0 + add
+            wpn = torch.zeros(n_waves + 1, dtype=torch.int64, device=dev); torch.cumsum((cnt + 63) // 64 * 64, 0, out=wpn[1:])
+            total = int(wpn[-1])
+            if total >= 2 ** 31:
+                raise ValueError('IncrementalBipartite: too many records for int32 offsets')
+            size = max(total, 64)
+            pw = torch.repeat_interleave(torch.arange(n_waves, device=dev), wpn[1:] - wpn[:-1], output_size=total)       # wave of every new position
+            k = torch.arange(total, device=dev, dtype=torch.int64) - wpn[pw]
+            is_old, is_new = k < cnt0[pw], (k >= cnt0[pw]) & (k < cnt[pw])
+            rec_col = torch.zeros(size, dtype=torch.int32, device=dev); rec_src = torch.zeros(size, dtype=torch.int32, device=dev)
+            po = torch.nonzero(is_old).flatten()
+            from_old = wp0[pw[po]] + k[po]
+            rec_col[po] = st['rec_col'][from_old]; rec_src[po] = src_old[from_old].to(torch.int32)
+            if nf:
+                start_new = torch.cumsum(add, 0) - add
+                pn = torch.nonzero(is_new).flatten()
+                from_new = start_new[pw[pn]] + (k[pn] - cnt0[pw[pn]])
+                rec_col[pn] = (cols[from_new] | (sl[from_new] << 24)).to(torch.int32); rec_src[pn] = eids[from_new].to(torch.int32)
+            pad_pos = torch.nonzero(~(is_old | is_new)).flatten()
+            if pad_pos.numel():
+                last = wpn[pw[pad_pos]] + cnt[pw[pad_pos]] - 1
+                ok = cnt[pw[pad_pos]] > 0
+                rec_col[pad_pos[ok]] = rec_col[last[ok]]
+            ns = dict(st)
+            ns.update({'wave_ptr': wpn.to(torch.int32), 'rec_col': rec_col, 'rec_src': rec_src, 'pad_pos': pad_pos, 'cnt': cnt, 'n_edges': st['n_edges'] + nf})
+            bp.sets.append(ns)
+        bp._bind(g, None)
+        return bp
 
 
 def _check_xy(A, X, name='X', rows=None):

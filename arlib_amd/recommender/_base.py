@@ -189,21 +189,53 @@ class GraphEncoder(nn.Module):
         self.sparse_norm_adj = adj
         self._eng = None
 
-    def _init_uiAdj_from_interactions(self, ui):
+    def _init_uiAdj_from_interactions(self, ui, n_real=None):
         """Same result as `_init_uiAdj(ui_adj + ui_adj.T)` with ui_adj's upper-right block = `ui` (the U' x I, possibly weighted,
         interaction matrix every attack assembles: attack/White/PGA.py:79-83, CLeaR.py:66-71, DLAttack.py:57-61), but the
-        (U'+I)^2 adjacency is never built on the host: the symmetric CSR is assembled and normalised on the device."""
-        m = sp.csr_matrix(ui, dtype=np.float32)
-        m.eliminate_zeros(); m.sort_indices()
+        (U'+I)^2 adjacency is never built on the host: the symmetric CSR is assembled and normalised on the device.
+        `n_real`: rows [0, n_real) are the real users, whose interactions do not change between the calls of one attack -- the device
+        image of that block (and its hop plan) is then kept and only the fake users' rows are merged in (ops.IncrementalBipartite);
+        the block is recognised by size and checksum, anything else falls back to the full build."""
+        m = ui if sp.isspmatrix_csr(ui) and ui.dtype == np.float32 else sp.csr_matrix(ui, dtype=np.float32)
         U, I = m.shape
-        u = torch.from_numpy(np.repeat(np.arange(U, dtype=np.int64), np.diff(m.indptr))).to(DEVICE)
-        g = ops.bipartite_graph(u, torch.from_numpy(m.indices.astype(np.int64)).to(DEVICE), U, I, weights=torch.from_numpy(m.data).to(DEVICE))
+        g = None
+        if n_real is not None and 0 < n_real < U:
+            g = self._incremental_graph(m, int(n_real))
+        if g is None:
+            m = sp.csr_matrix(m, dtype=np.float32, copy=(m is ui)); m.eliminate_zeros(); m.sort_indices()
+            u = torch.from_numpy(np.repeat(np.arange(U, dtype=np.int64), np.diff(m.indptr))).to(DEVICE)
+            g = ops.bipartite_graph(u, torch.from_numpy(m.indices.astype(np.int64)).to(DEVICE), U, I, weights=torch.from_numpy(m.data).to(DEVICE))
         adj = SparseNormAdj.__new__(SparseNormAdj)
         adj.shape = (U + I, U + I)
         adj._indptr = adj._indices = None                   # host images of the pattern are fetched only if somebody reads them
         adj.values, adj.dinv, adj._graph = g.val, g.dinv, g
         self.sparse_norm_adj = adj
         self._eng = None
+
+    def _incremental_graph(self, m, n_real):
+        """ops.IncrementalBipartite keyed by the real block's fingerprint; shared (not copied) by deep copies of this encoder."""
+        U, I = m.shape
+        F = U - n_real
+        e_real = int(m.indptr[n_real])
+        # fingerprint of the real block: edge count + strided samples of its three arrays, O(65 K) per call (the attacks never touch real
+        # rows; a caller that does changes the count or, with overwhelming probability, a sample).  A block that arrives in non-canonical
+        # form (unsorted / explicit zeros) never matches the canonical block's fingerprint and simply takes the full path every time.
+        def fingerprint(indptr, indices, data, nnz):
+            st = max(1, nnz // 65536)
+            return (n_real, F, I, nnz, int(np.add.reduce(indptr[:n_real + 1:max(1, n_real // 4096)], dtype=np.int64)),
+                    float(np.add.reduce(data[:nnz:st], dtype=np.float64)), int(np.add.reduce(indices[:nnz:st], dtype=np.int64)))
+        inc = getattr(self, '_arl_inc', None)
+        if inc is None or inc[0] != fingerprint(m.indptr, m.indices, m.data, e_real):
+            R = sp.csr_matrix(m[:n_real], dtype=np.float32); R.eliminate_zeros(); R.sort_indices()
+            u = torch.from_numpy(np.repeat(np.arange(n_real, dtype=np.int64), np.diff(R.indptr))).to(DEVICE)
+            w = None if bool(np.all(R.data == 1.0)) else torch.from_numpy(R.data).to(DEVICE)
+            inc = (fingerprint(R.indptr, R.indices, R.data, R.nnz),
+                   ops.IncrementalBipartite(u, torch.from_numpy(R.indices.astype(np.int64)).to(DEVICE), n_real, F, I, DEVICE, weights=w,
+                                            emb_size=self.latent_size if self.n_prop_layers else None))
+            self._arl_inc = inc
+        B = sp.csr_matrix(m[n_real:], dtype=np.float32); B.eliminate_zeros(); B.sort_indices()          # the fake users' rows: small
+        fu = torch.from_numpy(np.repeat(np.arange(F, dtype=np.int64), np.diff(B.indptr)))
+        return inc[1].update(fu, torch.from_numpy(B.indices.astype(np.int64)), None if bool(np.all(B.data == 1.0)) else torch.from_numpy(B.data))
 
     def attack_emb(self, users_emb_grad, items_emb_grad):
         with torch.no_grad():
@@ -271,6 +303,7 @@ class GraphEncoder(nn.Module):
     def __getstate__(self):
         st = dict(self.__dict__)
         st['_eng'] = None
+        st.pop('_arl_inc', None)
         return st
 
 

@@ -467,3 +467,75 @@ def test_score_mask_topk_warm_start_is_result_neutral(ops, d, masked):
     bad = cold_i.clone(); bad[:, 1:] = bad[:, :1]
     b_i, b_v = ops.score_mask_topk(T(Pu2), T(Pi), k, rp, mc, warm_idx=bad)
     assert torch.equal(b_i, ref_i) and torch.equal(b_v, ref_v)
+
+
+def test_bipartite_graph_device_build_matches_golden_and_oracle(ops, ml100k):
+    """ops.bipartite_graph (what every attack's _init_uiAdj goes through, and the array-native DataLoader's norm_adj): pattern and values
+    against the reference's normalize_graph_mat on ml-100k (g3_adj) and against its `_init_uiAdj` on a weighted graph with an isolated
+    node, plus the oracle's own build on a random weighted graph."""
+    g = golden('g3_adj.npz')
+    p = ml100k['pairs0']
+    o = np.lexsort((p[:, 1], p[:, 0]))
+    U, I = ml100k['U'], ml100k['I']
+    gr = ops.bipartite_graph(T(p[o, 0].astype(np.int64)), T(p[o, 1].astype(np.int64)), U, I)
+    assert np.array_equal(gr.rowptr.cpu().numpy(), g['norm_indptr']) and np.array_equal(gr.col.cpu().numpy(), g['norm_indices'])
+    assert rel_err(gr.val.cpu().numpy(), g['norm_data']) < 1e-6
+    Uw, Iw = (int(x) for x in g['w_shape'])
+    o = np.lexsort((g['w_R_col'], g['w_R_row']))
+    gw = ops.bipartite_graph(T(g['w_R_row'][o].astype(np.int64)), T(g['w_R_col'][o].astype(np.int64)), Uw, Iw, weights=T(g['w_R_val'][o]))
+    rows = np.repeat(np.arange(Uw + Iw), np.diff(gw.rowptr.cpu().numpy()))
+    ref = sp_coo(g['w_norm_val'], g['w_norm_row'], g['w_norm_col'], Uw + Iw)
+    got = sp_coo(gw.val.cpu().numpy(), rows, gw.col.cpu().numpy(), Uw + Iw)
+    assert abs(got - ref).max() <= 1e-5 * abs(ref).max() and (got != 0).nnz == (ref != 0).nnz
+    assert gw.dinv[7].item() == 0.0
+    rng = np.random.default_rng(8)
+    u, i = random_graph(rng, 500, 90, 7, hot_items=1, hot_deg=300, empty_users=(3,))
+    w = (rng.random(len(u)) + 0.25).astype(np.float32)
+    rowptr, col, ww = O.bipartite_csr(u, i, 500, 90, w)
+    gr = ops.bipartite_graph(T(u.astype(np.int64)), T(i.astype(np.int64)), 500, 90, weights=T(w))
+    assert np.array_equal(gr.rowptr.cpu().numpy(), rowptr) and np.array_equal(gr.col.cpu().numpy(), col)
+    assert rel_err(gr.val.cpu().numpy(), O.norm_adj_values(rowptr, col, ww)) < 1e-6
+
+
+def sp_coo(v, r, c, n):
+    import scipy.sparse as sp
+    return sp.csr_matrix((np.asarray(v, np.float64), (np.asarray(r), np.asarray(c))), shape=(n, n))
+
+
+@pytest.mark.parametrize('planned', [False, True])
+def test_incremental_bipartite_update_equals_fresh_build(ops, planned, monkeypatch):
+    """ops.IncrementalBipartite (real block fixed, fake users' rows replaced per attack epoch; the CSR merged and the blocked plan patched on
+    the device) against a fresh ops.bipartite_graph of the stacked interactions: identical pattern, bit-identical values, and -- with the
+    patched plan -- the same products as the CSR kernel, for several successive fake blocks (binary, weighted, empty, a fake user on a hot item)."""
+    if planned:
+        monkeypatch.setattr(ops, 'BLOCKED_MIN_NNZ', 0); monkeypatch.setattr(ops, 'BLOCKED_MIN_WAVES', 0)
+    rng = np.random.default_rng(21)
+    U, F, I, d = 3000, 7, 400, 64
+    u, i = random_graph(rng, U, I, 10, hot_items=2, hot_deg=2500, empty_users=(11,))
+    inc = ops.IncrementalBipartite(T(u.astype(np.int64)), T(i.astype(np.int64)), U, F, I, DEV, emb_size=d)
+    assert (inc.base is not None) == planned
+    Up, N = U + F, U + F + I
+    X = torch.randn(N, d, device=DEV)
+    for trial in range(4):
+        if trial == 2:
+            fu = np.zeros(0, np.int64); fi = np.zeros(0, np.int64); fw = None
+        else:
+            n_f = [30, 5, 0, 120][trial]
+            fu = np.repeat(np.arange(F), n_f); fi = np.concatenate([np.sort(rng.choice(I, n_f, replace=False)) for _ in range(F)])
+            if trial == 3:
+                fi[0] = 0 if fi[0] != 0 and 0 not in fi[:n_f] else fi[0]                 # a fake edge on the hottest (split) item row
+                fi[:n_f] = np.sort(fi[:n_f])
+            fw = None if trial != 1 else (rng.random(len(fu)) + 0.5).astype(np.float32)
+        g = inc.update(T(fu), T(fi), None if fw is None else T(fw))
+        au = np.concatenate([u.astype(np.int64), U + fu]); ai = np.concatenate([i.astype(np.int64), fi])
+        aw = None if fw is None else np.concatenate([np.ones(len(u), np.float32), fw])
+        o = np.lexsort((ai, au))
+        ref = ops.bipartite_graph(T(au[o]), T(ai[o]), Up, I, weights=None if aw is None else T(aw[o]))
+        assert torch.equal(g.rowptr, ref.rowptr) and torch.equal(g.col, ref.col) and torch.equal(g.val, ref.val) and torch.equal(g.dinv, ref.dinv)
+        assert (g.blocked is not None) == planned
+        y_ref = ops.spmm(ref, X)
+        assert rel_err(ops.spmm(g, X).cpu().numpy(), y_ref.cpu().numpy()) < 1e-6
+        if planned:
+            assert sum(s['n_edges'] for s in g.blocked.sets) == g.nnz
+            Z = torch.randn(N, d, device=DEV)
+            assert rel_err(ops.spmm(g, X, 0.5, -2.0, Z).cpu().numpy(), ops.spmm(ref, X, 0.5, -2.0, Z).cpu().numpy()) < 1e-6
