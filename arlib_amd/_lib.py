@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ARLIB_AMD_LIB') or os.path.join(_HERE, 'lib', 'libarlib_amd.so')      # override: developer builds (e.g. `make prof`)
-ABI_VERSION = 11
+ABI_VERSION = 12
 _lib = None
 
 
@@ -81,6 +81,9 @@ _SIGS = {
     'arl_ngcf_combine_bwd_f32': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     'arl_sfa_workspace_bytes': (_i64, [_i64, _i64]),
     'arl_sfa_l1_fwd_bwd_f32': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _f, C.c_int32, _vp, _vp, _vp, _vp]),
+    'arl_sfa_stage1_f32': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    'arl_sfa_stage2_f32': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    'arl_sfa_stage3_f32': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, C.c_int32, _vp, _vp, _vp, _vp]),
     'arl_sddmm_rows_dense_f32': (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp]),
     'arl_pga_update_f32': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     'arl_score_mask_topk_workspace_bytes': (_i64, [_i64, _i64]),

@@ -2108,6 +2108,67 @@ int arl_sfa_l1_fwd_bwd_f32(const float *X, const float *w, const float *r0, int6
     return ARL_OK;
 }
 
+// The same computation cut at its two global reductions, for row sets that are partitioned over ranks (user-sharded CLeaR step): the
+// caller sum-all-reduces r (d floats) between stage 1 and 2 and [a | S] (d + 1 floats) between stage 2 and 3.  One workspace for all three.
+static int sfa_stage_args(const float *X, const float *w, int64_t n_rows, int64_t d, void *workspace) {
+    if (!X || !w || !workspace) return ARL_E_NULL;
+    if (n_rows <= 0 || n_rows > 0x7fffffffll) return ARL_E_ARG;
+    if (d <= 0 || d > 256) return ARL_E_DIM;
+    return ARL_OK;
+}
+
+int arl_sfa_stage1_f32(const float *X, const float *w, const float *r0, int64_t n_rows, int64_t d, float *r_out, void *workspace, arl_stream_t stream) {
+    const int rc = sfa_stage_args(X, w, n_rows, d, workspace);
+    if (rc != ARL_OK) return rc;
+    if (!r0 || !r_out) return ARL_E_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    float *q = (float *)workspace, *s = q + n_rows, *part = s + n_rows, *coef = part + (size_t)kSfaMaxBlocks * kSfaStride;
+    const int64_t want = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int nblk = (int)(want < kSfaMaxBlocks ? want : kSfaMaxBlocks);
+    hipLaunchKernelGGL((sfa_reduce_pass_kernel<1>), dim3(nblk), dim3(kBlock), 0, st, X, w, r0, (int)n_rows, (int)d, q, part);
+    ARL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sfa_fold_kernel, dim3((unsigned)d), dim3(kBlock), 0, st, part, nblk, (int)d, r_out, coef + 514);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_sfa_stage2_f32(const float *X, const float *w, const float *r, int64_t n_rows, int64_t d, float *as_out, void *workspace, arl_stream_t stream) {
+    const int rc = sfa_stage_args(X, w, n_rows, d, workspace);
+    if (rc != ARL_OK) return rc;
+    if (!r || !as_out) return ARL_E_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    float *q = (float *)workspace, *s = q + n_rows, *part = s + n_rows;
+    const int64_t want = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int nblk = (int)(want < kSfaMaxBlocks ? want : kSfaMaxBlocks);
+    hipLaunchKernelGGL((sfa_reduce_pass_kernel<2>), dim3(nblk), dim3(kBlock), 0, st, X, w, r, (int)n_rows, (int)d, s, part);
+    ARL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sfa_fold_kernel, dim3((unsigned)d + 1), dim3(kBlock), 0, st, part, nblk, (int)d, as_out, as_out + d);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_sfa_stage3_f32(const float *X, const float *w, const float *r0, const float *r, const float *as, int64_t n_rows, int64_t d, int64_t numel_h,
+                       float scale, int32_t accumulate, float *loss_out, float *G, void *workspace, arl_stream_t stream) {
+    const int rc = sfa_stage_args(X, w, n_rows, d, workspace);
+    if (rc != ARL_OK) return rc;
+    if (!r0 || !r || !as || !loss_out) return ARL_E_NULL;
+    if (numel_h <= 0) return ARL_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    float *q = (float *)workspace, *s = q + n_rows, *part = s + n_rows, *coef = part + (size_t)kSfaMaxBlocks * kSfaStride;
+    hipError_t e = hipMemcpyAsync(coef, r, sizeof(float) * d, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(coef + 256, as, sizeof(float) * d, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(coef + 514, as + d, sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(sfa_finalize_kernel, dim3(1), dim3(kBlock), 0, st, (int)d, (float)(1.0 / (double)numel_h), coef, loss_out);
+    ARL_LAUNCH_CHECK();
+    if (G) {
+        const int64_t want = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+        hipLaunchKernelGGL(sfa_grad_kernel, dim3((unsigned)want), dim3(kBlock), 0, st, X, w, r0, q, s, coef, (int)n_rows, (int)d, scale, (int)accumulate, G);
+        ARL_LAUNCH_CHECK();
+    }
+    return ARL_OK;
+}
+
 int arl_sddmm_rows_dense_f32(const float *dY, const float *X, int64_t d, const int32_t *rows, int64_t n_rows_sel, int64_t col_off, int64_t n_cols,
                              float *out, arl_stream_t stream) {
     if (!dY || !X || !rows || !out) return ARL_E_NULL;

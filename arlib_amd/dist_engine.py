@@ -24,19 +24,55 @@ import numpy as np
 import torch
 
 
-class TorchDistComm:
-    """torch.distributed sum-all-reduce (NCCL backend = RCCL on ROCm)."""
+class _TimedWork:
+    """all_reduce handle whose wait() is bracketed by two events on the compute stream: their distance is the time the compute stream
+    stood still for the collective (exposed communication), whatever ran concurrently before."""
 
-    def __init__(self, group=None):
+    def __init__(self, work, comm):
+        self.work, self.comm = work, comm
+
+    def wait(self):
+        c = self.comm
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.work.wait()
+        e1.record()
+        c.waits.append((e0, e1))
+        return True
+
+
+class TorchDistComm:
+    """torch.distributed sum-all-reduce (NCCL backend = RCCL on ROCm).  measure=True records, for every wait on a collective, how long
+    the compute stream was blocked by it (exposed_ms() sums them after a synchronize; bench.py --gpus N prints it per rank)."""
+
+    def __init__(self, group=None, measure=False):
         import torch.distributed as dist
         self.dist, self.group = dist, group
+        self.measure = bool(measure)
+        self.waits = []
 
     def all_reduce_async(self, t):
-        return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        w = self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return _TimedWork(w, self) if self.measure else w
 
     def all_reduce(self, t):
+        if self.measure:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            e1.record()
+            self.waits.append((e0, e1))
+            return t
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
+
+    def exposed_ms(self, reset=True):
+        """Sum over the recorded waits of the compute-stream stall (call after torch.cuda.synchronize())."""
+        total = sum(a.elapsed_time(b) for a, b in self.waits)
+        n = len(self.waits)
+        if reset:
+            self.waits = []
+        return total, n
 
 
 def shard_bounds(n_users, world):
@@ -152,6 +188,157 @@ class ShardedPropagationEngine:
             cur, nxt = nxt, cur
         self.S.mul_(1.0 / (L + 1))
         return self.S
+
+    def forward_mean(self):
+        """forward() for either encoder family: mean of layers 0..L (LightGCN) or 1..L (skip_layer0: SimGCL, unperturbed)."""
+        if not self.skip0:
+            return self.forward()
+        L = self.L
+        cur, nxt = self.Ea, self.Eb
+        self._hop(self.E0, cur)
+        self.S.copy_(cur)
+        for _ in range(L - 1):
+            self._hop(cur, nxt)
+            self.S.add_(nxt)
+            cur, nxt = nxt, cur
+        self.S.mul_(1.0 / L)
+        return self.S
+
+    def backward_mean(self, G):
+        """dL/dE0 (local users + item replica) from dL/d(out) = G whose ITEM rows are per-rank partials: one I x d all-reduce completes
+        them, then the Horner form of the transposed mean (A symmetric): L hops, each with its item-row exchange."""
+        L = self.L
+        self.comm.all_reduce(G[self.Ul:])
+        bufs = [self.Ea, self.Eb]
+        acc = G
+        if self.skip0:                                    # (1/L) sum_{k=1..L} A^k G
+            for h in range(L - 1):
+                acc = self._hop(acc, bufs[h % 2], 1.0, 1.0, G)
+            return self._hop(acc, bufs[(L - 1) % 2], 1.0 / L)
+        s = 1.0 / (L + 1)                                 # (1/(L+1)) sum_{k=0..L} A^k G
+        for h in range(L):
+            a = s if h == L - 1 else 1.0
+            acc = self._hop(acc, bufs[h % 2], a, a, G, z_partial=False)
+        return acc
+
+    # ---- CLeaR's surrogate step (attack/White/CLeaR.py:73-129) on the user-sharded layout -- BASELINE config 4 (SimGCL + CLeaR, user-sharded):
+    # forward mean; every rank ranks ITS users against the replicated items (masked top-k, no exchange); the CW pairs (real user x target,
+    # negative = tail of that user's list) and the rows of H they generate belong to the user's rank, so
+    #   CW   = sum over ranks of local pair sums / (n_real T)             (1 scalar in the final all-reduce)
+    #   SFA  : the three weighted passes run on the local rows with the local multiplicities (users T; targets = local real users; negatives'
+    #          histogram), cut at the two global reductions r (d floats) and [a | S] (d + 1 floats)  -> 2 tiny all-reduces
+    #   dL/d(out): user rows complete on their owner, item rows per-rank partials -> the I x d all-reduce that opens backward_mean().
+    # Then Adam on the local user block + the item replica (identical on every rank).
+    def step_clear(self, targets, n_real, topk, mask_rowptr=None, mask_col=None, r0=None, warm_idx=None):
+        """targets: item ids; n_real: number of real users (global ids [0, n_real): the fake users are the last rows); mask_*: CSR of the
+        poisoned interactions over THIS rank's users; r0: the d-vector torch.randn(d) of CLeaR.py:100 (identical on every rank).
+        Returns (cw, sfa) as floats-on-device [2] and this rank's top-k lists."""
+        k, Ul, d, dev = self.k, self.Ul, self.d, self.device
+        T = len(targets)
+        out = self.forward_mean()
+        top_idx, _ = self.score_topk(out, min(int(topk), self.I), mask_rowptr, mask_col, warm_idx=warm_idx)
+        nl = int(min(max(int(n_real) - self.u0, 0), Ul))              # local real users: rows [0, nl)
+        tg = torch.as_tensor(list(targets), dtype=torch.int64, device=dev)
+        c = 1.0 / (float(n_real) * T)
+        G = torch.zeros_like(out)
+        w = torch.zeros(self.Nl, dtype=torch.float32, device=dev)
+        cw_local = torch.zeros((), dtype=torch.float32, device=dev)
+        if nl:
+            ue = out[:nl]
+            ranks = top_idx.shape[1] - 1 - torch.arange(T, device=dev)                  # successive .pop()s (CLeaR.py:84-88)
+            neg = top_idx[:nl][:, ranks].long()                                         # [nl, T]
+            tgt_rows = out[Ul + tg]                                                     # [T, d]
+            sum_u = ue.sum(0)
+            for t in range(T):
+                nrows = (neg[:, t] + Ul).to(torch.int32).contiguous()
+                ne = k.gather_rows(out, nrows, check_range=False)
+                cw_local = cw_local + c * ((ue * ne).sum() - (sum_u * tgt_rows[t]).sum())
+                G[:nl] += c * (ne - tgt_rows[t])
+                k.scatter_add_rows(G, nrows, ue.contiguous(), c, check_range=False)
+            G[Ul + tg] -= c * sum_u                                                     # every pair pulls its target: -c * sum of the local real users' rows
+            w[:nl] = float(T)
+            w[Ul:] = torch.bincount(neg.reshape(-1), minlength=self.I).to(torch.float32)
+            w[Ul + tg] += float(nl)
+        if r0 is None:
+            raise ValueError('step_clear: r0 must be given (the same d-vector on every rank)')
+        st = k.SfaStages(out.contiguous(), w, r0.to(dev, torch.float32).contiguous())
+        r = st.stage1(); self.comm.all_reduce(r)
+        a_s = st.stage2(r); self.comm.all_reduce(a_s)
+        sfa, _ = st.stage3(r, a_s, 3 * int(n_real) * T * d, out=G, scale=1.0, accumulate=True)
+        res = torch.stack([cw_local, torch.zeros((), device=dev)])
+        self.comm.all_reduce(res)
+        res[1] = sfa[0]
+        grad = self.backward_mean(G)
+        self.t += 1
+        k.adam_dense(self.E0, grad, self.m, self.v, self.lr, self.t, self.betas, self.eps)
+        return res, top_idx
+
+    # ---- NGCF (recommender/NGCF.py:197-212) on the user-sharded layout -- BASELINE config 5's training step.  Per layer ONE sparse hop
+    # P = A E (its item rows all-reduced, as every hop here) and a row-local dense part E' = leaky_relu((P + E) W1 + (P * E) W2) with the
+    # d x d weights REPLICATED; the item rows of E' are computed redundantly on every rank (they are replicas).  Backward: the weight
+    # gradients are sums over rows -> local user rows + (rank 0 only) the item rows, one [2d, d] all-reduce per layer; the table gradient
+    # goes back through the same hop (A symmetric).  Adam on the local user block, the item replica and the weight replicas.
+    def init_ngcf(self, W1s, W2s, slope=0.01):
+        """Attach the replicated layer weights (lists of [d, d] tensors, one pair per layer) and their Adam state."""
+        dev = self.device
+        self.W = [torch.cat([torch.as_tensor(a, dtype=torch.float32), torch.as_tensor(b, dtype=torch.float32)], 0).to(dev).contiguous() for a, b in zip(W1s, W2s)]
+        if len(self.W) != self.L or any(w.shape != (2 * self.d, self.d) for w in self.W):
+            raise ValueError('init_ngcf: one [d, d] pair of weights per layer')
+        self.Wm = [torch.zeros_like(w) for w in self.W]; self.Wv = [torch.zeros_like(w) for w in self.W]
+        self.slope = float(slope)
+
+    def step_ngcf(self, u, p, n):
+        k, L, Ul, d, dev = self.k, self.L, self.Ul, self.d, self.device
+        B = u.numel()
+        if not hasattr(self, 'W'):
+            raise ValueError('step_ngcf: call init_ngcf(W1s, W2s) first')
+        saved = []
+        ego = self.E0
+        acc = self.E0.clone()
+        for l in range(L):
+            P = self._hop(ego, torch.empty_like(ego))
+            ST = k.ngcf_combine(P, ego)
+            out_l = k.ngcf_act_(torch.mm(ST, self.W[l]), None, self.slope)
+            saved.append((ego, P, ST, out_l))
+            acc += out_l
+            ego = out_l
+        out = acc.mul_(1.0 / (L + 1))
+        lu, lp, ln = self._local_batch(u, p, n)
+        if self.ws is None or self.ws.numel() < 4 * max(B, 1):
+            self.ws = torch.empty(4 * max(B, 1), dtype=torch.float32, device=dev)
+        k.bpr_l2_partial(out, Ul, lu, lp, ln, B, self.ws, self.sums)
+        self.comm.all_reduce(self.sums)
+        nu_, np_ = torch.sqrt(self.sums[1]), torch.sqrt(self.sums[2])
+        self.loss_out[0] = self.sums[0] / B
+        self.loss_out[1] = self.reg * (nu_ + np_)
+        self.loss_out[2] = nu_
+        self.loss_out[3] = np_
+        G = torch.zeros_like(out)
+        if lu.numel():
+            k.bpr_l2_backward(out, Ul, lu, lp, ln, self.reg, self.loss_out, G, self.ws)
+        self.comm.all_reduce(G[Ul:])                                   # item rows: per-rank partials -> complete (replicated from here on)
+        G.mul_(1.0 / (L + 1))                                          # d(out)/d(layer_k) = 1/(L+1) for every layer
+        g_ego = G.clone()                                              # gradient reaching layer L's output
+        gWs = [None] * L
+        for l in range(L - 1, -1, -1):
+            ego_l, P, ST, out_l = saved[l]
+            gZ = k.ngcf_act_bwd(g_ego.contiguous(), out_l, self.slope)
+            # weight gradient: rows are partitioned (users) or replicated (items: counted on rank 0 only)
+            gW = torch.mm(ST[:Ul].t(), gZ[:Ul]) if Ul else torch.zeros(2 * d, d, device=dev)
+            if self.rank == 0:
+                gW = gW + torch.mm(ST[Ul:].t(), gZ[Ul:])
+            self.comm.all_reduce(gW)
+            gWs[l] = gW
+            gP, gE = k.ngcf_combine_bwd(torch.mm(gZ, self.W[l].t()), P, ego_l)
+            # g(ego_l) = A gP + gE (+ G/(L+1): layer l's own share of the mean); gP's item rows are replicas, so the hop's item-side partial
+            # sums over local users are completed by its all-reduce and gE / G are added after it
+            back = self._hop(gP.contiguous(), torch.empty_like(gP), 1.0, 1.0, gE, z_partial=False)
+            g_ego = back.add_(G)
+        self.t += 1
+        k.adam_dense(self.E0, g_ego, self.m, self.v, self.lr, self.t, self.betas, self.eps)
+        for l in range(L):
+            k.adam_dense(self.W[l], gWs[l].contiguous(), self.Wm[l], self.Wv[l], self.lr, self.t, self.betas, self.eps)
+        return self.loss_out
 
     def _local_batch(self, u, p, n):
         sel = (u >= self.u0) & (u < self.u1)

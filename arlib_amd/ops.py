@@ -856,6 +856,43 @@ def sfa_l1(X, w, r0, numel_h, want_grad=True, out=None, scale=1.0, accumulate=Fa
     return loss, G
 
 
+class SfaStages:
+    """arl_sfa_stage{1,2,3}_f32: the SFA L1 term of sfa_l1() cut at its two global reductions, for a table whose rows are partitioned over
+    ranks.  r = stage1(); all-reduce(r); a_s = stage2(r); all-reduce(a_s); loss, G = stage3(r, a_s)."""
+
+    def __init__(self, X, w, r0):
+        _dev(X, torch.float32, 'X', 2); _dev(w, torch.float32, 'w', 1); _dev(r0, torch.float32, 'r0', 1)
+        n, d = X.shape
+        if w.shape[0] != n or r0.shape[0] != d or n == 0 or d > 256:
+            raise ValueError('SfaStages: w must have one weight per row of X, r0 one entry per column, d <= 256')
+        self.X, self.w, self.r0, self.n, self.d = X, w, r0, n, d
+        self.ws = torch.empty(_lib.lib().arl_sfa_workspace_bytes(n, d) // 4, dtype=torch.float32, device=X.device)
+
+    def stage1(self):
+        r = torch.empty(self.d, dtype=torch.float32, device=self.X.device)
+        check(_lib.lib().arl_sfa_stage1_f32(_ptr(self.X), _ptr(self.w), _ptr(self.r0), self.n, self.d, _ptr(r), _ptr(self.ws), _stream()), 'arl_sfa_stage1_f32')
+        return r
+
+    def stage2(self, r):
+        _dev(r, torch.float32, 'r', 1)
+        a_s = torch.empty(self.d + 1, dtype=torch.float32, device=self.X.device)
+        check(_lib.lib().arl_sfa_stage2_f32(_ptr(self.X), _ptr(self.w), _ptr(r), self.n, self.d, _ptr(a_s), _ptr(self.ws), _stream()), 'arl_sfa_stage2_f32')
+        return a_s
+
+    def stage3(self, r, a_s, numel_h, out=None, scale=1.0, accumulate=False):
+        _dev(r, torch.float32, 'r', 1); _dev(a_s, torch.float32, 'a_s', 1)
+        if r.numel() != self.d or a_s.numel() != self.d + 1 or int(numel_h) <= 0:
+            raise ValueError('SfaStages.stage3: r[d], a_s[d + 1], numel_h > 0')
+        G = out if out is not None else torch.empty_like(self.X)
+        _dev(G, torch.float32, 'out', 2)
+        if G.shape != self.X.shape:
+            raise ValueError('SfaStages.stage3: out must have the shape of X')
+        loss = torch.empty(1, dtype=torch.float32, device=self.X.device)
+        check(_lib.lib().arl_sfa_stage3_f32(_ptr(self.X), _ptr(self.w), _ptr(self.r0), _ptr(r), _ptr(a_s), self.n, self.d, int(numel_h), float(scale),
+                                            int(bool(accumulate)), _ptr(loss), _ptr(G), _ptr(self.ws), _stream()), 'arl_sfa_stage3_f32')
+        return loss, G
+
+
 # ------------------------------------------------------------------------------------------------ attack primitives
 def sddmm_rows_dense(dY, X, rows, col_off, n_cols, out=None):
     _dev(dY, torch.float32, 'dY', 2); _dev(X, torch.float32, 'X', 2); _dev(rows, torch.int32, 'rows', 1)

@@ -297,6 +297,17 @@ int arl_ngcf_combine_bwd_f32(const float *gST, const float *P, const float *E, i
 int64_t arl_sfa_workspace_bytes(int64_t n_rows, int64_t d);
 int arl_sfa_l1_fwd_bwd_f32(const float *X, const float *w, const float *r0, int64_t n_rows, int64_t d, int64_t numel_h,
                            float scale, int32_t accumulate, float *loss_out, float *G, void *workspace, arl_stream_t stream);
+/* The same term cut at its two global reductions, for row sets partitioned over ranks (the user-sharded CLeaR surrogate step: the rows of H
+ * generated by a rank's own users -- their rows, the targets with weight = local real users, the local negatives' histogram): the caller
+ * sum-all-reduces r_out[d] after stage 1 and as_out[d + 1] = [a | S] after stage 2, then hands the reduced vectors to stage 3, which
+ * writes loss_out (the GLOBAL loss when numel_h is the global element count) and this rank's rows of G.  One workspace for all stages
+ * (arl_sfa_workspace_bytes).  stage1; stage2; stage3 without reductions = arl_sfa_l1_fwd_bwd_f32 (attack/White/CLeaR.py:98-125). */
+int arl_sfa_stage1_f32(const float *X, const float *w, const float *r0, int64_t n_rows, int64_t d, float *r_out, void *workspace,
+                       arl_stream_t stream);
+int arl_sfa_stage2_f32(const float *X, const float *w, const float *r, int64_t n_rows, int64_t d, float *as_out, void *workspace,
+                       arl_stream_t stream);
+int arl_sfa_stage3_f32(const float *X, const float *w, const float *r0, const float *r, const float *as, int64_t n_rows, int64_t d,
+                       int64_t numel_h, float scale, int32_t accumulate, float *loss_out, float *G, void *workspace, arl_stream_t stream);
 
 /* Gradient w.r.t. adjacency values restricted to `rows`, dense over the item block (the only entries PGA
  * uses; replaces autograd.grad(Loss, sparse_norm_adj) + to_dense() + slicing, attack/White/PGA.py:117-134):

@@ -144,3 +144,53 @@ def score_mask_topk(Pu, Pi, k, mask_rowptr=None, mask_col=None, exact=False, war
     mask = None if mask_rowptr is None else (mask_rowptr.numpy().astype(np.int64), mask_col.numpy())
     idx, val = O.score_mask_topk(Pu.numpy(), Pi.numpy(), k, mask)
     return torch.from_numpy(idx.astype(np.int32)), torch.from_numpy(val.astype(np.float32))
+
+
+class SfaStages:
+    """numpy restatement of arl_sfa_stage{1,2,3}_f32 (the weighted closed form that tests/test_oracle_attacks.py pins against the literal
+    reverse pass): partial sums over the given rows; the caller all-reduces between the stages."""
+
+    def __init__(self, X, w, r0):
+        self.X, self.w, self.r0 = X.numpy().astype(np.float64), w.numpy().astype(np.float64), r0.numpy().astype(np.float64)
+
+    def stage1(self):
+        self.q = self.X @ self.r0
+        return torch.from_numpy((self.X.T @ (self.w * self.q)).astype(np.float32))
+
+    def stage2(self, r):
+        rr = r.numpy().astype(np.float64)
+        self.s = self.X @ rr
+        a = self.X.T @ (self.w * np.sign(self.s))
+        return torch.from_numpy(np.concatenate([a, [(self.w * np.abs(self.s)).sum()]]).astype(np.float32))
+
+    def stage3(self, r, a_s, numel_h, out=None, scale=1.0, accumulate=False):
+        rr, a, S = r.numpy().astype(np.float64), a_s.numpy()[:-1].astype(np.float64), float(a_s.numpy()[-1])
+        A, Q = np.abs(rr).sum(), rr @ rr
+        g_r = ((A / Q) * a + (S / Q) * np.sign(rr) - (2 * S * A / Q ** 2) * rr) / numel_h
+        G = self.w[:, None] * ((A / (numel_h * Q)) * np.sign(self.s)[:, None] * rr[None, :] + self.q[:, None] * g_r[None, :] + (self.X @ g_r)[:, None] * self.r0[None, :])
+        G = torch.from_numpy((scale * G).astype(np.float32))
+        if out is not None:
+            out.copy_(out + G if accumulate else G)
+            G = out
+        return torch.tensor([S * A / (numel_h * Q)], dtype=torch.float32), G
+
+
+def ngcf_combine(P, E, out=None):
+    return torch.cat([P + E, P * E], 1)
+
+
+def ngcf_act_(Z, acc=None, slope=0.01):
+    Z.copy_(torch.where(Z > 0, Z, slope * Z))
+    if acc is not None:
+        acc.add_(Z)
+    return Z
+
+
+def ngcf_act_bwd(gOut, Out, slope=0.01):
+    return gOut * torch.where(Out > 0, torch.ones_like(Out), torch.full_like(Out, slope))
+
+
+def ngcf_combine_bwd(gST, P, E):
+    d = P.shape[1]
+    gS, gT = gST[:, :d], gST[:, d:]
+    return gS + gT * E, gS + gT * P

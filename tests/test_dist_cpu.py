@@ -166,3 +166,136 @@ def test_sharded_simgcl_step_gloo_matches_single_process_oracle(world):
     assert abs(ret['rec'] - ref_rec) <= RTOL * abs(ref_rec)
     assert abs(ret['cl'] - ref_cl) <= RTOL * abs(ref_cl)
     assert rel_err(ret['table'], ref_table) < RTOL
+
+
+# ---------------------------------------------------------------------------------------------- sharded attack / NGCF steps (BASELINE configs 4 and 5)
+def clear_problem(skip0):
+    U, I, d, _, pairs, E0, _ = small_problem()
+    rng = np.random.default_rng(9)
+    F, L, T, topk = 6, 2, 3, 10
+    n_real = U - F                                   # the last F users play the fake users (their rows are ordinary interaction rows here)
+    targets = [int(x) for x in rng.choice(I, T, replace=False)]
+    r0 = rng.standard_normal(d).astype(np.float32)
+    return U, I, d, L, pairs, E0, n_real, targets, topk, r0, skip0
+
+
+def oracle_clear_step(U, I, d, L, pairs, E0, n_real, targets, topk, r0, skip0):
+    """Single-process restatement of one CLeaR surrogate step with the oracle's pieces (the composition test_oracle_attacks pins on g7 / g19)."""
+    rowptr, col, w = O.bipartite_csr(pairs[:, 0], pairs[:, 1], U, I)
+    csr = (rowptr, col, O.norm_adj_values(rowptr, col, w))
+    out = O.lightgcn_forward(csr, E0, L, skip0=skip0)
+    idx, _ = O.score_mask_topk(out[:U], out[U:], topk, sp_mask(pairs, U, I, 0, U))
+    users, pos, neg = O.cw_pairs(idx, n_real, np.array(targets), pop=True)
+    cw, sfa, G = O.clear_loss_grad(out, U, users, pos, neg, r0)
+    grad = O.lightgcn_backward(csr, G, L, skip0=skip0)
+    m = np.zeros_like(E0); v = np.zeros_like(E0); E = E0.copy()
+    O.adam_step(E, grad, m, v, 0.005, 1)
+    return E, cw, sfa
+
+
+def _clear_worker(rank, world, port, ret, skip0):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import torch.distributed as dist
+    import cpu_kernels_shim as shim
+    from arlib_amd.dist_engine import ShardedPropagationEngine
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    U, I, d, L, pairs, E0, n_real, targets, topk, r0, _ = clear_problem(skip0)
+    eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cpu', rank, world, torch.from_numpy(E0), kernels=shim, skip_layer0=skip0)
+    m = sp_mask(pairs, U, I, eng.u0, eng.u1)
+    res, _ = eng.step_clear(targets, n_real, topk, torch.from_numpy(m[0].astype(np.int32)), torch.from_numpy(m[1]), r0=torch.from_numpy(r0))
+    full = eng.gather_full_table().numpy()
+    if rank == 0:
+        ret['table'], ret['cw'], ret['sfa'] = full, float(res[0]), float(res[1])
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,skip0', [(2, True), (3, True), (2, False)])
+def test_sharded_clear_step_gloo_matches_single_process_oracle(world, skip0):
+    """BASELINE config 4: the CLeaR surrogate step (CW + SFA through a SimGCL-shaped, skip-layer-0, or LightGCN-shaped mean) on user shards --
+    local masked top-k, local CW pairs, the SFA reductions cut at their two global sums, item-row gradient all-reduced -- equals the
+    single-process oracle composition."""
+    prob = clear_problem(skip0)
+    ref_table, ref_cw, ref_sfa = oracle_clear_step(*prob)
+    ret = mp.Manager().dict()
+    mp.spawn(_clear_worker, args=(world, free_port(), ret, skip0), nprocs=world, join=True)
+    assert abs(ret['cw'] - ref_cw) <= RTOL * abs(ref_cw) and abs(ret['sfa'] - ref_sfa) <= RTOL * abs(ref_sfa)
+    assert rel_err(ret['table'], ref_table) < RTOL
+
+
+def ngcf_problem():
+    U, I, d, _, pairs, E0, batches = small_problem()
+    rng = np.random.default_rng(13)
+    L = 2
+    W1 = [(rng.standard_normal((d, d)) * 0.3).astype(np.float32) for _ in range(L)]
+    W2 = [(rng.standard_normal((d, d)) * 0.3).astype(np.float32) for _ in range(L)]
+    return U, I, d, L, pairs, E0, batches[:2], W1, W2
+
+
+def torch_ngcf_steps(U, I, d, L, pairs, E0, batches, W1, W2, reg=1e-4, lr=0.005):
+    """Independent single-process reference: the reference's own layer expression (recommender/NGCF.py:197-212, both sparse hops) on a dense
+    fp64 adjacency with torch autograd and torch.optim.Adam."""
+    rowptr, col, w = O.bipartite_csr(pairs[:, 0], pairs[:, 1], U, I)
+    val = O.norm_adj_values(rowptr, col, w)
+    N = U + I
+    A = torch.zeros(N, N, dtype=torch.float64)
+    A[torch.from_numpy(np.repeat(np.arange(N), np.diff(rowptr))), torch.from_numpy(col.astype(np.int64))] = torch.from_numpy(val.astype(np.float64))
+    E = torch.nn.Parameter(torch.from_numpy(E0.astype(np.float64)))
+    Ws = [torch.nn.Parameter(torch.from_numpy(x.astype(np.float64))) for x in W1 + W2]
+    opt = torch.optim.Adam([E] + Ws, lr=lr)
+    losses = []
+    for bu, bp, bn in batches:
+        ego = E; layers = [ego]
+        for l in range(L):
+            t = ego @ Ws[l]
+            ego = torch.nn.functional.leaky_relu(A @ t + t + ((A @ ego) * ego) @ Ws[L + l])
+            layers.append(ego)
+        out = torch.stack(layers, 1).mean(1)
+        u, p, n = (torch.from_numpy(x.astype(np.int64)) for x in (bu, bp, bn))
+        ue, pe, ne = out[u], out[U + p], out[U + n]
+        loss = -torch.log(1e-7 + torch.sigmoid((ue * pe).sum(1) - (ue * ne).sum(1))).mean() + reg * (torch.norm(ue) + torch.norm(pe))
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(float(loss.detach()))
+    return E.detach().numpy(), [x.detach().numpy() for x in Ws], losses
+
+
+def _ngcf_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import torch.distributed as dist
+    import cpu_kernels_shim as shim
+    from arlib_amd.dist_engine import ShardedPropagationEngine
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    U, I, d, L, pairs, E0, batches, W1, W2 = ngcf_problem()
+    eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cpu', rank, world, torch.from_numpy(E0), kernels=shim)
+    eng.init_ngcf(W1, W2)
+    losses = []
+    for u, p, n in batches:
+        lo = eng.step_ngcf(torch.from_numpy(u), torch.from_numpy(p), torch.from_numpy(n))
+        losses.append(float(lo[0] + lo[1]))
+    full = eng.gather_full_table().numpy()
+    Wl = [w.numpy().copy() for w in eng.W]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, Wl[0])
+    if rank == 0:
+        ret['table'], ret['losses'], ret['W'] = full, losses, Wl
+        ret['w_replica_diff'] = float(max(np.abs(g - gathered[0]).max() for g in gathered))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_ngcf_steps_gloo_match_torch_autograd_reference(world):
+    """BASELINE config 5's training step: NGCF on user shards (one hop per layer with its item-row all-reduce, row-local dense part with
+    replicated weights, weight gradients all-reduced) against the reference's layer expression under torch autograd on a dense fp64 graph."""
+    prob = ngcf_problem()
+    ref_table, ref_W, ref_losses = torch_ngcf_steps(*prob)
+    ret = mp.Manager().dict()
+    mp.spawn(_ngcf_worker, args=(world, free_port(), ret), nprocs=world, join=True)
+    L, d = prob[3], prob[2]
+    assert np.allclose(ret['losses'], ref_losses, rtol=RTOL, atol=0)
+    assert rel_err(ret['table'], ref_table) < RTOL
+    for l in range(L):
+        assert rel_err(ret['W'][l][:d], ref_W[l]) < RTOL and rel_err(ret['W'][l][d:], ref_W[L + l]) < RTOL
+    assert ret['w_replica_diff'] == 0.0

@@ -119,3 +119,94 @@ def test_sharded_simgcl_two_ranks_hip_kernels():
     assert abs(ret['cl'] - ref_cl) <= RTOL * abs(ref_cl)
     assert rel_err(ret['table'], ref_table) < RTOL
     assert ret['replica_diff'] == 0.0
+
+
+def _clear_worker(rank, world, port, ret, skip0):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import torch.distributed as dist
+    from arlib_amd.dist_engine import ShardedPropagationEngine
+    from test_dist_cpu import clear_problem, sp_mask
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    U, I, d, L, pairs, E0, n_real, targets, topk, r0, _ = clear_problem(skip0)
+    eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cuda:0', rank, world, torch.from_numpy(E0), comm=HostStagedComm(), skip_layer0=skip0)
+    m = sp_mask(pairs, U, I, eng.u0, eng.u1)
+    res, _ = eng.step_clear(targets, n_real, topk, torch.from_numpy(m[0].astype(np.int32)).cuda(), torch.from_numpy(m[1]).cuda(), r0=torch.from_numpy(r0))
+    full = eng.gather_full_table().cpu().numpy()
+    if rank == 0:
+        ret['table'], ret['cw'], ret['sfa'] = full, float(res[0]), float(res[1])
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('skip0', [True, False])
+def test_sharded_clear_step_two_ranks_hip_kernels(skip0):
+    """BASELINE config 4 (SimGCL + CLeaR, user-sharded) with the real kernels: masked top-k per shard, staged SFA (arl_sfa_stage1/2/3),
+    item-row gradient exchange -- against the single-process oracle composition."""
+    if not torch.cuda.is_available():
+        pytest.fail('GPU tests need a GPU')
+    from test_dist_cpu import clear_problem, oracle_clear_step
+    ref_table, ref_cw, ref_sfa = oracle_clear_step(*clear_problem(skip0))
+    ret = _spawn(_clear_worker, (skip0,))
+    assert abs(ret['cw'] - ref_cw) <= RTOL * abs(ref_cw) and abs(ret['sfa'] - ref_sfa) <= RTOL * abs(ref_sfa)
+    assert rel_err(ret['table'], ref_table) < RTOL
+
+
+def _ngcf_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import torch.distributed as dist
+    from arlib_amd.dist_engine import ShardedPropagationEngine
+    from test_dist_cpu import ngcf_problem
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    U, I, d, L, pairs, E0, batches, W1, W2 = ngcf_problem()
+    eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cuda:0', rank, world, torch.from_numpy(E0), comm=HostStagedComm())
+    eng.init_ngcf(W1, W2)
+    losses = []
+    for u, p, n in batches:
+        lo = eng.step_ngcf(torch.from_numpy(u).cuda(), torch.from_numpy(p).cuda(), torch.from_numpy(n).cuda())
+        losses.append(float(lo[0] + lo[1]))
+    full = eng.gather_full_table().cpu().numpy()
+    if rank == 0:
+        ret['table'], ret['losses'], ret['W'] = full, losses, [w.cpu().numpy() for w in eng.W]
+    dist.destroy_process_group()
+
+
+def test_sharded_ngcf_two_ranks_hip_kernels():
+    """BASELINE config 5's training step (NGCF, user-sharded) with the real kernels against torch autograd on a dense fp64 graph."""
+    if not torch.cuda.is_available():
+        pytest.fail('GPU tests need a GPU')
+    from test_dist_cpu import ngcf_problem, torch_ngcf_steps
+    prob = ngcf_problem()
+    ref_table, ref_W, ref_losses = torch_ngcf_steps(*prob)
+    ret = _spawn(_ngcf_worker, ())
+    L, d = prob[3], prob[2]
+    assert np.allclose(ret['losses'], ref_losses, rtol=RTOL, atol=0)
+    assert rel_err(ret['table'], ref_table) < RTOL
+    for l in range(L):
+        assert rel_err(ret['W'][l][:d], ref_W[l]) < RTOL and rel_err(ret['W'][l][d:], ref_W[L + l]) < RTOL
+
+
+def test_sfa_stages_equal_monolithic_call():
+    """arl_sfa_stage1/2/3 chained without reductions = arl_sfa_l1_fwd_bwd_f32 bit for bit; split over two row blocks with the partial vectors
+    added in between = the same loss and gradient to rounding."""
+    if not torch.cuda.is_available():
+        pytest.fail('GPU tests need a GPU')
+    from arlib_amd import ops
+    g = torch.Generator().manual_seed(4)
+    n, d = 5000, 64
+    X = (torch.randn(n, d, generator=g) * 0.2).cuda(); w = torch.randint(0, 4, (n,), generator=g).float().cuda(); r0 = torch.randn(d, generator=g).cuda()
+    numel = int(w.sum().item()) * d
+    loss, G = ops.sfa_l1(X, w, r0, numel)
+    st = ops.SfaStages(X, w, r0)
+    r = st.stage1(); a_s = st.stage2(r)
+    loss2, G2 = st.stage3(r, a_s, numel)
+    assert torch.equal(loss, loss2) and torch.equal(G, G2)
+    h = 1777
+    sa, sb = ops.SfaStages(X[:h].contiguous(), w[:h].contiguous(), r0), ops.SfaStages(X[h:].contiguous(), w[h:].contiguous(), r0)
+    r = sa.stage1() + sb.stage1()
+    a_s = sa.stage2(r) + sb.stage2(r)
+    la, Ga = sa.stage3(r, a_s, numel); lb, Gb = sb.stage3(r, a_s, numel)
+    assert abs(la.item() - loss.item()) <= 1e-5 * abs(loss.item()) and la.item() == lb.item()
+    assert rel_err(torch.cat([Ga, Gb]).cpu().numpy(), G.cpu().numpy()) < 1e-5
