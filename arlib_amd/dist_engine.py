@@ -424,26 +424,27 @@ class ShardedPropagationEngine:
             k.spmm(self.Au, src, out=dst[:Ul])                 # exact user rows (gathers item rows of src)
             layers.append(dst)
         X = layers[-1]
-        self.C.zero_()
-        self.C[B:] = k.spmm_rows(self.Ai, X, item_rows, (), 1.0, check_range=False)     # partial; overlaps the last full all-reduce
+        # compact batch rows, already scaled by 1/(L+1): item rows = per-rank partial of the last hop (+ the layers' own rows, which are
+        # replicas: each added by one rank); user rows = complete on the owner, zero elsewhere.  One [3B, d] all-reduce completes them.
+        k.spmm_rows(self.Ai, X, item_rows, (), s, out=self.C[B:], check_range=False)     # gathers user rows only: overlaps the last full all-reduce
         if pending is not None:
             pending.wait()
+        for j, t in enumerate(layers):                    # replicated rows: layer j is contributed by rank j % world alone
+            if j % self.world == self.rank:
+                self.C[B:].add_(k.gather_rows(t, item_rows_packed, check_range=False), alpha=s)
         if Ul:
-            self.C[:B] = k.spmm_rows(self.Au, X, lu, [t[:Ul] for t in layers], 1.0, check_range=False) * ownf      # the owner contributes the row, others zeros
+            k.spmm_rows(self.Au, X, lu, [t[:Ul] for t in layers], s, out=self.C[:B], check_range=False)
+            self.C[:B].mul_(ownf)                                                 # the owner contributes the row, others zeros
+        else:
+            self.C[:B].zero_()
         self.comm.all_reduce(self.C)
-        for t in layers:
-            self.C[B:] += k.gather_rows(t, item_rows_packed, check_range=False)
-        self.C.mul_(s)
-        # loss on the whole batch (identical on every rank), compact per-sample gradients
+        # loss on the whole batch (identical on every rank), compact per-sample gradients; one launch puts them into G and marks the rows
+        # (foreign samples add exact zeros to a clamped local row)
         self.Gc.zero_()
         k.bpr_l2_fwd_bwd(self.C, B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self.ws, loss_out=self.loss_out, check_range=False)
-        if Ul:
-            k.scatter_add_rows(self.G, lu, self.Gc[:B] * ownf, 1.0, check_range=False)        # foreign samples add exact zeros to a clamped row
-            k.mark_rows_(self.flags, lu, 1, check_range=False)
-            k.mark_bits_(self.bits, lu, True, self.Nl, check_range=False)
-        k.scatter_add_rows(self.G, item_rows_packed, self.Gc[B:].contiguous(), 1.0, check_range=False)
-        k.mark_rows_(self.flags, item_rows_packed, 1, check_range=False)
-        k.mark_bits_(self.bits, item_rows_packed, True, self.Nl, check_range=False)
+        self.Gc[:B].mul_(ownf)
+        rows_l = torch.cat([lu, item_rows_packed])
+        k.batch_rows_set_(self.G, self.flags, self.bits, rows_l, self.Gc, 1.0, check_range=False)
         # backward (Horner).  hop 1: flag-masked gathers; later hops dense; G (complete on the item side) added through flags
         self.t += 1
         zu = self.flags[:Ul]
@@ -469,14 +470,7 @@ class ShardedPropagationEngine:
         pending.wait()
         prev_items.add_(self.G[Ul:], alpha=prev_a)
         k.adam_dense(self.E0[Ul:], acc[Ul:], self.m[Ul:], self.v[Ul:], self.lr, self.t, self.betas, self.eps)
-        # clear the sparse state
-        if Ul:
-            k.zero_rows_(self.G, lu, check_range=False)
-            k.mark_rows_(self.flags, lu, 0, check_range=False)
-            k.mark_bits_(self.bits, lu, False, self.Nl, check_range=False)
-        k.zero_rows_(self.G, item_rows_packed, check_range=False)
-        k.mark_rows_(self.flags, item_rows_packed, 0, check_range=False)
-        k.mark_bits_(self.bits, item_rows_packed, False, self.Nl, check_range=False)
+        k.batch_rows_clear_(self.G, self.flags, self.bits, rows_l, check_range=False)      # clear the sparse state
         return self.loss_out
 
     # ---- SimGCL (recommender/SimGCL.py:51-63,198-219) on the user-sharded layout -- BASELINE config 4's training step.

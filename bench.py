@@ -399,6 +399,26 @@ def main():
     ev.on = False
     ops.EVENT_HOOK = None
     loss = float(lo[0] + lo[1])
+    comm_diag = None
+    if sharded:
+        # diagnostic region (not part of any reported time): the same steps with an event pair around every wait on a collective -- per rank,
+        # how long the compute stream stood still for communication in one step
+        eng.comm.measure = True
+        eng.comm.waits = []
+        nd = min(args.steps, 10)
+        torch.cuda.synchronize(); barrier()
+        td = time.perf_counter()
+        for k in range(args.warmup, args.warmup + nd):
+            step(k)
+        torch.cuda.synchronize()
+        td = time.perf_counter() - td
+        ex_ms, n_waits = eng.comm.exposed_ms()
+        eng.comm.measure = False
+        import torch.distributed as dist
+        mine = {'rank': rank, 'exposed_comm_ms_per_step': ex_ms / nd, 'waits_per_step': n_waits / nd, 'ms_per_step_in_this_region': 1e3 * td / nd}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        comm_diag = allr
     # further timed regions of the same K steps (same batches again: the step's cost does not depend on the table values), each bracketed
     # like the first; `value` stays the first region (the contract), the list shows how repeatable it is
     region_s = [dt]
@@ -465,6 +485,9 @@ def main():
                                    'gather_model_bytes_per_launch': E * (8 + 4 * d) + 4 * N * d}
             else:
                 res['spmm_events_ms'] = {k: v[0] for k, v in evs.items()}
+        if comm_diag is not None:
+            res['communication'] = {'per_rank': comm_diag, 'note': 'separate diagnostic region: event pairs around every wait on an all-reduce; exposed = time the '
+                                    'compute stream was blocked by the collective (0 = fully hidden behind the SpMM kernels)'}
         if not sharded:
             # A/B: the reference-shaped step (all 2L hops over the full graph), same engine state, few steps
             other = (lambda k: eng.step(dev_batches[k, 0], dev_batches[k, 1], dev_batches[k, 2], rows=dev_rows[k])) if args.dense_step else \

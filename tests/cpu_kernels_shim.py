@@ -194,3 +194,15 @@ def ngcf_combine_bwd(gST, P, E):
     d = P.shape[1]
     gS, gT = gST[:, :d], gST[:, d:]
     return gS + gT * E, gS + gT * P
+
+
+def batch_rows_set_(G, flags, bits, idx, src, scale=1.0, check_range=True):
+    scatter_add_rows(G, idx, src, scale)
+    mark_rows_(flags, idx, 1)
+    mark_bits_(bits, idx, True, G.shape[0])
+
+
+def batch_rows_clear_(G, flags, bits, idx, check_range=True):
+    zero_rows_(G, idx)
+    mark_rows_(flags, idx, 0)
+    mark_bits_(bits, idx, False, G.shape[0])
