@@ -54,6 +54,8 @@ _SIGS = {
     'arl_spmm_blocked_layersum_f32': (C.c_int, [C.POINTER(arl_blocked), _vp, _i64, _vp, _vp, _vp, _vp]),
     'arl_spmm_blocked_adam_f32': (C.c_int, [C.POINTER(arl_blocked), _vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),
     'arl_lpt_deal': (C.c_int, [_i64, _vp, _i64, _i64, _vp, _vp]),
+    'arl_syn_v1_pairs': (_i64, [_i64, _i64, C.c_double, C.c_uint64, C.c_double, _i64, _i64, _vp, _i64]),
+    'arl_graph_digest': (C.c_uint64, [_vp, _i64]),
     'arl_spmm_tiled_f32': (C.c_int, [C.POINTER(arl_tiled), _vp, _i64, _f, _f, _vp, _vp, _vp, _vp]),
     'arl_spmm_tiled_adam_f32': (C.c_int, [C.POINTER(arl_tiled), _vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),
     'arl_spmm_csr_flagged_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _vp, _f, _f, _vp, _vp, _vp, _vp]),

@@ -9,6 +9,8 @@
 #include <cstdint>
 #include <cstddef>
 #include <queue>
+#include <cmath>
+#include <algorithm>
 #include <utility>
 #include <vector>
 #include "arlib_amd.h"
@@ -181,6 +183,78 @@ int arl_lpt_deal(int64_t n, const int32_t *weight_desc, int64_t n_bins, int64_t 
         if (fill[top.second] < cap) open.push(Load(top.first + weight_desc[r], top.second));
     }
     return ARL_OK;
+}
+
+// ---- SYN-v1: the synthetic interaction graphs of the benchmark, generated natively.  Every random number is a counter-based hash
+//   h(stream, index) = splitmix64(splitmix64(seed ^ stream * PHI) ^ index)
+// so this generator and the numpy one (arlib_amd/util/synthetic.py) emit the same pair list, checked by arl_graph_digest.
+static inline uint64_t syn_splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static inline uint64_t syn_hash(uint64_t base, uint64_t index) { return syn_splitmix64(index ^ base); }
+static inline uint64_t syn_base(uint64_t seed, uint64_t stream) { return syn_splitmix64(seed ^ (stream * 0x9E3779B97F4A7C15ull)); }
+static inline double syn_uniform(uint64_t h) { return ((double)(h >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+
+/* Writes the user-major sorted, de-duplicated (user, item) pairs into pairs_out [capacity][2] and returns their number (or the number
+ * needed, without writing, when pairs_out is NULL or capacity is too small); negative = argument error. */
+int64_t arl_syn_v1_pairs(int64_t n_users, int64_t n_items, double mean_deg, uint64_t seed, double sigma, int64_t deg_min, int64_t deg_max,
+                         int32_t *pairs_out, int64_t capacity) {
+    if (n_users <= 0 || n_items <= 0 || n_users > 0x7fffffffll || n_items > 0x7fffffffll || !(mean_deg > 0) || !(sigma >= 0) || deg_min < 0 || deg_max < deg_min)
+        return ARL_E_ARG;
+    const uint64_t b1 = syn_base(seed, 1), b2 = syn_base(seed, 2), b3 = syn_base(seed, 3), b4 = syn_base(seed, 4), b5 = syn_base(seed, 5);
+    const double mu = std::log(mean_deg) - 0.5 * sigma * sigma;
+    const double two_pi = 2.0 * 3.14159265358979323846;
+    const int64_t hi = deg_max < n_items ? deg_max : n_items;
+    std::vector<int64_t> deg((size_t)n_users);
+    int64_t total = 0;
+    for (int64_t u = 0; u < n_users; ++u) {
+        const double u1 = syn_uniform(syn_hash(b1, (uint64_t)u)), u2 = syn_uniform(syn_hash(b2, (uint64_t)u));
+        const double z = std::sqrt(-2.0 * std::log(u1)) * std::cos(two_pi * u2);
+        double dg = std::nearbyint(std::exp(mu + sigma * z));          // numpy rint: round half to even (default FP environment)
+        if (dg < (double)deg_min) dg = (double)deg_min;
+        if (dg > (double)hi) dg = (double)hi;
+        deg[(size_t)u] = (int64_t)dg;
+        total += deg[(size_t)u];
+    }
+    // pi = stable argsort of h(4, j)
+    std::vector<std::pair<uint64_t, int64_t>> hp((size_t)n_items);
+    for (int64_t j = 0; j < n_items; ++j) hp[(size_t)j] = std::make_pair(syn_hash(b4, (uint64_t)j), j);
+    std::stable_sort(hp.begin(), hp.end(), [](const std::pair<uint64_t, int64_t> &a, const std::pair<uint64_t, int64_t> &b) { return a.first < b.first; });
+    std::vector<int64_t> keys;
+    keys.reserve((size_t)(total + n_items));
+    int64_t k = 0;
+    for (int64_t u = 0; u < n_users; ++u)
+        for (int64_t t = 0; t < deg[(size_t)u]; ++t, ++k) {
+            const double r = syn_uniform(syn_hash(b3, (uint64_t)k));
+            int64_t pos = (int64_t)((double)n_items * r * r);
+            if (pos > n_items - 1) pos = n_items - 1;
+            keys.push_back(u * n_items + hp[(size_t)pos].second);
+        }
+    for (int64_t j = 0; j < n_items; ++j) keys.push_back((int64_t)(syn_hash(b5, (uint64_t)j) % (uint64_t)n_users) * n_items + j);      // no isolated item
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    const int64_t nnz = (int64_t)keys.size();
+    if (!pairs_out || capacity < nnz) return nnz;
+    for (int64_t e = 0; e < nnz; ++e) {
+        pairs_out[2 * e] = (int32_t)(keys[(size_t)e] / n_items);
+        pairs_out[2 * e + 1] = (int32_t)(keys[(size_t)e] % n_items);
+    }
+    return nnz;
+}
+
+/* Order-sensitive 64-bit digest of a pair list (the numpy twin is synthetic.graph_digest). */
+uint64_t arl_graph_digest(const int32_t *pairs, int64_t n) {
+    uint64_t acc = 0;
+    if (pairs)
+        for (int64_t e = 0; e < n; ++e) {
+            const uint64_t a = (uint64_t)(int64_t)pairs[2 * e], b = (uint64_t)(int64_t)pairs[2 * e + 1];
+            acc ^= syn_splitmix64((a * 0x100000001B3ull) ^ syn_splitmix64(b) ^ (uint64_t)e);
+        }
+    return acc ^ (uint64_t)(n > 0 ? n : 0);
 }
 
 }  // extern "C"

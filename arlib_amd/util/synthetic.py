@@ -63,6 +63,25 @@ def syn_v1_pairs(n_users, n_items, mean_deg=32.0, seed=2018, sigma=1.0, deg_min=
     return pairs
 
 
+def syn_v1_pairs_native(n_users, n_items, mean_deg=32.0, seed=2018, sigma=1.0, deg_min=4, deg_max=2048):
+    """The same pair list from the C++ generator in libarlib_amd.so (arl_syn_v1_pairs): int32 [nnz, 2]."""
+    from .. import _lib
+    L = _lib.lib()
+    need = L.arl_syn_v1_pairs(int(n_users), int(n_items), float(mean_deg), int(seed), float(sigma), int(deg_min), int(deg_max), None, 0)
+    if need < 0:
+        raise ValueError('arl_syn_v1_pairs: bad arguments (%d)' % need)
+    out = np.empty((need, 2), np.int32)
+    got = L.arl_syn_v1_pairs(int(n_users), int(n_items), float(mean_deg), int(seed), float(sigma), int(deg_min), int(deg_max), out.ctypes.data, need)
+    assert got == need
+    return out
+
+
+def graph_digest_native(pairs):
+    from .. import _lib
+    p = np.ascontiguousarray(pairs, dtype=np.int32)
+    return int(_lib.lib().arl_graph_digest(p.ctypes.data, len(p)))
+
+
 def graph_digest(pairs):
     """Order-sensitive 64-bit digest of the pair list (cross-implementation check)."""
     p = np.ascontiguousarray(pairs, dtype=np.int32).astype(np.uint64)

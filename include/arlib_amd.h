@@ -186,6 +186,16 @@ int arl_spmm_blocked_adam_f32(const arl_blocked *P, const float *X, int64_t d, f
  * slot (cap slots each); bin_out / slot_out receive the placement. */
 int arl_lpt_deal(int64_t n, const int32_t *weight_desc, int64_t n_bins, int64_t cap, int32_t *bin_out, int32_t *slot_out);
 
+/* SYN-v1, the benchmark's synthetic interaction graphs (no reference counterpart: ARLib ships fixed datasets, data/clean/),
+ * generated natively.  Every random number is a counter-based hash h(stream, index) = splitmix64(splitmix64(seed ^ stream * PHI) ^ index):
+ * log-normal user degrees (streams 1, 2), item draws with popularity density ~ x^-1/2 through a hash-derived item permutation (streams 3, 4),
+ * one extra edge per item so that none is isolated (stream 5); user-major sorted, de-duplicated int32 (user, item) pairs.  Returns the pair
+ * count; writes nothing and returns the count needed when pairs_out is NULL or capacity is too small.  arl_graph_digest is the
+ * order-sensitive checksum both this generator and the numpy one (arlib_amd/util/synthetic.py) are compared by. */
+int64_t arl_syn_v1_pairs(int64_t n_users, int64_t n_items, double mean_deg, uint64_t seed, double sigma, int64_t deg_min, int64_t deg_max,
+                         int32_t *pairs_out, int64_t capacity);
+uint64_t arl_graph_digest(const int32_t *pairs, int64_t n);
+
 /* L2-blocked ("tiled") SpMM: same results as arl_spmm_csr_f32 / _adam_f32 on the same adjacency, different schedule.
  * Output rows are dealt into BINS of <= cap rows with equal edge counts; one persistent workgroup per CU keeps a bin's fp32
  * accumulators in LDS for a sweep and walks column blocks of `col_block` rows in ascending order, so the gathered rows of X

@@ -31,6 +31,14 @@ def cfg2():
     return dict(data=data, U=U, I=I, nnz=nnz, rowptr=rowptr, col=col, A=A, Ab=Ab, dinv=dinv, ops=ops)
 
 
+def test_cfg2_graph_is_the_same_from_both_generators(cfg2):
+    """The benchmark graph itself: numpy and C++ SYN-v1 generators agree at the full size (32 095 419 pairs, cross-language digest)."""
+    from arlib_amd.util import synthetic as S
+    p = cfg2['data'].pairs0
+    q = S.syn_v1_pairs_native(cfg2['U'], cfg2['I'], 32.0, 2018)
+    assert len(p) == 32_095_419 and np.array_equal(p, q) and S.graph_digest(p) == S.graph_digest_native(q)
+
+
 def test_normalised_adjacency_fixed_point(cfg2):
     ops, A = cfg2['ops'], cfg2['A']
     deg = torch.from_numpy(np.diff(cfg2['rowptr']).astype(np.float32)).to(DEV)

@@ -447,3 +447,14 @@ def test_array_native_dataloader_at_scale_builds_in_seconds():
     row = pairs[pairs[:, 0] == int(u0), 1]
     assert list(d.training_set_u[u0]) == [str(x) for x in row.tolist()]
     assert d.matrix().nnz == len(pairs) and d.norm_adj.shape == (120_000, 120_000)
+
+
+def test_syn_v1_native_generator_equals_numpy_generator():
+    """the C++ SYN-v1 generator (arl_syn_v1_pairs) and the numpy one emit the same pair list -- compared element-wise and through
+    the cross-language digest (arl_graph_digest / synthetic.graph_digest) -- for several sizes, seeds and degree laws."""
+    from arlib_amd.util import synthetic as S
+    for U, I, kw in ((3000, 400, {}), (20000, 3000, dict(mean_deg=12.0, seed=7)), (100_000, 20_000, {}), (1500, 50, dict(mean_deg=40.0, seed=3, sigma=0.5, deg_min=1, deg_max=64))):
+        a, b = S.syn_v1_pairs(U, I, **kw), S.syn_v1_pairs_native(U, I, **kw)
+        assert np.array_equal(a, b)
+        assert S.graph_digest(a) == S.graph_digest_native(b) == S.graph_digest_native(a)
+    assert S.graph_digest_native(a[::-1].copy()) != S.graph_digest_native(a)           # order-sensitive
