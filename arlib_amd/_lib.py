@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ARLIB_AMD_LIB') or os.path.join(_HERE, 'lib', 'libarlib_amd.so')      # override: developer builds (e.g. `make prof`)
-ABI_VERSION = 12
+ABI_VERSION = 13
 _lib = None
 
 
@@ -81,6 +81,10 @@ _SIGS = {
     'arl_ngcf_act_f32': (C.c_int, [_vp, _vp, _i64, _i64, _f, _vp]),
     'arl_ngcf_act_bwd_f32': (C.c_int, [_vp, _vp, _i64, _i64, _f, _vp, _vp]),
     'arl_ngcf_combine_bwd_f32': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    'arl_ngcf_dense_fwd_f32': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _f, _vp, _vp]),
+    'arl_ngcf_dense_dgrad_f32': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f, _vp, _vp, _vp, _vp]),
+    'arl_ngcf_wgrad_workspace_bytes': (_i64, [_i64, _i64]),
+    'arl_ngcf_dense_wgrad_f32': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     'arl_sfa_workspace_bytes': (_i64, [_i64, _i64]),
     'arl_sfa_l1_fwd_bwd_f32': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _f, C.c_int32, _vp, _vp, _vp, _vp]),
     'arl_sfa_stage1_f32': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),

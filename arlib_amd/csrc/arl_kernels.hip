@@ -958,6 +958,187 @@ __global__ __launch_bounds__(kBlock) void ngcf_combine_bwd_kernel(const float4 *
     }
 }
 
+
+// ================================================================================================
+// NGCF dense layer on the matrix cores (recommender/NGCF.py:200-208), fp32 in / fp32 out with v_mfma_f32_16x16x4_f32 (exact fp32
+// products, fp32 accumulation): the layer's  Z = (P + E) W1 + (P * E) W2  is a [N, 2d] x [2d, d] product whose left operand is never
+// materialised -- a wave owns 16 rows, forms S = P + E and T = P * E in registers from one float4 per lane and operand, and streams the
+// d x d weights from LDS (row stride d + 4 floats: the four k-groups of a wave read four disjoint bank quarters).  The K order inside a
+// group of 16 is permuted so that lane (row, q) feeds k = 16 g + 4 q + j in step j: its float4 needs no shuffle; B is read to match.
+//   forward  : out = leaky_relu(Z)                                   reads P, E once, writes out once (was: 3 passes + a library GEMM)
+//   dgrad    : gZ = gOut * act'(out);  [gS | gT] = gZ [W1; W2]^T;  gP = gS + gT * E;  gE = gS + gT * P     (gZ is kept for wgrad)
+//   wgrad    : [gW1; gW2] = [S | T]^T gZ   per workgroup over its row tiles (4 waves split the 2d/16 row tiles of gW), partials summed
+//              in a fixed order by a second kernel (deterministic)
+// ================================================================================================
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int kNgcfBlock = 256;
+
+template <int D>
+__device__ __forceinline__ void ngcf_stage_weights(float *Wl, const float *__restrict__ W, int rows) {
+    constexpr int S = D + 4;
+    for (int t = threadIdx.x; t < rows * D; t += kNgcfBlock) Wl[(t / D) * S + (t % D)] = W[t];
+    __syncthreads();
+}
+
+template <int D>
+__global__ __launch_bounds__(kNgcfBlock) void ngcf_dense_fwd_kernel(const float *__restrict__ P, const float *__restrict__ E, const float *__restrict__ W,
+                                                                     long long n_rows, float slope, float *__restrict__ out) {
+    constexpr int S = D + 4, NT = D / 16, KG = D / 16;
+    extern __shared__ float Wl[];                           // [2 D][S]: W1 rows then W2 rows
+    ngcf_stage_weights<D>(Wl, W, 2 * D);
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const long long n_tiles = (n_rows + 15) / 16;
+    for (long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += (long long)gridDim.x * 4) {
+        const long long r = tile * 16 + c;
+        const bool rv = r < n_rows;
+        f32x4v acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int g = 0; g < KG; ++g) {
+            float4 p = make_float4(0.f, 0.f, 0.f, 0.f), e = p;
+            if (rv) { p = *reinterpret_cast<const float4 *>(P + r * D + 16 * g + 4 * q); e = *reinterpret_cast<const float4 *>(E + r * D + 16 * g + 4 * q); }
+            const float sv[4] = {p.x + e.x, p.y + e.y, p.z + e.z, p.w + e.w}, tv[4] = {p.x * e.x, p.y * e.y, p.z * e.z, p.w * e.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float *w1 = Wl + (16 * g + 4 * q + j) * S + c, *w2 = w1 + D * S;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[j], w1[16 * nt], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(tv[j], w2[16 * nt], acc[nt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long long row = tile * 16 + 4 * q + i;
+                const float z = acc[nt][i];
+                if (row < n_rows) out[row * D + 16 * nt + c] = z > 0.f ? z : z * slope;
+            }
+    }
+}
+
+// Wt = [W1; W2]^T, i.e. [D][2 D] row-major: the B operand of gZ [W1; W2]^T read exactly like the forward's
+template <int D>
+__global__ __launch_bounds__(kNgcfBlock) void ngcf_dense_dgrad_kernel(const float *__restrict__ gOut, const float *__restrict__ Out, const float *__restrict__ P,
+                                                                       const float *__restrict__ E, const float *__restrict__ Wt, long long n_rows, float slope,
+                                                                       float *__restrict__ gZ, float *__restrict__ gP, float *__restrict__ gE) {
+    constexpr int D2 = 2 * D, S = D2 + 4, NT = D2 / 16, KG = D / 16;
+    extern __shared__ float Wl[];                           // [D][S]
+    for (int t = threadIdx.x; t < D * D2; t += kNgcfBlock) Wl[(t / D2) * S + (t % D2)] = Wt[t];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const long long n_tiles = (n_rows + 15) / 16;
+    for (long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += (long long)gridDim.x * 4) {
+        const long long r = tile * 16 + c;
+        const bool rv = r < n_rows;
+        f32x4v acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int g = 0; g < KG; ++g) {
+            float4 go = make_float4(0.f, 0.f, 0.f, 0.f), o = go;
+            if (rv) { go = *reinterpret_cast<const float4 *>(gOut + r * D + 16 * g + 4 * q); o = *reinterpret_cast<const float4 *>(Out + r * D + 16 * g + 4 * q); }
+            const float4 gz = make_float4(go.x * (o.x > 0.f ? 1.f : slope), go.y * (o.y > 0.f ? 1.f : slope), go.z * (o.z > 0.f ? 1.f : slope), go.w * (o.w > 0.f ? 1.f : slope));
+            if (rv) *reinterpret_cast<float4 *>(gZ + r * D + 16 * g + 4 * q) = gz;
+            const float zv[4] = {gz.x, gz.y, gz.z, gz.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float *w = Wl + (16 * g + 4 * q + j) * S + c;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(zv[j], w[16 * nt], acc[nt], 0, 0, 0);
+            }
+        }
+        // tiles [0, D/16) hold gS, tiles [D/16, 2D/16) hold gT, both in the C layout: rows 4 q + i, column 16 nt + c
+#pragma unroll
+        for (int nt = 0; nt < D / 16; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long long row = tile * 16 + 4 * q + i;
+                if (row < n_rows) {
+                    const long long o = row * D + 16 * nt + c;
+                    const float gs = acc[nt][i], gt = acc[nt + D / 16][i];
+                    gP[o] = fmaf(gt, E[o], gs);
+                    gE[o] = fmaf(gt, P[o], gs);
+                }
+            }
+    }
+}
+
+// [gW1; gW2] partial of one workgroup.  A = [S | T]^T tile (M = 16 rows of gW, K = 4 data rows), B = gZ tile (K = 4 data rows, N = 16 columns of
+// gW).  M and N indices are PERMUTED so that one 16-B load per lane serves CP = D/16 tiles: lane c holds columns [c CP, (c + 1) CP) of its data row
+// (a full 256-B row per 16 lanes, coalesced), and tile t covers the columns {c CP + t}.  Every wave forms S, T for all 2 CP row tiles of gW
+// and owns the column tiles t = wave, wave + 4, ... (one gZ scalar per K step each).
+template <int D>
+__global__ __launch_bounds__(kNgcfBlock) void ngcf_dense_wgrad_kernel(const float *__restrict__ P, const float *__restrict__ E, const float *__restrict__ gZ,
+                                                                       long long n_rows, float *__restrict__ partial) {
+    constexpr int CP = D / 16, NPW = (CP + 3) / 4;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
+    f32x4v acc[2 * CP][NPW];
+#pragma unroll
+    for (int a = 0; a < 2 * CP; ++a)
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) acc[a][n] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    const long long n_tiles = (n_rows + 15) / 16;
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {                                   // K step: data rows tile * 16 + 4 st + q
+            const long long row = tile * 16 + 4 * st + q;
+            const bool rv = row < n_rows;
+            float sv[CP], tv[CP], bv[NPW];
+#pragma unroll
+            for (int k = 0; k < CP; ++k) {
+                const float pv = rv ? P[row * D + c * CP + k] : 0.f, ev = rv ? E[row * D + c * CP + k] : 0.f;      // CP consecutive floats: vectorised by the compiler
+                sv[k] = pv + ev; tv[k] = pv * ev;
+            }
+#pragma unroll
+            for (int n = 0; n < NPW; ++n) { const int t = wave + 4 * n; bv[n] = (rv && t < CP) ? gZ[row * D + c * CP + t] : 0.f; }
+#pragma unroll
+            for (int n = 0; n < NPW; ++n)
+                if (wave + 4 * n < CP) {
+#pragma unroll
+                    for (int k = 0; k < CP; ++k) {
+                        acc[k][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[k], bv[n], acc[k][n], 0, 0, 0);
+                        acc[CP + k][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(tv[k], bv[n], acc[CP + k][n], 0, 0, 0);
+                    }
+                }
+        }
+    }
+    // C layout: acc[a][n][i] = gW[row m, column nn] with m = (4 q + i) CP + (a mod CP) (+ D for the T half), nn = c CP + (wave + 4 n)
+    float *dst = partial + (size_t)blockIdx.x * 2 * D * D;
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+        const int t = wave + 4 * n;
+        if (t < CP)
+#pragma unroll
+            for (int a = 0; a < 2 * CP; ++a)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = (a < CP ? 0 : D) + (4 * q + i) * CP + (a % CP);
+                    dst[m * D + c * CP + t] = acc[a][n][i];
+                }
+    }
+}
+
+// gW[e] = sum over the partials, in a fixed order: 16 elements x 16 partial lanes per workgroup, then an LDS tree
+__global__ __launch_bounds__(kBlock) void ngcf_wgrad_fold_kernel(const float *__restrict__ partial, int n_part, int n_elem, float *__restrict__ gW) {
+    __shared__ float red[16][17];
+    const int e = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int t = blockIdx.x * 16 + e;
+    float s = 0.f;
+    if (t < n_elem)
+        for (int b = pl; b < n_part; b += 16) s += partial[(size_t)b * n_elem + t];
+    red[pl][e] = s;
+    __syncthreads();
+    if (pl == 0 && t < n_elem) {
+        float r = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r += red[k][e];
+        gW[t] = r;
+    }
+}
 // ================================================================================================
 // SimGCL perturbation (recommender/SimGCL.py:203-205)
 // ================================================================================================
@@ -2067,6 +2248,80 @@ int arl_ngcf_combine_bwd_f32(const float *gST, const float *P, const float *E, i
     ARL_LAUNCH_CHECK();
     return ARL_OK;
 }
+
+static int ngcf_dense_args(int64_t n, int64_t d) {
+    if (n < 0 || n > 0x7fffffffll * 16) return ARL_E_RANGE;
+    if (d != 16 && d != 32 && d != 64 && d != 128) return ARL_E_DIM;
+    return ARL_OK;
+}
+
+int arl_ngcf_dense_fwd_f32(const float *P, const float *E, const float *W, int64_t n, int64_t d, float slope, float *out, arl_stream_t stream) {
+    if (!P || !E || !W || !out) return ARL_E_NULL;
+    const int rc = ngcf_dense_args(n, d);
+    if (rc != ARL_OK) return rc;
+    if (n == 0) return ARL_OK;
+    const int64_t tiles = (n + 15) / 16;
+    const unsigned grid = (unsigned)((tiles + 3) / 4 < 2048 ? (tiles + 3) / 4 : 2048);
+    const size_t shm = sizeof(float) * 2 * (size_t)d * (size_t)(d + 4);
+#define ARL_NGCF_FWD(DV)                                                                                                                         \
+    do {                                                                                                                                         \
+        hipError_t e1 = hipFuncSetAttribute((const void *)ngcf_dense_fwd_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);     \
+        if (e1 != hipSuccess) return (int)e1;                                                                                                    \
+        hipLaunchKernelGGL((ngcf_dense_fwd_kernel<DV>), dim3(grid), dim3(kNgcfBlock), shm, (hipStream_t)stream, P, E, W, (long long)n, slope, out); \
+    } while (0)
+    if (d == 16) ARL_NGCF_FWD(16); else if (d == 32) ARL_NGCF_FWD(32); else if (d == 64) ARL_NGCF_FWD(64); else ARL_NGCF_FWD(128);
+#undef ARL_NGCF_FWD
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_ngcf_dense_dgrad_f32(const float *gOut, const float *Out, const float *P, const float *E, const float *Wt, int64_t n, int64_t d, float slope,
+                             float *gZ, float *gP, float *gE, arl_stream_t stream) {
+    if (!gOut || !Out || !P || !E || !Wt || !gZ || !gP || !gE) return ARL_E_NULL;
+    const int rc = ngcf_dense_args(n, d);
+    if (rc != ARL_OK) return rc;
+    if (n == 0) return ARL_OK;
+    const int64_t tiles = (n + 15) / 16;
+    const unsigned grid = (unsigned)((tiles + 3) / 4 < 2048 ? (tiles + 3) / 4 : 2048);
+    const size_t shm = sizeof(float) * (size_t)d * (size_t)(2 * d + 4);
+#define ARL_NGCF_DG(DV)                                                                                                                          \
+    do {                                                                                                                                         \
+        hipError_t e1 = hipFuncSetAttribute((const void *)ngcf_dense_dgrad_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);   \
+        if (e1 != hipSuccess) return (int)e1;                                                                                                    \
+        hipLaunchKernelGGL((ngcf_dense_dgrad_kernel<DV>), dim3(grid), dim3(kNgcfBlock), shm, (hipStream_t)stream, gOut, Out, P, E, Wt, (long long)n, slope, gZ, gP, gE); \
+    } while (0)
+    if (d == 16) ARL_NGCF_DG(16); else if (d == 32) ARL_NGCF_DG(32); else if (d == 64) ARL_NGCF_DG(64); else ARL_NGCF_DG(128);
+#undef ARL_NGCF_DG
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int64_t arl_ngcf_wgrad_workspace_bytes(int64_t n, int64_t d) {
+    if (n <= 0 || d <= 0) return 0;
+    const int64_t tiles = (n + 15) / 16;
+    const int64_t blocks = tiles < 512 ? tiles : 512;
+    return blocks * 2 * d * d * (int64_t)sizeof(float);
+}
+
+int arl_ngcf_dense_wgrad_f32(const float *P, const float *E, const float *gZ, int64_t n, int64_t d, float *gW, void *workspace, arl_stream_t stream) {
+    if (!P || !E || !gZ || !gW || !workspace) return ARL_E_NULL;
+    const int rc = ngcf_dense_args(n, d);
+    if (rc != ARL_OK) return rc;
+    if (n == 0) { hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * 2 * d * d, (hipStream_t)stream); return e == hipSuccess ? ARL_OK : (int)e; }
+    const int64_t tiles = (n + 15) / 16;
+    const unsigned blocks = (unsigned)(tiles < 512 ? tiles : 512);
+    float *part = (float *)workspace;
+    if (d == 16) hipLaunchKernelGGL((ngcf_dense_wgrad_kernel<16>), dim3(blocks), dim3(kNgcfBlock), 0, (hipStream_t)stream, P, E, gZ, (long long)n, part);
+    else if (d == 32) hipLaunchKernelGGL((ngcf_dense_wgrad_kernel<32>), dim3(blocks), dim3(kNgcfBlock), 0, (hipStream_t)stream, P, E, gZ, (long long)n, part);
+    else if (d == 64) hipLaunchKernelGGL((ngcf_dense_wgrad_kernel<64>), dim3(blocks), dim3(kNgcfBlock), 0, (hipStream_t)stream, P, E, gZ, (long long)n, part);
+    else hipLaunchKernelGGL((ngcf_dense_wgrad_kernel<128>), dim3(blocks), dim3(kNgcfBlock), 0, (hipStream_t)stream, P, E, gZ, (long long)n, part);
+    ARL_LAUNCH_CHECK();
+    const int n_elem = (int)(2 * d * d);
+    hipLaunchKernelGGL(ngcf_wgrad_fold_kernel, dim3((unsigned)((n_elem + 15) / 16)), dim3(kBlock), 0, (hipStream_t)stream, part, (int)blocks, n_elem, gW);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
 
 int arl_simgcl_perturb_f32(float *E, const float *noise, int64_t n, int64_t d, float eps, arl_stream_t stream) {
     if (!E || !noise) return ARL_E_NULL;

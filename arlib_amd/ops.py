@@ -1020,6 +1020,40 @@ def ngcf_combine_bwd(gST, P, E):
 
 
 # ------------------------------------------------------------------------------------------------ user-sharded loss
+NGCF_DENSE_WIDTHS = (16, 32, 64, 128)
+
+
+def ngcf_dense_fwd(P, E, Wcat, slope=0.01, out=None):
+    """leaky_relu((P + E) W1 + (P * E) W2) with Wcat = [W1; W2] ([2d, d]); the [N, 2d] operand is formed in registers (fp32 MFMA)."""
+    _dev(P, torch.float32, 'P', 2); _dev(E, torch.float32, 'E', 2); _dev(Wcat, torch.float32, 'Wcat', 2)
+    n, d = P.shape
+    if E.shape != P.shape or Wcat.shape != (2 * d, d) or d not in NGCF_DENSE_WIDTHS:
+        raise ValueError('ngcf_dense_fwd: P, E [n, d], Wcat [2d, d], d in %s' % (NGCF_DENSE_WIDTHS,))
+    out = torch.empty_like(P) if out is None else _dev(out, torch.float32, 'out', 2)
+    if out.shape != P.shape:
+        raise ValueError('ngcf_dense_fwd: out must have the shape of P')
+    check(_lib.lib().arl_ngcf_dense_fwd_f32(_ptr(P), _ptr(E), _ptr(Wcat), n, d, float(slope), _ptr(out), _stream()), 'arl_ngcf_dense_fwd_f32')
+    return out
+
+
+def ngcf_dense_bwd(gOut, Out, P, E, Wcat, slope=0.01):
+    """Backward of ngcf_dense_fwd: returns (gP, gE, gW [2d, d])."""
+    for t, nm in ((gOut, 'gOut'), (Out, 'Out'), (P, 'P'), (E, 'E'), (Wcat, 'Wcat')):
+        _dev(t, torch.float32, nm, 2)
+    n, d = P.shape
+    if gOut.shape != P.shape or Out.shape != P.shape or E.shape != P.shape or Wcat.shape != (2 * d, d) or d not in NGCF_DENSE_WIDTHS:
+        raise ValueError('ngcf_dense_bwd: gOut, Out, P, E [n, d], Wcat [2d, d], d in %s' % (NGCF_DENSE_WIDTHS,))
+    Wt = Wcat.t().contiguous()
+    gZ, gP, gE = torch.empty_like(P), torch.empty_like(P), torch.empty_like(P)
+    L = _lib.lib()
+    check(L.arl_ngcf_dense_dgrad_f32(_ptr(gOut), _ptr(Out), _ptr(P), _ptr(E), _ptr(Wt), n, d, float(slope), _ptr(gZ), _ptr(gP), _ptr(gE), _stream()),
+          'arl_ngcf_dense_dgrad_f32')
+    gW = torch.empty(2 * d, d, dtype=torch.float32, device=P.device)
+    ws = torch.empty(max(1, L.arl_ngcf_wgrad_workspace_bytes(n, d) // 4), dtype=torch.float32, device=P.device)
+    check(L.arl_ngcf_dense_wgrad_f32(_ptr(P), _ptr(E), _ptr(gZ), n, d, _ptr(gW), _ptr(ws), _stream()), 'arl_ngcf_dense_wgrad_f32')
+    return gP, gE, gW
+
+
 def bpr_l2_partial(emb, item_off, u, p, n, B_global, workspace, sums_out):
     """Per-sample BPR coefficients (into `workspace`) + local sums [sum loss terms, sum|u|^2, sum|p|^2] (into sums_out)."""
     _dev(emb, torch.float32, 'emb', 2); _dev(sums_out, torch.float32, 'sums_out', 1); _dev(workspace, torch.float32, 'workspace', 1)

@@ -1,8 +1,9 @@
 """NGCF (simplified, as in the reference's recommender/NGCF.py:173-212): per layer
     E' = leaky_relu( A(E W1) + E W1 + ((A E) * E) W2 ),   mean of L+1 layers.
 Since A(E W1) = (A E) W1 the layer needs ONE sparse hop, not the reference's two:  P = A E;  E' = leaky_relu((P + E) W1 + (P * E) W2).
-The hop (forward and its backward A^T dY = A dY) is the HIP SpMM kernel; the layer is one autograd node (`_Layer`) whose
-element-wise passes are HIP kernels and whose d x d products are one (forward) / two (backward) rocBLAS GEMMs on [S | T].
+The hop (forward and its backward A^T dY = A dY) is the HIP SpMM kernel; the layer is one autograd node (`_Layer`) whose dense part
+runs on the matrix cores in hand-written kernels (arl_ngcf_dense_{fwd,dgrad,wgrad}_f32: exact-fp32 MFMA, the [N, 2d] operand [P + E | P * E]
+formed in registers) for d in {16, 32, 64, 128}; other widths keep the element-wise kernels + library GEMM form.
 """
 import torch
 import torch.nn as nn
@@ -22,20 +23,29 @@ class _Layer(torch.autograd.Function):
     def forward(ctx, ego, W1, W2, graph, slope):
         ego = ego.contiguous()
         P = ops.spmm(graph, ego)
-        ST = ops.ngcf_combine(P, ego)
         Wcat = torch.cat([W1, W2], 0)
-        out = ops.ngcf_act_(torch.mm(ST, Wcat), None, slope)
-        ctx.save_for_backward(ego, P, ST, out, Wcat)
+        ctx.fused = ego.shape[1] in ops.NGCF_DENSE_WIDTHS
+        if ctx.fused:
+            out = ops.ngcf_dense_fwd(P, ego, Wcat, slope)
+            ctx.save_for_backward(ego, P, out, Wcat)
+        else:
+            ST = ops.ngcf_combine(P, ego)
+            out = ops.ngcf_act_(torch.mm(ST, Wcat), None, slope)
+            ctx.save_for_backward(ego, P, ST, out, Wcat)
         ctx.graph, ctx.slope = graph, slope
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        ego, P, ST, out, Wcat = ctx.saved_tensors
-        d = ego.shape[1]
-        gZ = ops.ngcf_act_bwd(g_out.contiguous(), out, ctx.slope)
-        gW = torch.mm(ST.t(), gZ)
-        gP, gE = ops.ngcf_combine_bwd(torch.mm(gZ, Wcat.t()), P, ego)
+        d = g_out.shape[1]
+        if ctx.fused:
+            ego, P, out, Wcat = ctx.saved_tensors
+            gP, gE, gW = ops.ngcf_dense_bwd(g_out.contiguous(), out, P, ego, Wcat, ctx.slope)
+        else:
+            ego, P, ST, out, Wcat = ctx.saved_tensors
+            gZ = ops.ngcf_act_bwd(g_out.contiguous(), out, ctx.slope)
+            gW = torch.mm(ST.t(), gZ)
+            gP, gE = ops.ngcf_combine_bwd(torch.mm(gZ, Wcat.t()), P, ego)
         g_ego = ops.spmm(ctx.graph, gP, 1.0, 1.0, gE)
         return g_ego, gW[:d], gW[d:], None, None
 
@@ -50,9 +60,14 @@ class _LastLayerRows(torch.autograd.Function):
         ego = ego.contiguous()
         P = ops.spmm_rows(graph, ego, rows, (), 1.0, check_range=False)
         E = ops.gather_rows(ego, rows, check_range=False)
-        ST = ops.ngcf_combine(P, E)
         Wcat = torch.cat([W1, W2], 0)
-        out = ops.ngcf_act_(torch.mm(ST, Wcat), None, slope)
+        ctx.fused = ego.shape[1] in ops.NGCF_DENSE_WIDTHS
+        if ctx.fused:
+            out = ops.ngcf_dense_fwd(P, E, Wcat, slope)
+            ST = P                                             # placeholder (not read)
+        else:
+            ST = ops.ngcf_combine(P, E)
+            out = ops.ngcf_act_(torch.mm(ST, Wcat), None, slope)
         ctx.save_for_backward(P, E, ST, out, Wcat, rows)
         ctx.graph, ctx.slope, ctx.shape = graph, slope, tuple(ego.shape)
         return out
@@ -61,9 +76,12 @@ class _LastLayerRows(torch.autograd.Function):
     def backward(ctx, g_out):
         P, E, ST, out, Wcat, rows = ctx.saved_tensors
         N, d = ctx.shape
-        gZ = ops.ngcf_act_bwd(g_out.contiguous(), out, ctx.slope)
-        gW = torch.mm(ST.t(), gZ)
-        gP, gE = ops.ngcf_combine_bwd(torch.mm(gZ, Wcat.t()), P, E)
+        if ctx.fused:
+            gP, gE, gW = ops.ngcf_dense_bwd(g_out.contiguous(), out, P, E, Wcat, ctx.slope)
+        else:
+            gZ = ops.ngcf_act_bwd(g_out.contiguous(), out, ctx.slope)
+            gW = torch.mm(ST.t(), gZ)
+            gP, gE = ops.ngcf_combine_bwd(torch.mm(gZ, Wcat.t()), P, E)
         Gp = torch.zeros(N, d, dtype=torch.float32, device=gP.device)
         ops.scatter_add_rows(Gp, rows, gP, 1.0, check_range=False)
         bits = torch.zeros((N + 31) // 32, dtype=torch.int32, device=gP.device)

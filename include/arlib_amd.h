@@ -291,6 +291,16 @@ int arl_ngcf_act_f32(float *Z, float *acc, int64_t n, int64_t d, float slope, ar
 int arl_ngcf_act_bwd_f32(const float *gOut, const float *Out, int64_t n, int64_t d, float slope, float *gZ, arl_stream_t stream);
 int arl_ngcf_combine_bwd_f32(const float *gST, const float *P, const float *E, int64_t n, int64_t d, float *gP, float *gE,
                              arl_stream_t stream);
+/* The same layer with its dense part on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation; d in {16, 32, 64, 128}):
+ * the [N, 2d] operand [P + E | P * E] of recommender/NGCF.py:200-208 is formed in registers, never in memory.
+ *   fwd   : out = leaky_relu((P + E) W1 + (P * E) W2),  W = [W1; W2] as [2d, d] row-major
+ *   dgrad : gZ = gOut * act'(Out);  gP = gS + gT * E,  gE = gS + gT * P  with [gS | gT] = gZ W^T;  Wt = W^T as [d, 2d] row-major; gZ is an output (wgrad reads it)
+ *   wgrad : gW [2d, d] = [P + E | P * E]^T gZ, per-workgroup partials in `workspace` (arl_ngcf_wgrad_workspace_bytes) summed in a fixed order */
+int arl_ngcf_dense_fwd_f32(const float *P, const float *E, const float *W, int64_t n, int64_t d, float slope, float *out, arl_stream_t stream);
+int arl_ngcf_dense_dgrad_f32(const float *gOut, const float *Out, const float *P, const float *E, const float *Wt, int64_t n, int64_t d, float slope,
+                             float *gZ, float *gP, float *gE, arl_stream_t stream);
+int64_t arl_ngcf_wgrad_workspace_bytes(int64_t n, int64_t d);
+int arl_ngcf_dense_wgrad_f32(const float *P, const float *E, const float *gZ, int64_t n, int64_t d, float *gW, void *workspace, arl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * White-box attack primitives.

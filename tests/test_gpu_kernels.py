@@ -539,3 +539,22 @@ def test_incremental_bipartite_update_equals_fresh_build(ops, planned, monkeypat
             assert sum(s['n_edges'] for s in g.blocked.sets) == g.nnz
             Z = torch.randn(N, d, device=DEV)
             assert rel_err(ops.spmm(g, X, 0.5, -2.0, Z).cpu().numpy(), ops.spmm(ref, X, 0.5, -2.0, Z).cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize('d,n', [(16, 1000), (32, 517), (64, 4099), (128, 2050), (64, 7)])
+def test_ngcf_dense_layer_on_mfma_matches_float64(ops, d, n):
+    """arl_ngcf_dense_{fwd,dgrad,wgrad}_f32 (fp32 MFMA, [P + E | P * E] formed in registers) against the layer written out in float64 torch with
+    autograd: output, gP, gE and both weight gradients; ragged last row tile; leaky-relu at both signs."""
+    g = torch.Generator().manual_seed(d + n)
+    P = (torch.randn(n, d, generator=g) * 0.5).to(DEV); E = (torch.randn(n, d, generator=g) * 0.5).to(DEV)
+    W = (torch.randn(2 * d, d, generator=g) * 0.2).to(DEV); gOut = torch.randn(n, d, generator=g).to(DEV)
+    out = ops.ngcf_dense_fwd(P, E, W, 0.01)
+    Pd, Ed, Wd = (t.double().requires_grad_(True) for t in (P, E, W))
+    ref = torch.nn.functional.leaky_relu(torch.cat([Pd + Ed, Pd * Ed], 1) @ Wd, 0.01)
+    assert rel_err(out.cpu().numpy(), ref.detach().cpu().numpy()) < 1e-5
+    assert int((out < 0).sum()) > 0 and int((out > 0).sum()) > 0
+    ref.backward(gOut.double())
+    gP, gE, gW = ops.ngcf_dense_bwd(gOut, out, P, E, W, 0.01)
+    assert rel_err(gP.cpu().numpy(), Pd.grad.cpu().numpy()) < 1e-5 and rel_err(gE.cpu().numpy(), Ed.grad.cpu().numpy()) < 1e-5
+    assert rel_err(gW.cpu().numpy(), Wd.grad.cpu().numpy()) < 1e-5
+    assert torch.equal(gW, ops.ngcf_dense_bwd(gOut, out, P, E, W, 0.01)[2])            # deterministic partial sums
