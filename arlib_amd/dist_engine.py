@@ -82,7 +82,7 @@ def shard_bounds(n_users, world):
     return starts
 
 
-def build_local_blocks(pairs, n_users, n_items, rank, world):
+def build_local_blocks(pairs, n_users, n_items, rank, world, normalise=True):
     """Host-side (numpy) construction of the rank's two CSR blocks from the user-major sorted pair list.
     Returns dict(u0, u1, Au=(rowptr,col,val), Ai=(rowptr,col,val)) with columns in the packed [Ul + I] index space."""
     pairs = np.asarray(pairs)
@@ -100,6 +100,8 @@ def build_local_blocks(pairs, n_users, n_items, rank, world):
     lu = u_all[lo:hi] - u0
     li = i_all[lo:hi]
     val = ((du[u_all[lo:hi]] * np.float32(1.0)) * di[li]).astype(np.float32)             # (dinv[r]*w)*dinv[c], w = 1
+    if not normalise:                 # raw 0/1 blocks + the degrees (ShardedPGA normalises in factors, the fake block changing every step)
+        val = np.ones(hi - lo, np.float32)
     rp_u = np.zeros(Ul + 1, np.int64)
     np.cumsum(np.bincount(lu, minlength=Ul), out=rp_u[1:])
     col_u = (li + Ul).astype(np.int32)
@@ -108,7 +110,9 @@ def build_local_blocks(pairs, n_users, n_items, rank, world):
     np.cumsum(np.bincount(li, minlength=I), out=rp_i[1:])
     col_i = lu[order].astype(np.int32)
     val_i = ((di[li[order]] * np.float32(1.0)) * du[u_all[lo:hi][order]]).astype(np.float32)
-    return dict(u0=u0, u1=u1, Au=(rp_u, col_u, val), Ai=(rp_i, col_i, val_i))
+    if not normalise:
+        val_i = np.ones(hi - lo, np.float32)
+    return dict(u0=u0, u1=u1, Au=(rp_u, col_u, val), Ai=(rp_i, col_i, val_i), deg_u=deg_u[u0:u1].copy(), deg_i=deg_i)
 
 
 class ShardedPropagationEngine:
@@ -573,3 +577,126 @@ class ShardedPropagationEngine:
         self.comm.all_reduce(full[:self.U])
         full[self.U:] = self.E0[self.Ul:]
         return full
+
+
+class ShardedPGA:
+    """PGA's gradient step w.r.t. the fake interactions (attack/White/PGA.py:92-142) on the user-sharded layout -- the attack-step half of
+    BASELINE configs 3 / 4 at N > 1.  Users [0, U + F) are split over the ranks like everywhere here; the F fake users are the LAST rows, so
+    they (and the fake block S [F, I], which only their rank ever holds) live on the last rank.  The poisoned operator is applied in factors,
+    as attack.White.PGA.FactoredFakeGraph does on one GPU:   A_hat X = D^-1/2 ( W_real (D^-1/2 X) + fake block ),
+      * W_real: the raw 0/1 blocks A_u / A_i of the REAL interactions (fixed; item-side partial sums all-reduced per hop, as in every hop here);
+      * fake block: S (D^-1/2 X)_items for the fake users' rows and S^T (D^-1/2 X)_fake added to the item partial -- on the owner rank only;
+      * degrees: real users fixed, fake users S's row sums (owner), items real degree + S's column sums (ONE [I]-float all-reduce per step).
+    CW pairs (real user x target, negative = tail of the user's masked top-k list) stay with the user's rank; dL/d(out) item rows are
+    per-rank partials (one I x d all-reduce).  The F x I block gradient needs rows of E_k / dE_k of the fake users and of all items: all on
+    the owner.  Exchanges per step: 1 [I] + (2L - 1) [I, d] hop reductions + 1 [I, d] gradient + 1 scalar."""
+
+    def __init__(self, pairs_real, n_real, n_fake, n_items, emb_size, n_layers, device, rank, world, table, comm=None, kernels=None, chunk=512):
+        if kernels is None:
+            from . import ops as kernels
+        self.k, self.comm = kernels, comm if comm is not None else TorchDistComm()
+        self.rank, self.world = rank, world
+        self.U, self.F, self.I, self.d, self.L = int(n_real), int(n_fake), int(n_items), int(emb_size), int(n_layers)
+        self.Up = self.U + self.F
+        b = build_local_blocks(pairs_real, self.Up, self.I, rank, world, normalise=False)
+        self.u0, self.u1 = b['u0'], b['u1']
+        self.Ul, self.Nl = self.u1 - self.u0, self.u1 - self.u0 + self.I
+        if shard_bounds(self.Up, world)[world - 1] > self.U:
+            raise ValueError('ShardedPGA: the fake users must all live on the last rank (F <= users per rank)')
+        self.owner = rank == world - 1
+        self.f0 = self.U - self.u0 if self.owner else self.Ul            # local row of the first fake user
+        self.device = torch.device(device)
+        self.Au = kernels.CSRGraph(*b['Au'], self.device, chunk=chunk, n_cols=self.Nl)
+        self.Ai = kernels.CSRGraph(*b['Ai'], self.device, chunk=chunk, n_cols=self.Nl)
+        self.deg_u = torch.from_numpy(b['deg_u']).to(self.device)
+        self.deg_i = torch.from_numpy(b['deg_i']).to(self.device)
+        table = torch.as_tensor(table, dtype=torch.float32)
+        if table.shape != (self.Up + self.I, self.d):
+            raise ValueError('table must be the full [U + F + I, d] table')
+        self.E0 = torch.cat([table[self.u0:self.u1], table[self.Up:]], 0).to(self.device).contiguous()
+        self.fake_rows = torch.arange(self.f0, self.Ul, dtype=torch.int32, device=self.device)
+        self.S = None
+
+    def set_block(self, S):
+        """S [F, I] on the owner (ignored elsewhere)."""
+        if self.owner:
+            self.S = torch.as_tensor(S, dtype=torch.float32).to(self.device).contiguous()
+
+    def _degrees(self):
+        cs = self.S.sum(0) if self.owner else torch.zeros(self.I, dtype=torch.float32, device=self.device)
+        self.comm.all_reduce(cs)
+        du = self.deg_u.clone()
+        if self.owner:
+            du[self.f0:] = self.S.sum(1)
+        rs = torch.cat([du, self.deg_i + cs])
+        self.dinv = torch.where(rs > 0, 1.0 / torch.sqrt(rs), torch.zeros_like(rs))
+        self._dcol = self.dinv[:, None].contiguous()
+
+    def _hop(self, X, alpha=1.0, beta=0.0, Z=None):
+        """alpha * (A_hat X) + beta * Z on the local rows (Z's item rows replicated)."""
+        k, Ul = self.k, self.Ul
+        Xs = X * self._dcol
+        Y = torch.empty_like(X)
+        k.spmm(self.Ai, Xs, out=Y[Ul:])                                 # partial over the local real users
+        if self.owner and self.F:
+            Y[Ul:].addmm_(self.S.t(), Xs[self.f0:Ul])                   # + the fake users' contribution to every item row
+        work = self.comm.all_reduce_async(Y[Ul:])
+        k.spmm(self.Au, Xs, out=Y[:Ul])
+        if self.owner and self.F:
+            Y[self.f0:Ul] += self.S @ Xs[Ul:]                           # the fake users' own rows
+        work.wait()
+        Y.mul_(self._dcol * alpha)
+        if beta != 0.0:
+            Y.add_(Z, alpha=beta)
+        return Y
+
+    def forward(self):
+        self._degrees()
+        E = [self.E0]
+        out = self.E0.clone()
+        for _ in range(self.L):
+            E.append(self._hop(E[-1]))
+            out += E[-1]
+        out /= (self.L + 1)
+        return out, E
+
+    def step(self, targets, top_idx):
+        """One gradient step on S.  top_idx: masked top-k lists of THIS rank's users from the inner epoch's forward (fixed over the epoch's
+        steps, PGA.py:99-108).  Returns the CW loss (device scalar, identical on every rank); S is updated in place on the owner."""
+        k, Ul, L, dev = self.k, self.Ul, self.L, self.device
+        T = len(targets)
+        out, E = self.forward()
+        nl = int(min(max(self.U - self.u0, 0), Ul))
+        tg = torch.as_tensor(list(targets), dtype=torch.int64, device=dev)
+        c = 1.0 / (float(self.U) * T)
+        G = torch.zeros_like(out)
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        if nl:
+            ue = out[:nl]
+            ranks = top_idx.shape[1] - 1 - torch.arange(T, device=dev)
+            neg = top_idx[:nl][:, ranks].long()
+            tgt_rows = out[Ul + tg]
+            sum_u = ue.sum(0)
+            for t in range(T):
+                nrows = (neg[:, t] + Ul).to(torch.int32).contiguous()
+                ne = k.gather_rows(out, nrows, check_range=False)
+                loss += c * ((ue * ne).sum() - (sum_u * tgt_rows[t]).sum())
+                G[:nl] += c * (ne - tgt_rows[t])
+                k.scatter_add_rows(G, nrows, ue.contiguous(), c, check_range=False)
+            G[Ul + tg] -= c * sum_u
+        self.comm.all_reduce(G[Ul:])
+        self.comm.all_reduce(loss)
+        s = 1.0 / (L + 1)
+        Gs = G * s
+        dE = [None] * (L + 1)
+        dE[L] = Gs
+        for kk in range(L - 1, 0, -1):
+            dE[kk] = self._hop(dE[kk + 1], 1.0, 1.0, Gs)
+        if self.owner and self.F:
+            block = torch.zeros(self.F, self.I, dtype=torch.float32, device=dev)
+            for kk in range(L):
+                k.sddmm_rows_dense(dE[kk + 1].contiguous(), E[kk].contiguous(), self.fake_rows, Ul, self.I, out=block)
+                k.sddmm_rows_dense(E[kk].contiguous(), dE[kk + 1].contiguous(), self.fake_rows, Ul, self.I, out=block)
+            self.last_block = block
+            k.pga_update_(self.S, block, self.dinv[self.f0:Ul].contiguous(), self.dinv[Ul:].contiguous())
+        return loss[0]

@@ -206,3 +206,13 @@ def batch_rows_clear_(G, flags, bits, idx, check_range=True):
     zero_rows_(G, idx)
     mark_rows_(flags, idx, 0)
     mark_bits_(bits, idx, False, G.shape[0])
+
+
+def sddmm_rows_dense(dY, X, rows, col_off, n_cols, out=None):
+    res = O.sddmm_rows_dense(dY.numpy(), X.numpy(), rows.numpy(), col_off, n_cols, out=None if out is None else out.numpy())
+    return out if out is not None else torch.from_numpy(res)
+
+
+def pga_update_(S, grad, dinv_rows=None, dinv_cols=None):
+    S.copy_(torch.from_numpy(O.pga_update(S.numpy(), grad.numpy(), None if dinv_rows is None else dinv_rows.numpy(), None if dinv_cols is None else dinv_cols.numpy())))
+    return S

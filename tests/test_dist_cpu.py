@@ -299,3 +299,70 @@ def test_sharded_ngcf_steps_gloo_match_torch_autograd_reference(world):
     for l in range(L):
         assert rel_err(ret['W'][l][:d], ref_W[l]) < RTOL and rel_err(ret['W'][l][d:], ref_W[L + l]) < RTOL
     assert ret['w_replica_diff'] == 0.0
+
+
+def pga_problem():
+    from arlib_amd.util import synthetic as S_
+    U, I, F, L, d, T, topk = 594, 90, 6, 2, 16, 3, 10
+    pairs = S_.syn_v1_pairs(U, I, mean_deg=10, seed=11)
+    rng = np.random.default_rng(17)
+    E0 = ((rng.random((U + F + I, d)) * 2 - 1) * 0.1).astype(np.float32)
+    targets = [int(x) for x in rng.choice(I, T, replace=False)]
+    S0 = np.zeros((F, I), np.float32)
+    S0[:, targets] = 1.0
+    S0[:, rng.choice(I, 9, replace=False)] = 0.5
+    S0[2, 5] = 0.0
+    return U, I, F, L, d, pairs, E0, targets, topk, S0
+
+
+def oracle_pga_steps(U, I, F, L, d, pairs, E0, targets, topk, S0, n_steps=2):
+    """Single-process oracle: top-k lists from the forward of the FIRST step's graph (PGA.py:99-108), then n gradient steps (O.pga_step, the
+    composition test_oracle_attacks pins on the reference's traced grad / S)."""
+    rp = np.zeros(U + 1, np.int64); np.cumsum(np.bincount(pairs[:, 0], minlength=U), out=rp[1:])
+    ri = pairs[:, 1].astype(np.int64)
+    csr, _ = O.pga_weighted_graph(rp, ri, U, F, I, S0)
+    out = O.lightgcn_forward(csr, E0, L)
+    Up = U + F
+    idx, _ = O.score_mask_topk(out[:Up], out[Up:], topk)
+    users, pos, neg = O.cw_pairs(idx, U, np.array(targets), pop=True)
+    S, losses = S0.copy(), []
+    for _ in range(n_steps):
+        grad, S, loss = O.pga_step(rp, ri, U, F, I, S, E0, L, users, pos, neg)
+        losses.append(float(loss))
+    return S, losses, idx
+
+
+def _pga_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import torch.distributed as dist
+    import cpu_kernels_shim as shim
+    from arlib_amd.dist_engine import ShardedPGA
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    U, I, F, L, d, pairs, E0, targets, topk, S0 = pga_problem()
+    eng = ShardedPGA(pairs, U, F, I, d, L, 'cpu', rank, world, torch.from_numpy(E0), kernels=shim)
+    eng.set_block(S0)
+    out, _ = eng.forward()
+    top_idx, _ = shim.score_mask_topk(out[:eng.Ul].contiguous(), out[eng.Ul:].contiguous(), topk)      # unmasked, as PGA.py:100-102
+    losses = [float(eng.step(targets, top_idx)) for _ in range(2)]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, top_idx.numpy())
+    if rank == world - 1:
+        ret['S'] = eng.S.numpy().copy()
+    if rank == 0:
+        ret['losses'], ret['top'] = losses, np.concatenate(gathered)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_pga_steps_gloo_match_single_process_oracle(world):
+    """PGA's gradient step on user shards (factored poisoned operator, fake block on the last rank, item-side partials all-reduced) against the
+    oracle's single-process pga_step: CW loss and the updated fake block after two steps."""
+    prob = pga_problem()
+    ref_S, ref_losses, ref_idx = oracle_pga_steps(*prob)
+    ret = mp.Manager().dict()
+    mp.spawn(_pga_worker, args=(world, free_port(), ret), nprocs=world, join=True)
+    assert (ret['top'] == ref_idx).mean() > 0.995
+    assert np.allclose(ret['losses'], ref_losses, rtol=RTOL, atol=0)
+    assert rel_err(ret['S'], ref_S) < RTOL and (ret['S'] != prob[-1]).any()

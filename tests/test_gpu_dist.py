@@ -210,3 +210,37 @@ def test_sfa_stages_equal_monolithic_call():
     la, Ga = sa.stage3(r, a_s, numel); lb, Gb = sb.stage3(r, a_s, numel)
     assert abs(la.item() - loss.item()) <= 1e-5 * abs(loss.item()) and la.item() == lb.item()
     assert rel_err(torch.cat([Ga, Gb]).cpu().numpy(), G.cpu().numpy()) < 1e-5
+
+
+def _pga_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import torch.distributed as dist
+    from arlib_amd import ops
+    from arlib_amd.dist_engine import ShardedPGA
+    from test_dist_cpu import pga_problem
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    U, I, F, L, d, pairs, E0, targets, topk, S0 = pga_problem()
+    eng = ShardedPGA(pairs, U, F, I, d, L, 'cuda:0', rank, world, torch.from_numpy(E0), comm=HostStagedComm())
+    eng.set_block(S0)
+    out, _ = eng.forward()
+    top_idx, _ = ops.score_mask_topk(out[:eng.Ul].contiguous(), out[eng.Ul:].contiguous(), topk)
+    losses = [float(eng.step(targets, top_idx)) for _ in range(2)]
+    if rank == world - 1:
+        ret['S'] = eng.S.cpu().numpy().copy()
+    if rank == 0:
+        ret['losses'] = losses
+    dist.destroy_process_group()
+
+
+def test_sharded_pga_two_ranks_hip_kernels():
+    """PGA's gradient step on two user shards with the real kernels (raw-adjacency hops, SDDMM block, tanh/clamp update) against the oracle."""
+    if not torch.cuda.is_available():
+        pytest.fail('GPU tests need a GPU')
+    from test_dist_cpu import pga_problem, oracle_pga_steps
+    prob = pga_problem()
+    ref_S, ref_losses, _ = oracle_pga_steps(*prob)
+    ret = _spawn(_pga_worker, ())
+    assert np.allclose(ret['losses'], ref_losses, rtol=RTOL, atol=0)
+    assert rel_err(ret['S'], ref_S) < RTOL
