@@ -388,12 +388,30 @@ class ArrayDataLoader(DataLoader):
         raise AttributeError('ArrayDataLoader: training_data is a view of the pair array; use append_training_rows()')
 
     def append_training_rows(self, rows):
+        """training_data.extend(rows): O(len(rows)) -- the pair / rating arrays live in buffers that grow geometrically (an attack appends
+        once per fake user: thousands of calls on a 3e7-row array)."""
         from .sampler import PairSampler
+        if not len(rows):
+            return
         tail = np.array([[self.user[r[0]], self.item[r[1]]] for r in rows], np.int32).reshape(-1, 2)
+        if tail.min() < 0 or tail[:, 1].max() >= len(self.item):
+            raise ValueError('append_training_rows: ids out of range')
+        rt = np.array([float(r[2]) if len(r) > 2 else 1.0 for r in rows], np.float64)
         sh = self.pair_sampler
-        self.pair_sampler = PairSampler(np.concatenate([sh.pairs, tail]), len(self.item), (sh.memb_rowptr, sh.memb_items))
-        self._rating = np.concatenate([self._rating, np.array([float(r[2]) if len(r) > 2 else 1.0 for r in rows], np.float64)])
-        self._uniform_rating = self._uniform_rating and bool(np.all(self._rating[-len(rows):] == self._rating[0])) if len(rows) else self._uniform_rating
+        n, m = sh.nnz, len(rows)
+        buf = self.__dict__.get('_pairs_buf')
+        if buf is None or buf.shape[0] < n + m or sh.pairs.base is not buf:
+            cap = max(n + m, int(1.25 * n) + 1024)
+            buf = np.empty((cap, 2), np.int32); buf[:n] = sh.pairs
+            rbuf = np.empty(cap, np.float64); rbuf[:n] = self._rating
+            self.__dict__['_pairs_buf'], self.__dict__['_rating_buf'] = buf, rbuf
+        rbuf = self.__dict__['_rating_buf']
+        buf[n:n + m] = tail; rbuf[n:n + m] = rt
+        ns = PairSampler.__new__(PairSampler)                         # same membership sets (fixed at construction, util/DataLoader.py:41), longer pair list
+        ns.pairs, ns.n_items, ns.memb_rowptr, ns.memb_items = buf[:n + m], len(self.item), sh.memb_rowptr, sh.memb_items
+        self.pair_sampler = ns
+        self._rating = rbuf[:n + m]
+        self._uniform_rating = self._uniform_rating and bool(np.all(rt == self._rating[0]))
         self._ui_adj = self._norm_adj = self._interaction_mat = None
 
     def _permute_ratings(self, order):
@@ -465,6 +483,8 @@ class ArrayDataLoader(DataLoader):
                 new.__dict__[k] = dict(v)
             elif k == '_rating':
                 new.__dict__[k] = v.copy()
+            elif k in ('_pairs_buf', '_rating_buf'):
+                continue                                          # the copy starts without spare capacity
             else:
                 new.__dict__[k] = copy.deepcopy(v, memo)
         return new

@@ -164,7 +164,7 @@ def test_clear_surrogate_loss_and_gradients_match_reference_trace():
     assert rel_err(model.embedding_dict['item_emb'].grad.cpu().numpy(), grads[I]) < RTOL
 
 
-@pytest.mark.parametrize('name', ['PGA', 'DLAttack', 'CLeaR'])
+@pytest.mark.parametrize('name', ['PGA', 'DLAttack', 'CLeaR', 'CLeaR_array_native', 'DLAttack_array_native', 'PGA_array_native'])
 def test_posion_data_attack_end_to_end(name, tmp_path, monkeypatch):
     """Whole posionDataAttack() on ml-100k with the reference's protocol; structural checks the reference run also satisfies
     (g7: DLAttack row sums [5, 46] (quirk Q6), CLeaR 51 = 46 fillers + 5 targets, PGA targets only at the default n = 0 (Q5))."""
@@ -174,8 +174,12 @@ def test_posion_data_attack_end_to_end(name, tmp_path, monkeypatch):
     from arlib_amd.recommender.LightGCN import LightGCN
     monkeypatch.chdir(tmp_path)
     g = golden('g7_attacks.npz')
+    # *_array_native: the same protocol on the array-native DataLoader (numpy images instead of the list / dict-of-dict containers: fake-user
+    # appends, deepcopy of the surrogate, matrix() and the sampler all go through ArrayDataLoader) -- same reference-recorded results
+    array_native = name.endswith('_array_native')
+    name = name.split('_')[0]
     seedSet(2018)
-    data = make_data()
+    data = make_data(array_native)
     rec = LightGCN(rec_args(emb_size=16, n_layers=2, maxEpoch=1), data)
     with contextlib.redirect_stdout(io.StringIO()):
         rec.train(Epoch=1, evalNum=5)
