@@ -306,6 +306,11 @@ def class_api_leg(torch, data, args, engine_ms):
 
 def main():
     args = parse()
+    # stdout carries exactly one line, the JSON: whatever libraries print there (RCCL's version banner at communicator start-up, the classes'
+    # reference-style progress lines) is sent to stderr for the life of the process, the result is written to the saved descriptor
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     import torch
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -523,7 +528,8 @@ def main():
             res['cpu_baseline'] = cpu_baseline(data, rowptr, col, val_np, E0.numpy(), batches, args, args.cpu_seconds, gpu_replay)
             if args.cpu_torch > 0:
                 res['cpu_baseline_torch'] = cpu_torch_baseline(torch, rowptr, col, val_np, E0, batches, U, args, min(args.cpu_torch + 1, len(batches)))
-        print(json.dumps(res))
+        result_out.write(json.dumps(res) + '\n')
+        result_out.flush()
     if sharded:
         import torch.distributed as dist
         dist.destroy_process_group()
