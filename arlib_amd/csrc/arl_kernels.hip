@@ -973,22 +973,26 @@ __global__ __launch_bounds__(kBlock) void ngcf_combine_bwd_kernel(const float4 *
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int kNgcfBlock = 256;
 
+// workgroup size of the fwd / dgrad kernels: the LDS image of the weights (135 KB at d = 128) allows one workgroup per CU there, so that one is
+// 16 waves wide (4 per SIMD); smaller widths fit several 4-wave workgroups per CU
+template <int D> struct NgcfBlk { static constexpr int value = D >= 128 ? 1024 : 256; };
+
 template <int D>
 __device__ __forceinline__ void ngcf_stage_weights(float *Wl, const float *__restrict__ W, int rows) {
     constexpr int S = D + 4;
-    for (int t = threadIdx.x; t < rows * D; t += kNgcfBlock) Wl[(t / D) * S + (t % D)] = W[t];
+    for (int t = threadIdx.x; t < rows * D; t += NgcfBlk<D>::value) Wl[(t / D) * S + (t % D)] = W[t];
     __syncthreads();
 }
 
 template <int D>
-__global__ __launch_bounds__(kNgcfBlock) void ngcf_dense_fwd_kernel(const float *__restrict__ P, const float *__restrict__ E, const float *__restrict__ W,
+__global__ __launch_bounds__(NgcfBlk<D>::value) void ngcf_dense_fwd_kernel(const float *__restrict__ P, const float *__restrict__ E, const float *__restrict__ W,
                                                                      long long n_rows, float slope, float *__restrict__ out) {
     constexpr int S = D + 4, NT = D / 16, KG = D / 16;
     extern __shared__ float Wl[];                           // [2 D][S]: W1 rows then W2 rows
     ngcf_stage_weights<D>(Wl, W, 2 * D);
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const long long n_tiles = (n_rows + 15) / 16;
-    for (long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += (long long)gridDim.x * 4) {
+    for (long long tile = (long long)blockIdx.x * (NgcfBlk<D>::value / 64) + (threadIdx.x >> 6); tile < n_tiles; tile += (long long)gridDim.x * (NgcfBlk<D>::value / 64)) {
         const long long r = tile * 16 + c;
         const bool rv = r < n_rows;
         f32x4v acc[NT];
@@ -1022,16 +1026,16 @@ __global__ __launch_bounds__(kNgcfBlock) void ngcf_dense_fwd_kernel(const float 
 
 // Wt = [W1; W2]^T, i.e. [D][2 D] row-major: the B operand of gZ [W1; W2]^T read exactly like the forward's
 template <int D>
-__global__ __launch_bounds__(kNgcfBlock) void ngcf_dense_dgrad_kernel(const float *__restrict__ gOut, const float *__restrict__ Out, const float *__restrict__ P,
+__global__ __launch_bounds__(NgcfBlk<D>::value) void ngcf_dense_dgrad_kernel(const float *__restrict__ gOut, const float *__restrict__ Out, const float *__restrict__ P,
                                                                        const float *__restrict__ E, const float *__restrict__ Wt, long long n_rows, float slope,
                                                                        float *__restrict__ gZ, float *__restrict__ gP, float *__restrict__ gE) {
     constexpr int D2 = 2 * D, S = D2 + 4, NT = D2 / 16, KG = D / 16;
     extern __shared__ float Wl[];                           // [D][S]
-    for (int t = threadIdx.x; t < D * D2; t += kNgcfBlock) Wl[(t / D2) * S + (t % D2)] = Wt[t];
+    for (int t = threadIdx.x; t < D * D2; t += NgcfBlk<D>::value) Wl[(t / D2) * S + (t % D2)] = Wt[t];
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const long long n_tiles = (n_rows + 15) / 16;
-    for (long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += (long long)gridDim.x * 4) {
+    for (long long tile = (long long)blockIdx.x * (NgcfBlk<D>::value / 64) + (threadIdx.x >> 6); tile < n_tiles; tile += (long long)gridDim.x * (NgcfBlk<D>::value / 64)) {
         const long long r = tile * 16 + c;
         const bool rv = r < n_rows;
         f32x4v acc[NT];
@@ -2261,13 +2265,15 @@ int arl_ngcf_dense_fwd_f32(const float *P, const float *E, const float *W, int64
     if (rc != ARL_OK) return rc;
     if (n == 0) return ARL_OK;
     const int64_t tiles = (n + 15) / 16;
-    const unsigned grid = (unsigned)((tiles + 3) / 4 < 2048 ? (tiles + 3) / 4 : 2048);
+    const int64_t wpb = d >= 128 ? 16 : 4;                           // waves per workgroup (NgcfBlk)
+    const int64_t want_blocks = (tiles + wpb - 1) / wpb, cap_blocks = d >= 128 ? 512 : 2048;
+    const unsigned grid = (unsigned)(want_blocks < cap_blocks ? want_blocks : cap_blocks);
     const size_t shm = sizeof(float) * 2 * (size_t)d * (size_t)(d + 4);
 #define ARL_NGCF_FWD(DV)                                                                                                                         \
     do {                                                                                                                                         \
         hipError_t e1 = hipFuncSetAttribute((const void *)ngcf_dense_fwd_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);     \
         if (e1 != hipSuccess) return (int)e1;                                                                                                    \
-        hipLaunchKernelGGL((ngcf_dense_fwd_kernel<DV>), dim3(grid), dim3(kNgcfBlock), shm, (hipStream_t)stream, P, E, W, (long long)n, slope, out); \
+        hipLaunchKernelGGL((ngcf_dense_fwd_kernel<DV>), dim3(grid), dim3(NgcfBlk<DV>::value), shm, (hipStream_t)stream, P, E, W, (long long)n, slope, out); \
     } while (0)
     if (d == 16) ARL_NGCF_FWD(16); else if (d == 32) ARL_NGCF_FWD(32); else if (d == 64) ARL_NGCF_FWD(64); else ARL_NGCF_FWD(128);
 #undef ARL_NGCF_FWD
@@ -2282,13 +2288,15 @@ int arl_ngcf_dense_dgrad_f32(const float *gOut, const float *Out, const float *P
     if (rc != ARL_OK) return rc;
     if (n == 0) return ARL_OK;
     const int64_t tiles = (n + 15) / 16;
-    const unsigned grid = (unsigned)((tiles + 3) / 4 < 2048 ? (tiles + 3) / 4 : 2048);
+    const int64_t wpb = d >= 128 ? 16 : 4;
+    const int64_t want_blocks = (tiles + wpb - 1) / wpb, cap_blocks = d >= 128 ? 512 : 2048;
+    const unsigned grid = (unsigned)(want_blocks < cap_blocks ? want_blocks : cap_blocks);
     const size_t shm = sizeof(float) * (size_t)d * (size_t)(2 * d + 4);
 #define ARL_NGCF_DG(DV)                                                                                                                          \
     do {                                                                                                                                         \
         hipError_t e1 = hipFuncSetAttribute((const void *)ngcf_dense_dgrad_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);   \
         if (e1 != hipSuccess) return (int)e1;                                                                                                    \
-        hipLaunchKernelGGL((ngcf_dense_dgrad_kernel<DV>), dim3(grid), dim3(kNgcfBlock), shm, (hipStream_t)stream, gOut, Out, P, E, Wt, (long long)n, slope, gZ, gP, gE); \
+        hipLaunchKernelGGL((ngcf_dense_dgrad_kernel<DV>), dim3(grid), dim3(NgcfBlk<DV>::value), shm, (hipStream_t)stream, gOut, Out, P, E, Wt, (long long)n, slope, gZ, gP, gE); \
     } while (0)
     if (d == 16) ARL_NGCF_DG(16); else if (d == 32) ARL_NGCF_DG(32); else if (d == 64) ARL_NGCF_DG(64); else ARL_NGCF_DG(128);
 #undef ARL_NGCF_DG
@@ -2299,7 +2307,8 @@ int arl_ngcf_dense_dgrad_f32(const float *gOut, const float *Out, const float *P
 int64_t arl_ngcf_wgrad_workspace_bytes(int64_t n, int64_t d) {
     if (n <= 0 || d <= 0) return 0;
     const int64_t tiles = (n + 15) / 16;
-    const int64_t blocks = tiles < 512 ? tiles : 512;
+    const int64_t cap = 512;
+    const int64_t blocks = tiles < cap ? tiles : cap;
     return blocks * 2 * d * d * (int64_t)sizeof(float);
 }
 
@@ -2309,7 +2318,8 @@ int arl_ngcf_dense_wgrad_f32(const float *P, const float *E, const float *gZ, in
     if (rc != ARL_OK) return rc;
     if (n == 0) { hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * 2 * d * d, (hipStream_t)stream); return e == hipSuccess ? ARL_OK : (int)e; }
     const int64_t tiles = (n + 15) / 16;
-    const unsigned blocks = (unsigned)(tiles < 512 ? tiles : 512);
+    const int64_t cap = 512;
+    const unsigned blocks = (unsigned)(tiles < cap ? tiles : cap);
     float *part = (float *)workspace;
     if (d == 16) hipLaunchKernelGGL((ngcf_dense_wgrad_kernel<16>), dim3(blocks), dim3(kNgcfBlock), 0, (hipStream_t)stream, P, E, gZ, (long long)n, part);
     else if (d == 32) hipLaunchKernelGGL((ngcf_dense_wgrad_kernel<32>), dim3(blocks), dim3(kNgcfBlock), 0, (hipStream_t)stream, P, E, gZ, (long long)n, part);
