@@ -1071,6 +1071,15 @@ __global__ __launch_bounds__(NgcfBlk<D>::value) void ngcf_dense_dgrad_kernel(con
     }
 }
 
+template <int CP>
+__device__ __forceinline__ void ngcf_load_cp(const float *__restrict__ p, float *o) {
+    if constexpr (CP % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < CP / 4; ++k) { const float4 v = *reinterpret_cast<const float4 *>(p + 4 * k); o[4 * k] = v.x; o[4 * k + 1] = v.y; o[4 * k + 2] = v.z; o[4 * k + 3] = v.w; }
+    } else if constexpr (CP == 2) { const float2 v = *reinterpret_cast<const float2 *>(p); o[0] = v.x; o[1] = v.y; }
+    else o[0] = p[0];
+}
+
 // [gW1; gW2] partial of one workgroup.  A = [S | T]^T tile (M = 16 rows of gW, K = 4 data rows), B = gZ tile (K = 4 data rows, N = 16 columns of
 // gW).  M and N indices are PERMUTED so that one 16-B load per lane serves CP = D/16 tiles: lane c holds columns [c CP, (c + 1) CP) of its data row
 // (a full 256-B row per 16 lanes, coalesced), and tile t covers the columns {c CP + t}.  Every wave forms S, T for all 2 CP row tiles of gW
@@ -1091,12 +1100,12 @@ __global__ __launch_bounds__(kNgcfBlock) void ngcf_dense_wgrad_kernel(const floa
         for (int st = 0; st < 4; ++st) {                                   // K step: data rows tile * 16 + 4 st + q
             const long long row = tile * 16 + 4 * st + q;
             const bool rv = row < n_rows;
-            float sv[CP], tv[CP], bv[NPW];
+            float sv[CP], tv[CP], bv[NPW], pv[CP], ev[CP];
 #pragma unroll
-            for (int k = 0; k < CP; ++k) {
-                const float pv = rv ? P[row * D + c * CP + k] : 0.f, ev = rv ? E[row * D + c * CP + k] : 0.f;      // CP consecutive floats: vectorised by the compiler
-                sv[k] = pv + ev; tv[k] = pv * ev;
-            }
+            for (int k = 0; k < CP; ++k) pv[k] = ev[k] = 0.f;
+            if (rv) { ngcf_load_cp<CP>(P + row * D + c * CP, pv); ngcf_load_cp<CP>(E + row * D + c * CP, ev); }      // 16-B loads: a full row per 16 lanes
+#pragma unroll
+            for (int k = 0; k < CP; ++k) { sv[k] = pv[k] + ev[k]; tv[k] = pv[k] * ev[k]; }
 #pragma unroll
             for (int n = 0; n < NPW; ++n) { const int t = wave + 4 * n; bv[n] = (rv && t < CP) ? gZ[row * D + c * CP + t] : 0.f; }
 #pragma unroll
