@@ -217,6 +217,71 @@ class PropagationEngine:
         ops.batch_rows_clear_(self.G, self.flags, self.bits, rows, check_range=False)
         return self.loss_out
 
+    # ---- NGCF (recommender/NGCF.py:47-64,197-212): the whole training iteration without autograd or a torch optimizer.  Per layer ONE hop
+    # P = A E (A(E W1) = (A E) W1) and the fp32-MFMA dense part (ops.ngcf_dense_*); sparse-batch schedule as in step(): the LAST layer is
+    # evaluated on the <= 3B batch rows only (row-subset hop + a [3B, 2d] dense part), its backward re-enters the table through the flag-masked
+    # hop; the Adam update of the tables is the epilogue of the last backward hop, the d x d weights get the dense Adam kernel.
+    def init_ngcf(self, weights):
+        """weights: [(W1_l, W2_l)] device tensors / Parameters, one pair per layer (updated in place by step_ngcf)."""
+        if len(weights) != self.L or any(tuple(w.shape) != (self.d, self.d) for pair in weights for w in pair):
+            raise ValueError('init_ngcf: one pair of [d, d] weights per layer')
+        self.ngcf_W = [(a.data if hasattr(a, 'data') else a, b.data if hasattr(b, 'data') else b) for a, b in weights]
+        z = lambda: torch.zeros(self.d, self.d, dtype=torch.float32, device=self.device)
+        self.ngcf_m = [(z(), z()) for _ in weights]
+        self.ngcf_v = [(z(), z()) for _ in weights]
+
+    def step_ngcf(self, u, p, n, rows=None, slope=0.01):
+        L, A, d = self.L, self.A, self.d
+        if L < 1 or not hasattr(self, 'ngcf_W') or d not in ops.NGCF_DENSE_WIDTHS:
+            raise ValueError('step_ngcf: needs n_layers >= 1, init_ngcf() and d in %s' % (ops.NGCF_DENSE_WIDTHS,))
+        B = u.numel()
+        if rows is None:
+            rows = torch.cat([u, p + self.U, n + self.U])
+        self._sparse_buffers(B)
+        if getattr(self, '_G_dirty', True):
+            self.G.zero_()
+            self._G_dirty = False
+        s = 1.0 / (L + 1)
+        Wcat = [torch.cat([a, b], 0) for a, b in self.ngcf_W]
+        # forward: L-1 full layers, the last one on the batch rows
+        egos, Ps = [self.E0], []
+        for l in range(L - 1):
+            P = ops.spmm(A, egos[-1])
+            Ps.append(P)
+            egos.append(ops.ngcf_dense_fwd(P, egos[-1], Wcat[l], slope))
+        P_r = ops.spmm_rows(A, egos[-1], rows, (), 1.0, nsplit=self.nsplit, check_range=False)
+        E_r = ops.gather_rows(egos[-1], rows, check_range=False)
+        out_r = ops.ngcf_dense_fwd(P_r, E_r, Wcat[L - 1], slope)
+        acc = out_r + E_r
+        for e in egos[:-1]:
+            acc += ops.gather_rows(e, rows, check_range=False)
+        acc *= s
+        self.Gc.zero_()
+        ops.bpr_l2_fwd_bwd(acc, B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self._ws, loss_out=self.loss_out, check_range=False)
+        Gs = self.Gc * s                                         # every layer's batch rows receive this share of dL/d(out) directly
+        # backward
+        self.t += 1
+        gP_r, gE_r, gW = ops.ngcf_dense_bwd(Gs, out_r, P_r, E_r, Wcat[L - 1], slope)
+        gWs = [None] * L
+        gWs[L - 1] = gW
+        ops.batch_rows_set_(self.G, self.flags, self.bits, rows, gP_r, 1.0, check_range=False)
+        g = ops.spmm_flagged(A, self.G, self.bits)              # A^T (rows' gP scattered) = A (...), A symmetric
+        ops.batch_rows_clear_(self.G, self.flags, self.bits, rows, check_range=False)
+        ops.scatter_add_rows(g, rows, gE_r + Gs, 1.0, check_range=False)
+        if L == 1:
+            ops.adam_dense(self.E0, g, self.m, self.v, self.lr, self.t, self.betas, self.eps)
+        for l in range(L - 2, -1, -1):
+            gP, gE, gWs[l] = ops.ngcf_dense_bwd(g, egos[l + 1], Ps[l], egos[l], Wcat[l], slope)
+            ops.scatter_add_rows(gE, rows, Gs, 1.0, check_range=False)
+            if l > 0:
+                g = ops.spmm(A, gP, 1.0, 1.0, gE)
+            else:
+                ops.spmm_adam(A, gP, 1.0, 1.0, gE, self.E0, self.m, self.v, self.lr, self.t, self.betas, self.eps)
+        for l in range(L):
+            for k in range(2):
+                ops.adam_dense(self.ngcf_W[l][k], gWs[l][k * d:(k + 1) * d], self.ngcf_m[l][k], self.ngcf_v[l][k], self.lr, self.t, self.betas, self.eps)
+        return self.loss_out
+
     def step_simgcl(self, u, p, n, cl_rate=0.2, tau=0.2, eps=0.1, noises=None):
         """One SimGCL training iteration (recommender/SimGCL.py:51-63,198-219) on the sparse-batch schedule.
 

@@ -149,8 +149,46 @@ class NGCF(Recommender):
         self._common_init(args, data, 'NGCF')
         self.model = NGCF_Encoder(self.data, self.args.emb_size, self.args.n_layers)
 
+    # ---- fused route: a stock Adam over exactly this model's parameters (tables + the 2L weights) is replaced by engine.step_ngcf
+    def _weight_params(self):
+        return [self.model.W[n + str(k)] for k in range(self.model.layers) for n in ('w1_', 'w2_')]
+
     def _fusable(self, optimizer):
-        return None                                       # extra dense weights: always the autograd route
+        g = optimizer.param_groups[0] if len(optimizer.param_groups) == 1 else None
+        if (type(optimizer) is not torch.optim.Adam or g is None or self.model.layers < 1 or self.model.latent_size not in ops.NGCF_DENSE_WIDTHS
+                or g.get('weight_decay', 0) != 0 or g.get('amsgrad', False) or g.get('maximize', False) or g.get('capturable', False)):
+            return None
+        mine = self._params() + self._weight_params()
+        if len(g['params']) != len(mine) or {id(q) for q in g['params']} != {id(q) for q in mine}:
+            return None
+        return 'adam'
+
+    def _fused_step(self, eng, u, p, n):
+        return eng.step_ngcf(u, p, n)
+
+    def _bind_optimizer_state(self, eng, optimizer, kind):
+        fresh = not any('exp_avg' in optimizer.state[q] for q in self._params() + self._weight_params())
+        super()._bind_optimizer_state(eng, optimizer, kind)
+        L = self.model.layers
+        if not hasattr(eng, 'ngcf_W') or any(a.data_ptr() != self.model.W['w1_%d' % k].data_ptr() for k, (a, b) in enumerate(eng.ngcf_W)):
+            eng.init_ngcf([(self.model.W['w1_%d' % k], self.model.W['w2_%d' % k]) for k in range(L)])
+        elif fresh:
+            for pair in eng.ngcf_m + eng.ngcf_v:
+                for t in pair:
+                    t.zero_()
+        for k in range(L):
+            for j, name in enumerate(('w1_', 'w2_')):
+                st = optimizer.state[self.model.W[name + str(k)]]
+                if 'exp_avg' in st and st['exp_avg'].data_ptr() != eng.ngcf_m[k][j].data_ptr():
+                    eng.ngcf_m[k][j].copy_(st['exp_avg']); eng.ngcf_v[k][j].copy_(st['exp_avg_sq'])
+                    eng.t = int(st['step'])
+                st['exp_avg'], st['exp_avg_sq'] = eng.ngcf_m[k][j], eng.ngcf_v[k][j]
+                st.setdefault('step', torch.tensor(float(eng.t)))
+
+    def _sync_optimizer_step(self, eng, optimizer, kind):
+        super()._sync_optimizer_step(eng, optimizer, kind)
+        for q in self._weight_params():
+            optimizer.state[q]['step'] = torch.tensor(float(eng.t))
 
     def train(self, requires_adjgrad=False, requires_embgrad=False, gradIterationNum=10, Epoch=0, optimizer=None, evalNum=5):
         return self._train_loop(Epoch, optimizer, evalNum, requires_embgrad=requires_embgrad, requires_adjgrad=requires_adjgrad,

@@ -511,7 +511,7 @@ class Recommender:
                     raise IndexError('batch index outside the embedding tables')
                 u, p, ng = (torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32)).to(DEVICE) for x in (user_idx, pos_idx, neg_idx))
             if eng is not None:
-                last = eng.step(u, p, ng)
+                last = self._fused_step(eng, u, p, ng)
                 continue
             outs = model(True) if self.train_forward_perturbed else model()
             rec_user_emb, rec_item_emb = outs[0], outs[1]

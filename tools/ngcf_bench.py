@@ -65,3 +65,20 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
 print(('rows-form ' if ROWS else 'full-table ') + 'NGCF d=%d L=%d on %dx%d (nnz %d): %.1f ms/step = %.0f interactions/s, loss %.5f, peak mem %.1f GB'
       % (d, L, U, I, nnz, 1e3 * dt, B / dt, float(loss.detach()), torch.cuda.max_memory_allocated() / 1e9))
+
+# the fused route (engine.step_ngcf: what NGCF(args, data).train() runs with its default optimizer): no autograd, no torch optimizer
+from arlib_amd.engine import PropagationEngine
+torch.cuda.empty_cache()
+eng = PropagationEngine(A, U, I, d, L, 1e-4, 0.005, dev, table=packed.clone())
+eng.init_ngcf([(enc.W['w1_%d' % k].detach().clone(), enc.W['w2_%d' % k].detach().clone()) for k in range(L)])
+u32, p32, n32 = u.to(torch.int32), p.to(torch.int32), n.to(torch.int32)
+for _ in range(2):
+    eng.step_ngcf(u32, p32, n32, rows=rows)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+K = 10
+for _ in range(K):
+    lo = eng.step_ngcf(u32, p32, n32, rows=rows)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / K
+print('fused engine.step_ngcf d=%d L=%d: %.1f ms/step = %.0f interactions/s, loss %.5f' % (d, L, 1e3 * dt, B / dt, float(lo[0] + lo[1])))
