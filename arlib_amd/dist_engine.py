@@ -296,13 +296,17 @@ class ShardedPropagationEngine:
         B = u.numel()
         if not hasattr(self, 'W'):
             raise ValueError('step_ngcf: call init_ngcf(W1s, W2s) first')
+        fused = hasattr(k, 'ngcf_dense_fwd') and d in getattr(k, 'NGCF_DENSE_WIDTHS', ())      # fp32-MFMA dense kernels (ops); the CPU test double has none
         saved = []
         ego = self.E0
         acc = self.E0.clone()
         for l in range(L):
             P = self._hop(ego, torch.empty_like(ego))
-            ST = k.ngcf_combine(P, ego)
-            out_l = k.ngcf_act_(torch.mm(ST, self.W[l]), None, self.slope)
+            if fused:
+                ST, out_l = None, k.ngcf_dense_fwd(P, ego, self.W[l], self.slope)
+            else:
+                ST = k.ngcf_combine(P, ego)
+                out_l = k.ngcf_act_(torch.mm(ST, self.W[l]), None, self.slope)
             saved.append((ego, P, ST, out_l))
             acc += out_l
             ego = out_l
@@ -326,14 +330,25 @@ class ShardedPropagationEngine:
         gWs = [None] * L
         for l in range(L - 1, -1, -1):
             ego_l, P, ST, out_l = saved[l]
-            gZ = k.ngcf_act_bwd(g_ego.contiguous(), out_l, self.slope)
             # weight gradient: rows are partitioned (users) or replicated (items: counted on rank 0 only)
-            gW = torch.mm(ST[:Ul].t(), gZ[:Ul]) if Ul else torch.zeros(2 * d, d, device=dev)
-            if self.rank == 0:
-                gW = gW + torch.mm(ST[Ul:].t(), gZ[Ul:])
+            if fused:
+                gP, gE = torch.empty_like(P), torch.empty_like(P)
+                gW = torch.zeros(2 * d, d, dtype=torch.float32, device=dev)
+                go = g_ego.contiguous()
+                for lo_, hi_, count in ((0, Ul, True), (Ul, self.Nl, self.rank == 0)):
+                    if hi_ > lo_:
+                        a, b, w_ = k.ngcf_dense_bwd(go[lo_:hi_], out_l[lo_:hi_], P[lo_:hi_], ego_l[lo_:hi_], self.W[l], self.slope)
+                        gP[lo_:hi_] = a; gE[lo_:hi_] = b
+                        if count:
+                            gW += w_
+            else:
+                gZ = k.ngcf_act_bwd(g_ego.contiguous(), out_l, self.slope)
+                gW = torch.mm(ST[:Ul].t(), gZ[:Ul]) if Ul else torch.zeros(2 * d, d, device=dev)
+                if self.rank == 0:
+                    gW = gW + torch.mm(ST[Ul:].t(), gZ[Ul:])
+                gP, gE = k.ngcf_combine_bwd(torch.mm(gZ, self.W[l].t()), P, ego_l)
             self.comm.all_reduce(gW)
             gWs[l] = gW
-            gP, gE = k.ngcf_combine_bwd(torch.mm(gZ, self.W[l].t()), P, ego_l)
             # g(ego_l) = A gP + gE (+ G/(L+1): layer l's own share of the mean); gP's item rows are replicas, so the hop's item-side partial
             # sums over local users are completed by its all-reduce and gE / G are added after it
             back = self._hop(gP.contiguous(), torch.empty_like(gP), 1.0, 1.0, gE, z_partial=False)
