@@ -29,8 +29,8 @@ TRAFFIC_BLOCKED, TRAFFIC_CSR = 'r02_pmc_traffic_blocked.json', 'r01_pmc_traffic.
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--users', type=int, default=1_000_000)
     ap.add_argument('--items', type=int, default=100_000)
     ap.add_argument('--mean-deg', type=float, default=32.0)
