@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ARLIB_AMD_LIB') or os.path.join(_HERE, 'lib', 'libarlib_amd.so')      # override: developer builds (e.g. `make prof`)
-ABI_VERSION = 13
+ABI_VERSION = 14
 _lib = None
 
 
@@ -20,7 +20,7 @@ class arl_csr(C.Structure):
     _fields_ = [('n_rows', C.c_int64), ('nnz', C.c_int64), ('rowptr', C.c_void_p), ('col', C.c_void_p), ('val', C.c_void_p),
                 ('chunk', C.c_int32), ('n_chunks', C.c_int64), ('chunk_row', C.c_void_p), ('chunk_begin', C.c_void_p),
                 ('chunk_end', C.c_void_p), ('n_long', C.c_int64), ('long_row', C.c_void_p), ('long_first', C.c_void_p),
-                ('long_count', C.c_void_p), ('partial', C.c_void_p)]
+                ('long_count', C.c_void_p), ('partial', C.c_void_p), ('row_tasks', C.c_void_p)]
 
 
 class arl_blocked(C.Structure):

@@ -51,6 +51,7 @@ struct CsrDev {
     int n_long;
     const int32_t *long_row, *long_first, *long_count;
     float *partial;
+    const int4 *row_tasks;        // optional (row, begin, end, 0) per row task, in the order the masked hop takes them
 };
 
 enum { EPI_AXPBY = 0, EPI_LAYERSUM = 1, EPI_ADAM = 2 };
@@ -219,8 +220,13 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_masked_gpr_kernel(CsrDev A, 
     if (task < A.n_chunks) {
         slot = (int)task; begin = A.chunk_begin[slot]; end = A.chunk_end[slot];
     } else if (task < total) {
-        row = (int)(task - A.n_chunks);
-        begin = A.rowptr[row]; end = A.rowptr[row + 1];
+        if (A.row_tasks) {                               // rows sorted by length: the wave's four rows are equally long, one 16-B record each
+            const int4 rt = A.row_tasks[task - A.n_chunks];
+            row = rt.x; begin = rt.y; end = rt.z;
+        } else {
+            row = (int)(task - A.n_chunks);
+            begin = A.rowptr[row]; end = A.rowptr[row + 1];
+        }
         if (A.n_chunks > 0 && end - begin > A.chunk) { end = begin; row = -1; }     // long row: summed by spmm_long_rows_kernel
     }
     const bool qact = (q * 4 < d);
@@ -484,6 +490,7 @@ int launch_spmm(const arl_csr *A, const float *X, int64_t d, const Epi &ep, hipS
     D.chunk = A->chunk; D.n_chunks = (int)A->n_chunks; D.chunk_row = A->chunk_row; D.chunk_begin = A->chunk_begin;
     D.chunk_end = A->chunk_end; D.n_long = (int)A->n_long; D.long_row = A->long_row; D.long_first = A->long_first;
     D.long_count = A->long_count; D.partial = A->partial;
+    D.row_tasks = xflags ? reinterpret_cast<const int4 *>(A->row_tasks) : nullptr;
     const long long tasks = (long long)D.n_rows + D.n_chunks;
     const unsigned grid = (unsigned)((tasks + kWavesPerBlock - 1) / kWavesPerBlock);
     const unsigned grid_long = (unsigned)((D.n_long + kWavesPerBlock - 1) / kWavesPerBlock);

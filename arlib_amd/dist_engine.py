@@ -143,6 +143,9 @@ class ShardedPropagationEngine:
             raise ValueError("schedule must be 'auto', 'csr' or 'blocked'")
         if schedule != 'csr' and hasattr(kernels, 'auto_blocked') and (schedule == 'blocked' or self.Au.nnz + self.Ai.nnz >= kernels.BLOCKED_MIN_NNZ):
             kernels.auto_blocked(self.Au, self.d, force=True); kernels.auto_blocked(self.Ai, self.d, force=True)
+        for gph in (self.Au, self.Ai):                       # flag-masked hops take the rows sorted by length (ops.CSRGraph.enable_masked_order)
+            if hasattr(gph, 'enable_masked_order') and gph.nnz >= 1_000_000:
+                gph.enable_masked_order()
         table = torch.as_tensor(table, dtype=torch.float32)
         if table.shape != (self.U + self.I, self.d):
             raise ValueError('table must be the full [U+I, d] initial table (every rank slices its own rows)')

@@ -42,6 +42,8 @@ class PropagationEngine:
         # full-table hops: register-blocked schedule (ops.BlockedPlan) for large graphs at d = 64, row-per-group CSR kernel otherwise
         if schedule != 'csr':
             ops.auto_blocked(graph, emb_size, split=self.U, force=(schedule == 'blocked'))
+        if graph is not None and graph.nnz >= ops.BLOCKED_MIN_NNZ:
+            graph.enable_masked_order()              # flag-masked hops take the rows sorted by length
         z = lambda: torch.zeros(self.N, self.d, dtype=torch.float32, device=self.device)
         self.E0 = z() if table is None else table
         if self.E0.shape != (self.N, self.d) or self.E0.dtype != torch.float32 or not self.E0.is_contiguous():

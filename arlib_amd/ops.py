@@ -127,7 +127,19 @@ class CSRGraph:
         g._partial = None
         g._rows_disabled = True
         g.blocked = None
+        g._row_tasks = None
         return g
+
+    def enable_masked_order(self):
+        """Attach the (row, begin, end, 0) task table of the flag-masked hop: rows in descending edge-count order, so the four lane groups of a
+        wave own rows of (nearly) equal length -- a wave lasts as long as its longest row, and row lengths are heavy-tailed.  Pattern-only:
+        shared by with_values() copies."""
+        if getattr(self, '_row_tasks', None) is None and self.n_rows > 0 and not getattr(self, '_rows_disabled', False):
+            rp = self.rowptr.long()
+            deg = rp[1:] - rp[:-1]
+            order = torch.sort(deg, descending=True, stable=True)[1]
+            self._row_tasks = torch.stack([order, rp[order], rp[order + 1], torch.zeros_like(order)], 1).to(torch.int32).contiguous()
+        return self
 
     def with_values(self, val):
         """Same pattern and plan, different edge values (shares index tensors)."""
@@ -151,6 +163,8 @@ class CSRGraph:
             s.chunk_row, s.chunk_begin, s.chunk_end = self.chunk_row.data_ptr(), self.chunk_begin.data_ptr(), self.chunk_end.data_ptr()
             s.long_row, s.long_first, s.long_count = self.long_row.data_ptr(), self.long_first.data_ptr(), self.long_count.data_ptr()
             s.partial = self._partial.data_ptr()
+        rt = getattr(self, '_row_tasks', None)
+        s.row_tasks = rt.data_ptr() if rt is not None else None
         return s
 
     def spmm_bytes(self, d):

@@ -81,6 +81,9 @@ typedef struct arl_csr {
     const int32_t *long_first;  /* [n_long] device: first chunk slot of the row                   */
     const int32_t *long_count;  /* [n_long] device: number of chunk slots                         */
     float *partial;             /* [n_chunks * d] device workspace                                */
+    const int32_t *row_tasks;   /* optional [n_rows][4] = (row, first edge, one past last edge, 0): the rows in the order the flag-masked
+                                 * hop should take them -- sorted by edge count, so that the four lane groups of a wave own rows of equal
+                                 * length (a wave lasts as long as its longest row).  NULL: rows in index order.               */
 } arl_csr;
 
 /* Degree-normalised edge values on device.  Replaces util/DataLoader.py:73-87 (normalize_graph_mat) and

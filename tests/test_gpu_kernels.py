@@ -515,7 +515,7 @@ def test_incremental_bipartite_update_equals_fresh_build(ops, planned, monkeypat
     inc = ops.IncrementalBipartite(T(u.astype(np.int64)), T(i.astype(np.int64)), U, F, I, DEV, emb_size=d)
     assert (inc.base is not None) == planned
     Up, N = U + F, U + F + I
-    X = torch.randn(N, d, device=DEV)
+    X = torch.randn(N, d, generator=torch.Generator().manual_seed(3)).to(DEV)
     for trial in range(4):
         if trial == 2:
             fu = np.zeros(0, np.int64); fi = np.zeros(0, np.int64); fw = None
@@ -534,11 +534,11 @@ def test_incremental_bipartite_update_equals_fresh_build(ops, planned, monkeypat
         assert torch.equal(g.rowptr, ref.rowptr) and torch.equal(g.col, ref.col) and torch.equal(g.val, ref.val) and torch.equal(g.dinv, ref.dinv)
         assert (g.blocked is not None) == planned
         y_ref = ops.spmm(ref, X)
-        assert rel_err(ops.spmm(g, X).cpu().numpy(), y_ref.cpu().numpy()) < 1e-6
+        assert rel_err(ops.spmm(g, X).cpu().numpy(), y_ref.cpu().numpy()) < 1e-5          # blocked vs CSR schedule: different summation order
         if planned:
             assert sum(s['n_edges'] for s in g.blocked.sets) == g.nnz
-            Z = torch.randn(N, d, device=DEV)
-            assert rel_err(ops.spmm(g, X, 0.5, -2.0, Z).cpu().numpy(), ops.spmm(ref, X, 0.5, -2.0, Z).cpu().numpy()) < 1e-6
+            Z = torch.randn(N, d, generator=torch.Generator().manual_seed(4)).to(DEV)
+            assert rel_err(ops.spmm(g, X, 0.5, -2.0, Z).cpu().numpy(), ops.spmm(ref, X, 0.5, -2.0, Z).cpu().numpy()) < 1e-5
 
 
 @pytest.mark.parametrize('d,n', [(16, 1000), (32, 517), (64, 4099), (128, 2050), (64, 7)])
@@ -558,3 +558,25 @@ def test_ngcf_dense_layer_on_mfma_matches_float64(ops, d, n):
     assert rel_err(gP.cpu().numpy(), Pd.grad.cpu().numpy()) < 1e-5 and rel_err(gE.cpu().numpy(), Ed.grad.cpu().numpy()) < 1e-5
     assert rel_err(gW.cpu().numpy(), Wd.grad.cpu().numpy()) < 1e-5
     assert torch.equal(gW, ops.ngcf_dense_bwd(gOut, out, P, E, W, 0.01)[2])            # deterministic partial sums
+
+
+def test_masked_hop_with_rows_taken_in_length_order(ops):
+    """ops.spmm_flagged on a graph with enable_masked_order() (what the engine does on large graphs: row tasks sorted by edge count, one
+    (row, begin, end) record per task) -- same numbers as the index-order launch, long rows and empty rows included, also after with_values()."""
+    rng = np.random.default_rng(33)
+    U, I, d = 5000, 300, 64
+    u, i = random_graph(rng, U, I, 9, hot_items=2, hot_deg=1800, empty_users=(4, 5, 4098))
+    rowptr, col, w, val = make_csr(u, i, U, I)
+    N = U + I
+    A1, A2 = ops.CSRGraph(rowptr, col, val, DEV, chunk=128), ops.CSRGraph(rowptr, col, val, DEV, chunk=128).enable_masked_order()
+    assert A2._row_tasks is not None and A2._row_tasks.shape == (N, 4) and A2.n_chunks > 0
+    rows = torch.from_numpy(rng.choice(N, 500, replace=False).astype(np.int32)).to(DEV)
+    G = torch.zeros(N, d, device=DEV); flags = torch.zeros(N, dtype=torch.uint8, device=DEV); bits = torch.zeros((N + 31) // 32, dtype=torch.int32, device=DEV)
+    ops.batch_rows_set_(G, flags, bits, rows, torch.randn(500, d, device=DEV))
+    y1 = ops.spmm_flagged(A1, G, bits, 0.5, 2.0, G, flags)
+    y2 = ops.spmm_flagged(A2, G, bits, 0.5, 2.0, G, flags)
+    assert torch.equal(y1, y2)                                                 # same per-row arithmetic, only the task order differs
+    assert rel_err(y2.cpu().numpy(), O.spmm((rowptr, col, val), G.cpu().numpy(), 0.5, 2.0, G.cpu().numpy())) < RTOL
+    B2 = A2.with_values(T((val * 0.5).astype(np.float32)))
+    assert B2._row_tasks is A2._row_tasks and torch.equal(ops.spmm_flagged(B2, G, bits), 0.5 * ops.spmm_flagged(A1, G, bits))
+    assert torch.equal(ops.spmm(A2, G), ops.spmm(A1, G))                       # other kernels ignore the table
