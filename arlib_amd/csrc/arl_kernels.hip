@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <math.h>
 #include "arlib_amd.h"
+#include <type_traits>
 
 #define ARL_LAUNCH_CHECK()                                  \
     do {                                                    \
@@ -1454,7 +1455,10 @@ __global__ __launch_bounds__(kBlock) void score_mask_topk_kernel(const float *__
 // Measured on MI355X: the f32 MFMA shares the SIMD's issue with the VALU (a second wave per SIMD hides latencies but its VALU
 // work does NOT overlap the other wave's f32 MFMAs), so every VALU instruction of the pre-filter/insert path is paid in full --
 // hence one subtract + one funnel shift per score, one ballot per phase, and the split-bf16 form below for the contraction.
-constexpr int kMU = 128;         // users per block
+#ifndef ARL_TOPK_NW
+#define ARL_TOPK_NW 8
+#endif
+constexpr int kMU = 16 * ARL_TOPK_NW;         // users per block
 #ifdef ARL_TOPK_PROF
 #define ARL_PROF_DECL long long P_acc[4] = {0, 0, 0, 0}, P_t0 = clock64(); const long long P_start = P_t0;
 #define ARL_PROF_TICK(SLOT) { const long long P_t = clock64(); P_acc[SLOT] += P_t - P_t0; P_t0 = P_t; }
@@ -1465,8 +1469,11 @@ constexpr int kMU = 128;         // users per block
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
-constexpr int kM16Block = 512;
+constexpr int kM16Block = 64 * ARL_TOPK_NW;
 constexpr int kBloomWords = 32;      // 1024 bits per user
+constexpr int kTopkRing = 4;         // staged item tiles in LDS (slots of the ring), a power of two
+constexpr int kTopkLead = 2;         // a wave writes its share of stage s + kTopkLead while it consumes stage s
+constexpr int kTopkBootItems = 4096; // items scored by the bootstrap pass of a cold call (a multiple of every stage size)
 __device__ __forceinline__ unsigned bloom_hash(int item) { return ((unsigned)item * 2654435761u) >> 22; }
 
 // SPLIT = true: the contraction runs on the bf16 matrix path with every fp32 operand split into three bf16 pieces
@@ -1476,6 +1483,7 @@ __device__ __forceinline__ unsigned bloom_hash(int item) { return ((unsigned)ite
 // the fp32 MFMA -- they leave the SIMD's vector issue free for the other wave's pre-filter and inserts.  `Pi` is then the
 // pre-split image [I][3][D] bf16 written by split_bf16x3_kernel.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) unsigned lds_u32;
 
 __global__ __launch_bounds__(kBlock) void split_bf16x3_kernel(const float *__restrict__ X, long long n, int d, __bf16 *__restrict__ out) {
     const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;          // one element each
@@ -1545,11 +1553,18 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
     constexpr int C16 = SRCB / 16;                                 // 16-byte pieces per item row
     constexpr int F4 = MST * C16;
     constexpr int PER = (F4 + kM16Block - 1) / kM16Block;
-    static_assert(PER >= 1 && PER <= 3, "staging assumes one to three 16-byte pieces per thread");
-    float4 nb0, nb1, nb2;                                          // named staging registers (an indexed array stayed in scratch)
-    nb0 = nb1 = nb2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool second = tid + kM16Block < F4, third = tid + 2 * kM16Block < F4;      // this thread moves a second / third piece
-    const int nstages = (I + MST - 1) / MST;
+    static_assert(PER >= 1 && PER <= 6, "staging assumes one to six 16-byte pieces per thread");
+    const int nstages = (I + MST - 1) / MST;                       // item stages
+    // Cold calls open with a BOOTSTRAP pass over the first kTopkBootItems items (NB stages; scores only, no lists): every lane keeps the
+    // four best scores it sees for each of its four user rows (a lane sees the items congruent to its column mod 16), so a row's 16
+    // lanes end with 64 scores of DISTINCT items.  The (k + m)-th best of those -- m = the row's interacted items inside the sample,
+    // which the mask may take out -- is a lower bound of the row's final k-th best score: the stream then restarts from item 0 with it
+    // as the starting threshold (the warm-start mechanism), and the ~k ln(I/k) record-setters of a cold stream (half of them in its
+    // first 2 %) drop to ~k (1 + ln(I / sample)).  Same instruction sequence on the same data: the sample's scores are bit-identical in
+    // both passes, so the k items the bound rests on pass it again.
+    const int NB = (!WARM && nstages >= 8 * (kTopkBootItems / MST)) ? kTopkBootItems / MST : 0;
+    const int nvirt = NB + nstages;                                // stages as the ring counts them: the bootstrap's, then the stream's
+    auto item_stage = [&](int v) { return v < NB ? v : v - NB; };
     auto stage_ptr = [&](int st, int p) {
         const int f = tid + p * kM16Block;
         const int item = min(st * MST + f / C16, I - 1);           // clamped, never selected on: rows past I are masked out of pm
@@ -1592,7 +1607,7 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const float t0 = WARM ? __shfl(thr0v, 4 * g + reg) : -INFINITY;
-        thrf[reg] = (u_base + 4 * g + reg < U) ? t0 : INFINITY;    // users past U never insert
+        thrf[reg] = (u_base + 4 * g + reg < U) ? t0 : INFINITY;    // users past U never insert (cold calls: reset after the bootstrap)
     }
     // The running top-k of each of the wave's 16 users is a SORTED list held in registers: lane j of tk[r] is the j-th largest key
     // of user row r (k <= 64 = one key per lane; 0 = empty, below every real key).  An insert is one 64-bit compare + ballot for
@@ -1603,7 +1618,9 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
     // Interacted-item mask: a 1024-bit Bloom filter per user in LDS answers "not interacted" for ~97 % of the pre-filter
     // survivors with one LDS read; only filter hits pay the binary search in global memory (7 dependent L2 round trips).
     constexpr int STAGEB = 2 * HALF;
-    unsigned *bloom = reinterpret_cast<unsigned *>(bt + 2 * STAGEB) + wv * 16 * kBloomWords;               // [16][kBloomWords]
+    unsigned *ring_ctr = reinterpret_cast<unsigned *>(bt + kTopkRing * STAGEB);                             // fill[kTopkRing], done[kTopkRing]
+    unsigned *bloom = ring_ctr + 2 * kTopkRing + wv * 16 * kBloomWords;                                     // [16][kBloomWords]
+    if (tid < 2 * kTopkRing) ring_ctr[tid] = 0u;
     if (mrp) {
         for (int t = lane; t < 16 * kBloomWords; t += kWave) bloom[t] = 0u;
         __builtin_amdgcn_wave_barrier();
@@ -1634,9 +1651,8 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
         }
         const unsigned th = (unsigned)__builtin_amdgcn_readlane((int)nh, k - 1);
         const unsigned tl = (unsigned)__builtin_amdgcn_readlane((int)nl, k - 1);
-        if constexpr (!WARM) return (th | tl) ? cand_score((unsigned long long)th << 32) : -INFINITY;
         const float t0 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(thr0v), row));
-        return (th | tl) ? fmaxf(cand_score((unsigned long long)th << 32), t0) : t0;     // t0: the warm-start bound
+        return (th | tl) ? fmaxf(cand_score((unsigned long long)th << 32), t0) : t0;     // t0: the warm-start / bootstrap bound (-inf if none)
     };
     // Pre-filter + inserts for the scores of one stage (16*SPP items x 16 users per phase: NSC scores per lane,
     // bit b = 4*s2 + reg  <->  item item0 + 16*s2 + c, user row 4g + reg).
@@ -1696,21 +1712,75 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
             }
         }
     };
+    // ---- bootstrap pass state: bl[reg][j] = j-th best score this lane has seen for user row 4g + reg (descending)
+    float bl[4][4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bl[reg][j] = -INFINITY;
+    auto boot_book = [&](const f32x4 (&ac)[NSUB]) {
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {                    // sorted insert, all four levels from the OLD values: 4 independent ops
+                const float sc = ac[sub][reg];
+                const float n3 = __builtin_amdgcn_fmed3f(bl[reg][2], bl[reg][3], sc), n2 = __builtin_amdgcn_fmed3f(bl[reg][1], bl[reg][2], sc);
+                const float n1 = __builtin_amdgcn_fmed3f(bl[reg][0], bl[reg][1], sc), n0 = fmaxf(bl[reg][0], sc);
+                bl[reg][0] = n0; bl[reg][1] = n1; bl[reg][2] = n2; bl[reg][3] = n3;
+            }
+    };
+    // the rows' (k + m)-th best of their 64 sample scores -> thr0v (lane r = row r) and thrf
+    auto boot_finish = [&]() {
+        int m16 = 0;                                               // lane r < 16: interacted items of row r inside the sample
+        if (mrp && lane < 16 && u_base + lane < U) {
+            const int b0 = mrp[u_base + lane];
+            int lo = b0, hi = mrp[u_base + lane + 1];
+            const int lim = NB * MST;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (mcol[mid] < lim) lo = mid + 1; else hi = mid; }
+            m16 = lo - b0;
+        }
+        float t0v = -INFINITY;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int m = __shfl(m16, 4 * g + reg);
+            const int nrem = 64 - (k + m);                         // how many of the 64 lie below the (k + m)-th best
+            for (int it = 0; it < 64 - k; ++it) {                  // wave-uniform trip count; a group stops removing at its own nrem
+                float gm = bl[reg][3];
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) gm = fminf(gm, __shfl_xor(gm, off, 16));
+                const unsigned long long eq = __ballot(bl[reg][3] == gm && it < nrem);
+                const unsigned mine = (unsigned)(eq >> (16 * g)) & 0xffffu;
+                if (mine != 0u && (__ffs(mine) - 1) == c) {        // the group's first lane holding the minimum drops it
+                    bl[reg][3] = bl[reg][2]; bl[reg][2] = bl[reg][1]; bl[reg][1] = bl[reg][0]; bl[reg][0] = INFINITY;
+                }
+            }
+            float gm = bl[reg][3];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) gm = fminf(gm, __shfl_xor(gm, off, 16));
+            const float t0 = (nrem >= 0 && u_base + 4 * g + reg < U) ? gm : -INFINITY;
+            thrf[reg] = (u_base + 4 * g + reg < U) ? t0 : INFINITY;
+            const float bc = __shfl(t0, 16 * (lane >> 2) + 0);     // lane r < 16 reads group r / 4 ...
+            if (lane < 16 && (lane & 3) == reg) t0v = bc;          // ... when this is row r's register
+        }
+        thr0v = t0v;
+    };
     ARL_PROF_DECL
     // Scores of one staged tile + their bookkeeping.
-    auto compute = [&](const unsigned char *buf, int st) {
+    auto compute = [&](auto boot_tag, const unsigned char *buf, int st, unsigned *done_slot) {
         f32x4 accs[NSUB];
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) accs[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (SPLIT) {
             bf16x8 bfr[NSUB][3][KS];
 #pragma unroll
-            for (int sub = 0; sub < NSUB; ++sub)
+            for (int plo = 0; plo < 3; ++plo)                      // planes in the order the terms below first use them: 0, 2, 1
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks)
+                    for (int sub = 0; sub < NSUB; ++sub) {
+                        const int pl = plo == 0 ? 0 : 3 - plo;
                         bfr[sub][pl][ks] = *reinterpret_cast<const bf16x8 *>(buf + (g & 1) * HALF + (sub * 16 + c) * RH + ((pl * 2 + (g >> 1)) * PPG + ks) * 16);
+                    }
             __builtin_amdgcn_sched_barrier(0);
             constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};      // (A piece, B piece), smallest products first
 #pragma unroll
@@ -1743,42 +1813,87 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
                 for (int sub = 0; sub < NSUB; ++sub) accs[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t + 3], bf[sub][t / 4].w, accs[sub], 0, 0, 0);
             }
         }
+        // the tile's fragments are in registers: the slot can be refilled while this wave does its bookkeeping
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add((lds_u32 *)done_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifdef ARL_TOPK_PROF
         { float sink = accs[0][0] + accs[NSUB - 1][3]; asm volatile("" ::"v"(sink)); ARL_PROF_TICK(1) }
 #endif
-        bookkeeping(accs, st);
+        if constexpr (decltype(boot_tag)::value) boot_book(accs);  // bootstrap stage (its own loop below, so `bl` is dead in the stream's)
+        else bookkeeping(accs, st - NB);
         ARL_PROF_TICK(2)
     };
-    // Global -> register -> LDS staging runs TWO stages ahead (register sets nb* / nc* alternate; the loop is unrolled by two so
-    // that no register copy has to wait for a load): with the short stages of the bf16 path one stage of lead did not cover
-    // the load latency and the wait showed up in front of every barrier.
-    float4 nc0, nc1, nc2;
-    nc0 = nc1 = nc2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto fetch = [&](int st, float4 &r0, float4 &r1, float4 &r2) {
-        r0 = *stage_ptr(st, 0);
-        if constexpr (PER > 1) { if (second) r1 = *stage_ptr(st, 1); }
-        if constexpr (PER > 2) { if (third) r2 = *stage_ptr(st, 2); }
+    // Staging: global -> registers (one stage of lead: the loads of stage t + 1 are issued right after stage t went to LDS) -> a RING
+    // of kTopkRing tiles in LDS.  No block barrier in the loop: every wave writes ITS share of stage s + kTopkLead into slot
+    // (s + kTopkLead) % kTopkRing once all waves have read the stage that occupied it (`done` counter), and consumes stage s once all
+    // shares of it are there (`fill` counter).  A wave may therefore run up to two stages ahead of the slowest one: the inserts come in
+    // bursts (half of them in the first 2 % of the stream) and with a barrier per stage every burst of one wave stalled the other
+    // seven (barrier wait was 18-34 % of the kernel); drifting apart, the waves also stop issuing their 24 KB of fragment reads at the
+    // same moment.  Counters only grow (stage t expects (t / ring + 1) * waves); LDS executes a wave's operations in order, so a
+    // wave's tile writes are in place before its increment is.
+    // Two register sets: the loads of stage t + 2 are in flight while stage t goes to LDS.  (Issuing them through inline assembly with
+    // counted `vmcnt` waits was tried: no gain, and unsafe -- the register allocator may split the live range of an asm output around
+    // a cold block, e.g. the mask's binary search, and copy the registers before the load has landed.)
+    static_assert(F4 % kM16Block == 0, "every thread moves the same number of pieces");
+    f32x4 nb[PER], nc[PER];
+#pragma unroll
+    for (int p = 0; p < PER; ++p) nb[p] = nc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int st, f32x4 (&r)[PER]) {
+#pragma unroll
+        for (int p = 0; p < PER; ++p) r[p] = *reinterpret_cast<const f32x4 *>(stage_ptr(st, p));
     };
-    auto stash = [&](unsigned char *buf, const float4 &r0, const float4 &r1, const float4 &r2) {
-        *lds_ptr(buf, 0) = r0;
-        if constexpr (PER > 1) { if (second) *lds_ptr(buf, 1) = r1; }
-        if constexpr (PER > 2) { if (third) *lds_ptr(buf, 2) = r2; }
+    auto stash = [&](unsigned char *buf, const f32x4 (&r)[PER]) {
+#pragma unroll
+        for (int p = 0; p < PER; ++p) *reinterpret_cast<f32x4 *>(lds_ptr(buf, p)) = r[p];
     };
-    fetch(0, nb0, nb1, nb2);
-    if (nstages > 1) fetch(1, nc0, nc1, nc2);
-    for (int st = 0; st < nstages; st += 2) {
-        stash(bt, nb0, nb1, nb2);
-        __syncthreads();                                           // one block barrier per stage
-        ARL_PROF_TICK(0)
-        if (st + 2 < nstages) fetch(st + 2, nb0, nb1, nb2);
-        compute(bt, st);
-        if (st + 1 < nstages) {                                    // block-uniform
-            stash(bt + STAGEB, nc0, nc1, nc2);
-            __syncthreads();
-            ARL_PROF_TICK(0)
-            if (st + 3 < nstages) fetch(st + 3, nc0, nc1, nc2);
-            compute(bt + STAGEB, st + 1);
+    auto slot = [&](int st) { return bt + (st & (kTopkRing - 1)) * STAGEB; };
+    auto signal = [&](unsigned *ctr) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add((lds_u32 *)ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto wait_ge = [&](unsigned *ctr, unsigned want) {             // explicit LDS loads: a flat load would also wait for the global prefetch
+        int spins = 0;
+        while ((unsigned)__builtin_amdgcn_readfirstlane((int)*(volatile lds_u32 *)ctr) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 26)) __builtin_trap();             // never reached: every wave signals every stage; a trap beats a hang
         }
+        asm volatile("" ::: "memory");
+    };
+    unsigned *fill_ctr = ring_ctr, *done_ctr = ring_ctr + kTopkRing;
+    constexpr unsigned NWV = kM16Block / kWave;
+    static_assert(kTopkLead == 2 && (kTopkRing & (kTopkRing - 1)) == 0, "the loop below is unrolled by the lead");
+    __syncthreads();                                               // counters zeroed (the only block barrier of the kernel)
+    // one step of the pipeline: stage st + 2 goes from register set r to LDS, set r is refilled with stage st + 4, stage st is consumed
+    auto step = [&](auto boot_tag, int st, f32x4 (&r)[PER]) {
+        const int t = st + kTopkLead;
+        if (t < nvirt) {
+            wait_ge(done_ctr + (t & (kTopkRing - 1)), NWV * (unsigned)(t / kTopkRing));          // stage t - ring has been read by every wave
+            stash(slot(t), r);
+            signal(fill_ctr + (t & (kTopkRing - 1)));
+            if (t + 2 < nvirt) fetch(item_stage(t + 2), r);
+        }
+        ARL_PROF_TICK(0)
+        wait_ge(fill_ctr + (st & (kTopkRing - 1)), NWV * (unsigned)(st / kTopkRing + 1));
+        ARL_PROF_TICK(3)
+        compute(boot_tag, slot(st), st, done_ctr + (st & (kTopkRing - 1)));
+    };
+    fetch(item_stage(0), nb);
+    if (nvirt > 1) fetch(item_stage(1), nc);
+    stash(slot(0), nb);
+    signal(fill_ctr + 0);
+    if (nvirt > 1) { stash(slot(1), nc); signal(fill_ctr + 1); }
+    if (nvirt > 2) fetch(item_stage(2), nb);
+    if (nvirt > 3) fetch(item_stage(3), nc);
+    if constexpr (!WARM) {
+        for (int st = 0; st < NB; st += 2) {                       // NB is even
+            step(std::true_type{}, st, nb);
+            step(std::true_type{}, st + 1, nc);
+        }
+        if (NB > 0) boot_finish();
+    }
+    for (int st = NB; st < nvirt; st += 2) {
+        step(std::false_type{}, st, nb);
+        if (st + 1 < nvirt) step(std::false_type{}, st + 1, nc);
     }
 #ifdef ARL_TOPK_PROF
     const long long P_loop = clock64() - P_start;
@@ -2493,7 +2608,7 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
         const bool split = workspace != nullptr && (d == 64 || d == 128);
         const int mst = d <= 16 ? 128 : (d <= 64 ? 64 : 32);
         const size_t stageb = 2 * (size_t)mst * ((split ? 6 : 4) * (size_t)d / 2 + 16);     // two half images of mst rows (STAGEB in the kernel)
-        const size_t shm_m = 2 * stageb + (mask_rowptr ? sizeof(unsigned) * kMU * kBloomWords : 0);
+        const size_t shm_m = kTopkRing * stageb + 2 * kTopkRing * sizeof(unsigned) + (mask_rowptr ? sizeof(unsigned) * kMU * kBloomWords : 0);
         const unsigned grid_m = (unsigned)((U + kMU - 1) / kMU);
         const void *image = Pi;
         if (split) {

@@ -421,6 +421,48 @@ def test_score_mask_topk(ops, U, I, d, k, masked, exact):
     assert same.mean() > 0.999
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('d,k', [(64, 50), (128, 20), (64, 64), (32, 10)])
+def test_score_mask_topk_bootstrap_threshold(ops, d, k):
+    """Cold calls with I >= 32 K open with a bootstrap pass over the first 4 096 items whose (k + m)-th best sample score pre-sets every
+    user's threshold (m = the user's interacted items inside the sample).  The bound must stay valid when the mask takes out exactly the
+    sample's best items: users here interact with their top-scoring items of the sample range (few, more than 64 - k, and none)."""
+    rng = np.random.default_rng(1000 * d + k)
+    U, I = 200, 40000
+    Pu = (rng.normal(size=(U, d)) * 0.1).astype(np.float32)
+    Pi = (rng.normal(size=(I, d)) * 0.1).astype(np.float32)
+    Pi[:4096] *= 1.5                                     # the sample range holds most of every user's best items
+    scores = Pu.astype(np.float64) @ Pi.astype(np.float64).T
+    lens = np.concatenate([np.zeros(40, np.int64), rng.integers(1, 14, 80), rng.integers(15, 120, 80)])
+    cols = []
+    for u in range(U):
+        best = np.argsort(-scores[u, :4096])[:lens[u]]   # interacted = the user's best items of the sample ...
+        extra = rng.choice(np.arange(4096, I), size=int(lens[u]) // 2, replace=False)       # ... plus some outside it
+        cols.append(np.unique(np.concatenate([best, extra])).astype(np.int32))
+    rp = np.concatenate([[0], np.cumsum([len(c) for c in cols])]).astype(np.int32)
+    mc = np.concatenate(cols + [np.zeros(1, np.int32)])[:max(int(rp[-1]), 1)]
+    for masked in (False, True):
+        sc = scores.copy()
+        if masked:
+            for u in range(U):
+                sc[u, cols[u]] = -10e8
+        ridx = np.argsort(-sc, axis=1, kind='stable')[:, :k]
+        rval = np.take_along_axis(sc, ridx, 1)
+        if masked:
+            idx, val = ops.score_mask_topk(T(Pu), T(Pi), k, T(rp), T(mc))
+        else:
+            idx, val = ops.score_mask_topk(T(Pu), T(Pi), k)
+        idx, val = idx.cpu().numpy(), val.cpu().numpy()
+        assert rel_err(val, rval.astype(np.float32)) < 1e-5
+        assert (val[:, :-1] >= val[:, 1:]).all()
+        same = idx == ridx
+        assert same.mean() > 0.999
+        for r, c in np.argwhere(~same):                  # differences are near-ties of the split-bf16 contraction
+            assert abs(rval[r, c] - val[r, c]) <= 1e-5 * max(1.0, abs(rval[r, c]))
+        ex_i, ex_v = ops.score_mask_topk(T(Pu), T(Pi), k, T(rp) if masked else None, T(mc) if masked else None, exact=True)
+        assert rel_err(ex_v.cpu().numpy(), rval.astype(np.float32)) < 1e-5 and (ex_i.cpu().numpy() == ridx).mean() > 0.999
+
+
 def test_topn_project_rows(ops):
     rng = np.random.default_rng(6)
     M = rng.random((7, 1412)).astype(np.float32)
