@@ -1555,14 +1555,14 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
     constexpr int PER = (F4 + kM16Block - 1) / kM16Block;
     static_assert(PER >= 1 && PER <= 6, "staging assumes one to six 16-byte pieces per thread");
     const int nstages = (I + MST - 1) / MST;                       // item stages
-    // Cold calls open with a BOOTSTRAP pass over the first kTopkBootItems items (NB stages; scores only, no lists): every lane keeps the
+    // Calls over long item streams open with a BOOTSTRAP pass over the first kTopkBootItems items (NB stages; scores only, no lists): every lane keeps the
     // four best scores it sees for each of its four user rows (a lane sees the items congruent to its column mod 16), so a row's 16
     // lanes end with 64 scores of DISTINCT items.  The (k + m)-th best of those -- m = the row's interacted items inside the sample,
     // which the mask may take out -- is a lower bound of the row's final k-th best score: the stream then restarts from item 0 with it
     // as the starting threshold (the warm-start mechanism), and the ~k ln(I/k) record-setters of a cold stream (half of them in its
     // first 2 %) drop to ~k (1 + ln(I / sample)).  Same instruction sequence on the same data: the sample's scores are bit-identical in
     // both passes, so the k items the bound rests on pass it again.
-    const int NB = (!WARM && nstages >= 8 * (kTopkBootItems / MST)) ? kTopkBootItems / MST : 0;
+    const int NB = nstages >= 8 * (kTopkBootItems / MST) ? kTopkBootItems / MST : 0;
     const int nvirt = NB + nstages;                                // stages as the ring counts them: the bootstrap's, then the stream's
     auto item_stage = [&](int v) { return v < NB ? v : v - NB; };
     auto stage_ptr = [&](int st, int p) {
@@ -1757,7 +1757,8 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
             float gm = bl[reg][3];
 #pragma unroll
             for (int off = 1; off < 16; off <<= 1) gm = fminf(gm, __shfl_xor(gm, off, 16));
-            const float t0 = (nrem >= 0 && u_base + 4 * g + reg < U) ? gm : -INFINITY;
+            float t0 = (nrem >= 0 && u_base + 4 * g + reg < U) ? gm : -INFINITY;
+            if constexpr (WARM) t0 = fmaxf(t0, __shfl(thr0v, 4 * g + reg));       // both are valid lower bounds: keep the better one
             thrf[reg] = (u_base + 4 * g + reg < U) ? t0 : INFINITY;
             const float bc = __shfl(t0, 16 * (lane >> 2) + 0);     // lane r < 16 reads group r / 4 ...
             if (lane < 16 && (lane & 3) == reg) t0v = bc;          // ... when this is row r's register
@@ -1866,6 +1867,7 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
     // one step of the pipeline: stage st + 2 goes from register set r to LDS, set r is refilled with stage st + 4, stage st is consumed
     auto step = [&](auto boot_tag, int st, f32x4 (&r)[PER]) {
         const int t = st + kTopkLead;
+
         if (t < nvirt) {
             wait_ge(done_ctr + (t & (kTopkRing - 1)), NWV * (unsigned)(t / kTopkRing));          // stage t - ring has been read by every wave
             stash(slot(t), r);
@@ -1884,13 +1886,11 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
     if (nvirt > 1) { stash(slot(1), nc); signal(fill_ctr + 1); }
     if (nvirt > 2) fetch(item_stage(2), nb);
     if (nvirt > 3) fetch(item_stage(3), nc);
-    if constexpr (!WARM) {
-        for (int st = 0; st < NB; st += 2) {                       // NB is even
-            step(std::true_type{}, st, nb);
-            step(std::true_type{}, st + 1, nc);
-        }
-        if (NB > 0) boot_finish();
+    for (int st = 0; st < NB; st += 2) {                           // NB is even
+        step(std::true_type{}, st, nb);
+        step(std::true_type{}, st + 1, nc);
     }
+    if (NB > 0) boot_finish();
     for (int st = NB; st < nvirt; st += 2) {
         step(std::false_type{}, st, nb);
         if (st + 1 < nvirt) step(std::false_type{}, st + 1, nc);
