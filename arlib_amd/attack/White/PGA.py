@@ -110,7 +110,7 @@ class FactoredFakeGraph:
         self.S = self.dinv = None
 
     def set_block(self, S):
-        self.S = S
+        self.S = S if S.is_contiguous() else S.contiguous()
         rs = self.base_rowsum.clone()
         rs[self.U:self.Up] = S.sum(1)
         rs[self.Up:] += S.sum(0)
@@ -118,29 +118,28 @@ class FactoredFakeGraph:
         self._dcol = self.dinv[:, None].contiguous()
         return self
 
-    def _fake_rows_product(self, Xi):
-        """S [F, I] @ Xi [I, d]: a skinny product with a 10^5-long reduction, for which the BLAS library picks a slow kernel (0.2 ms at
-        F = 64, I = 100 K, d = 64); cut the reduction into panels (batched product + sum: 0.03 ms) when I has a suitable divisor."""
-        I = self.I
-        c = next((c for c in range(max(1, I // 2048), min(I, I // 512) + 1) if I % c == 0), 0) if I >= 8192 else 0
-        if not c:
-            return self.S @ Xi
-        return torch.bmm(self.S.view(self.F, c, I // c).permute(1, 0, 2), Xi.view(c, I // c, Xi.shape[1])).sum(0)
-
-    def hop(self, X, alpha=1.0, beta=0.0, Z=None):
-        """alpha * (A_hat @ X) + beta * Z."""
+    def hop(self, X, alpha=1.0, beta=0.0, Z=None, items_only=False):
+        """alpha * (A_hat @ X) + beta * Z.   items_only: the caller reads the fake users' and the items' rows only (the last backward hop of a
+        PGA step: its output feeds nothing but the F x I block gradient) -- the real users' rows may be left unwritten, which saves the
+        user-row launch of the blocked plan (half a hop)."""
         Xs = X * self._dcol
-        Y = ops.spmm(self.W, Xs, alpha, beta, Z, row_scale=self.dinv)          # alpha D^-1/2 (W Xs) + beta Z in the SpMM epilogue
         U, Up = self.U, self.Up
-        Y[U:Up].addcmul_(self._fake_rows_product(Xs[Up:]), self._dcol[U:Up], value=alpha)
-        Y[Up:].addcmul_(self.S.t() @ Xs[U:Up], self._dcol[Up:], value=alpha)
+        Y = ops.spmm(self.W, Xs, alpha, beta, Z, row_scale=self.dinv, rows_from=Up if items_only else 0)    # alpha D^-1/2 (W Xs) + beta Z in the epilogue
+        if items_only:                                                     # W has no edges on the fake users' rows: what the skipped launch would have written
+            if beta != 0.0:
+                torch.mul(Z[U:Up], beta, out=Y[U:Up])
+            else:
+                Y[U:Up].zero_()
+        # the fake block as two hand-written dense products (row slices of contiguous tables are contiguous)
+        ops.fake_block_rows_(self.S, Xs[Up:], Y[U:Up], rscale=self.dinv[U:Up], alpha=alpha)
+        ops.fake_block_cols_(self.S, Xs[U:Up], Y[Up:], rscale=self.dinv[Up:], alpha=alpha)
         return Y
 
 
-def _hop(graph, X, alpha=1.0, beta=0.0, Z=None):
+def _hop(graph, X, alpha=1.0, beta=0.0, Z=None, items_only=False):
     """One application of the poisoned normalised adjacency: a CSRGraph (FakeBlockGraph) or a FactoredFakeGraph."""
     if hasattr(graph, 'hop'):
-        return graph.hop(X, alpha, beta, Z)
+        return graph.hop(X, alpha, beta, Z, items_only=items_only)
     return ops.spmm(graph, X, alpha, beta, Z)
 
 
@@ -226,7 +225,7 @@ def pga_block_gradient(graph, fake_rows, Up, I, E0, L, G):
     dE = [None] * (L + 1)
     dE[L] = Gs
     for k in range(L - 1, 0, -1):
-        dE[k] = _hop(graph, dE[k + 1], 1.0, 1.0, Gs)
+        dE[k] = _hop(graph, dE[k + 1], 1.0, 1.0, Gs, items_only=(k == 1))     # dE[1] is read on the fake users' and the items' rows only
     block = torch.zeros(fake_rows.numel(), I, dtype=torch.float32, device=E0.device)
     for k in range(L):
         ops.sddmm_rows_dense(dE[k + 1], E[k], fake_rows, Up, I, out=block)
@@ -249,7 +248,7 @@ def pga_step_block(graph, fake_rows, Up, I, E0, L, M):
     dE = [None] * (L + 1)
     dE[L] = Gs
     for k in range(L - 1, 0, -1):
-        dE[k] = _hop(graph, dE[k + 1], 1.0, 1.0, Gs)
+        dE[k] = _hop(graph, dE[k + 1], 1.0, 1.0, Gs, items_only=(k == 1))     # dE[1] is read on the fake users' and the items' rows only
     block = torch.zeros(fake_rows.numel(), I, dtype=torch.float32, device=E0.device)
     for k in range(L):
         ops.sddmm_rows_dense(dE[k + 1], E[k], fake_rows, Up, I, out=block)

@@ -1313,6 +1313,128 @@ __global__ __launch_bounds__(kBlock) void sddmm_rows_dense_kernel(const float *_
 
 // S = clamp(S - 0.2*tanh(g)), g = dinv_r[row] * dinv_c[col] * grad, and g = 0 where S has no stored entry (S == 0):
 // autograd.grad w.r.t. the sparse adjacency only yields pattern entries (attack/White/PGA.py:117-139).
+// ---- the F x I fake-user block of the poisoned adjacency as two dense products (attack/White/PGA.py:118-134: the reference multiplies
+// by a dense (U+F+I)^2 matrix; the factored operator needs only S (D^-1/2 X)_items for the fake users' rows and S^T (D^-1/2 X)_fake for
+// the item rows).  Both kernels stage a 64 x 64 tile of S in LDS per wave and read it back as broadcast float4s: four FMAs per LDS
+// read, lane = embedding column, the accumulators of a tile in registers; plain fp32 FMA chains in a fixed order (deterministic).
+constexpr int kFbT = 64;                 // tile edge (rows of S, items)
+constexpr int kFbChunk = 64;             // items per wave task of the row product (split-K: partials are combined in task order)
+
+__device__ __forceinline__ void fb_stage_tile(float *tile, const float *__restrict__ S, int F, long long I, int f0, long long i0, int lane) {
+    // tile[f][j] = S[f0 + f][i0 + j] (0 where out of range); 16 passes of 64 lanes x 4 floats
+#pragma unroll 4
+    for (int pass = 0; pass < 16; ++pass) {
+        const int idx = pass * 64 + lane, f = idx >> 4, part = idx & 15;
+        const long long i = i0 + 4 * part;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f0 + f < F) {
+            const float *src = S + (long long)(f0 + f) * I + i;
+            if (i + 3 < I && ((((long long)(f0 + f) * I + i) & 3) == 0)) v = *reinterpret_cast<const float4 *>(src);
+            else { if (i < I) v.x = src[0]; if (i + 1 < I) v.y = src[1]; if (i + 2 < I) v.z = src[2]; if (i + 3 < I) v.w = src[3]; }
+        }
+        *reinterpret_cast<float4 *>(tile + f * kFbT + 4 * part) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// partial[task][f][c] = sum over the task's items (kFbChunk, in 64-item tiles) of S[f0 + f][i] * X[i][c0 + c]
+__global__ __launch_bounds__(kBlock) void fake_block_rows_kernel(const float *__restrict__ S, int F, long long I, const float *__restrict__ X, int d,
+                                                                  int n_chunks, float *__restrict__ partial) {
+    __shared__ float tiles[kWavesPerBlock][kFbT * kFbT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int chunk = blockIdx.x * kWavesPerBlock + wv;
+    if (chunk >= n_chunks) return;
+    const int c0 = blockIdx.y * 64, f0 = blockIdx.z * kFbT;
+    const int col = c0 + lane;
+    float *tile = tiles[wv];
+    float acc[kFbT];
+#pragma unroll
+    for (int f = 0; f < kFbT; ++f) acc[f] = 0.f;
+    for (int sub = 0; sub < kFbChunk / kFbT; ++sub) {
+        const long long i0 = (long long)chunk * kFbChunk + sub * kFbT;
+        if (i0 >= I) break;
+        float x[kFbT];                                             // the tile's operand rows, this lane's column: all loads in flight together
+#pragma unroll
+        for (int j = 0; j < kFbT; ++j) x[j] = (i0 + j < I && col < d) ? X[(i0 + j) * d + col] : 0.f;
+        __builtin_amdgcn_wave_barrier();
+        fb_stage_tile(tile, S, F, I, f0, i0, lane);
+#pragma unroll
+        for (int f = 0; f < kFbT; ++f) {
+#pragma unroll
+            for (int j4 = 0; j4 < kFbT / 4; ++j4) {
+                const float4 s4 = *reinterpret_cast<const float4 *>(tile + f * kFbT + 4 * j4);
+                acc[f] = fmaf(s4.x, x[4 * j4], acc[f]); acc[f] = fmaf(s4.y, x[4 * j4 + 1], acc[f]);
+                acc[f] = fmaf(s4.z, x[4 * j4 + 2], acc[f]); acc[f] = fmaf(s4.w, x[4 * j4 + 3], acc[f]);
+            }
+        }
+    }
+    float *o = partial + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * n_chunks + chunk) * (kFbT * 64);
+#pragma unroll
+    for (int f = 0; f < kFbT; ++f) o[f * 64 + lane] = acc[f];
+}
+
+// Y[f][c] += alpha * rscale[f] * sum_task partial[task][f][c].  One 1024-thread workgroup per output row and 64-column block: lane =
+// column, the 16 waves take the tasks round-robin (task k -> wave k % 16, ascending), their sums are added in wave order: a fixed tree.
+constexpr int kFbFinishWaves = 16;
+__global__ __launch_bounds__(kFbFinishWaves * 64) void fake_block_rows_finish_kernel(const float *__restrict__ partial, int n_chunks, int F, int d,
+                                                                                    const float *__restrict__ rscale, float alpha, float *__restrict__ Y) {
+    __shared__ float part[kFbFinishWaves][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int f = blockIdx.x, cy = blockIdx.y, ny = gridDim.y;
+    const int fz = f / kFbT;
+    const float *p = partial + ((size_t)fz * ny + cy) * n_chunks * (kFbT * 64) + (f % kFbT) * 64 + lane;
+    float sum = 0.f;
+    for (int k = wv; k < n_chunks; k += kFbFinishWaves) sum += p[(size_t)k * (kFbT * 64)];
+    part[wv][lane] = sum;
+    __syncthreads();
+    const int c = cy * 64 + lane;
+    if (wv == 0 && c < d) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < kFbFinishWaves; ++w) tot += part[w][lane];
+        Y[(size_t)f * d + c] += alpha * (rscale ? rscale[f] : 1.f) * tot;
+    }
+}
+
+// Y[i][c] += alpha * rscale[i] * sum_f S[f][i] * Xf[f][c]: a wave owns 64 items x 64 columns
+__global__ __launch_bounds__(kBlock) void fake_block_cols_kernel(const float *__restrict__ S, int F, long long I, const float *__restrict__ Xf, int d,
+                                                                  const float *__restrict__ rscale, float alpha, float *__restrict__ Y) {
+    __shared__ float tiles[kWavesPerBlock][kFbT * kFbT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long i0 = ((long long)blockIdx.x * kWavesPerBlock + wv) * kFbT;
+    if (i0 >= I) return;
+    const int col = blockIdx.y * 64 + lane;
+    float *tile = tiles[wv];
+    float acc[kFbT];
+#pragma unroll
+    for (int j = 0; j < kFbT; ++j) acc[j] = 0.f;
+    for (int f0 = 0; f0 < F; f0 += kFbT) {
+        __builtin_amdgcn_wave_barrier();
+        fb_stage_tile(tile, S, F, I, f0, i0, lane);
+        float xfv[kFbT];                                           // this lane's column of the tile's fake-user rows, loaded together
+#pragma unroll
+        for (int f = 0; f < kFbT; ++f) xfv[f] = (f0 + f < F && col < d) ? Xf[(size_t)(f0 + f) * d + col] : 0.f;
+#pragma unroll
+        for (int f = 0; f < kFbT; ++f) {                           // rows past F were staged as zeros
+            const float xf = xfv[f];
+#pragma unroll
+            for (int j4 = 0; j4 < kFbT / 4; ++j4) {
+                const float4 s4 = *reinterpret_cast<const float4 *>(tile + f * kFbT + 4 * j4);
+                acc[4 * j4] = fmaf(s4.x, xf, acc[4 * j4]); acc[4 * j4 + 1] = fmaf(s4.y, xf, acc[4 * j4 + 1]);
+                acc[4 * j4 + 2] = fmaf(s4.z, xf, acc[4 * j4 + 2]); acc[4 * j4 + 3] = fmaf(s4.w, xf, acc[4 * j4 + 3]);
+            }
+        }
+    }
+    if (col >= d) return;
+#pragma unroll
+    for (int j = 0; j < kFbT; ++j) {
+        const long long i = i0 + j;
+        if (i < I) Y[i * d + col] += alpha * (rscale ? rscale[i] : 1.f) * acc[j];
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void pga_update_kernel(float *__restrict__ S, const float *__restrict__ grad, const float *__restrict__ dinv_r,
                                                              const float *__restrict__ dinv_c, long long rows, long long cols) {
     const long long n = rows * cols;
@@ -2588,6 +2710,40 @@ int arl_pga_update_f32(float *S, const float *grad, const float *dinv_rows, cons
     if (rows == 0 || cols == 0) return ARL_OK;
     hipLaunchKernelGGL(pga_update_kernel, dim3(grid_for(rows * cols, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, S, grad, dinv_rows, dinv_cols,
                        (long long)rows, (long long)cols);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int64_t arl_fake_block_rows_workspace_bytes(int64_t F, int64_t I, int64_t d) {
+    if (F <= 0 || I <= 0 || d <= 0) return 0;
+    const int64_t n_chunks = (I + kFbChunk - 1) / kFbChunk;
+    return (int64_t)sizeof(float) * ((F + kFbT - 1) / kFbT) * ((d + 63) / 64) * n_chunks * kFbT * 64;
+}
+
+int arl_fake_block_rows_f32(const float *S, int64_t F, int64_t I, const float *X, int64_t d, const float *rscale, float alpha, float *Y, void *workspace,
+                            arl_stream_t stream) {
+    if (!S || !X || !Y || !workspace) return ARL_E_NULL;
+    if (F < 0 || I < 0 || F > 0x7fffffffll || F * d > 0x7fffffffll) return ARL_E_ARG;
+    if (d <= 0 || d > 256 || (d & 3)) return ARL_E_DIM;
+    if (F == 0 || I == 0) return ARL_OK;
+    const int n_chunks = (int)((I + kFbChunk - 1) / kFbChunk);
+    const dim3 grid((unsigned)((n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), (unsigned)((d + 63) / 64), (unsigned)((F + kFbT - 1) / kFbT));
+    hipLaunchKernelGGL(fake_block_rows_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, S, (int)F, (long long)I, X, (int)d, n_chunks, (float *)workspace);
+    ARL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fake_block_rows_finish_kernel, dim3((unsigned)F, (unsigned)((d + 63) / 64)), dim3(kFbFinishWaves * 64), 0, (hipStream_t)stream, (const float *)workspace, n_chunks,
+                       (int)F, (int)d, rscale, alpha, Y);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_fake_block_cols_f32(const float *S, int64_t F, int64_t I, const float *Xf, int64_t d, const float *rscale, float alpha, float *Y, arl_stream_t stream) {
+    if (!S || !Xf || !Y) return ARL_E_NULL;
+    if (F < 0 || I < 0 || F > 0x7fffffffll) return ARL_E_ARG;
+    if (d <= 0 || d > 256 || (d & 3)) return ARL_E_DIM;
+    if (F == 0 || I == 0) return ARL_OK;
+    const long long n_tiles = (I + kFbT - 1) / kFbT;
+    const dim3 grid((unsigned)((n_tiles + kWavesPerBlock - 1) / kWavesPerBlock), (unsigned)((d + 63) / 64), 1);
+    hipLaunchKernelGGL(fake_block_cols_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, S, (int)F, (long long)I, Xf, (int)d, rscale, alpha, Y);
     ARL_LAUNCH_CHECK();
     return ARL_OK;
 }

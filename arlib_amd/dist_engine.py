@@ -657,11 +657,17 @@ class ShardedPGA:
         Y = torch.empty_like(X)
         k.spmm(self.Ai, Xs, out=Y[Ul:])                                 # partial over the local real users
         if self.owner and self.F:
-            Y[Ul:].addmm_(self.S.t(), Xs[self.f0:Ul])                   # + the fake users' contribution to every item row
+            if hasattr(k, 'fake_block_cols_'):                          # + the fake users' contribution to every item row (hand-written product;
+                k.fake_block_cols_(self.S, Xs[self.f0:Ul], Y[Ul:])      #   the oracle-backed CPU test double has no such kernel)
+            else:
+                Y[Ul:].addmm_(self.S.t(), Xs[self.f0:Ul])
         work = self.comm.all_reduce_async(Y[Ul:])
         k.spmm(self.Au, Xs, out=Y[:Ul])
         if self.owner and self.F:
-            Y[self.f0:Ul] += self.S @ Xs[Ul:]                           # the fake users' own rows
+            if hasattr(k, 'fake_block_rows_'):                          # the fake users' own rows
+                k.fake_block_rows_(self.S, Xs[Ul:], Y[self.f0:Ul])
+            else:
+                Y[self.f0:Ul] += self.S @ Xs[Ul:]
         work.wait()
         Y.mul_(self._dcol * alpha)
         if beta != 0.0:

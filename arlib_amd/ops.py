@@ -365,14 +365,17 @@ def auto_blocked(graph, d, split=None, force=False):
     return graph
 
 
-def _spmm_dispatch(A, d, blocked_call, csr_call):
+def _spmm_dispatch(A, d, blocked_call, csr_call, rows_from=0):
     """Run one full-table SpMM: through the blocked plan (+ its hub rows through the chunked CSR kernel) when the graph has one
-    and d = 64 or 128, else through the CSR kernel.  The callables take the ctypes struct pointer."""
+    and d = 64 or 128, else through the CSR kernel.  The callables take the ctypes struct pointer.  rows_from > 0: the caller does not
+    read output rows below it -- launches of the plan that only produce such rows are skipped (the CSR schedule ignores the hint)."""
     bp = A.blocked
     if bp is None or d not in (64, 128):
         csr_call(C.byref(A._struct(d)))
         return
     for k in range(len(bp.sets)):
+        if bp.sets[k]['hi'] <= rows_from:
+            continue
         blocked_call(C.byref(bp.struct(k, d)))
     if bp.hub is not None:
         csr_call(C.byref(bp.hub._struct(d)))
@@ -570,9 +573,10 @@ def _check_xy(A, X, name='X', rows=None):
     return d
 
 
-def spmm(A, X, alpha=1.0, beta=0.0, Z=None, out=None, row_scale=None):
+def spmm(A, X, alpha=1.0, beta=0.0, Z=None, out=None, row_scale=None, rows_from=0):
     """out = alpha * (A @ X) + beta * Z.   X: [A.n_cols, d]; out, Z: [A.n_rows, d].   row_scale [n_rows] (optional): the product's rows are
-    multiplied by it in the epilogue, out = alpha * diag(row_scale) (A @ X) + beta * Z."""
+    multiplied by it in the epilogue, out = alpha * diag(row_scale) (A @ X) + beta * Z.   rows_from (optional hint): output rows below it
+    are not needed and MAY be left unwritten (a blocked plan skips the launches that only produce them)."""
     d = _check_xy(A, X, 'X', A.n_cols)
     Y = torch.empty(A.n_rows, d, dtype=torch.float32, device=X.device) if out is None else out
     if _check_xy(A, Y, 'out') != d or Y.data_ptr() == X.data_ptr():
@@ -587,10 +591,11 @@ def spmm(A, X, alpha=1.0, beta=0.0, Z=None, out=None, row_scale=None):
         if row_scale.numel() != A.n_rows:
             raise ValueError('spmm: row_scale needs one entry per output row')
         _spmm_dispatch(A, d, lambda p: check(L.arl_spmm_blocked_rscale_f32(p, _ptr(X), d, _ptr(row_scale), alpha, beta, zp, _ptr(Y), st), 'arl_spmm_blocked_rscale_f32'),
-                       lambda p: check(L.arl_spmm_csr_rscale_f32(p, _ptr(X), d, _ptr(row_scale), alpha, beta, zp, _ptr(Y), st), 'arl_spmm_csr_rscale_f32'))
+                       lambda p: check(L.arl_spmm_csr_rscale_f32(p, _ptr(X), d, _ptr(row_scale), alpha, beta, zp, _ptr(Y), st), 'arl_spmm_csr_rscale_f32'),
+                       rows_from=rows_from)
     else:
         _spmm_dispatch(A, d, lambda p: check(L.arl_spmm_blocked_f32(p, _ptr(X), d, alpha, beta, zp, None, _ptr(Y), st), 'arl_spmm_blocked_f32'),
-                       lambda p: check(L.arl_spmm_csr_f32(p, _ptr(X), d, alpha, beta, zp, _ptr(Y), st), 'arl_spmm_csr_f32'))
+                       lambda p: check(L.arl_spmm_csr_f32(p, _ptr(X), d, alpha, beta, zp, _ptr(Y), st), 'arl_spmm_csr_f32'), rows_from=rows_from)
     if tok is not None:
         EVENT_HOOK.end(tok)
     return Y
@@ -922,6 +927,47 @@ def sddmm_rows_dense(dY, X, rows, col_off, n_cols, out=None):
             raise ValueError('sddmm_rows_dense: out shape mismatch')
     check(_lib.lib().arl_sddmm_rows_dense_f32(_ptr(dY), _ptr(X), X.shape[1], _ptr(rows), rows.numel(), col_off, n_cols, _ptr(out), _stream()), 'arl_sddmm_rows_dense_f32')
     return out
+
+
+_FB_WS = {}
+
+
+def fake_block_rows_(S, X, Y, rscale=None, alpha=1.0):
+    """In place: Y[f] += alpha * rscale[f] * (S @ X)[f]   (S: [F, I] fake-user block, X: [I, d] item rows, Y: [F, d]) -- the fake users' rows of
+    the poisoned adjacency product (attack/White/PGA.py:118-134); hand-written fp32 kernel, deterministic."""
+    _dev(S, torch.float32, 'S', 2); _dev(X, torch.float32, 'X', 2); _dev(Y, torch.float32, 'Y', 2)
+    F, I = S.shape
+    d = X.shape[1]
+    if X.shape[0] != I or Y.shape != (F, d):
+        raise ValueError('fake_block_rows_: shapes S %s X %s Y %s' % (tuple(S.shape), tuple(X.shape), tuple(Y.shape)))
+    if rscale is not None:
+        _dev(rscale, torch.float32, 'rscale', 1)
+        if rscale.numel() != F:
+            raise ValueError('fake_block_rows_: rscale length')
+    L = _lib.lib()
+    need = L.arl_fake_block_rows_workspace_bytes(F, I, d)
+    key = (S.device, need)
+    ws = _FB_WS.get(key)
+    if ws is None:
+        _FB_WS.clear()
+        ws = _FB_WS[key] = torch.empty(max(need, 4), dtype=torch.uint8, device=S.device)
+    check(L.arl_fake_block_rows_f32(_ptr(S), F, I, _ptr(X), d, _ptr(rscale), float(alpha), _ptr(Y), _ptr(ws), _stream()), 'arl_fake_block_rows_f32')
+    return Y
+
+
+def fake_block_cols_(S, Xf, Y, rscale=None, alpha=1.0):
+    """In place: Y[i] += alpha * rscale[i] * (S^T @ Xf)[i]   (Xf: [F, d] fake users' rows, Y: [I, d] item rows)."""
+    _dev(S, torch.float32, 'S', 2); _dev(Xf, torch.float32, 'Xf', 2); _dev(Y, torch.float32, 'Y', 2)
+    F, I = S.shape
+    d = Xf.shape[1]
+    if Xf.shape[0] != F or Y.shape != (I, d):
+        raise ValueError('fake_block_cols_: shapes S %s Xf %s Y %s' % (tuple(S.shape), tuple(Xf.shape), tuple(Y.shape)))
+    if rscale is not None:
+        _dev(rscale, torch.float32, 'rscale', 1)
+        if rscale.numel() != I:
+            raise ValueError('fake_block_cols_: rscale length')
+    check(_lib.lib().arl_fake_block_cols_f32(_ptr(S), F, I, _ptr(Xf), d, _ptr(rscale), float(alpha), _ptr(Y), _stream()), 'arl_fake_block_cols_f32')
+    return Y
 
 
 def pga_update_(S, grad, dinv_rows=None, dinv_cols=None):

@@ -337,6 +337,17 @@ int arl_sfa_stage3_f32(const float *X, const float *w, const float *r0, const fl
  *   out[t, j] += <dY[rows[t]], X[col_off + j]> ,  0 <= j < n_cols.   out: [n_rows_sel, n_cols]. */
 int arl_sddmm_rows_dense_f32(const float *dY, const float *X, int64_t d, const int32_t *rows, int64_t n_rows_sel,
                              int64_t col_off, int64_t n_cols, float *out, arl_stream_t stream);
+/* The F x I fake-user block S of the poisoned adjacency applied as two dense products (attack/White/PGA.py:118-134 multiplies by the
+ * dense (U+F+I)^2 matrix; the factored operator needs only these two blocks of it).  S: [F, I] row-major, d % 4 == 0, d <= 256.
+ *   rows:  Y[f, :] += alpha * rscale[f] * sum_i S[f, i] * X[i, :]      X: [I, d] (the item rows), Y: [F, d], rscale: [F] or NULL (= 1)
+ *   cols:  Y[i, :] += alpha * rscale[i] * sum_f S[f, i] * Xf[f, :]     Xf: [F, d] (the fake users' rows), Y: [I, d], rscale: [I] or NULL
+ * fp32 FMA chains in a fixed order (the row product is split over 64-item chunks whose partials are added in a fixed tree):
+ * deterministic.  workspace (rows only): arl_fake_block_rows_workspace_bytes(F, I, d) bytes of device memory. */
+int64_t arl_fake_block_rows_workspace_bytes(int64_t F, int64_t I, int64_t d);
+int arl_fake_block_rows_f32(const float *S, int64_t F, int64_t I, const float *X, int64_t d, const float *rscale, float alpha, float *Y,
+                            void *workspace, arl_stream_t stream);
+int arl_fake_block_cols_f32(const float *S, int64_t F, int64_t I, const float *Xf, int64_t d, const float *rscale, float alpha, float *Y,
+                            arl_stream_t stream);
 /* Projected-gradient step on the fake-user block S [rows, cols] (attack/White/PGA.py:118-139):
  *   g = dinv_rows[r] * grad[r,c] * dinv_cols[c]   (D^-1/2 grad D^-1/2; either scale vector may be NULL = 1)
  *   g = 0 where S[r,c] == 0                       (autograd.grad on a sparse tensor only yields pattern entries)

@@ -463,6 +463,30 @@ def test_score_mask_topk_bootstrap_threshold(ops, d, k):
         assert rel_err(ex_v.cpu().numpy(), rval.astype(np.float32)) < 1e-5 and (ex_i.cpu().numpy() == ridx).mean() > 0.999
 
 
+@pytest.mark.parametrize('F,I,d', [(64, 100000, 64), (5, 777, 32), (130, 301, 128), (64, 1000, 16), (1, 4, 4), (7, 12345, 256)])
+def test_fake_block_products(ops, F, I, d):
+    """The F x I fake-user block of the poisoned adjacency as two dense products (attack/White/PGA.py:118-134) against float64."""
+    g = torch.Generator().manual_seed(F * 1000 + I)
+    S = torch.rand(F, I, generator=g)
+    S[S < 0.3] = 0.0
+    X = torch.randn(I, d, generator=g); Xf = torch.randn(F, d, generator=g)
+    rs_f = torch.rand(F, generator=g) + 0.1; rs_i = torch.rand(I, generator=g) + 0.1
+    Y0f = torch.randn(F, d, generator=g); Y0i = torch.randn(I, d, generator=g)
+    ref_rows = Y0f.double() + 0.7 * rs_f.double()[:, None] * (S.double() @ X.double())
+    ref_cols = Y0i.double() - 1.3 * rs_i.double()[:, None] * (S.double().t() @ Xf.double())
+    Yf, Yi = Y0f.cuda(), Y0i.cuda()
+    ops.fake_block_rows_(S.cuda(), X.cuda(), Yf, rscale=rs_f.cuda(), alpha=0.7)
+    ops.fake_block_cols_(S.cuda(), Xf.cuda(), Yi, rscale=rs_i.cuda(), alpha=-1.3)
+    assert rel_err(Yf.cpu().numpy(), ref_rows.numpy()) < 2e-6
+    assert rel_err(Yi.cpu().numpy(), ref_cols.numpy()) < 2e-6
+    # no scale vector, deterministic (two calls give the same bits)
+    A = torch.zeros(F, d, device='cuda'); B = torch.zeros(F, d, device='cuda')
+    ops.fake_block_rows_(S.cuda(), X.cuda(), A); ops.fake_block_rows_(S.cuda(), X.cuda(), B)
+    assert torch.equal(A, B) and rel_err(A.cpu().numpy(), (S.double() @ X.double()).numpy()) < 2e-6
+    with pytest.raises(ValueError):
+        ops.fake_block_rows_(S.cuda(), X.cuda()[:-1].contiguous(), Yf)
+
+
 def test_topn_project_rows(ops):
     rng = np.random.default_rng(6)
     M = rng.random((7, 1412)).astype(np.float32)
