@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ARLIB_AMD_LIB') or os.path.join(_HERE, 'lib', 'libarlib_amd.so')      # override: developer builds (e.g. `make prof`)
-ABI_VERSION = 15
+ABI_VERSION = 16
 _lib = None
 
 
@@ -92,6 +92,7 @@ _SIGS = {
     'arl_sfa_stage3_f32': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, C.c_int32, _vp, _vp, _vp, _vp]),
     'arl_sddmm_rows_dense_f32': (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp]),
     'arl_pga_update_f32': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    'arl_tables_sum_f32': (C.c_int, [_vp, _i64, _i64, C.c_float, _vp, _vp]),
     'arl_fake_block_rows_workspace_bytes': (_i64, [_i64, _i64, _i64]),
     'arl_fake_block_rows_f32': (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, C.c_float, _vp, _vp, _vp]),
     'arl_fake_block_cols_f32': (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, C.c_float, _vp, _vp]),

@@ -210,9 +210,10 @@ def cw_operator_from_topk(n_nodes, Up, n_real, targets, neg, device):
     return ops.CSRGraph(rowptr, col, val, device, validate=False), neg_cnt
 
 
-def cw_loss_and_grad_op(M, out):
-    G = ops.spmm(M, out)
-    return 0.5 * (out * G).sum(), G
+def cw_loss_and_grad_op(M, out, scale=1.0):
+    """L = 1/2 out^T M out and scale * dL/d(out) = scale * M out (the scale folded into the SpMM's epilogue)."""
+    G = ops.spmm(M, out, alpha=scale)
+    return (0.5 / scale) * (out * G).sum(), G
 
 
 def pga_block_gradient(graph, fake_rows, Up, I, E0, L, G):
@@ -237,14 +238,11 @@ def pga_step_block(graph, fake_rows, Up, I, E0, L, M):
     """Forward (layers kept), CW gradient through the operator M, backward, and the F x I block -- one PGA gradient step
     minus the update (PGA.py:99-134)."""
     E = [E0]
-    out = E0.clone()
     for k in range(L):
         E.append(_hop(graph, E[k]))
-        out += E[-1]
-    out /= (L + 1)
-    loss, G = cw_loss_and_grad_op(M, out)
     s = 1.0 / (L + 1)
-    Gs = G * s
+    out = ops.tables_sum(E, s)                                            # the mean over layers in one pass
+    loss, Gs = cw_loss_and_grad_op(M, out, s)                             # Gs = dL/d(out) / (L + 1): what every layer receives
     dE = [None] * (L + 1)
     dE[L] = Gs
     for k in range(L - 1, 0, -1):

@@ -301,6 +301,16 @@ __global__ __launch_bounds__(kBlock) void subset_finish_kernel(const float *__re
     *reinterpret_cast<float4 *>(out_c + (size_t)t * d + q * 4) = make_float4(alpha * a.x, alpha * a.y, alpha * a.z, alpha * a.w);
 }
 
+// out = alpha * sum_k layers[k]  (element-wise over up to 8 equally shaped tables; the LightGCN mean over layers, LightGCN.py:236-240,
+// in ONE pass instead of a clone + L adds + a division)
+__global__ __launch_bounds__(kBlock) void tables_sum_kernel(LayerPtrs L, long long n4, float alpha, float4 *__restrict__ out) {
+    for (long long t = (long long)blockIdx.x * kBlock + threadIdx.x; t < n4; t += (long long)gridDim.x * kBlock) {
+        float4 a = reinterpret_cast<const float4 *>(L.p[0])[t];
+        for (int k = 1; k < L.n; ++k) a = add4(a, reinterpret_cast<const float4 *>(L.p[k])[t]);
+        out[t] = make_float4(alpha * a.x, alpha * a.y, alpha * a.z, alpha * a.w);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void mark_rows_kernel(uint8_t *__restrict__ flags, const int32_t *__restrict__ idx, int n, int value) {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     if (t < n) flags[idx[t]] = (uint8_t)value;
@@ -1570,7 +1580,8 @@ __global__ __launch_bounds__(kBlock) void score_mask_topk_kernel(const float *__
 // ---- MFMA form of the streaming score + mask + top-k (d in {16,32,64,128}, k <= 64) ---------------------------------------
 // scores = Pu . Pi^T is the one dense contraction of the path (2*U*I*d flop; 1.3e13 at cfg2), so it goes on the matrix cores.
 // A block owns 128 users for the whole kernel (their A fragments stay in registers) and streams item tiles of Pi through a
-// double-buffered LDS image (one __syncthreads per stage, global loads two stages ahead).  8 waves, 16 users each
+// ring of four LDS images without block barriers (per-slot fill / done counters, global loads two stages ahead; calls over long
+// item streams open with a bootstrap pass that pre-sets the users' thresholds -- both described in the kernel).  8 waves, 16 users each
 // (16x16 MFMA shapes): lane l supplies A[user l&15][k] and B[k][item l&15] for its contiguous k range [Q*(l>>4), Q*(l>>4)+Q)
 // (a permutation of the contraction index, irrelevant to the sum); C: item = l&15, user row = 4*(l>>4) + reg.
 // Top-k per user is a sorted list in registers (see `tk_hi/tk_lo` in the kernel).
@@ -1639,7 +1650,7 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
     constexpr int RH = NPL * 2 * PPG * 16 + 16;
     constexpr int HALF = (D <= 16 ? 128 : (D <= 64 ? 64 : 32)) * RH;
     static_assert(HALF % 256 == 0 && (RH / 16) % 2 == 1, "half images must be bank-aligned");
-    constexpr int MST = D <= 16 ? 128 : (D <= 64 ? 64 : 32);       // items staged per block barrier
+    constexpr int MST = D <= 16 ? 128 : (D <= 64 ? 64 : 32);       // items per stage (one slot of the ring)
     constexpr int NSUB = MST / 16;                                 // 16-item sub-tiles per stage
     constexpr int SPP = NSUB >= 2 ? 2 : 1;                         // sub-tiles per insert phase (at most 32 items)
     constexpr int NPH = NSUB / SPP;
@@ -2411,6 +2422,19 @@ int arl_sgd_dense_f32(float *p, const float *g, int64_t n, float lr, arl_stream_
     if (n < 0) return ARL_E_ARG;
     if (n == 0) return ARL_OK;
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, p, g, (long long)n, lr);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_tables_sum_f32(const float *const *tables, int64_t n_tables, int64_t n_elems, float alpha, float *out, arl_stream_t stream) {
+    if (!tables || !out) return ARL_E_NULL;
+    if (n_tables < 1 || n_tables > 8 || n_elems < 0 || (n_elems & 3)) return ARL_E_ARG;
+    if (n_elems == 0) return ARL_OK;
+    LayerPtrs LP = {};
+    LP.n = (int)n_tables;
+    for (int k = 0; k < LP.n; ++k) { if (!tables[k]) return ARL_E_NULL; LP.p[k] = tables[k]; }
+    const long long n4 = n_elems / 4;
+    hipLaunchKernelGGL(tables_sum_kernel, dim3(grid_for(n4, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, LP, n4, alpha, (float4 *)out);
     ARL_LAUNCH_CHECK();
     return ARL_OK;
 }

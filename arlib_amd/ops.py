@@ -929,6 +929,26 @@ def sddmm_rows_dense(dY, X, rows, col_off, n_cols, out=None):
     return out
 
 
+def tables_sum(tables, alpha=1.0, out=None):
+    """alpha * sum of up to 8 equally shaped fp32 tables in one pass (the LightGCN layer mean with alpha = 1/(L+1))."""
+    if not 1 <= len(tables) <= 8:
+        raise ValueError('tables_sum: 1..8 tables')
+    for t in tables:
+        _dev(t, torch.float32, 'table')
+        if t.shape != tables[0].shape:
+            raise ValueError('tables_sum: shape mismatch')
+    if tables[0].numel() % 4:
+        raise ValueError('tables_sum: element count must be a multiple of 4')
+    if out is None:
+        out = torch.empty_like(tables[0])
+    _dev(out, torch.float32, 'out')
+    if out.shape != tables[0].shape:
+        raise ValueError('tables_sum: out shape mismatch')
+    arr = (C.c_void_p * len(tables))(*[t.data_ptr() for t in tables])
+    check(_lib.lib().arl_tables_sum_f32(C.cast(arr, C.c_void_p), len(tables), tables[0].numel(), float(alpha), _ptr(out), _stream()), 'arl_tables_sum_f32')
+    return out
+
+
 _FB_WS = {}
 
 

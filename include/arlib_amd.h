@@ -337,6 +337,11 @@ int arl_sfa_stage3_f32(const float *X, const float *w, const float *r0, const fl
  *   out[t, j] += <dY[rows[t]], X[col_off + j]> ,  0 <= j < n_cols.   out: [n_rows_sel, n_cols]. */
 int arl_sddmm_rows_dense_f32(const float *dY, const float *X, int64_t d, const int32_t *rows, int64_t n_rows_sel,
                              int64_t col_off, int64_t n_cols, float *out, arl_stream_t stream);
+/* out = alpha * (tables[0] + ... + tables[n_tables-1]), element-wise over n_elems floats (n_elems % 4 == 0, 1 <= n_tables <= 8): the mean
+ * over the propagated layers (recommender/LightGCN.py:236-240: torch.stack(...).mean) in one pass.  tables: HOST array of device pointers;
+ * out may alias one of them. */
+int arl_tables_sum_f32(const float *const *tables, int64_t n_tables, int64_t n_elems, float alpha, float *out, arl_stream_t stream);
+
 /* The F x I fake-user block S of the poisoned adjacency applied as two dense products (attack/White/PGA.py:118-134 multiplies by the
  * dense (U+F+I)^2 matrix; the factored operator needs only these two blocks of it).  S: [F, I] row-major, d % 4 == 0, d <= 256.
  *   rows:  Y[f, :] += alpha * rscale[f] * sum_i S[f, i] * X[i, :]      X: [I, d] (the item rows), Y: [F, d], rscale: [F] or NULL (= 1)

@@ -487,6 +487,20 @@ def test_fake_block_products(ops, F, I, d):
         ops.fake_block_rows_(S.cuda(), X.cuda()[:-1].contiguous(), Yf)
 
 
+def test_tables_sum(ops):
+    """alpha * (t0 + ... + tk) in one pass (the layer mean of LightGCN.py:236-240), also in place."""
+    g = torch.Generator().manual_seed(3)
+    ts = [torch.randn(1001, 64, generator=g) for _ in range(4)]
+    ref = 0.25 * (((ts[0] + ts[1]) + ts[2]) + ts[3])
+    dts = [t.cuda() for t in ts]
+    assert torch.equal(ops.tables_sum(dts, 0.25).cpu(), ref)
+    assert torch.equal(ops.tables_sum(dts[:1], 2.0).cpu(), 2.0 * ts[0])
+    out = ops.tables_sum(dts, 0.25, out=dts[0])
+    assert out is dts[0] and torch.equal(out.cpu(), ref)
+    with pytest.raises(ValueError):
+        ops.tables_sum([dts[1], dts[2][:-1].contiguous()])
+
+
 def test_topn_project_rows(ops):
     rng = np.random.default_rng(6)
     M = rng.random((7, 1412)).astype(np.float32)

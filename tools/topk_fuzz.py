@@ -11,7 +11,11 @@ bad = 0
 for case in range(n_cases):
     d = int(rng.choice([4, 8, 16, 20, 32, 48, 64, 128, 256]))
     U = int(rng.integers(1, 700)); I = int(rng.integers(1, 3000))
+    if case % 8 == 7:                           # long item streams: the bootstrap-threshold pass runs from 32 K items on (MFMA path: d in 16/32/64/128, k <= 64)
+        U = int(rng.integers(1, 300)); I = int(rng.integers(32768, 70000)); d = int(rng.choice([16, 32, 64, 128]))
     k = int(rng.integers(1, min(I, 128) + 1))
+    if case % 8 == 7 and rng.random() < 0.8:
+        k = int(rng.integers(1, 65))
     scale = float(rng.choice([1e-3, 0.1, 1.0, 30.0]))
     Pu = torch.from_numpy((rng.standard_normal((U, d)) * scale).astype(np.float32)).to(dev)
     Pi = torch.from_numpy((rng.standard_normal((I, d)) * scale).astype(np.float32)).to(dev)
@@ -22,9 +26,17 @@ for case in range(n_cases):
     sc = (Pu.double() @ Pi.double().T)
     if masked:
         lens = rng.integers(0, min(I, 80) + 1, U)
-        if rng.random() < 0.2:
+        if case % 8 == 7 and rng.random() < 0.5:  # interacted items piled up inside the bootstrap's sample range, where they score best
+            Pi[:4096] *= 2.0
+            sc = (Pu.double() @ Pi.double().T)
+        if rng.random() < 0.2 and I < 3000:
             lens[:] = max(I - max(k // 2, 1), 0)                                  # fewer than k unmasked items
-        cols = [np.sort(rng.choice(I, int(n), replace=False)).astype(np.int32) for n in lens]
+        if case % 8 == 7:
+            top = torch.topk(sc[:, :4096], 80, dim=1)[1].cpu().numpy()
+            cols = [np.unique(np.concatenate([top[u, :int(n)], rng.choice(I, int(n) // 3, replace=False)])).astype(np.int32) for u, n in enumerate(lens)]
+            lens = np.array([len(c) for c in cols])
+        else:
+            cols = [np.sort(rng.choice(I, int(n), replace=False)).astype(np.int32) for n in lens]
         rp = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(dev)
         flat = np.concatenate(cols) if lens.sum() else np.zeros(1, np.int32)
         mc = torch.from_numpy(flat.astype(np.int32)).to(dev)
