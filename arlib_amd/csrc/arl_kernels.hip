@@ -1321,6 +1321,26 @@ __global__ __launch_bounds__(kBlock) void sddmm_rows_dense_kernel(const float *_
     }
 }
 
+// d = 64 form: a lane keeps ITS item row in 64 registers, a wave owns 64 items and walks all listed rows; dY[rows[t]] is wave-uniform, so
+// its 64 values arrive through scalar loads and every product is one v_fmac with a scalar operand (the general kernel above spends a
+// broadcast global load and an LDS read per FMA).
+__global__ __launch_bounds__(kBlock) void sddmm_rows_dense64_kernel(const float *__restrict__ dY, const float *__restrict__ X, const int32_t *__restrict__ rows,
+                                                                     int n_sel, long long col_off, int n_cols, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int j = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * 64 + lane;
+    float x[64];
+    const float4 *xr = reinterpret_cast<const float4 *>(X + (size_t)(col_off + min(j, n_cols - 1)) * 64);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { const float4 v = xr[q]; x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w; }
+    for (int t = 0; t < n_sel; ++t) {
+        const float *dy = dY + (size_t)__builtin_amdgcn_readfirstlane(rows[t]) * 64;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) s = fmaf(dy[k], x[k], s);
+        if (j < n_cols) out[(size_t)t * n_cols + j] += s;
+    }
+}
+
 // S = clamp(S - 0.2*tanh(g)), g = dinv_r[row] * dinv_c[col] * grad, and g = 0 where S has no stored entry (S == 0):
 // autograd.grad w.r.t. the sparse adjacency only yields pattern entries (attack/White/PGA.py:117-139).
 // ---- the F x I fake-user block of the poisoned adjacency as two dense products (attack/White/PGA.py:118-134: the reference multiplies
@@ -2717,6 +2737,13 @@ int arl_sddmm_rows_dense_f32(const float *dY, const float *X, int64_t d, const i
     if (d <= 0 || d > 256 || n_rows_sel < 0 || n_cols < 0 || col_off < 0) return ARL_E_ARG;
     if (n_cols > 0x7fffffffll || n_rows_sel > 0x7fffffffll) return ARL_E_RANGE;
     if (n_rows_sel == 0 || n_cols == 0) return ARL_OK;
+    if (d == 64) {
+        const long long waves = (n_cols + 63) / 64;
+        hipLaunchKernelGGL(sddmm_rows_dense64_kernel, dim3((unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, dY, X, rows,
+                           (int)n_rows_sel, (long long)col_off, (int)n_cols, out);
+        ARL_LAUNCH_CHECK();
+        return ARL_OK;
+    }
     const size_t shm = sizeof(float) * 64 * (size_t)(d + 1);
     if (shm > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)sddmm_rows_dense_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
