@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ARLIB_AMD_LIB') or os.path.join(_HERE, 'lib', 'libarlib_amd.so')      # override: developer builds (e.g. `make prof`)
-ABI_VERSION = 16
+ABI_VERSION = 17
 _lib = None
 
 
@@ -77,6 +77,7 @@ _SIGS = {
     'arl_infonce_workspace_bytes': (_i64, [_i64, _i64]),
     'arl_infonce_fwd_bwd_f32': (C.c_int, [_vp, _vp, _i64, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     'arl_simgcl_perturb_f32': (C.c_int, [_vp, _vp, _i64, _i64, _f, _vp]),
+    'arl_simgcl_perturb_rng_f32': (C.c_int, [_vp, _vp, _i64, _i64, _vp, _f, C.c_uint64, C.c_uint64, _vp]),
     'arl_ngcf_combine_f32': (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     'arl_ngcf_act_f32': (C.c_int, [_vp, _vp, _i64, _i64, _f, _vp]),
     'arl_ngcf_act_bwd_f32': (C.c_int, [_vp, _vp, _i64, _i64, _f, _vp, _vp]),

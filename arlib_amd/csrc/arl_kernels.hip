@@ -1188,6 +1188,46 @@ __global__ __launch_bounds__(kBlock) void simgcl_perturb_kernel(float *__restric
     }
 }
 
+// The same perturbation with the noise drawn inside the kernel: u(row, k) = uniform [0,1) from a counter-based hash of
+// (seed, stream, row_id * d + k) -- what torch.rand_like(ego) supplies in recommender/SimGCL.py:203-205, without materialising an
+// [N, d] noise table, a clone of the operand, or a second pass.  dst may alias src.  row_ids (optional): the operand holds the listed
+// rows of a larger table and gets exactly the noise those rows would get in a full-table call with the same (seed, stream).
+__device__ __forceinline__ unsigned long long arl_splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(kBlock) void simgcl_perturb_rng_kernel(const float *__restrict__ src, float *__restrict__ dst, int n, int d,
+                                                                     const int32_t *__restrict__ row_ids, float eps, unsigned long long key) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const unsigned long long base = (unsigned long long)(row_ids ? row_ids[r] : r) * (unsigned long long)d;
+    float u[4];                                                    // d <= 256: at most four columns per lane
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = lane + q * kWave;
+        u[q] = 0.f;
+        if (k < d) {
+            u[q] = (float)(arl_splitmix64(key ^ (base + k)) >> 40) * (1.0f / 16777216.0f);      // 24 random bits -> [0, 1)
+            s = fmaf(u[q], u[q], s);
+        }
+    }
+    s = wave_sum(s);
+    const float sc = eps / fmaxf(sqrtf(s), 1e-12f);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = lane + q * kWave;
+        if (k < d) {
+            const float x = src[(size_t)r * d + k];
+            const float sg = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+            dst[(size_t)r * d + k] = x + sg * u[q] * sc;
+        }
+    }
+}
+
 // ================================================================================================
 // CLeaR spectral-feature-augmentation L1 term (attack/White/CLeaR.py:98-125)
 // ================================================================================================
@@ -2629,6 +2669,19 @@ int arl_ngcf_dense_wgrad_f32(const float *P, const float *E, const float *gZ, in
     return ARL_OK;
 }
 
+
+int arl_simgcl_perturb_rng_f32(const float *src, float *dst, int64_t n, int64_t d, const int32_t *row_ids, float eps, uint64_t seed, uint64_t stream_id,
+                               arl_stream_t stream) {
+    if (!src || !dst) return ARL_E_NULL;
+    if (n < 0 || d <= 0 || d > 256 || n > 0x7fffffffll) return ARL_E_ARG;
+    if (n == 0) return ARL_OK;
+    unsigned long long key = seed ^ (stream_id * 0x9E3779B97F4A7C15ull);          // one hash of (seed, stream) keys the whole call
+    key += 0x9E3779B97F4A7C15ull; key = (key ^ (key >> 30)) * 0xBF58476D1CE4E5B9ull; key = (key ^ (key >> 27)) * 0x94D049BB133111EBull; key ^= key >> 31;
+    hipLaunchKernelGGL(simgcl_perturb_rng_kernel, dim3((unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, src, dst,
+                       (int)n, (int)d, row_ids, eps, key);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
 
 int arl_simgcl_perturb_f32(float *E, const float *noise, int64_t n, int64_t d, float eps, arl_stream_t stream) {
     if (!E || !noise) return ARL_E_NULL;

@@ -311,7 +311,26 @@ class PropagationEngine:
         iidx = torch.unique(p.long()) + U
         rows_cl = torch.cat([uidx, iidx]).to(torch.int32)
         nu = uidx.numel()
-        rnd = (lambda v, k: noises[v][k]) if noises is not None else (lambda v, k: torch.rand(N, d, device=self.device))
+        # noise: injected tables (parity tests) or, by default, drawn inside the perturbation kernel from a seed taken once from torch's global
+        # generator and a running stream number -- one "draw" per hop and view like the reference's rand_like calls, but no [N, d] noise table,
+        # no clone of the operand, and the compact last-hop rows get exactly the values a full-table draw would have given them
+        rng_mode = noises is None
+        if rng_mode:
+            if getattr(self, '_noise_seed', None) is None:
+                self._noise_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                self._noise_stream = 0
+            stream0 = self._noise_stream
+            self._noise_stream += 2 * L
+        rnd = (lambda v, k: noises[v][k]) if noises is not None else None
+        def perturb_full(src, v, k, out=None):                          # hop-k table of view v
+            if rng_mode:
+                return ops.simgcl_perturb_rng(src, eps, self._noise_seed, stream0 + v * L + k, out=out)
+            dst = src.clone() if out is None else out.copy_(src)
+            return ops.simgcl_perturb_(dst, rnd(v, k), eps)
+        def perturb_rows(src, v, k, sel):                               # compact rows `sel` of the hop-k table of view v, in place
+            if rng_mode:
+                return ops.simgcl_perturb_rng(src, eps, self._noise_seed, stream0 + v * L + k, out=src, row_ids=sel)
+            return ops.simgcl_perturb_(src, rnd(v, k)[sel.long()].contiguous(), eps)
         # ---- forwards
         E1 = ops.spmm(A, self.E0, out=self.hops[0])                       # shared first hop
         def finish(first, view):                                            # hops 2..L on table `first`; returns compact rows [rows_sel, d]
@@ -320,14 +339,14 @@ class PropagationEngine:
             for k in range(1, L - 1):
                 nxt = ops.spmm(A, cur)
                 if view is not None:
-                    ops.simgcl_perturb_(nxt, rnd(view, k), eps)
+                    perturb_full(nxt, view, k, out=nxt)
                 layers.append(nxt); cur = nxt
             if L == 1:
                 return ops.gather_rows(first, sel, check_range=False)
             if view is None:
                 return ops.spmm_rows(A, cur, sel, layers, inv, nsplit=self.nsplit, check_range=False)
             last = ops.spmm_rows(A, cur, sel, (), 1.0, nsplit=self.nsplit, check_range=False)
-            ops.simgcl_perturb_(last, rnd(view, L - 1)[sel.long()].contiguous(), eps)
+            perturb_rows(last, view, L - 1, sel)
             for t in layers:
                 last += ops.gather_rows(t, sel, check_range=False)
             return last * inv
@@ -337,8 +356,7 @@ class PropagationEngine:
         ops.scatter_add_rows(self.G, rows, self.Gc, 1.0, check_range=False)
         views = []
         for v in (0, 1):
-            E1p = E1.clone()
-            ops.simgcl_perturb_(E1p, rnd(v, 0), eps)
+            E1p = perturb_full(E1, v, 0)
             views.append(finish(E1p, v))
         lu, du1, du2 = ops.infonce_fwd_bwd(views[0][:nu].contiguous(), views[1][:nu].contiguous(), tau)
         li, di1, di2 = ops.infonce_fwd_bwd(views[0][nu:].contiguous(), views[1][nu:].contiguous(), tau)

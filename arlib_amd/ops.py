@@ -843,6 +843,25 @@ def infonce_fwd_bwd(v1, v2, tau, want_grad=True, upstream=1.0):
     return loss, d1, d2
 
 
+def simgcl_perturb_rng(src, eps, seed, stream_id, out=None, row_ids=None):
+    """out = src + sign(src) * normalize(u) * eps with u ~ uniform[0,1) drawn inside the kernel from (seed, stream_id, row, column): the
+    SimGCL perturbation (SimGCL.py:203-205) without a noise table or a clone.  out may be src (in place).  row_ids (int32, optional): src holds
+    those rows of a larger table; they get the noise of a full-table call with the same (seed, stream_id)."""
+    _dev(src, torch.float32, 'src', 2)
+    if out is None:
+        out = torch.empty_like(src)
+    _dev(out, torch.float32, 'out', 2)
+    if out.shape != src.shape:
+        raise ValueError('simgcl_perturb_rng: out shape mismatch')
+    if row_ids is not None:
+        _dev(row_ids, torch.int32, 'row_ids', 1)
+        if row_ids.numel() != src.shape[0]:
+            raise ValueError('simgcl_perturb_rng: one row id per row')
+    check(_lib.lib().arl_simgcl_perturb_rng_f32(_ptr(src), _ptr(out), src.shape[0], src.shape[1], _ptr(row_ids), float(eps), int(seed) & (2 ** 64 - 1),
+                                                int(stream_id) & (2 ** 64 - 1), _stream()), 'arl_simgcl_perturb_rng_f32')
+    return out
+
+
 def simgcl_perturb_(E, noise, eps):
     _dev(E, torch.float32, 'E', 2); _dev(noise, torch.float32, 'noise', 2)
     if E.shape != noise.shape:

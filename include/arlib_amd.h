@@ -279,6 +279,13 @@ int arl_infonce_fwd_bwd_f32(const float *v1, const float *v2, int64_t n, int64_t
 
 /* SimGCL perturbation -- recommender/SimGCL.py:203-205: E += sign(E) * normalize(noise, dim=-1) * eps, in place. */
 int arl_simgcl_perturb_f32(float *E, const float *noise, int64_t n, int64_t d, float eps, arl_stream_t stream);
+/* The same perturbation with the noise drawn inside the kernel (recommender/SimGCL.py:203-205: random_noise = torch.rand_like(ego)):
+ *   dst[r, k] = src[r, k] + sign(src[r, k]) * u[r, k] / max(||u[r, :]||, 1e-12) * eps,
+ *   u[r, k] = uniform [0, 1) from a counter-based hash of (seed, stream_id, row * d + k), row = row_ids ? row_ids[r] : r.
+ * No noise table, no clone of the operand (dst may alias src); with row_ids the operand is a compact slice of a larger table and receives
+ * exactly the noise its rows get in a full-table call with the same (seed, stream_id).  d <= 256. */
+int arl_simgcl_perturb_rng_f32(const float *src, float *dst, int64_t n, int64_t d, const int32_t *row_ids, float eps, uint64_t seed,
+                               uint64_t stream_id, arl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * NGCF layer glue -- recommender/NGCF.py:200-208:  E' = leaky_relu((P + E) W1 + (P * E) W2),  P = A_hat E.

@@ -501,6 +501,31 @@ def test_tables_sum(ops):
         ops.tables_sum([dts[1], dts[2][:-1].contiguous()])
 
 
+@pytest.mark.parametrize('d', [64, 16, 128, 200])
+def test_simgcl_perturb_rng(ops, d):
+    """SimGCL.py:203-205 with the noise drawn in the kernel: sign-aligned, every row moved by exactly eps, uniform-looking directions,
+    reproducible per (seed, stream), and a compact slice receives the noise of the same rows of a full-table call."""
+    g = torch.Generator().manual_seed(d)
+    n, eps = 5000, 0.1
+    src = torch.randn(n, d, generator=g).cuda()
+    src[7] = 0.0                                             # sign(0) = 0: the row stays put
+    a = ops.simgcl_perturb_rng(src, eps, 1234, 5)
+    delta = (a - src).double()
+    assert bool((delta * torch.sign(src).double() >= 0).all())
+    nrm = delta.norm(dim=1)
+    keep = torch.ones(n, dtype=torch.bool, device='cuda'); keep[7] = False
+    assert float((nrm[keep] - eps).abs().max()) < 1e-6 and float(nrm[7]) == 0.0
+    u = (delta.abs() / eps)[keep]                            # = u / ||u||, u ~ U[0,1)^d: mean component about sqrt(3)/2 / sqrt(d)
+    assert abs(float(u.mean()) * d ** 0.5 - 0.866) < 0.02
+    assert torch.equal(a, ops.simgcl_perturb_rng(src, eps, 1234, 5))                       # reproducible
+    assert not torch.equal(a, ops.simgcl_perturb_rng(src, eps, 1234, 6)) and not torch.equal(a, ops.simgcl_perturb_rng(src, eps, 1235, 5))
+    sel = torch.tensor([3, 4999, 17, 17, 0], dtype=torch.int32, device='cuda')
+    part = ops.simgcl_perturb_rng(src[sel.long()].contiguous(), eps, 1234, 5, row_ids=sel)
+    assert torch.equal(part, a[sel.long()])
+    b = src.clone(); ops.simgcl_perturb_rng(b, eps, 1234, 5, out=b)                      # in place
+    assert torch.equal(a, b)
+
+
 def test_topn_project_rows(ops):
     rng = np.random.default_rng(6)
     M = rng.random((7, 1412)).astype(np.float32)
