@@ -526,7 +526,14 @@ class ShardedPropagationEngine:
                 dst = bufs[h % 2]
                 self._hop(cur, dst)
                 if view is not None:
-                    k.simgcl_perturb_(dst, noise(view, h), eps)
+                    if noises is None and hasattr(k, 'simgcl_perturb_rng'):
+                        # noise drawn inside the kernel from (seed, step/view/hop stream, GLOBAL row id, column): the replicated item rows are
+                        # bit-identical on every rank by construction, and the draw does not depend on the world size
+                        if getattr(self, '_gid', None) is None:
+                            self._gid = torch.cat([torch.arange(self.u0, self.u1, device=dev), torch.arange(self.U, self.U + self.I, device=dev)]).to(torch.int32)
+                        k.simgcl_perturb_rng(dst, eps, 0x51AC1, (self.t * 2 + view) * L + h, out=dst, row_ids=self._gid)
+                    else:
+                        k.simgcl_perturb_(dst, noise(view, h), eps)
                 if h == 0:
                     acc.copy_(dst)
                 else:
