@@ -296,8 +296,8 @@ class PropagationEngine:
             backward operator (1/L) sum_{k=1..L} A^k: the three sparse output gradients are summed first and ONE Horner pass
             (flag-masked first hop, Adam fused into the last) replaces three.
         L = 2: 2 full hops + 1 masked + 3 row-subset hops instead of 12 full hops.
-        noises: optional [view][hop] full [N,d] tensors (parity tests); default torch.rand on the device, one [N,d] draw per
-        hop and view exactly like the reference's rand_like calls.  Returns (loss_out, cl_loss) device tensors."""
+        noises: optional [view][hop] full [N,d] tensors (parity tests); default: uniform noise drawn inside the perturbation kernel, one
+        stream per hop and view (the reference's rand_like calls).  Returns (loss_out, cl_loss) device tensors."""
         if not self.skip0 or self.optimizer != 'adam':
             raise ValueError('step_simgcl needs a skip_layer0 engine with Adam')
         L, A, U, N, d = self.L, self.A, self.U, self.N, self.d
@@ -387,8 +387,8 @@ class PropagationEngine:
         unique positive items.  Sparse-batch schedule: L-1 full hops + a row-subset hop forward; backward
             acc_L = c_L,  acc_k = c_k + A acc_{k+1},  dE0 = A acc_1,   c_k = G_mean / L + [k == layer_cl] G_cl
         with the first hop gathering flagged rows only and Adam fused into the last (default L=2: 2 full hops in all).
-        noises: optional [hop] full [N,d] tensors (parity tests); default one torch.rand draw per hop like the reference's
-        rand_like.  Returns (loss_out, cl_loss)."""
+        noises: optional [hop] full [N,d] tensors (parity tests); default: uniform noise drawn inside the perturbation kernel, one stream
+        per hop (the reference's rand_like).  Returns (loss_out, cl_loss)."""
         if not self.skip0 or self.optimizer != 'adam':
             raise ValueError('step_xsimgcl needs a skip_layer0 engine with Adam')
         L, A, U, N, d = self.L, self.A, self.U, self.N, self.d
@@ -405,15 +405,27 @@ class PropagationEngine:
         rows_cl = torch.cat([uidx, iidx]).to(torch.int32)
         nu = uidx.numel()
         sel = torch.cat([rows, rows_cl])                                    # compact rows: [0,3B) BPR, then the CL rows
-        rnd = (lambda k: noises[k]) if noises is not None else (lambda k: torch.rand(N, d, device=self.device))
+        rng_mode = noises is None                                           # default: noise drawn inside the perturbation kernel (step_simgcl)
+        if rng_mode:
+            if getattr(self, '_noise_seed', None) is None:
+                self._noise_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                self._noise_stream = 0
+            stream0 = self._noise_stream
+            self._noise_stream += L
         # ---- forward
         layers, cur = [], self.E0
         for k in range(L - 1):
             nxt = ops.spmm(A, cur, out=self.hops[k % len(self.hops)] if L <= 3 else None)
-            ops.simgcl_perturb_(nxt, rnd(k), eps)
+            if rng_mode:
+                ops.simgcl_perturb_rng(nxt, eps, self._noise_seed, stream0 + k, out=nxt)
+            else:
+                ops.simgcl_perturb_(nxt, noises[k], eps)
             layers.append(nxt); cur = nxt
         last = ops.spmm_rows(A, cur, sel, (), 1.0, nsplit=self.nsplit, check_range=False)
-        ops.simgcl_perturb_(last, rnd(L - 1)[sel.long()].contiguous(), eps)
+        if rng_mode:
+            ops.simgcl_perturb_rng(last, eps, self._noise_seed, stream0 + L - 1, out=last, row_ids=sel)
+        else:
+            ops.simgcl_perturb_(last, noises[L - 1][sel.long()].contiguous(), eps)
         mean_c = last.clone()
         for t in layers:
             mean_c += ops.gather_rows(t, sel, check_range=False)
