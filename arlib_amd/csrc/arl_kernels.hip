@@ -1676,7 +1676,49 @@ __device__ __forceinline__ unsigned bloom_hash(int item) { return ((unsigned)ite
 // the fp32 MFMA -- they leave the SIMD's vector issue free for the other wave's pre-filter and inserts.  `Pi` is then the
 // pre-split image [I][3][D] bf16 written by split_bf16x3_kernel.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) unsigned lds_u32;
+
+// Split form used by SPLIT = true (compile-time choice; both kept):
+//   1: three bf16 pieces, six products (above);
+//   2: TWO fp16 pieces of the operand scaled by a power of two, three products ah*bh + ah*bl + al*bh.  Each table is scaled so that its
+//      largest magnitude lands in [2^13, 2^14): the high piece keeps 11 significant bits, the low piece the next 11 (it stays a normal
+//      fp16 number for every element within 2^12 of the table's maximum), every product of two pieces is exact in fp32, and the dropped
+//      al*bl term is <= 2^-22 |a||b| -- 2^-21 per product in all, the size of the rounding differences between two fp32 summation orders
+//      of a d = 64 dot product.  Half the matrix work and 2/3 of the LDS and global bytes of form 1.  Scores, thresholds and the sorted
+//      lists live in the scaled domain (scale = 2^(eu + ei), exact); only the final values are scaled back.
+#ifndef ARL_TOPK_SPLIT_MODE
+#define ARL_TOPK_SPLIT_MODE 2
+#endif
+constexpr int kSplitMode = ARL_TOPK_SPLIT_MODE;
+constexpr int kSplitPlanes = kSplitMode == 1 ? 3 : 2;
+
+// largest |x| of a table as float bits (non-negative floats order like unsigned ints): *out must be zeroed first
+__global__ __launch_bounds__(kBlock) void absmax_bits_kernel(const float *__restrict__ X, long long n, unsigned *__restrict__ out) {
+    unsigned m = 0u;
+    for (long long t = (long long)blockIdx.x * kBlock + threadIdx.x; t < n; t += (long long)gridDim.x * kBlock) m = max(m, __float_as_uint(fabsf(X[t])));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+// power of two that brings a table whose largest magnitude has float bits `mbits` into [2^13, 2^14) (1 for an all-zero or non-finite table)
+__device__ __forceinline__ float split_scale(unsigned mbits) {
+    const int e = (int)(mbits >> 23);                              // biased exponent of the maximum
+    if (e == 0 || e >= 255) return 1.f;
+    const int se = min(max(127 + 13 - (e - 127), 127 - 40), 127 + 40);      // 2^(13 - (e - 127)), kept within 2^+-40 (the product of two scales must not overflow)
+    return __uint_as_float((unsigned)se << 23);
+}
+__global__ __launch_bounds__(kBlock) void split_f16x2_kernel(const float *__restrict__ X, long long n, int d, const unsigned *__restrict__ mbits,
+                                                              _Float16 *__restrict__ out) {
+    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;          // one element each
+    if (t >= n) return;
+    const long long row = t / d;
+    const int kcol = (int)(t - row * d);
+    const float x = X[t] * split_scale(*mbits);
+    const _Float16 h = (_Float16)x;
+    _Float16 *o = out + row * 2 * d + kcol;
+    o[0] = h; o[d] = (_Float16)(x - (float)h);
+}
 
 __global__ __launch_bounds__(kBlock) void split_bf16x3_kernel(const float *__restrict__ X, long long n, int d, __bf16 *__restrict__ out) {
     const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;          // one element each
@@ -1697,15 +1739,15 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
                                                                             const int32_t *__restrict__ mrp, const int32_t *__restrict__ mcol, int k,
                                                                             int32_t *__restrict__ top_idx, float *__restrict__ top_val,
                                                                             const float *__restrict__ Pi_f32, const int32_t *__restrict__ warm_idx,
-                                                                            int *__restrict__ underflow) {
+                                                                            int *__restrict__ underflow, const unsigned *__restrict__ table_max_bits) {
     constexpr int Q = D / 4;                                       // contraction indices per lane: [Q*g, Q*g + Q)
-    constexpr int SRCB = SPLIT ? 3 * D * 2 : D * 4;                // bytes per item row in global memory
+    constexpr int SRCB = SPLIT ? kSplitPlanes * D * 2 : D * 4;     // bytes per item row in global memory
     // LDS image of a staged tile.  The hardware services a ds_read_b128 in four fixed 16-lane groups that mix lanes of two
     // k-groups (g, g+1); with plain [row][plane][k] rows every group hit two banks twice (SQ_LDS_BANK_CONFLICT = 44 % of the LDS
     // cycles).  Two half images -- k-groups with g even / g odd -- a multiple of 256 B apart, rows of an odd number of 16-B units:
     // every group tiles the 64 banks exactly.
     //   offset(row, plane, g, piece) = (g&1)*HALF + row*RH + ((plane*2 + (g>>1))*PPG + piece)*16
-    constexpr int NPL = SPLIT ? 3 : 1;                             // planes (bf16 pieces of the split) per item row
+    constexpr int NPL = SPLIT ? kSplitPlanes : 1;                  // planes (pieces of the split) per item row
     constexpr int PPG = SPLIT ? Q / 8 : Q / 4;                     // 16-byte pieces per k-group and plane
     constexpr int RH = NPL * 2 * PPG * 16 + 16;
     constexpr int HALF = (D <= 16 ? 128 : (D <= 64 ? 64 : 32)) * RH;
@@ -1732,9 +1774,22 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
             a[t] = v.x; a[t + 1] = v.y; a[t + 2] = v.z; a[t + 3] = v.w;
         }
     }
-    constexpr int KS = SPLIT ? Q / 8 : 1;                          // bf16 MFMAs (8 indices per lane each) per operand pair
+    constexpr int KS = SPLIT ? Q / 8 : 1;                          // 16-bit MFMAs (8 indices per lane each) per operand pair
+    constexpr bool F16 = SPLIT && kSplitMode == 2;
     bf16x8 af[3][KS];
-    if constexpr (SPLIT) {
+    f16x8 ah[2][KS];
+    // scaled domain of the fp16 form: scores = true scores * score_scale (a power of two); 1 otherwise
+    float score_scale = 1.f, score_unscale = 1.f;
+    if constexpr (F16) {
+        const float su = split_scale(table_max_bits[1]), si = split_scale(table_max_bits[0]);
+        score_scale = su * si; score_unscale = (1.f / su) * (1.f / si);
+#pragma unroll
+        for (int t = 0; t < Q; ++t) {
+            const float x = a[t] * su;
+            const _Float16 h = (_Float16)x;
+            ah[0][t / 8][t % 8] = h; ah[1][t / 8][t % 8] = (_Float16)(x - (float)h);
+        }
+    } else if constexpr (SPLIT) {
 #pragma unroll
         for (int t = 0; t < Q; ++t) {
             const __bf16 h = (__bf16)a[t];
@@ -1790,7 +1845,7 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
                 ni = fmaf(y.x, y.x, ni); ni = fmaf(y.y, y.y, ni); ni = fmaf(y.z, y.z, ni); ni = fmaf(y.w, y.w, ni);
                 nu = fmaf(x.x, x.x, nu); nu = fmaf(x.y, x.y, nu); nu = fmaf(x.z, x.z, nu); nu = fmaf(x.w, x.w, nu);
             }
-            float lb = lane < k ? sdot - 8e-6f * sqrtf(nu * ni) - 1e-30f : INFINITY;
+            float lb = lane < k ? (sdot - 8e-6f * sqrtf(nu * ni)) * score_scale - 1e-30f : INFINITY;     // thresholds live in the scaled domain
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) lb = fminf(lb, __shfl_xor(lb, off));
             if (lane == r) thr0v = lb;
@@ -1887,7 +1942,7 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
                         int lo = mrp[u], hi = mrp[u + 1];
                         const int end = hi;
                         while (lo < hi) { const int mid = (lo + hi) >> 1; if (mcol[mid] < item) lo = mid + 1; else hi = mid; }
-                        if (lo < end && mcol[lo] == item) sc = -10e8f;      // stays in the list only while it holds fewer than k real items
+                        if (lo < end && mcol[lo] == item) sc = -10e8f * score_scale;      // (-10e8 once scaled back) stays in the list only while it holds fewer than k real items
                     }
                 }
                 const unsigned long long mykey = pack_cand(sc, item);
@@ -1964,7 +2019,27 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
         f32x4 accs[NSUB];
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) accs[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (SPLIT) {
+        if constexpr (F16) {
+            f16x8 bfr[NSUB][2][KS];
+#pragma unroll
+            for (int plo = 0; plo < 2; ++plo)                      // the low pieces first: the first (smallest) term uses them
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int sub = 0; sub < NSUB; ++sub) {
+                        const int pl = 1 - plo;
+                        bfr[sub][pl][ks] = *reinterpret_cast<const f16x8 *>(buf + (g & 1) * HALF + (sub * 16 + c) * RH + ((pl * 2 + (g >> 1)) * PPG + ks) * 16);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int TA[3] = {0, 1, 0}, TB[3] = {1, 0, 0};    // ah*bl, al*bh, ah*bh: smallest products first
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int sub = 0; sub < NSUB; ++sub)
+                        accs[sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[TA[term]][ks], bfr[sub][TB[term]][ks], accs[sub], 0, 0, 0);
+        } else if constexpr (SPLIT) {
             bf16x8 bfr[NSUB][3][KS];
 #pragma unroll
             for (int plo = 0; plo < 3; ++plo)                      // planes in the order the terms below first use them: 0, 2, 1
@@ -2028,17 +2103,19 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
     // Two register sets: the loads of stage t + 2 are in flight while stage t goes to LDS.  (Issuing them through inline assembly with
     // counted `vmcnt` waits was tried: no gain, and unsafe -- the register allocator may split the live range of an asm output around
     // a cold block, e.g. the mask's binary search, and copy the registers before the load has landed.)
-    static_assert(F4 % kM16Block == 0, "every thread moves the same number of pieces");
+    // (with 8-wave workgroups every thread moves the same number of pieces; other workgroup sizes leave the last pass partial)
     f32x4 nb[PER], nc[PER];
 #pragma unroll
     for (int p = 0; p < PER; ++p) nb[p] = nc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto fetch = [&](int st, f32x4 (&r)[PER]) {
 #pragma unroll
-        for (int p = 0; p < PER; ++p) r[p] = *reinterpret_cast<const f32x4 *>(stage_ptr(st, p));
+        for (int p = 0; p < PER; ++p)
+            if ((p + 1) * kM16Block <= F4 || tid + p * kM16Block < F4) r[p] = *reinterpret_cast<const f32x4 *>(stage_ptr(st, p));
     };
     auto stash = [&](unsigned char *buf, const f32x4 (&r)[PER]) {
 #pragma unroll
-        for (int p = 0; p < PER; ++p) *reinterpret_cast<f32x4 *>(lds_ptr(buf, p)) = r[p];
+        for (int p = 0; p < PER; ++p)
+            if ((p + 1) * kM16Block <= F4 || tid + p * kM16Block < F4) *reinterpret_cast<f32x4 *>(lds_ptr(buf, p)) = r[p];
     };
     auto slot = [&](int st) { return bt + (st & (kTopkRing - 1)) * STAGEB; };
     auto signal = [&](unsigned *ctr) {
@@ -2097,7 +2174,7 @@ __global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const
         if (u < U && lane < k) {
             const unsigned long long key = ((unsigned long long)tk_hi[r] << 32) | tk_lo[r];
             top_idx[(size_t)u * k + lane] = cand_item(key);
-            top_val[(size_t)u * k + lane] = cand_score(key);
+            top_val[(size_t)u * k + lane] = cand_score(key) * score_unscale;
             if (WARM && lane == k - 1 && key == 0ull) atomicOr(underflow, 1);          // the warm threshold excluded too much
         }
     }
@@ -2867,14 +2944,28 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
     if (k <= 64 && (d == 16 || d == 32 || d == 64 || d == 128)) {        // matrix-core path
         const bool split = workspace != nullptr && (d == 64 || d == 128);
         const int mst = d <= 16 ? 128 : (d <= 64 ? 64 : 32);
-        const size_t stageb = 2 * (size_t)mst * ((split ? 6 : 4) * (size_t)d / 2 + 16);     // two half images of mst rows (STAGEB in the kernel)
+        const size_t stageb = 2 * (size_t)mst * ((split ? 2 * kSplitPlanes : 4) * (size_t)d / 2 + 16);     // two half images of mst rows (STAGEB in the kernel)
         const size_t shm_m = kTopkRing * stageb + 2 * kTopkRing * sizeof(unsigned) + (mask_rowptr ? sizeof(unsigned) * kMU * kBloomWords : 0);
         const unsigned grid_m = (unsigned)((U + kMU - 1) / kMU);
         const void *image = Pi;
+        const unsigned *max_bits = nullptr;
         if (split) {
             const long long n = (long long)I * d;
-            hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, Pi, n, (int)d,
-                               (__bf16 *)workspace);
+            if (kSplitMode == 2) {
+                // workspace: [I][2][d] fp16 image (4 I d bytes), then the two tables' largest magnitudes (float bits: items, users)
+                unsigned *mb = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + 4 * (size_t)n);
+                if (hipMemsetAsync(mb, 0, 2 * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) return ARL_E_ARG;
+                hipLaunchKernelGGL(absmax_bits_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, Pi, n, mb);
+                ARL_LAUNCH_CHECK();
+                hipLaunchKernelGGL(absmax_bits_kernel, dim3(grid_for(U * d, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, Pu, (long long)(U * d), mb + 1);
+                ARL_LAUNCH_CHECK();
+                hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, Pi, n, (int)d, mb,
+                                   (_Float16 *)workspace);
+                max_bits = mb;
+            } else {
+                hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, Pi, n, (int)d,
+                                   (__bf16 *)workspace);
+            }
             ARL_LAUNCH_CHECK();
             image = workspace;
         }
@@ -2883,7 +2974,7 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
             hipError_t em = hipFuncSetAttribute((const void *)score_mask_topk_mfma16_kernel<DV, SP, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m); \
             if (em != hipSuccess) return (int)em;                                                                                      \
             hipLaunchKernelGGL((score_mask_topk_mfma16_kernel<DV, SP, WM>), dim3(grid_m), dim3(kM16Block), shm_m, (hipStream_t)stream, Pu, image, (int)U, (int)I, \
-                               mask_rowptr, mask_col, (int)k, top_idx, top_val, Pi, warm_idx, underflow);                              \
+                               mask_rowptr, mask_col, (int)k, top_idx, top_val, Pi, warm_idx, underflow, max_bits);                    \
         } while (0)
 #define ARL_TOPK_CASE(DV, SP) do { if (warm_idx) ARL_TOPK_CASE2(DV, SP, true); else ARL_TOPK_CASE2(DV, SP, false); } while (0)
         if (d == 16) ARL_TOPK_CASE(16, false);
