@@ -1648,10 +1648,13 @@ __global__ __launch_bounds__(kBlock) void score_mask_topk_kernel(const float *__
 // Measured on MI355X: the f32 MFMA shares the SIMD's issue with the VALU (a second wave per SIMD hides latencies but its VALU
 // work does NOT overlap the other wave's f32 MFMAs), so every VALU instruction of the pre-filter/insert path is paid in full --
 // hence one subtract + one funnel shift per score, one ballot per phase, and the split-bf16 form below for the contraction.
-#ifndef ARL_TOPK_NW
-#define ARL_TOPK_NW 8
+#ifndef ARL_TOPK_SPLIT_MODE
+#define ARL_TOPK_SPLIT_MODE 2
 #endif
-constexpr int kMU = 16 * ARL_TOPK_NW;         // users per block
+// Waves per workgroup (16 users each): 12 for the fp16-split d = 64 form, whose 156-160 registers allow three waves per SIMD (a third wave
+// to fill the matrix pipe and the vector issue while the other two wait: 19.6 -> 17.6 ms, cfg2 masked pass 86 -> 69 ms); 8 for the
+// forms that need more than 168 registers.
+constexpr int topk_waves(int D, bool SPLIT) { return (SPLIT && D == 64 && ARL_TOPK_SPLIT_MODE == 2) ? 12 : 8; }
 #ifdef ARL_TOPK_PROF
 #define ARL_PROF_DECL long long P_acc[4] = {0, 0, 0, 0}, P_t0 = clock64(); const long long P_start = P_t0;
 #define ARL_PROF_TICK(SLOT) { const long long P_t = clock64(); P_acc[SLOT] += P_t - P_t0; P_t0 = P_t; }
@@ -1662,7 +1665,6 @@ constexpr int kMU = 16 * ARL_TOPK_NW;         // users per block
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
-constexpr int kM16Block = 64 * ARL_TOPK_NW;
 constexpr int kBloomWords = 32;      // 1024 bits per user
 constexpr int kTopkRing = 4;         // staged item tiles in LDS (slots of the ring), a power of two
 constexpr int kTopkLead = 2;         // a wave writes its share of stage s + kTopkLead while it consumes stage s
@@ -1687,9 +1689,6 @@ typedef __attribute__((address_space(3))) unsigned lds_u32;
 //      al*bl term is <= 2^-22 |a||b| -- 2^-21 per product in all, the size of the rounding differences between two fp32 summation orders
 //      of a d = 64 dot product.  Half the matrix work and 2/3 of the LDS and global bytes of form 1.  Scores, thresholds and the sorted
 //      lists live in the scaled domain (scale = 2^(eu + ei), exact); only the final values are scaled back.
-#ifndef ARL_TOPK_SPLIT_MODE
-#define ARL_TOPK_SPLIT_MODE 2
-#endif
 constexpr int kSplitMode = ARL_TOPK_SPLIT_MODE;
 constexpr int kSplitPlanes = kSplitMode == 1 ? 3 : 2;
 
@@ -1735,11 +1734,12 @@ __global__ __launch_bounds__(kBlock) void split_bf16x3_kernel(const float *__res
 }
 
 template <int D, bool SPLIT, bool WARM>
-__global__ __launch_bounds__(kM16Block) void score_mask_topk_mfma16_kernel(const float *__restrict__ Pu, const void *__restrict__ Pi_image, int U, int I,
+__global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfma16_kernel(const float *__restrict__ Pu, const void *__restrict__ Pi_image, int U, int I,
                                                                             const int32_t *__restrict__ mrp, const int32_t *__restrict__ mcol, int k,
                                                                             int32_t *__restrict__ top_idx, float *__restrict__ top_val,
                                                                             const float *__restrict__ Pi_f32, const int32_t *__restrict__ warm_idx,
                                                                             int *__restrict__ underflow, const unsigned *__restrict__ table_max_bits) {
+    constexpr int kM16Block = 64 * topk_waves(D, SPLIT), kMU = 16 * topk_waves(D, SPLIT);       // threads / users per workgroup
     constexpr int Q = D / 4;                                       // contraction indices per lane: [Q*g, Q*g + Q)
     constexpr int SRCB = SPLIT ? kSplitPlanes * D * 2 : D * 4;     // bytes per item row in global memory
     // LDS image of a staged tile.  The hardware services a ds_read_b128 in four fixed 16-lane groups that mix lanes of two
@@ -2945,8 +2945,10 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
         const bool split = workspace != nullptr && (d == 64 || d == 128);
         const int mst = d <= 16 ? 128 : (d <= 64 ? 64 : 32);
         const size_t stageb = 2 * (size_t)mst * ((split ? 2 * kSplitPlanes : 4) * (size_t)d / 2 + 16);     // two half images of mst rows (STAGEB in the kernel)
-        const size_t shm_m = kTopkRing * stageb + 2 * kTopkRing * sizeof(unsigned) + (mask_rowptr ? sizeof(unsigned) * kMU * kBloomWords : 0);
-        const unsigned grid_m = (unsigned)((U + kMU - 1) / kMU);
+        const int nwaves = (split && d == 64 && kSplitMode == 2) ? 12 : 8;       // topk_waves(D, SPLIT)
+        const int users_per_wg = 16 * nwaves;
+        const size_t shm_m = kTopkRing * stageb + 2 * kTopkRing * sizeof(unsigned) + (mask_rowptr ? sizeof(unsigned) * users_per_wg * kBloomWords : 0);
+        const unsigned grid_m = (unsigned)((U + users_per_wg - 1) / users_per_wg);
         const void *image = Pi;
         const unsigned *max_bits = nullptr;
         if (split) {
@@ -2973,7 +2975,7 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
         do {                                                                                                                           \
             hipError_t em = hipFuncSetAttribute((const void *)score_mask_topk_mfma16_kernel<DV, SP, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m); \
             if (em != hipSuccess) return (int)em;                                                                                      \
-            hipLaunchKernelGGL((score_mask_topk_mfma16_kernel<DV, SP, WM>), dim3(grid_m), dim3(kM16Block), shm_m, (hipStream_t)stream, Pu, image, (int)U, (int)I, \
+            hipLaunchKernelGGL((score_mask_topk_mfma16_kernel<DV, SP, WM>), dim3(grid_m), dim3(64 * topk_waves(DV, SP)), shm_m, (hipStream_t)stream, Pu, image, (int)U, (int)I, \
                                mask_rowptr, mask_col, (int)k, top_idx, top_val, Pi, warm_idx, underflow, max_bits);                    \
         } while (0)
 #define ARL_TOPK_CASE(DV, SP) do { if (warm_idx) ARL_TOPK_CASE2(DV, SP, true); else ARL_TOPK_CASE2(DV, SP, false); } while (0)
