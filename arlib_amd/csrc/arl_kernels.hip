@@ -1654,7 +1654,10 @@ __global__ __launch_bounds__(kBlock) void score_mask_topk_kernel(const float *__
 // Waves per workgroup (16 users each): 12 for the fp16-split d = 64 form, whose 156-160 registers allow three waves per SIMD (a third wave
 // to fill the matrix pipe and the vector issue while the other two wait: 19.6 -> 17.6 ms, cfg2 masked pass 86 -> 69 ms); 8 for the
 // forms that need more than 168 registers.
-constexpr int topk_waves(int D, bool SPLIT) { return (SPLIT && D == 64 && ARL_TOPK_SPLIT_MODE == 2) ? 12 : 8; }
+#ifndef ARL_TOPK_D128_WAVES
+#define ARL_TOPK_D128_WAVES 8
+#endif
+constexpr int topk_waves(int D, bool SPLIT) { return (SPLIT && ARL_TOPK_SPLIT_MODE == 2) ? (D == 64 ? 12 : (D == 128 ? ARL_TOPK_D128_WAVES : 8)) : 8; }
 #ifdef ARL_TOPK_PROF
 #define ARL_PROF_DECL long long P_acc[4] = {0, 0, 0, 0}, P_t0 = clock64(); const long long P_start = P_t0;
 #define ARL_PROF_TICK(SLOT) { const long long P_t = clock64(); P_acc[SLOT] += P_t - P_t0; P_t0 = P_t; }
@@ -2945,7 +2948,7 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
         const bool split = workspace != nullptr && (d == 64 || d == 128);
         const int mst = d <= 16 ? 128 : (d <= 64 ? 64 : 32);
         const size_t stageb = 2 * (size_t)mst * ((split ? 2 * kSplitPlanes : 4) * (size_t)d / 2 + 16);     // two half images of mst rows (STAGEB in the kernel)
-        const int nwaves = (split && d == 64 && kSplitMode == 2) ? 12 : 8;       // topk_waves(D, SPLIT)
+        const int nwaves = topk_waves((int)d, split);
         const int users_per_wg = 16 * nwaves;
         const size_t shm_m = kTopkRing * stageb + 2 * kTopkRing * sizeof(unsigned) + (mask_rowptr ? sizeof(unsigned) * users_per_wg * kBloomWords : 0);
         const unsigned grid_m = (unsigned)((U + users_per_wg - 1) / users_per_wg);
