@@ -1651,11 +1651,11 @@ __global__ __launch_bounds__(kBlock) void score_mask_topk_kernel(const float *__
 #ifndef ARL_TOPK_SPLIT_MODE
 #define ARL_TOPK_SPLIT_MODE 2
 #endif
-// Waves per workgroup (16 users each): 12 for the fp16-split d = 64 form, whose 156-160 registers allow three waves per SIMD (a third wave
-// to fill the matrix pipe and the vector issue while the other two wait: 19.6 -> 17.6 ms, cfg2 masked pass 86 -> 69 ms); 8 for the
-// forms that need more than 168 registers.
+// Waves per workgroup (16 users each): 12 for the fp16-split forms -- three waves per SIMD, a third wave to fill the matrix pipe and the
+// vector issue while the other two wait (d = 64, 156-160 registers: 19.6 -> 17.6 ms, cfg2 masked pass 86 -> 69 ms; d = 128, held to 168
+// registers with 8 spilled: 25.8 -> 22.2 ms at 192 K x 100 K); 8 for the exact-fp32 forms (174-182 registers).
 #ifndef ARL_TOPK_D128_WAVES
-#define ARL_TOPK_D128_WAVES 8
+#define ARL_TOPK_D128_WAVES 12
 #endif
 constexpr int topk_waves(int D, bool SPLIT) { return (SPLIT && ARL_TOPK_SPLIT_MODE == 2) ? (D == 64 ? 12 : (D == 128 ? ARL_TOPK_D128_WAVES : 8)) : 8; }
 #ifdef ARL_TOPK_PROF
