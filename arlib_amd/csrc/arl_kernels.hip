@@ -1657,7 +1657,10 @@ __global__ __launch_bounds__(kBlock) void score_mask_topk_kernel(const float *__
 #ifndef ARL_TOPK_D128_WAVES
 #define ARL_TOPK_D128_WAVES 12
 #endif
-constexpr int topk_waves(int D, bool SPLIT) { return (SPLIT && ARL_TOPK_SPLIT_MODE == 2) ? (D == 64 ? 12 : (D == 128 ? ARL_TOPK_D128_WAVES : 8)) : 8; }
+#ifndef ARL_TOPK_D64_WAVES
+#define ARL_TOPK_D64_WAVES 12
+#endif
+constexpr int topk_waves(int D, bool SPLIT) { return (SPLIT && ARL_TOPK_SPLIT_MODE == 2) ? (D == 64 ? ARL_TOPK_D64_WAVES : (D == 128 ? ARL_TOPK_D128_WAVES : 8)) : 8; }
 #ifdef ARL_TOPK_PROF
 #define ARL_PROF_DECL long long P_acc[4] = {0, 0, 0, 0}, P_t0 = clock64(); const long long P_start = P_t0;
 #define ARL_PROF_TICK(SLOT) { const long long P_t = clock64(); P_acc[SLOT] += P_t - P_t0; P_t0 = P_t; }
@@ -2023,25 +2026,31 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) accs[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (F16) {
-            f16x8 bfr[NSUB][2][KS];
-#pragma unroll
-            for (int plo = 0; plo < 2; ++plo)                      // the low pieces first: the first (smallest) term uses them
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                    for (int sub = 0; sub < NSUB; ++sub) {
-                        const int pl = 1 - plo;
-                        bfr[sub][pl][ks] = *reinterpret_cast<const f16x8 *>(buf + (g & 1) * HALF + (sub * 16 + c) * RH + ((pl * 2 + (g >> 1)) * PPG + ks) * 16);
-                    }
-            __builtin_amdgcn_sched_barrier(0);
+            // fragments of GRP sub-tiles at a time (all of the stage, or two when the workgroup runs four waves per SIMD on 128 registers)
+            constexpr int GRP = (topk_waves(D, SPLIT) >= 16 && NSUB > 2) ? 2 : NSUB;
             constexpr int TA[3] = {0, 1, 0}, TB[3] = {1, 0, 0};    // ah*bl, al*bh, ah*bh: smallest products first
 #pragma unroll
-            for (int term = 0; term < 3; ++term)
+            for (int s0 = 0; s0 < NSUB; s0 += GRP) {
+                f16x8 bfr[GRP][2][KS];
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
+                for (int plo = 0; plo < 2; ++plo)                  // the low pieces first: the first (smallest) term uses them
 #pragma unroll
-                    for (int sub = 0; sub < NSUB; ++sub)
-                        accs[sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[TA[term]][ks], bfr[sub][TB[term]][ks], accs[sub], 0, 0, 0);
+                    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                        for (int sub = 0; sub < GRP; ++sub) {
+                            const int pl = 1 - plo;
+                            bfr[sub][pl][ks] = *reinterpret_cast<const f16x8 *>(buf + (g & 1) * HALF + ((s0 + sub) * 16 + c) * RH + ((pl * 2 + (g >> 1)) * PPG + ks) * 16);
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                        for (int sub = 0; sub < GRP; ++sub)
+                            accs[s0 + sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[TA[term]][ks], bfr[sub][TB[term]][ks], accs[s0 + sub], 0, 0, 0);
+                if constexpr (GRP < NSUB) __builtin_amdgcn_sched_barrier(0);
+            }
         } else if constexpr (SPLIT) {
             bf16x8 bfr[NSUB][3][KS];
 #pragma unroll
