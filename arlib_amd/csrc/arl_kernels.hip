@@ -1651,14 +1651,15 @@ __global__ __launch_bounds__(kBlock) void score_mask_topk_kernel(const float *__
 #ifndef ARL_TOPK_SPLIT_MODE
 #define ARL_TOPK_SPLIT_MODE 2
 #endif
-// Waves per workgroup (16 users each): 12 for the fp16-split forms -- three waves per SIMD, a third wave to fill the matrix pipe and the
-// vector issue while the other two wait (d = 64, 156-160 registers: 19.6 -> 17.6 ms, cfg2 masked pass 86 -> 69 ms; d = 128, held to 168
-// registers with 8 spilled: 25.8 -> 22.2 ms at 192 K x 100 K); 8 for the exact-fp32 forms (174-182 registers).
+// Waves per workgroup (16 users each).  The fp16-split forms run more than two waves per SIMD -- further waves to fill the matrix pipe and
+// the vector issue while the others wait: d = 64 with 16 waves = four per SIMD (124-126 registers once the fragments of a stage are loaded
+// two sub-tiles at a time; 8 -> 12 -> 16 waves: 19.6 -> 17.6 -> 16.3 ms at 200 K x 100 K, cfg2 masked pass 86 -> 69 -> 63 ms), d = 128 with
+// 12 = three per SIMD (held to 168 registers with 8 spilled: 25.8 -> 22.2 ms at 192 K x 100 K); the exact-fp32 forms (174-182 registers) keep 8.
 #ifndef ARL_TOPK_D128_WAVES
 #define ARL_TOPK_D128_WAVES 12
 #endif
 #ifndef ARL_TOPK_D64_WAVES
-#define ARL_TOPK_D64_WAVES 12
+#define ARL_TOPK_D64_WAVES 16
 #endif
 constexpr int topk_waves(int D, bool SPLIT) { return (SPLIT && ARL_TOPK_SPLIT_MODE == 2) ? (D == 64 ? ARL_TOPK_D64_WAVES : (D == 128 ? ARL_TOPK_D128_WAVES : 8)) : 8; }
 #ifdef ARL_TOPK_PROF

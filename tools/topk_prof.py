@@ -15,7 +15,7 @@ t0 = time.perf_counter()
 idx, val = ops.score_mask_topk(Pu, Pi, k, exact=os.environ.get('EXACT', '0') == '1')
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-NW = int(os.environ.get('NW', 12 if d == 64 and os.environ.get('EXACT', '0') != '1' else 8))
+NW = int(os.environ.get('NW', 16 if d == 64 and os.environ.get('EXACT', '0') != '1' else 8))
 v = val.view(U // (16 * NW), NW, 16 * k)[:, :, :6].double().mean(0).cpu().numpy()      # [wave, section]
 print('k=%d d=%d: %.1f ms' % (k, d, dt * 1e3))
 for w in range(NW):
