@@ -1654,7 +1654,7 @@ __global__ __launch_bounds__(kBlock) void score_mask_topk_kernel(const float *__
 // Waves per workgroup (16 users each).  The fp16-split forms run more than two waves per SIMD -- further waves to fill the matrix pipe and
 // the vector issue while the others wait: d = 64 with 16 waves = four per SIMD (124-126 registers once the fragments of a stage are loaded
 // two sub-tiles at a time; 8 -> 12 -> 16 waves: 19.6 -> 17.6 -> 16.3 ms at 200 K x 100 K, cfg2 masked pass 86 -> 69 -> 63 ms), d = 128 with
-// 12 = three per SIMD (held to 168 registers with 8 spilled: 25.8 -> 22.2 ms at 192 K x 100 K); the exact-fp32 forms (174-182 registers) keep 8.
+// 12 = three per SIMD (146 registers with the fragments loaded one sub-tile at a time: 25.8 -> 21.7 ms at 192 K x 100 K); the exact-fp32 forms (174-182 registers) keep 8.
 #ifndef ARL_TOPK_D128_WAVES
 #define ARL_TOPK_D128_WAVES 12
 #endif
@@ -2028,7 +2028,7 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
         for (int sub = 0; sub < NSUB; ++sub) accs[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (F16) {
             // fragments of GRP sub-tiles at a time (all of the stage, or two when the workgroup runs four waves per SIMD on 128 registers)
-            constexpr int GRP = (topk_waves(D, SPLIT) >= 16 && NSUB > 2) ? 2 : NSUB;
+            constexpr int GRP = (topk_waves(D, SPLIT) >= 16 && NSUB > 2) ? 2 : ((D >= 128 && topk_waves(D, SPLIT) >= 12) ? 1 : NSUB);
             constexpr int TA[3] = {0, 1, 0}, TB[3] = {1, 0, 0};    // ah*bl, al*bh, ah*bh: smallest products first
 #pragma unroll
             for (int s0 = 0; s0 < NSUB; s0 += GRP) {
@@ -2143,6 +2143,11 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
         }
         asm volatile("" ::: "memory");
     };
+#ifdef ARL_TOPK_STATIC_PRIO
+    // the waves of a SIMD are served oldest first: without help the workgroup's later waves run ~1.6x longer than its first four and
+    // the ring makes those wait.  Static priority by age group evens them out.
+    switch (wv >> 2) { case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; case 3: __builtin_amdgcn_s_setprio(3); break; default: break; }
+#endif
     unsigned *fill_ctr = ring_ctr, *done_ctr = ring_ctr + kTopkRing;
     constexpr unsigned NWV = kM16Block / kWave;
     static_assert(kTopkLead == 2 && (kTopkRing & (kTopkRing - 1)) == 0, "the loop below is unrolled by the lead");
