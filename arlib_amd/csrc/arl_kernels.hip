@@ -2143,11 +2143,6 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
         }
         asm volatile("" ::: "memory");
     };
-#ifdef ARL_TOPK_STATIC_PRIO
-    // the waves of a SIMD are served oldest first: without help the workgroup's later waves run ~1.6x longer than its first four and
-    // the ring makes those wait.  Static priority by age group evens them out.
-    switch (wv >> 2) { case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; case 3: __builtin_amdgcn_s_setprio(3); break; default: break; }
-#endif
     unsigned *fill_ctr = ring_ctr, *done_ctr = ring_ctr + kTopkRing;
     constexpr unsigned NWV = kM16Block / kWave;
     static_assert(kTopkLead == 2 && (kTopkRing & (kTopkRing - 1)) == 0, "the loop below is unrolled by the lead");
