@@ -207,7 +207,11 @@ def attack_leg(torch, ops, data, E0_dev, args):
             'value': 1.0 / dt, 'unit': 'steps/s', 'ms_per_step': 1e3 * dt, 'fake_users': F, 'targets': 5, 'cw_loss': float(loss),
             'algorithmic_bytes_per_step': step_bytes, 'hbm_frac': step_bytes / dt / 1e9 / HBM_PEAK_GBS,
             'cpu_baseline': cpu,
-            'score_topk_pass': {'seconds': topk_s, 'tflops': 2.0 * (U + F) * I * d / topk_s / 1e12, 'note': 'once per inner epoch, not per step'},
+            'score_topk_pass': {'seconds': topk_s, 'tflops': 2.0 * (U + F) * I * d / topk_s / 1e12,
+                                'roofline': {'bound': 'mfma', 'achieved': 3 * 2.0 * (U + F) * I * d / topk_s / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s',
+                                             'frac': 3 * 2.0 * (U + F) * I * d / topk_s / 1e12 / 2500.0,
+                                             'note': 'fp16 matrix flops executed: every fp32 product is three fp16 products (split operands); dense fp16/bf16 MFMA peak'},
+                                'note': '`tflops` = fp32-equivalent (2 U I d); once per inner epoch, not per step'},
             'setup_seconds': setup_s}
 
 
