@@ -372,9 +372,10 @@ int arl_pga_update_f32(float *S, const float *grad, const float *dinv_rows, cons
  * k <= 128.
  * workspace == NULL: scores are the exact fp32 contraction (bitwise an fmaf chain over d).
  * workspace != NULL (arl_score_mask_topk_workspace_bytes(I, d) bytes) and d in {64, 128}: the contraction runs on
- * the bf16 matrix path with every fp32 operand split in three bf16 pieces, six partial products accumulated in
- * fp32 -- scores within ~2e-7 relative of the exact ones (the size of fp32 summation-order differences), 2x faster;
- * the workspace receives the split image of Pi.  Other d ignore the workspace.
+ * the 16-bit matrix path with every fp32 operand (scaled by a power of two chosen per table on the device) split in
+ * two fp16 pieces, three partial products accumulated in fp32 -- scores within ~1e-6 relative of the exact ones
+ * (the size of fp32 summation-order differences), 3x faster; the workspace receives the split image of Pi and the
+ * two tables' largest magnitudes.  Other d ignore the workspace.
  * warm_idx (optional, matrix-core path only): [U, k] DISTINCT candidate items per user, e.g. the previous call's top_idx when
  * the tables moved little; it only pre-sets each user's threshold (same result, ~6x fewer list inserts).  If a candidate has
  * become masked the threshold may exclude too much: *underflow (int32, zeroed by the caller) is then set non-zero and the
