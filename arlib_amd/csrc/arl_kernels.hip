@@ -67,6 +67,7 @@ struct Epi {
     float *P, *M, *V;        // ADAM
     float step_size, inv_bc2_sqrt, b1, b2, eps;
     const float *rscale;     // AXPBY, optional: y = alpha * rscale[row] * (A x)[row] + beta * z (a diagonal factor applied to the product)
+    int ld;                  // row stride (floats) of every table the epilogue touches; 0 = the kernel's own width (dense tables)
 };
 
 // Accumulate sum_e val[e] * X[col[e], 4q..4q+3] over edges [begin,end) for this lane's column quad.
@@ -128,7 +129,7 @@ __device__ __forceinline__ float4 group_reduce(float4 a) {
 
 template <int MODE>
 __device__ __forceinline__ void spmm_epilogue(const Epi &ep, int row, int d, int q, float4 a) {
-    const size_t o = (size_t)row * d + q * 4;
+    const size_t o = (size_t)row * (ep.ld ? ep.ld : d) + q * 4;
     if (MODE == EPI_AXPBY) {
         const float al = ep.rscale ? ep.alpha * ep.rscale[row] : ep.alpha;
         float4 y = make_float4(al * a.x, al * a.y, al * a.z, al * a.w);
@@ -543,12 +544,13 @@ struct BlockedDev {
     const int32_t *rec_col;       // col | slot << 24
     const float *rec_val;
     float *partial;               // [n_pieces][d] raw sums of split-row pieces (wave_rows entry -(2 + t))
+    int ld;                       // row stride (floats) of the operand table; 0 = the kernel's own width
 };
 
 // spmm_epilogue for CPL adjacent columns per lane (d = 64 * CPL); same arithmetic (a wave writes one 256-B / 512-B row at a time)
 template <int MODE, int CPL>
 __device__ __forceinline__ void spmm_epilogue1(const Epi &ep, int row, int lane, const float *a) {
-    const size_t o = ((size_t)row * 64 + lane) * CPL;
+    const size_t o = (size_t)row * (ep.ld ? ep.ld : 64 * CPL) + lane * CPL;
     const bool zr = ep.Z && (!ep.zflags || ep.zflags[row]);
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
@@ -587,6 +589,7 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked64_kernel(BlockedDev P, co
         for (int r = 0; r < 32; ++r) acc[c][r] = 0.f;
     const int begin = P.wave_ptr[w], end = P.wave_ptr[w + 1];
     const float *xl = X + lane * CPL;
+    const int ldx = P.ld ? P.ld : 64 * CPL;
     int rc = 0; float rv = 0.f;
     if (begin < end) { rc = __builtin_nontemporal_load(P.rec_col + begin + lane); rv = __builtin_nontemporal_load(P.rec_val + begin + lane); }
     for (int base = begin; base < end; base += 64) {
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked64_kernel(BlockedDev P, co
 #pragma unroll
             for (int t = 0; t < UNR; ++t) {
                 cs[t] = __builtin_amdgcn_readlane(c_cur, j + t);
-                const float *src = xl + (size_t)(cs[t] & 0xffffff) * (64 * CPL);
+                const float *src = xl + (size_t)(cs[t] & 0xffffff) * ldx;
                 if (CPL == 2) { const float2 v2 = *reinterpret_cast<const float2 *>(src); x[t][0] = v2.x; x[t][CPL - 1] = v2.y; }
                 else x[t][0] = src[0];
             }
@@ -626,6 +629,9 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked64_kernel(BlockedDev P, co
     }
 }
 
+#ifndef ARL_D128_HALF_HOPS
+#define ARL_D128_HALF_HOPS 1
+#endif
 template <int MODE>
 int launch_spmm_blocked(const arl_blocked *P, const float *X, int64_t d, const Epi &ep, hipStream_t st) {
     if (!P || !X) return ARL_E_NULL;
@@ -636,11 +642,45 @@ int launch_spmm_blocked(const arl_blocked *P, const float *X, int64_t d, const E
     if (!P->wave_ptr || !P->wave_rows || !P->rec_col || !P->rec_val) return ARL_E_NULL;
     if (P->n_split < 0 || P->n_split > 0x7fffffffll) return ARL_E_RANGE;
     if (P->n_split > 0 && (!P->split_row || !P->split_first || !P->split_count || !P->partial)) return ARL_E_NULL;
-    BlockedDev D = {(int)P->n_waves, P->wave_ptr, P->wave_rows, P->rec_col, P->rec_val, P->partial};
+    BlockedDev D = {(int)P->n_waves, P->wave_ptr, P->wave_rows, P->rec_col, P->rec_val, P->partial, 0};
     const int64_t wpg = P->waves_per_group ? P->waves_per_group : kWavesPerBlock;
     if (wpg != 1 && wpg != 2 && wpg != 4) return ARL_E_ARG;
     const dim3 grid((unsigned)((P->n_waves + wpg - 1) / wpg)), block((unsigned)(wpg * kWave));
     if (P->loads_in_flight != 16 && P->loads_in_flight != 32) return ARL_E_ARG;
+#if ARL_D128_HALF_HOPS
+    if (d == 128) {
+        // d = 128 as two d = 64 passes over the column halves of the 128-wide tables (row stride 128): the one-column-per-lane kernel moves
+        // 12.2 TB/s of gathered rows, the two-column one 10.3 (fewer rows in flight at 118 registers) -- the second pass over the 8-B
+        // record stream costs less than that buys.  The split rows' pieces of a half use the front of `partial` and are combined before
+        // the next half overwrites them (stream order).
+        for (int half = 0; half < 2; ++half) {
+            Epi e2 = ep;
+            e2.ld = 128;
+            const int off = 64 * half;
+            if (e2.Z) e2.Z += off;
+            if (e2.Y) e2.Y += off;
+            if (e2.S_in) e2.S_in += off;
+            if (e2.S) e2.S += off;
+            if (e2.P) e2.P += off;
+            if (e2.M) e2.M += off;
+            if (e2.V) e2.V += off;
+            BlockedDev D2 = D;
+            D2.ld = 128;
+            if (P->rows_per_wave == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<16, MODE, 16, 1>), grid, block, 0, st, D2, X + off, e2);
+            else if (P->loads_in_flight == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE, 16, 1>), grid, block, 0, st, D2, X + off, e2);
+            else hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE, 32, 1>), grid, block, 0, st, D2, X + off, e2);
+            ARL_LAUNCH_CHECK();
+            if (P->n_split > 0) {
+                CsrDev C = {};
+                C.n_long = (int)P->n_split; C.long_row = P->split_row; C.long_first = P->split_first; C.long_count = P->split_count; C.partial = P->partial;
+                const unsigned grid_long = (unsigned)((C.n_long + kWavesPerBlock - 1) / kWavesPerBlock);
+                hipLaunchKernelGGL((spmm_long_rows_kernel<16, MODE>), dim3(grid_long), dim3(kBlock), 0, st, C, 64, e2);
+                ARL_LAUNCH_CHECK();
+            }
+        }
+        return ARL_OK;
+    }
+#endif
     if (d == 128) {                                      // two columns per lane: 64 accumulator registers, 16 rows in flight
         if (P->rows_per_wave == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<16, MODE, 16, 2>), grid, block, 0, st, D, X, ep);
         else hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE, 16, 2>), grid, block, 0, st, D, X, ep);
