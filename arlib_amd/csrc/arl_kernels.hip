@@ -67,7 +67,7 @@ struct Epi {
     float *P, *M, *V;        // ADAM
     float step_size, inv_bc2_sqrt, b1, b2, eps;
     const float *rscale;     // AXPBY, optional: y = alpha * rscale[row] * (A x)[row] + beta * z (a diagonal factor applied to the product)
-    int ld;                  // row stride (floats) of every table the epilogue touches; 0 = the kernel's own width (dense tables)
+    int ld;                  // split-row combine only: row stride (floats) of the tables when it is not the kernel's width (0 = dense)
 };
 
 // Accumulate sum_e val[e] * X[col[e], 4q..4q+3] over edges [begin,end) for this lane's column quad.
@@ -129,7 +129,7 @@ __device__ __forceinline__ float4 group_reduce(float4 a) {
 
 template <int MODE>
 __device__ __forceinline__ void spmm_epilogue(const Epi &ep, int row, int d, int q, float4 a) {
-    const size_t o = (size_t)row * (ep.ld ? ep.ld : d) + q * 4;
+    const size_t o = (size_t)row * d + q * 4;
     if (MODE == EPI_AXPBY) {
         const float al = ep.rscale ? ep.alpha * ep.rscale[row] : ep.alpha;
         float4 y = make_float4(al * a.x, al * a.y, al * a.z, al * a.w);
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void spmm_long_rows_kernel(CsrDev A, int d,
     if (q * 4 < d)
         for (int s = g; s < cnt; s += G) a = add4(a, *reinterpret_cast<const float4 *>(A.partial + (size_t)(first + s) * d + q * 4));
     a = group_reduce<LPR>(a);
-    if (lane < LPR && q * 4 < d) spmm_epilogue<MODE>(ep, A.long_row[t], d, q, a);
+    if (lane < LPR && q * 4 < d) spmm_epilogue<MODE>(ep, A.long_row[t], ep.ld ? ep.ld : d, q, a);      // ep.ld: the tables' row stride when it is not d
 }
 
 
@@ -544,13 +544,12 @@ struct BlockedDev {
     const int32_t *rec_col;       // col | slot << 24
     const float *rec_val;
     float *partial;               // [n_pieces][d] raw sums of split-row pieces (wave_rows entry -(2 + t))
-    int ld;                       // row stride (floats) of the operand table; 0 = the kernel's own width
 };
 
 // spmm_epilogue for CPL adjacent columns per lane (d = 64 * CPL); same arithmetic (a wave writes one 256-B / 512-B row at a time)
-template <int MODE, int CPL>
+template <int MODE, int CPL, int LD>
 __device__ __forceinline__ void spmm_epilogue1(const Epi &ep, int row, int lane, const float *a) {
-    const size_t o = (size_t)row * (ep.ld ? ep.ld : 64 * CPL) + lane * CPL;
+    const size_t o = (size_t)row * LD + lane * CPL;
     const bool zr = ep.Z && (!ep.zflags || ep.zflags[row]);
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
@@ -575,7 +574,7 @@ __device__ __forceinline__ void spmm_epilogue1(const Epi &ep, int row, int lane,
     }
 }
 
-template <int RPW, int MODE, int UNR, int CPL>
+template <int RPW, int MODE, int UNR, int CPL, int LD = 64 * CPL>       // LD: row stride (floats) of the operand and of every table the epilogue touches
 __global__ __launch_bounds__(kBlock) void spmm_blocked64_kernel(BlockedDev P, const float *__restrict__ X, Epi ep) {
     static_assert(RPW == 16 || RPW == 32, "accumulators are 32-register vectors");
     static_assert(CPL == 1 || CPL == 2, "d = 64 (one column per lane) or d = 128 (two adjacent columns per lane)");
@@ -589,7 +588,6 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked64_kernel(BlockedDev P, co
         for (int r = 0; r < 32; ++r) acc[c][r] = 0.f;
     const int begin = P.wave_ptr[w], end = P.wave_ptr[w + 1];
     const float *xl = X + lane * CPL;
-    const int ldx = P.ld ? P.ld : 64 * CPL;
     int rc = 0; float rv = 0.f;
     if (begin < end) { rc = __builtin_nontemporal_load(P.rec_col + begin + lane); rv = __builtin_nontemporal_load(P.rec_val + begin + lane); }
     for (int base = begin; base < end; base += 64) {
@@ -601,7 +599,7 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked64_kernel(BlockedDev P, co
 #pragma unroll
             for (int t = 0; t < UNR; ++t) {
                 cs[t] = __builtin_amdgcn_readlane(c_cur, j + t);
-                const float *src = xl + (size_t)(cs[t] & 0xffffff) * ldx;
+                const float *src = xl + (size_t)(cs[t] & 0xffffff) * LD;
                 if (CPL == 2) { const float2 v2 = *reinterpret_cast<const float2 *>(src); x[t][0] = v2.x; x[t][CPL - 1] = v2.y; }
                 else x[t][0] = src[0];
             }
@@ -620,7 +618,7 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked64_kernel(BlockedDev P, co
         float a[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) a[c] = acc[c][r];
-        if (row >= 0) spmm_epilogue1<MODE, CPL>(ep, row, lane, a);
+        if (row >= 0) spmm_epilogue1<MODE, CPL, LD>(ep, row, lane, a);
         else if (row < -1) {                                     // piece of a split (hub) row: raw sum, combined by spmm_long_rows_kernel
             float *dst = P.partial + ((size_t)(-row - 2) * 64 + lane) * CPL;
 #pragma unroll
@@ -642,7 +640,7 @@ int launch_spmm_blocked(const arl_blocked *P, const float *X, int64_t d, const E
     if (!P->wave_ptr || !P->wave_rows || !P->rec_col || !P->rec_val) return ARL_E_NULL;
     if (P->n_split < 0 || P->n_split > 0x7fffffffll) return ARL_E_RANGE;
     if (P->n_split > 0 && (!P->split_row || !P->split_first || !P->split_count || !P->partial)) return ARL_E_NULL;
-    BlockedDev D = {(int)P->n_waves, P->wave_ptr, P->wave_rows, P->rec_col, P->rec_val, P->partial, 0};
+    BlockedDev D = {(int)P->n_waves, P->wave_ptr, P->wave_rows, P->rec_col, P->rec_val, P->partial};
     const int64_t wpg = P->waves_per_group ? P->waves_per_group : kWavesPerBlock;
     if (wpg != 1 && wpg != 2 && wpg != 4) return ARL_E_ARG;
     const dim3 grid((unsigned)((P->n_waves + wpg - 1) / wpg)), block((unsigned)(wpg * kWave));
@@ -664,11 +662,9 @@ int launch_spmm_blocked(const arl_blocked *P, const float *X, int64_t d, const E
             if (e2.P) e2.P += off;
             if (e2.M) e2.M += off;
             if (e2.V) e2.V += off;
-            BlockedDev D2 = D;
-            D2.ld = 128;
-            if (P->rows_per_wave == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<16, MODE, 16, 1>), grid, block, 0, st, D2, X + off, e2);
-            else if (P->loads_in_flight == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE, 16, 1>), grid, block, 0, st, D2, X + off, e2);
-            else hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE, 32, 1>), grid, block, 0, st, D2, X + off, e2);
+            if (P->rows_per_wave == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<16, MODE, 16, 1, 128>), grid, block, 0, st, D, X + off, e2);
+            else if (P->loads_in_flight == 16) hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE, 16, 1, 128>), grid, block, 0, st, D, X + off, e2);
+            else hipLaunchKernelGGL((spmm_blocked64_kernel<32, MODE, 32, 1, 128>), grid, block, 0, st, D, X + off, e2);
             ARL_LAUNCH_CHECK();
             if (P->n_split > 0) {
                 CsrDev C = {};
