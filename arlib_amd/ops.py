@@ -1028,7 +1028,7 @@ def pga_update_(S, grad, dinv_rows=None, dinv_cols=None):
 
 def score_mask_topk(Pu, Pi, k, mask_rowptr=None, mask_col=None, exact=False, warm_idx=None):
     """top-k of Pu @ Pi.T per user with an optional interacted-item mask (CSR over users), streamed.
-    exact=True: scores are the exact fp32 contraction; default: split-bf16 matrix path for d in {64, 128} (scores within
+    exact=True: scores are the exact fp32 contraction; default: split-fp16 matrix path (two fp16 pieces of the power-of-two-scaled operands, three products) for d in {64, 128} (scores within
     ~1e-6 relative, faster), exact otherwise.
     warm_idx: optional int32 [U, k] of DISTINCT candidate items per user (e.g. the previous call's result while the tables
     moved little): pre-sets the thresholds, same result, fewer inserts; if a candidate turned out masked the call is repeated

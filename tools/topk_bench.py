@@ -14,7 +14,7 @@ t0 = time.perf_counter()
 idx, val = ops.score_mask_topk(Pu, Pi, k, exact=exact)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print('U=%d I=%d d=%d k=%d %s: %.1f ms, %.1f TFLOP/s (fp32-equivalent)' % (U, I, d, k, 'exact-f32' if exact else 'split-bf16', dt * 1e3, 2.0 * U * I * d / dt / 1e12))
+print('U=%d I=%d d=%d k=%d %s: %.1f ms, %.1f TFLOP/s (fp32-equivalent)' % (U, I, d, k, 'exact-f32' if exact else 'split-fp16', dt * 1e3, 2.0 * U * I * d / dt / 1e12))
 if not exact and os.environ.get('CMP', '1') == '1':
     n = min(U, 20000)
     i2, v2 = ops.score_mask_topk(Pu[:n].contiguous(), Pi, k, exact=True)

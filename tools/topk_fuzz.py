@@ -1,4 +1,4 @@
-"""Randomised cross-check of score_mask_topk (all paths: exact-f32 / split-bf16 / VALU fallback, masked or not, warm or cold)
+"""Randomised cross-check of score_mask_topk (all paths: exact-f32 / split-fp16 / VALU fallback, masked or not, warm or cold)
 against dense torch scoring + topk on many small random shapes.   python3 tools/topk_fuzz.py [n_cases]"""
 import os, sys
 import numpy as np, torch
