@@ -331,18 +331,73 @@ __global__ __launch_bounds__(kBlock) void zero_rows_kernel(float *__restrict__ d
     for (int k = lane; k < d; k += kWave) o[k] = 0.f;
 }
 
-// The sparse-batch step touches <= 3B rows of three node-sized arrays (gradient table, byte flags, bitmap) with the same index list:
-// once to add the batch gradients and mark the rows, once to clear everything again.  One launch each instead of three (at ml-100k
-// size a launch is a measurable part of the step).  Duplicate indices are fine: the adds accumulate, the marks are idempotent.
-__global__ __launch_bounds__(kBlock) void batch_rows_set_kernel(float *__restrict__ G, uint8_t *__restrict__ flags, uint32_t *__restrict__ bits,
-                                                                 const int32_t *__restrict__ idx, int n, int d, const float *__restrict__ src, float scale) {
+// ---- ordered accumulation (no float atomics): dst[idx[t]] += scale * src[t], duplicates summed in ascending t.
+// One wave per contribution t of the window [c0, c1).  The wave scans the window's index list 256 entries per trip (coalesced; the list is a
+// few KB and stays in L1): if an EARLIER entry names the same row the wave exits -- the first entry of a row is its owner -- otherwise it
+// adds the row's contributions one after the other in index order, starting from the value already in dst.  That is the association of CPU
+// index_put_(accumulate=True), i.e. of the reference's gathers under autograd (recommender/LightGCN.py:51-56, util/loss.py:5-9), and it
+// is bit-identical from run to run.  Work is O(n^2 / 64) wave-trips, so a launch covers at most kOrderedWindow entries; longer lists run
+// as successive launches (stream order keeps the result deterministic).
+constexpr int kOrderedWindow = 16384;
+
+// Scan of the window by one wave: `on_hit(tt)` runs, in ascending tt, for every entry tt whose row (`rowof(tt)`) equals `row`.  Returns false --
+// the wave must exit -- as soon as an entry BEFORE t names the row (that entry's wave owns it).
+template <class RowOf, class OnHit>
+__device__ __forceinline__ bool ordered_scan(int c0, int c1, int t, long long row, int lane, RowOf rowof, OnHit on_hit) {
+    for (int base = c0; base < c1; base += 256) {
+        long long v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = base + 64 * i + lane;
+            v[i] = j < c1 ? (long long)rowof(j) : -1ll;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned long long m = __ballot(v[i] == row);
+            const int b0 = base + 64 * i;
+            if (b0 < t) {
+                const int lim = t - b0;
+                if (lim >= 64 ? m != 0ull : (m & ((1ull << lim) - 1ull)) != 0ull) return false;
+            }
+            while (m) {
+                const int tt = b0 + __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                on_hit(tt);
+            }
+        }
+    }
+    return true;
+}
+
+// MARK: also set the row's byte flag and bitmap bit (the sparse-batch step touches three node-sized arrays with one index list: once to
+// add the batch gradients and mark the rows, once to clear everything again; one launch each)
+template <bool MARK>
+__global__ __launch_bounds__(kBlock) void rows_add_ordered_kernel(float *__restrict__ dst, uint8_t *__restrict__ flags, uint32_t *__restrict__ bits,
+                                                                   const int32_t *__restrict__ idx, int c0, int c1, int d,
+                                                                   const float *__restrict__ src, float scale) {
     const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (t >= n) return;
-    const int row = idx[t];
-    float *o = G + (size_t)row * d;
-    for (int k = lane; k < d; k += kWave) atomicAdd(o + k, scale * src[(size_t)t * d + k]);
-    if (lane == 0) {
+    const int t = c0 + blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (t >= c1) return;
+    const long long row = idx[t];
+    float *o = dst + (size_t)row * d;
+    for (int k0 = 0; k0 < d; k0 += 256) {
+        float acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int k = k0 + 64 * i + lane; acc[i] = k < d ? o[k] : 0.f; }
+        const bool owner = ordered_scan(c0, c1, t, row, lane, [&](int j) { return idx[j]; }, [&](int tt) {
+#pragma clang fp contract(off)                       // index_put_ adds the ROUNDED product scale * src: no fused multiply-add here
+            const float *s = src + (size_t)tt * d;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = k0 + 64 * i + lane;
+                if (k < d) { const float c = scale * s[k]; acc[i] = acc[i] + c; }
+            }
+        });
+        if (!owner) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int k = k0 + 64 * i + lane; if (k < d) o[k] = acc[i]; }
+    }
+    if (MARK && lane == 0) {
         flags[row] = 1;
         atomicOr(bits + (row >> 5), 1u << (row & 31));
     }
@@ -789,23 +844,49 @@ __global__ __launch_bounds__(kBlock) void bpr_finalize_kernel(int B, float reg, 
     }
 }
 
+// Backward of BPR + L2 into the rows of G, ordered (no float atomics; see rows_add_ordered_kernel).  The 3B contributions are numbered
+// t = b (user row of sample b), B + b (its positive item), 2B + b (its negative item): a user row receives its samples' terms in sample
+// order, an item row its positive-role terms in sample order and then its negative-role ones -- the order in which autograd's three
+// index_put_(accumulate) calls of the reference add them (recommender/LightGCN.py:51-52).
 __global__ __launch_bounds__(kBlock) void bpr_bwd_kernel(const float *__restrict__ emb, int d, long long item_off,
                                                           const int32_t *__restrict__ ui, const int32_t *__restrict__ pi,
                                                           const int32_t *__restrict__ ni, int B, float reg, float upstream,
                                                           const float *__restrict__ ws, const float *__restrict__ out,
-                                                          float *__restrict__ G) {
+                                                          float *__restrict__ G, int c0, int c1) {
     const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (b >= B) return;
-    const size_t ru = (size_t)ui[b] * d, rp = (size_t)(item_off + pi[b]) * d, rn = (size_t)(item_off + ni[b]) * d;
-    const float g = ws[b] * upstream;
+    const int t = c0 + blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (t >= c1) return;
+#define ARL_ROWOF_BPR(j) ((j) < B ? (long long)ui[j] : ((j) < 2 * B ? item_off + pi[(j) - B] : item_off + ni[(j) - 2 * B]))
+    const long long row = ARL_ROWOF_BPR(t);
     const float cu = out[2] > 0.f ? upstream * reg / out[2] : 0.f, cp = out[3] > 0.f ? upstream * reg / out[3] : 0.f;
-    for (int k = lane; k < d; k += kWave) {
-        const float uk = emb[ru + k], pk = emb[rp + k], nk = emb[rn + k];
-        atomicAdd(G + ru + k, fmaf(g, pk - nk, cu * uk));
-        atomicAdd(G + rp + k, fmaf(g, uk, cp * pk));
-        atomicAdd(G + rn + k, -g * uk);
+    float *o = G + (size_t)row * d;
+    const float *own = emb + (size_t)row * d;
+    for (int k0 = 0; k0 < d; k0 += 256) {
+        float acc[4], mine[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int k = k0 + 64 * i + lane; acc[i] = k < d ? o[k] : 0.f; mine[i] = k < d ? own[k] : 0.f; }
+        const bool owner = ordered_scan(c0, c1, t, row, lane, [&](int j) { return ARL_ROWOF_BPR(j); }, [&](int tt) {
+            const int kind = tt / B, b = tt - kind * B;
+            const float g = ws[b] * upstream;
+            const float *x = emb + (size_t)(kind == 0 ? item_off + pi[b] : (long long)ui[b]) * d;   // the other operand: positive row (user term) / user row (item terms)
+            const float *y = emb + (size_t)(item_off + ni[b]) * d;                                // negative row (user term only)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = k0 + 64 * i + lane;
+                if (k < d) {
+                    float c;
+                    if (kind == 0) c = fmaf(g, x[k] - y[k], cu * mine[i]);
+                    else if (kind == 1) c = fmaf(g, x[k], cp * mine[i]);
+                    else c = -g * x[k];
+                    acc[i] = __fadd_rn(acc[i], c);
+                }
+            }
+        });
+        if (!owner) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int k = k0 + 64 * i + lane; if (k < d) o[k] = acc[i]; }
     }
+#undef ARL_ROWOF_BPR
 }
 
 // ================================================================================================
@@ -859,15 +940,6 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float *__rest
     const float *s = src + (size_t)idx[t] * d;
     for (int k = lane; k < d; k += kWave) dst[(size_t)t * d + k] = s[k];
 }
-__global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(float *__restrict__ dst, const int32_t *__restrict__ idx, int n, int d,
-                                                                   const float *__restrict__ src, float scale) {
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (t >= n) return;
-    float *o = dst + (size_t)idx[t] * d;
-    for (int k = lane; k < d; k += kWave) atomicAdd(o + k, scale * src[(size_t)t * d + k]);
-}
-
 // ================================================================================================
 // InfoNCE (util/loss.py:42-49).  workspace (floats): a[n*d] | b[n*d] | n1[n] | n2[n] | ttl[n] | rowloss[n] | da[n*d] | db[n*d]
 // ================================================================================================
@@ -2275,6 +2347,19 @@ inline unsigned grid_for(long long work_items, int per_block, unsigned cap = 204
 
 }  // namespace
 
+// ordered BPR backward over the 3B contributions, kOrderedWindow per launch
+static int launch_bpr_bwd(const float *emb, int64_t d, int64_t item_off, const int32_t *u, const int32_t *p, const int32_t *n, int64_t B, float reg,
+                          float upstream, const float *ws, const float *norms, float *G, hipStream_t st) {
+    const int64_t total = 3 * B;
+    for (int64_t c0 = 0; c0 < total; c0 += kOrderedWindow) {
+        const int64_t c1 = c0 + kOrderedWindow < total ? c0 + kOrderedWindow : total;
+        hipLaunchKernelGGL(bpr_bwd_kernel, dim3((unsigned)((c1 - c0 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, st, emb, (int)d,
+                           (long long)item_off, u, p, n, (int)B, reg, upstream, ws, norms, G, (int)c0, (int)c1);
+        ARL_LAUNCH_CHECK();
+    }
+    return ARL_OK;
+}
+
 // =================================================================================================
 // C ABI
 // =================================================================================================
@@ -2501,9 +2586,12 @@ int arl_batch_rows_set_f32(float *G, uint8_t *flags, uint32_t *bits, const int32
     if (!G || !flags || !bits || !idx || !src) return ARL_E_NULL;
     if (n < 0 || n > 0x7fffffffll || d <= 0 || d > 0x7fffffffll) return ARL_E_ARG;
     if (n == 0) return ARL_OK;
-    hipLaunchKernelGGL(batch_rows_set_kernel, dim3((unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, G, flags,
-                       bits, idx, (int)n, (int)d, src, scale);
-    ARL_LAUNCH_CHECK();
+    for (int64_t c0 = 0; c0 < n; c0 += kOrderedWindow) {                 // ordered (atomic-free) accumulation, one window per launch
+        const int64_t c1 = c0 + kOrderedWindow < n ? c0 + kOrderedWindow : n;
+        hipLaunchKernelGGL(rows_add_ordered_kernel<true>, dim3((unsigned)((c1 - c0 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
+                           (hipStream_t)stream, G, flags, bits, idx, (int)c0, (int)c1, (int)d, src, scale);
+        ARL_LAUNCH_CHECK();
+    }
     return ARL_OK;
 }
 
@@ -2541,9 +2629,8 @@ int arl_bpr_l2_fwd_bwd_f32(const float *emb, int64_t d, int64_t item_off, const 
     hipLaunchKernelGGL(bpr_finalize_kernel, dim3(1), dim3(kBlock), 0, st, (int)B, reg, ws, loss_out, 0);
     ARL_LAUNCH_CHECK();
     if (G) {
-        hipLaunchKernelGGL(bpr_bwd_kernel, dim3(grid), dim3(kBlock), 0, st, emb, (int)d, (long long)item_off, u, p, n, (int)B, reg, upstream, ws,
-                           loss_out, G);
-        ARL_LAUNCH_CHECK();
+        const int rc = launch_bpr_bwd(emb, d, item_off, u, p, n, B, reg, upstream, ws, loss_out, G, st);
+        if (rc) return rc;
     }
     return ARL_OK;
 }
@@ -2573,11 +2660,7 @@ int arl_bpr_l2_backward_f32(const float *emb, int64_t d, int64_t item_off, const
     if (d <= 0 || B_local < 0 || item_off < 0) return ARL_E_ARG;
     if (B_local > 0x7fffffffll / 4 || d > 0x7fffffffll) return ARL_E_RANGE;
     if (B_local == 0) return ARL_OK;
-    const unsigned grid = (unsigned)((B_local + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL(bpr_bwd_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, emb, (int)d, (long long)item_off, u, p, n, (int)B_local, reg,
-                       upstream, (const float *)workspace, norms4, G);
-    ARL_LAUNCH_CHECK();
-    return ARL_OK;
+    return launch_bpr_bwd(emb, d, item_off, u, p, n, B_local, reg, upstream, (const float *)workspace, norms4, G, (hipStream_t)stream);
 }
 
 int arl_adam_dense_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps, int64_t step,
@@ -2639,9 +2722,12 @@ int arl_scatter_add_rows_f32(float *dst, const int32_t *idx, int64_t n, int64_t 
     if (!src || !idx || !dst) return ARL_E_NULL;
     if (n < 0 || d <= 0 || n > 0x7fffffffll || d > 0x7fffffffll) return ARL_E_ARG;
     if (n == 0) return ARL_OK;
-    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, dst,
-                       idx, (int)n, (int)d, src, scale);
-    ARL_LAUNCH_CHECK();
+    for (int64_t c0 = 0; c0 < n; c0 += kOrderedWindow) {
+        const int64_t c1 = c0 + kOrderedWindow < n ? c0 + kOrderedWindow : n;
+        hipLaunchKernelGGL(rows_add_ordered_kernel<false>, dim3((unsigned)((c1 - c0 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
+                           (hipStream_t)stream, dst, (uint8_t *)nullptr, (uint32_t *)nullptr, idx, (int)c0, (int)c1, (int)d, src, scale);
+        ARL_LAUNCH_CHECK();
+    }
     return ARL_OK;
 }
 

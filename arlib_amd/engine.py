@@ -232,7 +232,9 @@ class PropagationEngine:
         self.ngcf_m = [(z(), z()) for _ in weights]
         self.ngcf_v = [(z(), z()) for _ in weights]
 
-    def step_ngcf(self, u, p, n, rows=None, slope=0.01):
+    def step_ngcf(self, u, p, n, rows=None, slope=0.01, capture=None):
+        """capture: optional dict; receives the table gradient ('table') and the weight gradients ('W') of this step (diagnostics / tests:
+        the Adam update then runs as a separate dense launch instead of the last hop's epilogue -- same numbers)."""
         L, A, d = self.L, self.A, self.d
         if L < 1 or not hasattr(self, 'ngcf_W') or d not in ops.NGCF_DENSE_WIDTHS:
             raise ValueError('step_ngcf: needs n_layers >= 1, init_ngcf() and d in %s' % (ops.NGCF_DENSE_WIDTHS,))
@@ -251,7 +253,10 @@ class PropagationEngine:
             P = ops.spmm(A, egos[-1])
             Ps.append(P)
             egos.append(ops.ngcf_dense_fwd(P, egos[-1], Wcat[l], slope))
-        P_r = ops.spmm_rows(A, egos[-1], rows, (), 1.0, nsplit=self.nsplit, check_range=False)
+        # same edge-range split as the autograd route (NGCF._LastLayerRows): leaky_relu's derivative jumps at 0, so a pre-activation within
+        # rounding of 0 can land on either side of the kink under a different summation order and change that row's gradient by ~1 % --
+        # with one association for both routes they stay bit-identical (and both sit on the reference's side on its captured steps)
+        P_r = ops.spmm_rows(A, egos[-1], rows, (), 1.0, nsplit=ops.ROWS_NSPLIT, check_range=False)
         E_r = ops.gather_rows(egos[-1], rows, check_range=False)
         out_r = ops.ngcf_dense_fwd(P_r, E_r, Wcat[L - 1], slope)
         acc = out_r + E_r
@@ -271,14 +276,21 @@ class PropagationEngine:
         ops.batch_rows_clear_(self.G, self.flags, self.bits, rows, check_range=False)
         ops.scatter_add_rows(g, rows, gE_r + Gs, 1.0, check_range=False)
         if L == 1:
+            if capture is not None:
+                capture['table'] = g.clone()
             ops.adam_dense(self.E0, g, self.m, self.v, self.lr, self.t, self.betas, self.eps)
         for l in range(L - 2, -1, -1):
             gP, gE, gWs[l] = ops.ngcf_dense_bwd(g, egos[l + 1], Ps[l], egos[l], Wcat[l], slope)
             ops.scatter_add_rows(gE, rows, Gs, 1.0, check_range=False)
             if l > 0:
                 g = ops.spmm(A, gP, 1.0, 1.0, gE)
+            elif capture is not None:
+                capture['table'] = ops.spmm(A, gP, 1.0, 1.0, gE)
+                ops.adam_dense(self.E0, capture['table'], self.m, self.v, self.lr, self.t, self.betas, self.eps)
             else:
                 ops.spmm_adam(A, gP, 1.0, 1.0, gE, self.E0, self.m, self.v, self.lr, self.t, self.betas, self.eps)
+        if capture is not None:
+            capture['W'] = [w.clone() for w in gWs]
         for l in range(L):
             for k in range(2):
                 ops.adam_dense(self.ngcf_W[l][k], gWs[l][k * d:(k + 1) * d], self.ngcf_m[l][k], self.ngcf_v[l][k], self.lr, self.t, self.betas, self.eps)

@@ -679,7 +679,10 @@ def spmm_flagged(A, X, xflags=None, alpha=1.0, beta=0.0, Z=None, zflags=None, ou
     return Y
 
 
-def spmm_rows(A, X, rows, layers=(), alpha=1.0, nsplit=16, out=None, workspace=None, check_range=True):
+ROWS_NSPLIT = 16     # default number of edge ranges per listed row of the row-subset hop
+
+
+def spmm_rows(A, X, rows, layers=(), alpha=1.0, nsplit=ROWS_NSPLIT, out=None, workspace=None, check_range=True):
     """out[t] = alpha * ( sum_k layers[k][rows[t]] + (A @ X)[rows[t]] ) for the listed rows only (duplicates allowed)."""
     d = _check_xy(A, X, 'X', A.n_cols)
     _dev(rows, torch.int32, 'rows', 1)

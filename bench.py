@@ -45,9 +45,11 @@ def parse():
     ap.add_argument('--no-kernel-events', action='store_true', help='do not bracket SpMM launches with HIP events')
     ap.add_argument('--attack-steps', type=int, default=5, help='PGA gradient steps to time at N=1 (0 disables the attack leg)')
     ap.add_argument('--fake-users', type=int, default=64)
+    ap.add_argument('--clear-steps', type=int, default=15, help='CLeaR surrogate steps to time at N=1 (median and spread are printed)')
     ap.add_argument('--schedule', default='auto', choices=['auto', 'csr', 'blocked'], help='full-graph hop schedule (engine.PropagationEngine)')
     ap.add_argument('--repeats', type=int, default=3, help='timed regions of K steps each: the first is the contract figure (`value`), all are listed with median and spread')
     ap.add_argument('--api-steps', type=int, default=200, help='steps of LightGCN(args, DataLoader).train() to time through the class API at N=1 (0 disables)')
+    ap.add_argument('--l2-ceiling', type=int, default=1, help='measure the hop with every gather an L2 hit (roofline.attainable); 0 disables')
     ap.add_argument('--dense-step', action='store_true', help='time the reference-shaped step (all 2L hops on the full graph) as the main number')
     return ap.parse_args()
 
@@ -79,6 +81,36 @@ class SpmmEvents:
         for tag, s, e in self.recs:
             out.setdefault(tag, []).append(s.elapsed_time(e))
         return {k: (float(np.mean(v)), len(v)) for k, v in out.items()}
+
+
+def l2_ceiling(torch, ops, rowptr, col, U, d, dev, chunk, reps=10):
+    """The hop's attainable time on this schedule: the SAME plan builder, records, waves and instruction stream with every column folded into a
+    2 MB window of the operand (col & 8191), so that every 256-B row gather is an L2 hit.  What remains is the L2 -> CU gather rate the
+    microarchitecture guide quotes for L2-resident rows (66-73 GB/s per CU); HBM-side bytes no longer matter.  Returns ms per full-graph hop."""
+    import ctypes as C
+    from arlib_amd import _lib
+    c = col.copy()
+    eu = int(rowptr[U])
+    c[:eu] = U + ((c[:eu] - U) & 8191)
+    c[eu:] = c[eu:] & 8191
+    N = len(rowptr) - 1
+    A = ops.CSRGraph(rowptr, c, np.ones(len(c), np.float32), dev, chunk=chunk, validate=False).enable_blocked(split=U)
+    X = torch.randn(N, d, device=dev); Y = torch.empty(N, d, device=dev)
+    st = ops._stream()
+    structs = [A.blocked.struct(k, d) for k in range(len(A.blocked.sets))]
+
+    def hop():
+        for s in structs:
+            _lib.check(_lib.lib().arl_spmm_blocked_f32(C.byref(s), X.data_ptr(), d, 1.0, 0.0, None, None, Y.data_ptr(), st), 'arl_spmm_blocked_f32')
+    for _ in range(3):
+        hop()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        hop()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
 
 
 def cpu_baseline(data, rowptr, col, val_np, E0, batches, args, target_s, gpu_replay=None):
@@ -259,14 +291,18 @@ def clear_leg(torch, ops, data, A, E0_dev, args):
         opt.step()
         return float(cw.detach()), float(sfa.detach())
     step(); torch.cuda.synchronize()
-    n = max(1, min(args.attack_steps, 5))
+    n = max(1, args.clear_steps)
+    per = []
     t0 = time.perf_counter()
     for _ in range(n):
-        cw, sfa = step(True)
-    torch.cuda.synchronize()
+        ts = time.perf_counter()
+        cw, sfa = step(True)                                 # synchronises after the forward; the float() reads of the losses end the step
+        torch.cuda.synchronize()
+        per.append(time.perf_counter() - ts)
     dt = (time.perf_counter() - t0) / n
     return {'metric': 'attack-grad steps/sec (CLeaR surrogate step: CW + SFA, LightGCN d=%d L=%d)' % (d, L), 'value': 1.0 / dt, 'unit': 'steps/s',
-            'ms_per_step': 1e3 * dt, 'ms_forward_topk_loss': 1e3 * parts['forward+topk+loss'] / n, 'targets': 5, 'pairs': U * 5,
+            'ms_per_step': 1e3 * dt, 'steps_timed': n, 'ms_per_step_median': 1e3 * float(np.median(per)), 'ms_per_step_min': 1e3 * min(per), 'ms_per_step_max': 1e3 * max(per),
+            'ms_forward_topk_loss': 1e3 * parts['forward+topk+loss'] / n, 'targets': 5, 'pairs': U * 5,
             'cw_loss': cw, 'sfa_loss': sfa, 'score_flops_per_step': 2.0 * U * I * d,
             'note': 'dominated by the U x I scoring pass (compute-bound line item, SURVEY 8d); peak memory %.1f GB' % (torch.cuda.max_memory_allocated() / 1e9)}
 
@@ -467,7 +503,7 @@ def main():
             'setup_seconds': setup_s,
         }
         if evs:
-            # dominant kernel: spmm_rows_kernel<16,*> (+ its long-row combine), one event pair per C-ABI SpMM call
+            # dominant kernel: the full-graph hop (spmm_blocked64_kernel x2 + split-row combine), one event pair per C-ABI SpMM call
             # full-graph launches only (the row-subset and flag-masked hops are separate, much shorter kernels)
             allv = [s.elapsed_time(e) for tag, s, e in ev.recs if tag in ('axpby', 'layersum', 'adam')]
             avg_ms = float(np.mean(allv))
@@ -481,8 +517,23 @@ def main():
             except Exception:
                 traffic = None
             if not sharded:
+                # per variant: the plain hop moves S_spmm = 8E + 4(N+1) + 8Nd algorithmic bytes; the Adam-epilogue hop reads the operand
+                # and rewrites p, m, v instead of writing Y: 8E + 4(N+1) + 4Nd + 24Nd
+                var_bytes = {'axpby': spmm_bytes, 'layersum': spmm_bytes + 8 * N * d, 'adam': 8 * E + 4 * (N + 1) + 28 * N * d}
+                per_variant = {k: {'ms': v[0], 'launches': v[1], 'algorithmic_bytes': var_bytes[k], 'GB/s': var_bytes[k] / (v[0] * 1e-3) / 1e9,
+                                   'frac': var_bytes[k] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS} for k, v in evs.items() if k in var_bytes}
+                attain = None
+                if A.blocked is not None and args.l2_ceiling:
+                    ceil_ms = l2_ceiling(torch, ops, rowptr, col, U, d, dev, args.chunk)
+                    plain_ms = evs['axpby'][0] if 'axpby' in evs else avg_ms
+                    attain = {'ms': ceil_ms, 'GB/s': spmm_bytes / (ceil_ms * 1e-3) / 1e9, 'frac_of_peak': spmm_bytes / (ceil_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              'plain_hop_ms': plain_ms, 'source': 'L2-resident gather of this plan (columns & 8191: every 256-B row gather an L2 hit), measured in this run',
+                              'note': 'one fp32 row gather per edge is bounded by the L2->CU gather rate (MI355X_MICROARCH.md, Indexed rows: 66-73 GB/s per CU), '
+                                      'not by HBM: E x 4d bytes through the vector L1 per hop'}
                 res['roofline'] = {'bound': 'hbm', 'achieved': spmm_bytes / (avg_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                    'frac': spmm_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': traffic,
+                                   'attainable': attain, 'frac_of_attainable': (attain['ms'] / attain['plain_hop_ms']) if attain else None,
+                                   'per_variant': per_variant,
                                    'traffic_source': (traffic_src + ' (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of this workload, gfx950-corrected; NOT measured in this run)') if traffic is not None else None,
                                    'kernel': ('one full-graph hop = spmm_blocked64_kernel<%d,*> x%d (user rows, item rows; %d rows above the per-set threshold dealt as strided '
                                               'pieces + spmm_long_rows_kernel combine, %d rows on the chunked CSR kernel); avg over %d hops'

@@ -24,6 +24,19 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b)) / (den if den > 0 else 1.0))
 
 
+def row_err(a, b, floor=1e-3):
+    """Row-wise relative error: max over rows of ||a_r - b_r||_2 / max(||b_r||_2, floor * max_r ||b_r||_2).  Unlike rel_err (a max-norm over
+    the whole tensor, which a few large rows dominate) every row is held to the bar at its own magnitude; the floor keeps rows that are
+    (nearly) zero in the reference from dividing by nothing: they are held to `floor` of the largest row's norm instead."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    if a.ndim == 1:
+        a = a[:, None]; b = b[:, None]
+    a = a.reshape(a.shape[0], -1); b = b.reshape(b.shape[0], -1)
+    nb = np.sqrt((b * b).sum(1))
+    den = np.maximum(nb, floor * (nb.max() if nb.size and nb.max() > 0 else 1.0))
+    return float((np.sqrt(((a - b) ** 2).sum(1)) / den).max()) if nb.size else 0.0
+
+
 # fp32 parity tolerance stated by BASELINE.json north_star ("fp32 embeddings within 1e-4 rel")
 RTOL = 1e-4
 

@@ -328,6 +328,58 @@ def test_gather_scatter_rows(ops):
     assert rel_err(dst.cpu().numpy(), ref) < 1e-5
 
 
+def _seq_add(dst, idx, src, scale):
+    """CPU index_put_(accumulate) association: contributions added one after the other in index order, fp32, product rounded first."""
+    out = dst.copy()
+    c = (np.float32(scale) * src).astype(np.float32)
+    np.add.at(out, idx.astype(np.int64), c)           # unbuffered, in order, in the array's own precision
+    return out
+
+
+@pytest.mark.parametrize('n,d', [(333, 64), (6144, 64), (40000, 16), (700, 300)])
+def test_ordered_accumulation_is_sequential_and_bit_exact(ops, n, d):
+    """scatter_add_rows / batch_rows_set_ add duplicate rows IN INDEX ORDER (no float atomics): the result equals a sequential fp32 sum
+    bit for bit -- heavy duplicates, a list longer than one launch window (16 384), a width above one 256-column pass -- and two runs agree."""
+    rng = np.random.default_rng(n + d)
+    N = 500
+    idx = rng.integers(0, N, n).astype(np.int32); idx[: n // 8] = 7; idx[-5:] = 7; idx[n // 2] = N - 1
+    src = (rng.standard_normal((n, d)) * 10.0 ** rng.integers(-6, 3, (n, 1))).astype(np.float32)     # wide dynamic range: order matters
+    base = rng.standard_normal((N, d)).astype(np.float32)
+    want = _seq_add(base, idx, src, 0.37)
+    outs = []
+    for _ in range(2):
+        dst = T(base.copy())
+        ops.scatter_add_rows(dst, T(idx), T(src), 0.37)
+        outs.append(dst.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], want)
+    perm = rng.permutation(n)                                                                         # another order gives other bits (the test has teeth)
+    assert not np.array_equal(_seq_add(base, idx[perm], src[perm], 0.37), want)
+    G = T(base.copy()); flags = torch.zeros(N, dtype=torch.uint8, device=DEV); bits = torch.zeros((N + 31) // 32, dtype=torch.int32, device=DEV)
+    ops.batch_rows_set_(G, flags, bits, T(idx), T(src), 0.37)
+    assert np.array_equal(G.cpu().numpy(), want)
+    wantf = np.zeros(N, np.uint8); wantf[idx] = 1
+    assert np.array_equal(flags.cpu().numpy(), wantf)
+
+
+def test_bpr_backward_ordered(ops):
+    """BPR + L2 backward with repeated users / items in the batch: bit-identical run to run, equal to the oracle within fp32 rounding; a batch
+    longer than one launch window too."""
+    rng = np.random.default_rng(77)
+    U, I, d = 40, 30, 64
+    emb = (rng.standard_normal((U + I, d)) * 0.1).astype(np.float32)
+    for B in (512, 7000):
+        u = rng.integers(0, U, B).astype(np.int32); p = rng.integers(0, I, B).astype(np.int32); n = rng.integers(0, I, B).astype(np.int32)
+        res = []
+        for _ in range(2):
+            G = torch.zeros(U + I, d, device=DEV)
+            lo = ops.bpr_l2_fwd_bwd(T(emb), U, T(u), T(p), T(n), 1e-3, G)
+            res.append((G.cpu().numpy(), lo.cpu().numpy()))
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+        lb, lr_, Gref = O.bpr_l2(emb, U, u, p, n, 1e-3)
+        assert rel_err(res[0][0], Gref) < 1e-5 and abs(float(res[0][1][0]) - lb) <= 1e-5 * abs(lb)
+
+
 @pytest.mark.parametrize('tag', ['a', 'b', 'c'])
 def test_infonce_golden(ops, tag):
     g = golden('g6_infonce.npz')
