@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ARLIB_AMD_LIB') or os.path.join(_HERE, 'lib', 'libarlib_amd.so')      # override: developer builds (e.g. `make prof`)
-ABI_VERSION = 17
+ABI_VERSION = 18
 _lib = None
 
 
@@ -60,20 +60,22 @@ _SIGS = {
     'arl_spmm_tiled_adam_f32': (C.c_int, [C.POINTER(arl_tiled), _vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),
     'arl_spmm_csr_flagged_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _vp, _f, _f, _vp, _vp, _vp, _vp]),
     'arl_spmm_csr_rows_workspace_bytes': (_i64, [_i64, _i64, _i64]),
-    'arl_spmm_csr_rows_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _vp, _i64, _i64, _vp, _i64, _f, _vp, _vp, _vp]),
+    'arl_spmm_csr_rows_f32': (C.c_int, [C.POINTER(arl_csr), _vp, _i64, _vp, _i64, _i64, _vp, _i64, _f, _vp, _vp, _vp, _vp]),
     'arl_mark_rows_u8': (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     'arl_mark_rows_bits_u32': (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     'arl_zero_rows_f32': (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
-    'arl_batch_rows_set_f32': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _f, _vp]),
-    'arl_batch_rows_clear_f32': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    'arl_batch_rows_set_f32': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _f, _vp, _vp, _vp]),
+    'arl_batch_rows_clear_f32': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     'arl_bpr_l2_workspace_bytes': (_i64, [_i64]),
-    'arl_bpr_l2_fwd_bwd_f32': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _f, _f, _vp, _vp, _vp, _vp]),
+    'arl_bpr_l2_fwd_bwd_f32': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _f, _f, _vp, _vp, _vp, _i32, _vp]),
     'arl_bpr_l2_partial_f32': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     'arl_bpr_l2_backward_f32': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _f, _f, _vp, _vp, _vp, _vp]),
     'arl_adam_dense_f32': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i64, _vp]),
     'arl_sgd_dense_f32': (C.c_int, [_vp, _vp, _i64, _f, _vp]),
     'arl_gather_rows_f32': (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     'arl_scatter_add_rows_f32': (C.c_int, [_vp, _vp, _i64, _i64, _vp, _f, _vp]),
+    'arl_rows_axpy_unique_f32': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _f, _vp]),
+    'arl_shard_batch_prep_i32': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     'arl_infonce_workspace_bytes': (_i64, [_i64, _i64]),
     'arl_infonce_fwd_bwd_f32': (C.c_int, [_vp, _vp, _i64, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     'arl_simgcl_perturb_f32': (C.c_int, [_vp, _vp, _i64, _i64, _f, _vp]),
@@ -99,6 +101,13 @@ _SIGS = {
     'arl_fake_block_cols_f32': (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, C.c_float, _vp, _vp]),
     'arl_score_mask_topk_workspace_bytes': (_i64, [_i64, _i64]),
     'arl_score_mask_topk_f32': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'arl_comm_load': (C.c_int, [C.c_char_p]),
+    'arl_comm_unique_id': (C.c_int, [_vp]),
+    'arl_comm_init': (C.c_int, [_vp, _i64, _i64, C.POINTER(C.c_void_p)]),
+    'arl_comm_destroy': (C.c_int, [_vp]),
+    'arl_item_exchange_range': (C.c_int, [_i64, _i64, _i64, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
+    'arl_allreduce_item_workspace_bytes': (_i64, [_i64, _i64, _i64]),
+    'arl_allreduce_item_f32': (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     'arl_topn_project_rows_f32': (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
 }
 EXPORTS = tuple(_SIGS)

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void spmm_subset_kernel(CsrDev A, const flo
 
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void subset_finish_kernel(const float *__restrict__ partial, int n, int nsplit, int d, const int32_t *__restrict__ rows,
-                                                                LayerPtrs L, float alpha, float *__restrict__ out_c) {
+                                                                LayerPtrs L, float alpha, float *__restrict__ out_c, const float *__restrict__ row_weight) {
     constexpr int G = kWave / LPR;
     const int lane = threadIdx.x & (kWave - 1);
     const int g = lane / LPR, q = lane % LPR;
@@ -299,7 +299,8 @@ __global__ __launch_bounds__(kBlock) void subset_finish_kernel(const float *__re
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k = 0; k < L.n; ++k) a = add4(a, *reinterpret_cast<const float4 *>(L.p[k] + (size_t)r * d + q * 4));
     for (int s = 0; s < nsplit; ++s) a = add4(a, *reinterpret_cast<const float4 *>(partial + ((size_t)t * nsplit + s) * d + q * 4));
-    *reinterpret_cast<float4 *>(out_c + (size_t)t * d + q * 4) = make_float4(alpha * a.x, alpha * a.y, alpha * a.z, alpha * a.w);
+    const float w = row_weight ? alpha * row_weight[t] : alpha;             // optional per-listed-row factor (user-sharded batch: 1 on the owner, 0 elsewhere)
+    *reinterpret_cast<float4 *>(out_c + (size_t)t * d + q * 4) = make_float4(w * a.x, w * a.y, w * a.z, w * a.w);
 }
 
 // out = alpha * sum_k layers[k]  (element-wise over up to 8 equally shaped tables; the LightGCN mean over layers, LightGCN.py:236-240,
@@ -369,17 +370,40 @@ __device__ __forceinline__ bool ordered_scan(int c0, int c1, int t, long long ro
     return true;
 }
 
+// Which rows does the list name more than once?  One thread per entry sets the row's bit in `bits`; an entry that finds it already set
+// sets the row's bit in `dup`.  WHICH entry arrives second is a race, the resulting SET of duplicated rows is not.  With it the accumulation
+// kernel below scans the list only for the duplicated rows (a few hundred of a 6 144-row batch) -- 44 -> ~10 us per call at cfg2.
+__global__ __launch_bounds__(kBlock) void rows_mark_dups_kernel(uint32_t *__restrict__ bits, uint32_t *__restrict__ dup, const int32_t *__restrict__ idx, int n) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n) return;
+    const int row = idx[t];
+    const uint32_t m = 1u << (row & 31);
+    if (atomicOr(bits + (row >> 5), m) & m) atomicOr(dup + (row >> 5), m);
+}
+
 // MARK: also set the row's byte flag and bitmap bit (the sparse-batch step touches three node-sized arrays with one index list: once to
 // add the batch gradients and mark the rows, once to clear everything again; one launch each)
 template <bool MARK>
 __global__ __launch_bounds__(kBlock) void rows_add_ordered_kernel(float *__restrict__ dst, uint8_t *__restrict__ flags, uint32_t *__restrict__ bits,
                                                                    const int32_t *__restrict__ idx, int c0, int c1, int d,
-                                                                   const float *__restrict__ src, float scale) {
+                                                                   const float *__restrict__ src, float scale, const float *__restrict__ row_scale,
+                                                                   const uint32_t *__restrict__ dup) {
     const int lane = threadIdx.x & 63;
     const int t = c0 + blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (t >= c1) return;
     const long long row = idx[t];
     float *o = dst + (size_t)row * d;
+    if (dup && !((dup[row >> 5] >> (row & 31)) & 1u)) {               // the list names this row once (rows_mark_dups_kernel): no scan, no order to keep
+        const float sc = row_scale ? scale * row_scale[t] : scale;
+        const float *s = src + (size_t)t * d;
+        for (int k = lane; k < d; k += kWave) {
+#pragma clang fp contract(off)
+            const float c = sc * s[k];
+            o[k] = o[k] + c;
+        }
+        if (MARK && lane == 0) flags[row] = 1;
+        return;
+    }
     for (int k0 = 0; k0 < d; k0 += 256) {
         float acc[4];
 #pragma unroll
@@ -387,10 +411,11 @@ __global__ __launch_bounds__(kBlock) void rows_add_ordered_kernel(float *__restr
         const bool owner = ordered_scan(c0, c1, t, row, lane, [&](int j) { return idx[j]; }, [&](int tt) {
 #pragma clang fp contract(off)                       // index_put_ adds the ROUNDED product scale * src: no fused multiply-add here
             const float *s = src + (size_t)tt * d;
+            const float sc = row_scale ? scale * row_scale[tt] : scale;     // optional per-contribution factor (sharded batch: 1 for own samples, 0 for foreign ones)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int k = k0 + 64 * i + lane;
-                if (k < d) { const float c = scale * s[k]; acc[i] = acc[i] + c; }
+                if (k < d) { const float c = sc * s[k]; acc[i] = acc[i] + c; }
             }
         });
         if (!owner) return;
@@ -403,7 +428,7 @@ __global__ __launch_bounds__(kBlock) void rows_add_ordered_kernel(float *__restr
     }
 }
 __global__ __launch_bounds__(kBlock) void batch_rows_clear_kernel(float *__restrict__ G, uint8_t *__restrict__ flags, uint32_t *__restrict__ bits,
-                                                                   const int32_t *__restrict__ idx, int n, int d) {
+                                                                   const int32_t *__restrict__ idx, int n, int d, uint32_t *__restrict__ dup) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (t >= n) return;
@@ -413,6 +438,7 @@ __global__ __launch_bounds__(kBlock) void batch_rows_clear_kernel(float *__restr
     if (lane == 0) {
         flags[row] = 0;
         atomicAnd(bits + (row >> 5), ~(1u << (row & 31)));
+        if (dup) atomicAnd(dup + (row >> 5), ~(1u << (row & 31)));
     }
 }
 
@@ -844,6 +870,37 @@ __global__ __launch_bounds__(kBlock) void bpr_finalize_kernel(int B, float reg, 
     }
 }
 
+// dst[r] += alpha * src[r] ONCE for every distinct row r of the list (duplicates in the list are ignored): adds the listed rows of a table that
+// is zero elsewhere (the sparse batch gradient G) into a dense one without a pass over the whole table.
+__global__ __launch_bounds__(kBlock) void rows_axpy_unique_kernel(float *__restrict__ dst, const float *__restrict__ src, const int32_t *__restrict__ idx,
+                                                                   int c0, int c1, int d, float alpha) {
+    const int lane = threadIdx.x & 63;
+    const int t = c0 + blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (t >= c1) return;
+    const long long row = idx[t];
+    // first occurrence in the WHOLE list (windows are independent launches, so the scan always starts at 0)
+    if (!ordered_scan(0, t, t, row, lane, [&](int j) { return idx[j]; }, [&](int) {})) return;
+    float *o = dst + (size_t)row * d;
+    const float *x = src + (size_t)row * d;
+    for (int k = lane; k < d; k += kWave) o[k] = fmaf(alpha, x[k], o[k]);
+}
+
+// user-sharded batch: local row ids, ownership weights and the packed row lists of one global batch in ONE launch (replaces ~10 element-wise
+// ATen launches per step).  Samples of other ranks' users keep a clamped local row id and weight 0 (static shapes, no host sync).
+__global__ __launch_bounds__(kBlock) void shard_batch_prep_kernel(const int32_t *__restrict__ u, const int32_t *__restrict__ p, const int32_t *__restrict__ n,
+                                                                   int B, int u0, int u1, int32_t *__restrict__ lu, float *__restrict__ own,
+                                                                   int32_t *__restrict__ item_rows, int32_t *__restrict__ rows_l) {
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= B) return;
+    const int Ul = u1 - u0;
+    const int uu = u[b];
+    const int l = min(max(uu - u0, 0), max(Ul - 1, 0));
+    lu[b] = l; own[b] = (uu >= u0 && uu < u1) ? 1.f : 0.f; own[B + b] = 1.f; own[2 * B + b] = 1.f;      // [3B]: per-contribution factors of [u | p | n]
+    const int pp = p[b], nn = n[b];
+    item_rows[b] = pp; item_rows[B + b] = nn;
+    rows_l[b] = l; rows_l[B + b] = Ul + pp; rows_l[2 * B + b] = Ul + nn;
+}
+
 // Backward of BPR + L2 into the rows of G, ordered (no float atomics; see rows_add_ordered_kernel).  The 3B contributions are numbered
 // t = b (user row of sample b), B + b (its positive item), 2B + b (its negative item): a user row receives its samples' terms in sample
 // order, an item row its positive-role terms in sample order and then its negative-role ones -- the order in which autograd's three
@@ -852,10 +909,11 @@ __global__ __launch_bounds__(kBlock) void bpr_bwd_kernel(const float *__restrict
                                                           const int32_t *__restrict__ ui, const int32_t *__restrict__ pi,
                                                           const int32_t *__restrict__ ni, int B, float reg, float upstream,
                                                           const float *__restrict__ ws, const float *__restrict__ out,
-                                                          float *__restrict__ G, int c0, int c1) {
+                                                          float *__restrict__ G, int c0, int c1, int distinct) {
     const int lane = threadIdx.x & 63;
     const int t = c0 + blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (t >= c1) return;
+    if (distinct) { c0 = t; c1 = t + 1; }                           // the caller guarantees 3B distinct rows (compact batch form): every entry owns its row
 #define ARL_ROWOF_BPR(j) ((j) < B ? (long long)ui[j] : ((j) < 2 * B ? item_off + pi[(j) - B] : item_off + ni[(j) - 2 * B]))
     const long long row = ARL_ROWOF_BPR(t);
     const float cu = out[2] > 0.f ? upstream * reg / out[2] : 0.f, cp = out[3] > 0.f ? upstream * reg / out[3] : 0.f;
@@ -1783,7 +1841,10 @@ typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
 constexpr int kBloomWords = 32;      // 1024 bits per user
 constexpr int kTopkRing = 4;         // staged item tiles in LDS (slots of the ring), a power of two
 constexpr int kTopkLead = 2;         // a wave writes its share of stage s + kTopkLead while it consumes stage s
-constexpr int kTopkBootItems = 4096; // items scored by the bootstrap pass of a cold call (a multiple of every stage size)
+#ifndef ARL_TOPK_BOOT_ITEMS
+#define ARL_TOPK_BOOT_ITEMS 4096
+#endif
+constexpr int kTopkBootItems = ARL_TOPK_BOOT_ITEMS; // items scored by the bootstrap pass of a cold call (a multiple of every stage size)
 __device__ __forceinline__ unsigned bloom_hash(int item) { return ((unsigned)item * 2654435761u) >> 22; }
 
 // SPLIT = true: the contraction runs on the bf16 matrix path with every fp32 operand split into three bf16 pieces
@@ -1809,11 +1870,26 @@ constexpr int kSplitPlanes = kSplitMode == 1 ? 3 : 2;
 
 // largest |x| of a table as float bits (non-negative floats order like unsigned ints): *out must be zeroed first
 __global__ __launch_bounds__(kBlock) void absmax_bits_kernel(const float *__restrict__ X, long long n, unsigned *__restrict__ out) {
+    // 16-byte loads, one atomic per WORKGROUP: 65 K same-address atomics (one per wave of the old form) serialise at ~12 ns each -- 0.8 ms
+    // for a 256 MB table that streams in 50 us
+    __shared__ unsigned part[kWavesPerBlock];
     unsigned m = 0u;
-    for (long long t = (long long)blockIdx.x * kBlock + threadIdx.x; t < n; t += (long long)gridDim.x * kBlock) m = max(m, __float_as_uint(fabsf(X[t])));
+    const bool al = ((uintptr_t)X & 15u) == 0;
+    const long long n4 = al ? n / 4 : 0;
+    const float4 *X4 = reinterpret_cast<const float4 *>(X);
+    for (long long t = (long long)blockIdx.x * kBlock + threadIdx.x; t < n4; t += (long long)gridDim.x * kBlock) {
+        const float4 v = X4[t];
+        m = max(max(m, __float_as_uint(fabsf(v.x))), max(__float_as_uint(fabsf(v.y)), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w)))));
+    }
+    for (long long t = n4 * 4 + (long long)blockIdx.x * kBlock + threadIdx.x; t < n; t += (long long)gridDim.x * kBlock) m = max(m, __float_as_uint(fabsf(X[t])));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWavesPerBlock; ++w) m = max(m, part[w]);
+        if (m) atomicMax(out, m);
+    }
 }
 // power of two that brings a table whose largest magnitude has float bits `mbits` into [2^13, 2^14) (1 for an all-zero or non-finite table)
 __device__ __forceinline__ float split_scale(unsigned mbits) {
@@ -1925,7 +2001,8 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     // as the starting threshold (the warm-start mechanism), and the ~k ln(I/k) record-setters of a cold stream (half of them in its
     // first 2 %) drop to ~k (1 + ln(I / sample)).  Same instruction sequence on the same data: the sample's scores are bit-identical in
     // both passes, so the k items the bound rests on pass it again.
-    const int NB = nstages >= 8 * (kTopkBootItems / MST) ? kTopkBootItems / MST : 0;
+    // sample size: kTopkBootItems, at most a quarter of the stream, an even number of stages; streams under 32 K items run cold
+    const int NB = I >= 32768 ? (min(kTopkBootItems, I / 4) / (2 * MST)) * 2 : 0;
     const int nvirt = NB + nstages;                                // stages as the ring counts them: the bootstrap's, then the stream's
     auto item_stage = [&](int v) { return v < NB ? v : v - NB; };
     auto stage_ptr = [&](int st, int p) {
@@ -2349,12 +2426,12 @@ inline unsigned grid_for(long long work_items, int per_block, unsigned cap = 204
 
 // ordered BPR backward over the 3B contributions, kOrderedWindow per launch
 static int launch_bpr_bwd(const float *emb, int64_t d, int64_t item_off, const int32_t *u, const int32_t *p, const int32_t *n, int64_t B, float reg,
-                          float upstream, const float *ws, const float *norms, float *G, hipStream_t st) {
+                          float upstream, const float *ws, const float *norms, float *G, hipStream_t st, int distinct = 0) {
     const int64_t total = 3 * B;
     for (int64_t c0 = 0; c0 < total; c0 += kOrderedWindow) {
         const int64_t c1 = c0 + kOrderedWindow < total ? c0 + kOrderedWindow : total;
         hipLaunchKernelGGL(bpr_bwd_kernel, dim3((unsigned)((c1 - c0 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, st, emb, (int)d,
-                           (long long)item_off, u, p, n, (int)B, reg, upstream, ws, norms, G, (int)c0, (int)c1);
+                           (long long)item_off, u, p, n, (int)B, reg, upstream, ws, norms, G, (int)c0, (int)c1, distinct);
         ARL_LAUNCH_CHECK();
     }
     return ARL_OK;
@@ -2529,7 +2606,8 @@ int64_t arl_spmm_csr_rows_workspace_bytes(int64_t n_rows_sel, int64_t nsplit, in
 }
 
 int arl_spmm_csr_rows_f32(const arl_csr *A, const float *X, int64_t d, const int32_t *rows, int64_t n_rows_sel, int64_t nsplit,
-                          const float *const *layers, int64_t n_layers, float alpha, float *out_c, void *workspace, arl_stream_t stream) {
+                          const float *const *layers, int64_t n_layers, float alpha, const float *row_weight, float *out_c, void *workspace,
+                          arl_stream_t stream) {
     if (!A || !X || !rows || !out_c || !workspace || !A->rowptr) return ARL_E_NULL;
     if (A->nnz > 0 && (!A->col || !A->val)) return ARL_E_NULL;
     if (n_layers < 0 || n_layers > 8 || (n_layers > 0 && !layers)) return ARL_E_ARG;
@@ -2551,7 +2629,7 @@ int arl_spmm_csr_rows_f32(const arl_csr *A, const float *X, int64_t d, const int
         hipLaunchKernelGGL((spmm_subset_kernel<LPRV>), dim3(grid), dim3(kBlock), 0, st, D, X, di, rows, n, ns, part);          \
         ARL_LAUNCH_CHECK();                                                                                                    \
         const unsigned g2 = (unsigned)((n + kWavesPerBlock * (kWave / LPRV) - 1) / (kWavesPerBlock * (kWave / LPRV)));         \
-        hipLaunchKernelGGL((subset_finish_kernel<LPRV>), dim3(g2), dim3(kBlock), 0, st, part, n, ns, di, rows, LP, alpha, out_c); \
+        hipLaunchKernelGGL((subset_finish_kernel<LPRV>), dim3(g2), dim3(kBlock), 0, st, part, n, ns, di, rows, LP, alpha, out_c, row_weight); \
         ARL_LAUNCH_CHECK();                                                                                                    \
     } while (0)
     if (d <= 16) ARL_SUBSET_CASE(4);
@@ -2582,25 +2660,29 @@ int arl_mark_rows_bits_u32(uint32_t *bits, const int32_t *idx, int64_t n, int32_
 }
 
 int arl_batch_rows_set_f32(float *G, uint8_t *flags, uint32_t *bits, const int32_t *idx, int64_t n, int64_t d, const float *src, float scale,
-                           arl_stream_t stream) {
+                           const float *row_scale, uint32_t *dup_bits, arl_stream_t stream) {
     if (!G || !flags || !bits || !idx || !src) return ARL_E_NULL;
     if (n < 0 || n > 0x7fffffffll || d <= 0 || d > 0x7fffffffll) return ARL_E_ARG;
     if (n == 0) return ARL_OK;
+    if (dup_bits) {
+        hipLaunchKernelGGL(rows_mark_dups_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, bits, dup_bits, idx, (int)n);
+        ARL_LAUNCH_CHECK();
+    }
     for (int64_t c0 = 0; c0 < n; c0 += kOrderedWindow) {                 // ordered (atomic-free) accumulation, one window per launch
         const int64_t c1 = c0 + kOrderedWindow < n ? c0 + kOrderedWindow : n;
         hipLaunchKernelGGL(rows_add_ordered_kernel<true>, dim3((unsigned)((c1 - c0 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
-                           (hipStream_t)stream, G, flags, bits, idx, (int)c0, (int)c1, (int)d, src, scale);
+                           (hipStream_t)stream, G, flags, bits, idx, (int)c0, (int)c1, (int)d, src, scale, row_scale, (const uint32_t *)dup_bits);
         ARL_LAUNCH_CHECK();
     }
     return ARL_OK;
 }
 
-int arl_batch_rows_clear_f32(float *G, uint8_t *flags, uint32_t *bits, const int32_t *idx, int64_t n, int64_t d, arl_stream_t stream) {
+int arl_batch_rows_clear_f32(float *G, uint8_t *flags, uint32_t *bits, const int32_t *idx, int64_t n, int64_t d, uint32_t *dup_bits, arl_stream_t stream) {
     if (!G || !flags || !bits || !idx) return ARL_E_NULL;
     if (n < 0 || n > 0x7fffffffll || d <= 0 || d > 0x7fffffffll) return ARL_E_ARG;
     if (n == 0) return ARL_OK;
     hipLaunchKernelGGL(batch_rows_clear_kernel, dim3((unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, G, flags,
-                       bits, idx, (int)n, (int)d);
+                       bits, idx, (int)n, (int)d, dup_bits);
     ARL_LAUNCH_CHECK();
     return ARL_OK;
 }
@@ -2617,7 +2699,7 @@ int arl_zero_rows_f32(float *dst, const int32_t *idx, int64_t n, int64_t d, arl_
 int64_t arl_bpr_l2_workspace_bytes(int64_t B) { return B < 0 ? 0 : (int64_t)sizeof(float) * 4 * B; }
 
 int arl_bpr_l2_fwd_bwd_f32(const float *emb, int64_t d, int64_t item_off, const int32_t *u, const int32_t *p, const int32_t *n, int64_t B,
-                           float reg, float upstream, float *loss_out, float *G, void *workspace, arl_stream_t stream) {
+                           float reg, float upstream, float *loss_out, float *G, void *workspace, int32_t distinct_rows, arl_stream_t stream) {
     if (!emb || !u || !p || !n || !loss_out || !workspace) return ARL_E_NULL;
     if (d <= 0 || B <= 0 || item_off < 0) return ARL_E_ARG;
     if (B > 0x7fffffffll / 4 || d > 0x7fffffffll) return ARL_E_RANGE;
@@ -2629,7 +2711,7 @@ int arl_bpr_l2_fwd_bwd_f32(const float *emb, int64_t d, int64_t item_off, const 
     hipLaunchKernelGGL(bpr_finalize_kernel, dim3(1), dim3(kBlock), 0, st, (int)B, reg, ws, loss_out, 0);
     ARL_LAUNCH_CHECK();
     if (G) {
-        const int rc = launch_bpr_bwd(emb, d, item_off, u, p, n, B, reg, upstream, ws, loss_out, G, st);
+        const int rc = launch_bpr_bwd(emb, d, item_off, u, p, n, B, reg, upstream, ws, loss_out, G, st, distinct_rows != 0);
         if (rc) return rc;
     }
     return ARL_OK;
@@ -2725,9 +2807,33 @@ int arl_scatter_add_rows_f32(float *dst, const int32_t *idx, int64_t n, int64_t 
     for (int64_t c0 = 0; c0 < n; c0 += kOrderedWindow) {
         const int64_t c1 = c0 + kOrderedWindow < n ? c0 + kOrderedWindow : n;
         hipLaunchKernelGGL(rows_add_ordered_kernel<false>, dim3((unsigned)((c1 - c0 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
-                           (hipStream_t)stream, dst, (uint8_t *)nullptr, (uint32_t *)nullptr, idx, (int)c0, (int)c1, (int)d, src, scale);
+                           (hipStream_t)stream, dst, (uint8_t *)nullptr, (uint32_t *)nullptr, idx, (int)c0, (int)c1, (int)d, src, scale, (const float *)nullptr,
+                           (const uint32_t *)nullptr);
         ARL_LAUNCH_CHECK();
     }
+    return ARL_OK;
+}
+
+int arl_rows_axpy_unique_f32(float *dst, const float *src, const int32_t *idx, int64_t n, int64_t d, float alpha, arl_stream_t stream) {
+    if (!src || !idx || !dst) return ARL_E_NULL;
+    if (n < 0 || d <= 0 || n > 0x7fffffffll || d > 0x7fffffffll || dst == src) return ARL_E_ARG;
+    for (int64_t c0 = 0; c0 < n; c0 += kOrderedWindow) {
+        const int64_t c1 = c0 + kOrderedWindow < n ? c0 + kOrderedWindow : n;
+        hipLaunchKernelGGL(rows_axpy_unique_kernel, dim3((unsigned)((c1 - c0 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
+                           (hipStream_t)stream, dst, src, idx, (int)c0, (int)c1, (int)d, alpha);
+        ARL_LAUNCH_CHECK();
+    }
+    return ARL_OK;
+}
+
+int arl_shard_batch_prep_i32(const int32_t *u, const int32_t *p, const int32_t *n, int64_t B, int64_t u0, int64_t u1, int32_t *lu, float *own,
+                             int32_t *item_rows, int32_t *rows_l, arl_stream_t stream) {
+    if (!u || !p || !n || !lu || !own || !item_rows || !rows_l) return ARL_E_NULL;
+    if (B < 0 || B > 0x7fffffffll / 3 || u0 < 0 || u1 < u0 || u1 > 0x7fffffffll) return ARL_E_ARG;
+    if (B == 0) return ARL_OK;
+    hipLaunchKernelGGL(shard_batch_prep_kernel, dim3((unsigned)((B + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, u, p, n, (int)B, (int)u0,
+                       (int)u1, lu, own, item_rows, rows_l);
+    ARL_LAUNCH_CHECK();
     return ARL_OK;
 }
 
@@ -3092,9 +3198,9 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
                 // workspace: [I][2][d] fp16 image (4 I d bytes), then the two tables' largest magnitudes (float bits: items, users)
                 unsigned *mb = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + 4 * (size_t)n);
                 if (hipMemsetAsync(mb, 0, 2 * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) return ARL_E_ARG;
-                hipLaunchKernelGGL(absmax_bits_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, Pi, n, mb);
+                hipLaunchKernelGGL(absmax_bits_kernel, dim3(grid_for(n / 4 + 1, kBlock, 2048u)), dim3(kBlock), 0, (hipStream_t)stream, Pi, n, mb);
                 ARL_LAUNCH_CHECK();
-                hipLaunchKernelGGL(absmax_bits_kernel, dim3(grid_for(U * d, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, Pu, (long long)(U * d), mb + 1);
+                hipLaunchKernelGGL(absmax_bits_kernel, dim3(grid_for(U * d / 4 + 1, kBlock, 2048u)), dim3(kBlock), 0, (hipStream_t)stream, Pu, (long long)(U * d), mb + 1);
                 ARL_LAUNCH_CHECK();
                 hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, Pi, n, (int)d, mb,
                                    (_Float16 *)workspace);

@@ -41,21 +41,91 @@ class _TimedWork:
         return True
 
 
+class _StreamWork:
+    """Handle of an exchange enqueued on the communication stream: wait() makes the CALLER's current stream wait for it (no host block)."""
+
+    def __init__(self, done_event):
+        self.done = done_event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.done)
+        return True
+
+
 class TorchDistComm:
     """torch.distributed sum-all-reduce (NCCL backend = RCCL on ROCm).  measure=True records, for every wait on a collective, how long
-    the compute stream was blocked by it (exposed_ms() sums them after a synchronize; bench.py --gpus N prints it per rank)."""
+    the compute stream was blocked by it (exposed_ms() sums them after a synchronize; bench.py --gpus N prints it per rank).
 
-    def __init__(self, group=None, measure=False):
+    item_exchange = 'direct' (or ARL_ITEM_EXCHANGE=direct): GPU buffers of at least `direct_min_bytes` go through the C ABI's
+    arl_allreduce_item_f32 -- a direct reduce-scatter + all-gather over the xGMI links on a communication stream of its own --
+    instead of the library all-reduce; everything else (the 3-float loss sums, CPU tensors) stays with torch.distributed."""
+
+    def __init__(self, group=None, measure=False, item_exchange=None, n_chunks=4, direct_min_bytes=1 << 20):
+        import os
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.measure = bool(measure)
         self.waits = []
+        self.item_exchange = item_exchange or os.environ.get('ARL_ITEM_EXCHANGE', 'torch')
+        if self.item_exchange not in ('torch', 'direct'):
+            raise ValueError("item_exchange must be 'torch' or 'direct'")
+        self.n_chunks, self.direct_min_bytes = int(n_chunks), int(direct_min_bytes)
+        self._native = None
+
+    # ---- native exchange (built lazily: needs an initialised process group to carry the communicator id)
+    def _native_comm(self, device):
+        if self._native is None:
+            import ctypes as C
+            import os
+            from . import _lib
+            L = _lib.lib()
+            cand = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')          # the RCCL instance torch itself runs on
+            _lib.check(L.arl_comm_load(cand.encode() if os.path.exists(cand) else None), 'arl_comm_load')
+            rank, world = self.dist.get_rank(self.group), self.dist.get_world_size(self.group)
+            ident = C.create_string_buffer(128)
+            if rank == 0:
+                _lib.check(L.arl_comm_unique_id(ident), 'arl_comm_unique_id')
+            box = [bytes(ident.raw)]
+            self.dist.broadcast_object_list(box, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            handle = C.c_void_p()
+            _lib.check(L.arl_comm_init(box[0], rank, world, C.byref(handle)), 'arl_comm_init')
+            self._native = dict(L=L, handle=handle, world=world, stream=torch.cuda.Stream(device=device), ws=None)
+        return self._native
+
+    def _direct(self, t):
+        import ctypes as C
+        from . import _lib
+        nat = self._native_comm(t.device)
+        L, n = nat['L'], t.numel()
+        need = L.arl_allreduce_item_workspace_bytes(n, nat['world'], self.n_chunks)
+        if nat['ws'] is None or nat['ws'].numel() * 4 < need:
+            nat['ws'] = torch.empty(max(need // 4, 4), dtype=torch.float32, device=t.device)
+        side = nat['stream']
+        side.wait_event(torch.cuda.current_stream().record_event())          # the producer of `t` runs on the caller's stream
+        _lib.check(L.arl_allreduce_item_f32(nat['handle'], C.c_void_p(t.data_ptr()), n, self.n_chunks, C.c_void_p(nat['ws'].data_ptr()),
+                                            C.c_void_p(side.cuda_stream)), 'arl_allreduce_item_f32')
+        return _StreamWork(side.record_event())
+
+    def _use_direct(self, t):
+        return (self.item_exchange == 'direct' and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+                and t.numel() * 4 >= self.direct_min_bytes and t.data_ptr() % 16 == 0)
+
+    def close(self):
+        if self._native is not None:
+            self._native['L'].arl_comm_destroy(self._native['handle'])
+            self._native = None
 
     def all_reduce_async(self, t):
+        if self._use_direct(t):
+            w = self._direct(t)
+            return _TimedWork(w, self) if self.measure else w
         w = self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
         return _TimedWork(w, self) if self.measure else w
 
     def all_reduce(self, t):
+        if self._use_direct(t):
+            self.all_reduce_async(t).wait()
+            return t
         if self.measure:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -419,20 +489,21 @@ class ShardedPropagationEngine:
         if getattr(self, '_sp_B', None) != B:
             self.flags = torch.zeros(self.Nl, dtype=torch.uint8, device=dev)
             self.bits = torch.zeros((self.Nl + 31) // 32, dtype=torch.int32, device=dev)
+            self.dup_bits = torch.zeros_like(self.bits)
             self.C = torch.zeros(3 * B, d, dtype=torch.float32, device=dev)
             self.Gc = torch.zeros(3 * B, d, dtype=torch.float32, device=dev)
             self.ar = torch.arange(B, dtype=torch.int32, device=dev)
             self.arB = self.ar + B
             self.ws = torch.empty(4 * B, dtype=torch.float32, device=dev)
             self.hops = [self.Ea, self.Eb] + [torch.empty_like(self.Ea) for _ in range(max(0, L - 3))]
+            self._prep = None
             self.G.zero_()
             self._sp_B = B
-        # static shapes, no host sync: samples of other ranks' users are kept with a clamped row id and a zero weight
-        own = ((u >= self.u0) & (u < self.u1))
-        ownf = own.to(torch.float32).unsqueeze(1)
-        lu = (u - self.u0).clamp_(0, max(Ul - 1, 0)).to(torch.int32).contiguous()
-        item_rows = torch.cat([p, n]).to(torch.int32).contiguous()              # item ids of ALL samples, [2B]
-        item_rows_packed = item_rows + Ul
+        # static shapes, no host sync: samples of other ranks' users are kept with a clamped row id and a zero weight.  One launch builds
+        # the local row ids, the ownership weights and the packed row lists (arl_shard_batch_prep_i32)
+        self._prep = k.shard_batch_prep(u, p, n, self.u0, self.u1, out=self._prep)
+        lu, own, item_rows, rows_l = self._prep
+        item_rows_packed = rows_l[B:]
         # forward.  Software pipeline over hops: the item-row all-reduce of hop h runs behind A_u(h) AND A_i(h+1) -- the
         # item-side kernel of the next hop only gathers USER rows, which are local and already final.
         layers = [self.E0]
@@ -446,28 +517,31 @@ class ShardedPropagationEngine:
             k.spmm(self.Au, src, out=dst[:Ul])                 # exact user rows (gathers item rows of src)
             layers.append(dst)
         X = layers[-1]
-        # compact batch rows, already scaled by 1/(L+1): item rows = per-rank partial of the last hop (+ the layers' own rows, which are
-        # replicas: each added by one rank); user rows = complete on the owner, zero elsewhere.  One [3B, d] all-reduce completes them.
-        k.spmm_rows(self.Ai, X, item_rows, (), s, out=self.C[B:], check_range=False)     # gathers user rows only: overlaps the last full all-reduce
+        # compact batch rows, already scaled by 1/(L+1): item rows = per-rank partial of the last hop + the layers' own rows, which are
+        # replicas: layer j is contributed by rank j % world alone (its rows ride in the row-subset hop's epilogue); user rows = complete on the
+        # owner, zero elsewhere (row weight `own`).  One [3B, d] all-reduce completes them.
+        if pending is not None and L >= 2:
+            # the last full hop's item rows (layers[-1][Ul:]) must be complete before they are read below as a replicated layer
+            mine = [t[Ul:] for j, t in enumerate(layers[:-1]) if j % self.world == self.rank]
+        else:
+            mine = [t[Ul:] for j, t in enumerate(layers) if j % self.world == self.rank]
+        k.spmm_rows(self.Ai, X, item_rows, mine, s, out=self.C[B:], check_range=False)      # gathers user rows only: overlaps the last full all-reduce
         if pending is not None:
             pending.wait()
-        for j, t in enumerate(layers):                    # replicated rows: layer j is contributed by rank j % world alone
-            if j % self.world == self.rank:
-                self.C[B:].add_(k.gather_rows(t, item_rows_packed, check_range=False), alpha=s)
+            if L >= 2 and (L - 1) % self.world == self.rank:   # the newest layer's item rows, readable only now
+                self.C[B:].add_(k.gather_rows(X, item_rows_packed, check_range=False), alpha=s)
         if Ul:
-            k.spmm_rows(self.Au, X, lu, [t[:Ul] for t in layers], s, out=self.C[:B], check_range=False)
-            self.C[:B].mul_(ownf)                                                 # the owner contributes the row, others zeros
+            k.spmm_rows(self.Au, X, lu, [t[:Ul] for t in layers], s, out=self.C[:B], check_range=False, row_weight=own[:B])
         else:
             self.C[:B].zero_()
         self.comm.all_reduce(self.C)
-        # loss on the whole batch (identical on every rank), compact per-sample gradients; one launch puts them into G and marks the rows
-        # (foreign samples add exact zeros to a clamped local row)
+        # loss on the whole batch (identical on every rank), compact per-sample gradients; one launch puts them into G (foreign samples:
+        # factor 0 on a clamped local row) and marks the rows
         self.Gc.zero_()
-        k.bpr_l2_fwd_bwd(self.C, B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self.ws, loss_out=self.loss_out, check_range=False)
-        self.Gc[:B].mul_(ownf)
-        rows_l = torch.cat([lu, item_rows_packed])
-        k.batch_rows_set_(self.G, self.flags, self.bits, rows_l, self.Gc, 1.0, check_range=False)
-        # backward (Horner).  hop 1: flag-masked gathers; later hops dense; G (complete on the item side) added through flags
+        k.bpr_l2_fwd_bwd(self.C, B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self.ws, loss_out=self.loss_out, check_range=False, distinct_rows=True)
+        k.batch_rows_set_(self.G, self.flags, self.bits, rows_l, self.Gc, 1.0, check_range=False, row_scale=own, dup_bits=self.dup_bits)
+        # backward (Horner).  hop 1: flag-masked gathers; later hops dense; G (complete on the item side, <= 2B distinct rows) is added to
+        # the reduced item rows by a row-list kernel instead of a pass over the whole I x d block
         self.t += 1
         zu = self.flags[:Ul]
         acc = self.G
@@ -482,17 +556,17 @@ class ShardedPropagationEngine:
             k.spmm_flagged(self.Ai, acc, xf, a, 0.0, None, None, out=dst[Ul:])     # partial item rows (gathers acc's user rows)
             if pending is not None:                                                # complete acc's item rows before A_u reads them
                 pending.wait()
-                prev_items.add_(self.G[Ul:], alpha=prev_a)
-            pending, prev_items, prev_a = self.comm.all_reduce_async(dst[Ul:]), dst[Ul:], a
+                k.rows_axpy_unique_(prev_items, self.G, item_rows_packed, prev_a, check_range=False)
+            pending, prev_items, prev_a = self.comm.all_reduce_async(dst[Ul:]), dst, a
             if last:
                 k.spmm_adam(self.Au, acc, a, a, self.G[:Ul], self.E0[:Ul], self.m[:Ul], self.v[:Ul], self.lr, self.t, self.betas, self.eps, zflags=zu)
             else:
                 k.spmm_flagged(self.Au, acc, xf, a, a, self.G[:Ul], zu, out=dst[:Ul])
             acc = dst
         pending.wait()
-        prev_items.add_(self.G[Ul:], alpha=prev_a)
+        k.rows_axpy_unique_(prev_items, self.G, item_rows_packed, prev_a, check_range=False)
         k.adam_dense(self.E0[Ul:], acc[Ul:], self.m[Ul:], self.v[Ul:], self.lr, self.t, self.betas, self.eps)
-        k.batch_rows_clear_(self.G, self.flags, self.bits, rows_l, check_range=False)      # clear the sparse state
+        k.batch_rows_clear_(self.G, self.flags, self.bits, rows_l, check_range=False, dup_bits=self.dup_bits)      # clear the sparse state
         return self.loss_out
 
     # ---- SimGCL (recommender/SimGCL.py:51-63,198-219) on the user-sharded layout -- BASELINE config 4's training step.

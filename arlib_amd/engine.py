@@ -148,7 +148,7 @@ class PropagationEngine:
         if getattr(self, '_G_dirty', True):
             self.G.zero_()
             self._G_dirty = False
-        ops.batch_rows_set_(self.G, self.flags, self.bits, rows, g_rows.contiguous(), 1.0, check_range=False)
+        ops.batch_rows_set_(self.G, self.flags, self.bits, rows, g_rows.contiguous(), 1.0, check_range=False, dup_bits=self.dup_bits)
         if L == 1:
             out = ops.spmm_flagged(A, self.G, self.bits, s, s, self.G, self.flags)
         else:
@@ -156,7 +156,7 @@ class PropagationEngine:
             for k in range(1, L - 1):
                 acc = ops.spmm_flagged(A, acc, None, 1.0, 1.0, self.G, self.flags, out=self.hops[k % 2 if len(self.hops) == 2 else k])
             out = ops.spmm_flagged(A, acc, None, s, s, self.G, self.flags)
-        ops.batch_rows_clear_(self.G, self.flags, self.bits, rows, check_range=False)
+        ops.batch_rows_clear_(self.G, self.flags, self.bits, rows, check_range=False, dup_bits=self.dup_bits)
         return out
 
     def loss_and_grad_out(self, out, u, p, n):
@@ -204,8 +204,8 @@ class PropagationEngine:
         ops.spmm_rows(A, layers[-1], rows, layers, s, nsplit=self.nsplit, out=self.out_c, workspace=self.rows_ws, check_range=False)
         # loss + compact per-sample gradients (rows [0,B) users, [B,2B) positives, [2B,3B) negatives of out_c)
         self.Gc.zero_()
-        ops.bpr_l2_fwd_bwd(self.out_c, B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self._ws, loss_out=self.loss_out, check_range=False)
-        ops.batch_rows_set_(self.G, self.flags, self.bits, rows, self.Gc, 1.0, check_range=False)      # duplicates accumulate; rows marked
+        ops.bpr_l2_fwd_bwd(self.out_c, B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self._ws, loss_out=self.loss_out, check_range=False, distinct_rows=True)
+        ops.batch_rows_set_(self.G, self.flags, self.bits, rows, self.Gc, 1.0, check_range=False, dup_bits=self.dup_bits)      # duplicates accumulate in order; rows marked
         # backward (Horner): first hop gathers flagged rows only; G is read through the flags everywhere
         self.t += 1
         if L == 1:
@@ -216,7 +216,7 @@ class PropagationEngine:
             for k in range(1, L - 1):
                 acc = ops.spmm_flagged(A, acc, None, 1.0, 1.0, self.G, self.flags, out=self.hops[k % 2 if len(self.hops) == 2 else k])
             ops.spmm_adam(A, acc, s, s, self.G, self.E0, self.m, self.v, self.lr, self.t, self.betas, self.eps, zflags=self.flags)
-        ops.batch_rows_clear_(self.G, self.flags, self.bits, rows, check_range=False)
+        ops.batch_rows_clear_(self.G, self.flags, self.bits, rows, check_range=False, dup_bits=self.dup_bits)
         return self.loss_out
 
     # ---- NGCF (recommender/NGCF.py:47-64,197-212): the whole training iteration without autograd or a torch optimizer.  Per layer ONE hop
@@ -264,16 +264,16 @@ class PropagationEngine:
             acc += ops.gather_rows(e, rows, check_range=False)
         acc *= s
         self.Gc.zero_()
-        ops.bpr_l2_fwd_bwd(acc, B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self._ws, loss_out=self.loss_out, check_range=False)
+        ops.bpr_l2_fwd_bwd(acc, B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self._ws, loss_out=self.loss_out, check_range=False, distinct_rows=True)
         Gs = self.Gc * s                                         # every layer's batch rows receive this share of dL/d(out) directly
         # backward
         self.t += 1
         gP_r, gE_r, gW = ops.ngcf_dense_bwd(Gs, out_r, P_r, E_r, Wcat[L - 1], slope)
         gWs = [None] * L
         gWs[L - 1] = gW
-        ops.batch_rows_set_(self.G, self.flags, self.bits, rows, gP_r, 1.0, check_range=False)
+        ops.batch_rows_set_(self.G, self.flags, self.bits, rows, gP_r, 1.0, check_range=False, dup_bits=self.dup_bits)
         g = ops.spmm_flagged(A, self.G, self.bits)              # A^T (rows' gP scattered) = A (...), A symmetric
-        ops.batch_rows_clear_(self.G, self.flags, self.bits, rows, check_range=False)
+        ops.batch_rows_clear_(self.G, self.flags, self.bits, rows, check_range=False, dup_bits=self.dup_bits)
         ops.scatter_add_rows(g, rows, gE_r + Gs, 1.0, check_range=False)
         if L == 1:
             if capture is not None:
@@ -364,7 +364,7 @@ class PropagationEngine:
             return last * inv
         out_c = finish(E1, None)
         self.Gc.zero_()
-        ops.bpr_l2_fwd_bwd(out_c, B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self._ws, loss_out=self.loss_out, check_range=False)
+        ops.bpr_l2_fwd_bwd(out_c, B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self._ws, loss_out=self.loss_out, check_range=False, distinct_rows=True)
         ops.scatter_add_rows(self.G, rows, self.Gc, 1.0, check_range=False)
         views = []
         for v in (0, 1):
@@ -390,7 +390,7 @@ class PropagationEngine:
             ops.adam_dense(self.E0, tmp, self.m, self.v, self.lr, self.t, self.betas, self.eps)
         else:
             ops.spmm_adam(A, acc, inv, 0.0, None, self.E0, self.m, self.v, self.lr, self.t, self.betas, self.eps)
-        ops.batch_rows_clear_(self.G, self.flags, self.bits, allrows, check_range=False)
+        ops.batch_rows_clear_(self.G, self.flags, self.bits, allrows, check_range=False, dup_bits=self.dup_bits)
         return self.loss_out, cl_loss
 
     def step_xsimgcl(self, u, p, n, cl_rate=0.2, tau=0.1, eps=0.1, layer_cl=1, noises=None):
@@ -446,7 +446,7 @@ class PropagationEngine:
         # ---- losses and compact gradients
         self.Gc.zero_()
         ops.bpr_l2_fwd_bwd(mean_c[:3 * B].contiguous(), B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self._ws, loss_out=self.loss_out,
-                           check_range=False)
+                           check_range=False, distinct_rows=True)
         mcl = mean_c[3 * B:]
         lu, du1, du2 = ops.infonce_fwd_bwd(mcl[:nu].contiguous(), cl_c[:nu].contiguous(), tau)
         li, di1, di2 = ops.infonce_fwd_bwd(mcl[nu:].contiguous(), cl_c[nu:].contiguous(), tau)
@@ -485,7 +485,7 @@ class PropagationEngine:
                 acc = ops.spmm_flagged(A, acc, None, 1.0, 1.0, self.G, self.flags, out=dst)
                 level -= 1
             ops.spmm_adam(A, acc, 1.0, 0.0, None, self.E0, self.m, self.v, self.lr, self.t, self.betas, self.eps)
-        ops.batch_rows_clear_(self.G, self.flags, self.bits, allrows, check_range=False)
+        ops.batch_rows_clear_(self.G, self.flags, self.bits, allrows, check_range=False, dup_bits=self.dup_bits)
         return self.loss_out, cl_loss
 
     def step_sgl(self, u, p, n, view1, view2, cl_rate=0.2, tau=0.2):
@@ -515,7 +515,7 @@ class PropagationEngine:
             return ops.spmm_rows(graph, layers[-1], sel, layers, s, nsplit=self.nsplit, check_range=False)
 
         def backward_into(graph, sel, grad_c, dst, accumulate):             # dst (+)= dL/dE0 of a pass whose output gradient is grad_c at rows sel
-            ops.batch_rows_set_(self.G, self.flags, self.bits, sel, grad_c, 1.0, check_range=False)
+            ops.batch_rows_set_(self.G, self.flags, self.bits, sel, grad_c, 1.0, check_range=False, dup_bits=self.dup_bits)
             beta, Z = (1.0, dst) if accumulate else (0.0, None)
             if L == 1:
                 tmp = ops.spmm_flagged(graph, self.G, self.bits, s, s, self.G, self.flags, out=self._sgl_hops[0])
@@ -528,12 +528,12 @@ class PropagationEngine:
                 dst.add_(tmp)
             else:
                 dst.copy_(tmp)
-            ops.batch_rows_clear_(self.G, self.flags, self.bits, sel, check_range=False)
+            ops.batch_rows_clear_(self.G, self.flags, self.bits, sel, check_range=False, dup_bits=self.dup_bits)
 
         # clean pass: BPR + L2 on the batch rows
         out_c = forward_rows(self.A, rows)
         self.Gc.zero_()
-        ops.bpr_l2_fwd_bwd(out_c, B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self._ws, loss_out=self.loss_out, check_range=False)
+        ops.bpr_l2_fwd_bwd(out_c, B, self.ar, self.ar, self.arB, self.reg, self.Gc, workspace=self._ws, loss_out=self.loss_out, check_range=False, distinct_rows=True)
         # the two views at the contrastive rows, one InfoNCE over users and items together
         v1 = forward_rows(view1, rows_cl)
         v2 = forward_rows(view2, rows_cl)
@@ -557,6 +557,7 @@ class PropagationEngine:
             self._sb_cache = {}
             self.flags = torch.zeros(self.N, dtype=torch.uint8, device=dev)          # byte per row: read once per OUTPUT row (epilogue)
             self.bits = torch.zeros((self.N + 31) // 32, dtype=torch.int32, device=dev)   # bit per node: read once per EDGE (masked hop)
+            self.dup_bits = torch.zeros_like(self.bits)                                   # rows a batch names more than once (ordered accumulation)
             self.nsplit = 32            # edge ranges per batch row in the row-subset hop (cfg2 sweep: 8: 0.56 ms, 16: 0.33, 32/64: 0.21, 128: 0.36)
             # forward needs E_1..E_{L-1} alive at the same time; Ea/Eb cover L <= 3
             self.hops = [self.Ea, self.Eb] + [torch.empty_like(self.Ea) for _ in range(max(0, self.L - 3))]

@@ -682,7 +682,7 @@ def spmm_flagged(A, X, xflags=None, alpha=1.0, beta=0.0, Z=None, zflags=None, ou
 ROWS_NSPLIT = 16     # default number of edge ranges per listed row of the row-subset hop
 
 
-def spmm_rows(A, X, rows, layers=(), alpha=1.0, nsplit=ROWS_NSPLIT, out=None, workspace=None, check_range=True):
+def spmm_rows(A, X, rows, layers=(), alpha=1.0, nsplit=ROWS_NSPLIT, out=None, workspace=None, check_range=True, row_weight=None):
     """out[t] = alpha * ( sum_k layers[k][rows[t]] + (A @ X)[rows[t]] ) for the listed rows only (duplicates allowed)."""
     d = _check_xy(A, X, 'X', A.n_cols)
     _dev(rows, torch.int32, 'rows', 1)
@@ -705,8 +705,10 @@ def spmm_rows(A, X, rows, layers=(), alpha=1.0, nsplit=ROWS_NSPLIT, out=None, wo
     arr = (C.c_void_p * max(len(layers), 1))(*[t.data_ptr() for t in layers])
     s = A._struct(d)
     tok = EVENT_HOOK.begin('rows') if EVENT_HOOK is not None else None
-    check(_lib.lib().arl_spmm_csr_rows_f32(C.byref(s), _ptr(X), d, _ptr(rows), n, nsplit, C.cast(arr, C.c_void_p), len(layers), alpha, _ptr(out),
-                                           _ptr(workspace), _stream()), 'arl_spmm_csr_rows_f32')
+    if row_weight is not None and (_dev(row_weight, torch.float32, 'row_weight', 1).numel() != n):
+        raise ValueError('spmm_rows: row_weight must have one entry per listed row')
+    check(_lib.lib().arl_spmm_csr_rows_f32(C.byref(s), _ptr(X), d, _ptr(rows), n, nsplit, C.cast(arr, C.c_void_p), len(layers), alpha, _ptr(row_weight),
+                                           _ptr(out), _ptr(workspace), _stream()), 'arl_spmm_csr_rows_f32')
     if tok is not None:
         EVENT_HOOK.end(tok)
     return out
@@ -720,8 +722,10 @@ def mark_rows_(flags, idx, value, check_range=True):
     return flags
 
 
-def batch_rows_set_(G, flags, bits, idx, src, scale=1.0, check_range=True):
-    """G[idx[t]] += scale * src[t] (duplicates accumulate), flags[idx[t]] = 1, bit idx[t] of `bits` set: one launch."""
+def batch_rows_set_(G, flags, bits, idx, src, scale=1.0, check_range=True, row_scale=None, dup_bits=None):
+    """G[idx[t]] += scale * row_scale[t] * src[t] (duplicates accumulate in index order: ordered, no float atomics), flags[idx[t]] = 1,
+    bit idx[t] of `bits` set.  row_scale: optional [n] per-contribution factors.  dup_bits: optional second all-zero bitmap like `bits`; a first
+    launch records the rows named more than once in it and only those take the ordered scan (pass it to batch_rows_clear_ too)."""
     _dev(G, torch.float32, 'G', 2); _dev(flags, torch.uint8, 'flags', 1); _dev(bits, torch.int32, 'bits', 1); _dev(idx, torch.int32, 'idx', 1)
     _dev(src, torch.float32, 'src', 2)
     N, d = G.shape
@@ -729,18 +733,25 @@ def batch_rows_set_(G, flags, bits, idx, src, scale=1.0, check_range=True):
         raise ValueError('batch_rows_set_: shape mismatch')
     if check_range and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= N):
         raise IndexError('batch_rows_set_: index out of range')
-    check(_lib.lib().arl_batch_rows_set_f32(_ptr(G), _ptr(flags), _ptr(bits), _ptr(idx), idx.numel(), d, _ptr(src), scale, _stream()), 'arl_batch_rows_set_f32')
+    if row_scale is not None and _dev(row_scale, torch.float32, 'row_scale', 1).numel() != idx.numel():
+        raise ValueError('batch_rows_set_: row_scale must have one entry per index')
+    if dup_bits is not None and _dev(dup_bits, torch.int32, 'dup_bits', 1).numel() != bits.numel():
+        raise ValueError('batch_rows_set_: dup_bits must have the size of bits')
+    check(_lib.lib().arl_batch_rows_set_f32(_ptr(G), _ptr(flags), _ptr(bits), _ptr(idx), idx.numel(), d, _ptr(src), scale, _ptr(row_scale), _ptr(dup_bits),
+                                            _stream()), 'arl_batch_rows_set_f32')
 
 
-def batch_rows_clear_(G, flags, bits, idx, check_range=True):
-    """Rows idx of G zeroed, their byte flags and bitmap bits cleared: one launch."""
+def batch_rows_clear_(G, flags, bits, idx, check_range=True, dup_bits=None):
+    """Rows idx of G zeroed, their byte flags and bitmap bits (and `dup_bits` bits, when given) cleared: one launch."""
     _dev(G, torch.float32, 'G', 2); _dev(flags, torch.uint8, 'flags', 1); _dev(bits, torch.int32, 'bits', 1); _dev(idx, torch.int32, 'idx', 1)
     N, d = G.shape
     if flags.numel() != N or bits.numel() != (N + 31) // 32:
         raise ValueError('batch_rows_clear_: shape mismatch')
     if check_range and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= N):
         raise IndexError('batch_rows_clear_: index out of range')
-    check(_lib.lib().arl_batch_rows_clear_f32(_ptr(G), _ptr(flags), _ptr(bits), _ptr(idx), idx.numel(), d, _stream()), 'arl_batch_rows_clear_f32')
+    if dup_bits is not None and _dev(dup_bits, torch.int32, 'dup_bits', 1).numel() != bits.numel():
+        raise ValueError('batch_rows_clear_: dup_bits must have the size of bits')
+    check(_lib.lib().arl_batch_rows_clear_f32(_ptr(G), _ptr(flags), _ptr(bits), _ptr(idx), idx.numel(), d, _ptr(dup_bits), _stream()), 'arl_batch_rows_clear_f32')
 
 def mark_bits_(bits, idx, set_, n_nodes, check_range=True):
     """Set / clear bits idx[t] of a node bitmap (int32 words)."""
@@ -769,9 +780,10 @@ def _check_idx(t, name, hi, B=None):
     return t
 
 
-def bpr_l2_fwd_bwd(emb, item_off, u, p, n, reg, G=None, upstream=1.0, workspace=None, loss_out=None, check_range=True):
+def bpr_l2_fwd_bwd(emb, item_off, u, p, n, reg, G=None, upstream=1.0, workspace=None, loss_out=None, check_range=True, distinct_rows=False):
     """BPR + L2 on rows gathered from the combined table; returns loss_out = [bpr, reg_term, ||U_b||, ||P_b||] (device).
-    If G is given, the gradient w.r.t. `emb` rows is atomically added into it."""
+    If G is given, the gradient w.r.t. `emb` rows is added into it, duplicates in sample order (ordered, no float atomics).
+    distinct_rows=True: the caller guarantees 3B pairwise distinct rows (the compact [3B, d] form with arange indices): no ownership scan."""
     _dev(emb, torch.float32, 'emb', 2)
     N, d = emb.shape
     B = u.numel()
@@ -793,7 +805,7 @@ def bpr_l2_fwd_bwd(emb, item_off, u, p, n, reg, G=None, upstream=1.0, workspace=
     if loss_out is None:
         loss_out = torch.empty(4, dtype=torch.float32, device=emb.device)
     check(_lib.lib().arl_bpr_l2_fwd_bwd_f32(_ptr(emb), d, item_off, _ptr(u), _ptr(p), _ptr(n), B, reg, upstream, _ptr(loss_out), _ptr(G),
-                                            _ptr(workspace), _stream()), 'arl_bpr_l2_fwd_bwd_f32')
+                                            _ptr(workspace), 1 if distinct_rows else 0, _stream()), 'arl_bpr_l2_fwd_bwd_f32')
     return loss_out
 
 
@@ -829,6 +841,36 @@ def scatter_add_rows(dst, idx, src, scale=1.0, check_range=True):
         raise IndexError('scatter_add_rows: index out of range')
     check(_lib.lib().arl_scatter_add_rows_f32(_ptr(dst), _ptr(idx), idx.numel(), dst.shape[1], _ptr(src), scale, _stream()), 'arl_scatter_add_rows_f32')
     return dst
+
+
+def rows_axpy_unique_(dst, src, idx, alpha=1.0, check_range=True):
+    """dst[r] += alpha * src[r] once per DISTINCT row r listed in idx (src: a table that is zero outside the listed rows, e.g. the sparse
+    batch gradient: its rows reach a dense table without a pass over the whole table)."""
+    _dev(dst, torch.float32, 'dst', 2); _dev(src, torch.float32, 'src', 2); _dev(idx, torch.int32, 'idx', 1)
+    if src.shape != dst.shape or src.data_ptr() == dst.data_ptr():
+        raise ValueError('rows_axpy_unique_: dst and src must be distinct tables of one shape')
+    if check_range and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= dst.shape[0]):
+        raise IndexError('rows_axpy_unique_: index out of range')
+    check(_lib.lib().arl_rows_axpy_unique_f32(_ptr(dst), _ptr(src), _ptr(idx), idx.numel(), dst.shape[1], float(alpha), _stream()), 'arl_rows_axpy_unique_f32')
+    return dst
+
+
+def shard_batch_prep(u, p, n, u0, u1, out=None):
+    """Bookkeeping of one global batch on a user shard [u0, u1), one launch: returns (lu [B] local row ids, clamped; own [3B] = [1.0 / 0.0 per
+    sample | ones]: the factors of the batch's user / positive / negative contributions; item_rows [2B] = [p | n]; rows_l [3B] =
+    [lu | Ul + p | Ul + n]).  `out`: the four tensors of a previous call with the same B, reused."""
+    for t, nm in ((u, 'u'), (p, 'p'), (n, 'n')):
+        _dev(t, torch.int32, nm, 1)
+    B = u.numel()
+    if p.numel() != B or n.numel() != B or not (0 <= u0 <= u1):
+        raise ValueError('shard_batch_prep: u, p, n must have one length and 0 <= u0 <= u1')
+    if out is None:
+        out = (torch.empty(B, dtype=torch.int32, device=u.device), torch.empty(3 * B, dtype=torch.float32, device=u.device),
+               torch.empty(2 * B, dtype=torch.int32, device=u.device), torch.empty(3 * B, dtype=torch.int32, device=u.device))
+    lu, own, item_rows, rows_l = out
+    check(_lib.lib().arl_shard_batch_prep_i32(_ptr(u), _ptr(p), _ptr(n), B, int(u0), int(u1), _ptr(lu), _ptr(own), _ptr(item_rows), _ptr(rows_l), _stream()),
+          'arl_shard_batch_prep_i32')
+    return out
 
 
 def infonce_fwd_bwd(v1, v2, tau, want_grad=True, upstream=1.0):

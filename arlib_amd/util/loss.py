@@ -32,13 +32,13 @@ class _BprL2Rows(torch.autograd.Function):
         G = torch.zeros_like(packed)
         # the fused kernel produces d(bpr + reg-term); isolate one of them by a second call with reg = 0 when needed
         if ctx.which == 'both':
-            ops.bpr_l2_fwd_bwd(packed, B, ar, ar, ar + B, ctx.reg, G, upstream=1.0, check_range=False)
+            ops.bpr_l2_fwd_bwd(packed, B, ar, ar, ar + B, ctx.reg, G, upstream=1.0, check_range=False, distinct_rows=True)
         elif ctx.which == 'bpr':
-            ops.bpr_l2_fwd_bwd(packed, B, ar, ar, ar + B, 0.0, G, upstream=1.0, check_range=False)
+            ops.bpr_l2_fwd_bwd(packed, B, ar, ar, ar + B, 0.0, G, upstream=1.0, check_range=False, distinct_rows=True)
         else:
-            ops.bpr_l2_fwd_bwd(packed, B, ar, ar, ar + B, ctx.reg, G, upstream=1.0, check_range=False)
+            ops.bpr_l2_fwd_bwd(packed, B, ar, ar, ar + B, ctx.reg, G, upstream=1.0, check_range=False, distinct_rows=True)
             G2 = torch.zeros_like(packed)
-            ops.bpr_l2_fwd_bwd(packed, B, ar, ar, ar + B, 0.0, G2, upstream=1.0, check_range=False)
+            ops.bpr_l2_fwd_bwd(packed, B, ar, ar, ar + B, 0.0, G2, upstream=1.0, check_range=False, distinct_rows=True)
             G -= G2
         G *= gout
         return G[:B], G[B:2 * B], G[2 * B:], None, None

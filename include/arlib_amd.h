@@ -124,28 +124,35 @@ int arl_spmm_csr_adam_f32(const arl_csr *A, const float *X, int64_t d, float alp
  *   arl_spmm_csr_flagged_f32  Y = alpha*(A X) + beta*Z where X is zero except on rows whose bit is set in the bitmap xbits
  *                             (uint32 words, bit c&31 of word c>>5; NULL = dense gather) and Z is read only where
  *                             zflags != 0 (NULL = everywhere).  xbits: ceil(n_cols/32) words, zflags: [n_rows] bytes.
- *   arl_spmm_csr_rows_f32     out_c[t] = alpha * ( sum_k layers[k][rows[t]] + (A X)[rows[t]] ), t < n_rows_sel: only the
+ *   arl_spmm_csr_rows_f32     out_c[t] = alpha * w[t] * ( sum_k layers[k][rows[t]] + (A X)[rows[t]] ), t < n_rows_sel: only the
  *                             listed rows are produced (duplicates allowed).  Each row is cut into `nsplit` edge ranges;
  *                             workspace = arl_spmm_csr_rows_workspace_bytes(n_rows_sel, nsplit, d).  layers: HOST array of
- *                             n_layers (<= 8) device pointers to [n_rows, d] tables.
+ *                             n_layers (<= 8) device pointers to [n_rows, d] tables.  row_weight: optional [n_rows_sel] factors
+ *                             w (NULL = 1; the user-sharded step passes 1 for samples whose user the rank owns, 0 otherwise).
  *   arl_spmm_csr_adam_f32's zflags has the same meaning (NULL = read Z everywhere).
  *   arl_mark_rows_u8 / arl_zero_rows_f32: flags[idx[t]] = value / dst[idx[t], :] = 0 -- set and clear the batch's sparse state. */
 int arl_spmm_csr_flagged_f32(const arl_csr *A, const float *X, int64_t d, const uint32_t *xbits, float alpha, float beta,
                              const float *Z, const uint8_t *zflags, float *Y, arl_stream_t stream);
 int64_t arl_spmm_csr_rows_workspace_bytes(int64_t n_rows_sel, int64_t nsplit, int64_t d);
 int arl_spmm_csr_rows_f32(const arl_csr *A, const float *X, int64_t d, const int32_t *rows, int64_t n_rows_sel,
-                          int64_t nsplit, const float *const *layers, int64_t n_layers, float alpha, float *out_c,
-                          void *workspace, arl_stream_t stream);
+                          int64_t nsplit, const float *const *layers, int64_t n_layers, float alpha, const float *row_weight,
+                          float *out_c, void *workspace, arl_stream_t stream);
 int arl_mark_rows_u8(uint8_t *flags, const int32_t *idx, int64_t n, int32_t value, arl_stream_t stream);
 /* set (set != 0) or clear the bits idx[t] of a bitmap with atomic OR / AND (duplicates allowed) */
 int arl_mark_rows_bits_u32(uint32_t *bits, const int32_t *idx, int64_t n, int32_t set, arl_stream_t stream);
 int arl_zero_rows_f32(float *dst, const int32_t *idx, int64_t n, int64_t d, arl_stream_t stream);
-/* The three per-batch updates of the sparse-batch step on one index list, fused: G[idx[t]] += scale * src[t] (accumulating over
- * duplicates), flags[idx[t]] = 1, bit idx[t] of `bits` set -- and the clearing counterpart (rows zeroed, flag and bit cleared). */
+/* The three per-batch updates of the sparse-batch step on one index list, fused: G[idx[t]] += scale * row_scale[t] * src[t]
+ * (row_scale optional, NULL = 1), flags[idx[t]] = 1, bit idx[t] of `bits` set -- and the clearing counterpart (rows zeroed, flag and
+ * bit cleared).  Duplicates accumulate IN INDEX ORDER, one wave per distinct row, starting from the value already in G: the association
+ * of CPU index_put_(accumulate=True), i.e. of the reference's gathers under autograd (recommender/LightGCN.py:51-56); no float atomics,
+ * bit-identical from run to run.
+ * dup_bits (optional, a second bitmap of the size of `bits`, all-zero on entry like `bits`): a first launch records in it the rows the list
+ * names more than once, so that only those are summed by the ordered scan and every other row is a plain add (44 -> ~10 us at cfg2); the
+ * clearing call takes the same pointer and zeroes it again. */
 int arl_batch_rows_set_f32(float *G, uint8_t *flags, uint32_t *bits, const int32_t *idx, int64_t n, int64_t d,
-                           const float *src, float scale, arl_stream_t stream);
+                           const float *src, float scale, const float *row_scale, uint32_t *dup_bits, arl_stream_t stream);
 int arl_batch_rows_clear_f32(float *G, uint8_t *flags, uint32_t *bits, const int32_t *idx, int64_t n, int64_t d,
-                             arl_stream_t stream);
+                             uint32_t *dup_bits, arl_stream_t stream);
 
 /* Register-blocked SpMM (d = 64: one column per lane; d = 128: two adjacent columns per lane, 16 operand rows in flight): the same three operations as arl_spmm_csr_f32 / _layersum_f32 / _adam_f32, for the rows
  * of a PLAN.  A wave owns up to rows_per_wave (16 or 32) output rows with register accumulators and consumes one record stream
@@ -228,14 +235,17 @@ int arl_spmm_tiled_adam_f32(const arl_tiled *T, const float *X, int64_t d, float
  * rec_user_emb[user_idx] ... (recommender/LightGCN.py:51-52) and their autograd (index_put accumulate).
  *   loss_out[0] = mean(-log(1e-7 + sigmoid(<u,p>-<u,n>)))   loss_out[1] = reg*(||U_b||_F + ||P_b||_F)
  *   loss_out[2] = ||U_b||_F   loss_out[3] = ||P_b||_F
- *   G[row] += upstream * d(loss)/d(emb[row])  (atomic scatter-add; duplicates accumulate; G pre-zeroed or
- *   holding other gradient terms).  G may be NULL for forward only.
+ *   G[row] += upstream * d(loss)/d(emb[row]): duplicates accumulate IN SAMPLE ORDER (a user row: its samples' terms in order; an item
+ *   row: its positive-role terms in order, then its negative-role ones -- autograd's three index_put_(accumulate) of the reference),
+ *   one wave per distinct row, no float atomics, bit-identical from run to run; G pre-zeroed or holding other gradient terms.
+ *   G may be NULL for forward only.  distinct_rows != 0: the caller guarantees that the 3B rows u[b], item_off + p[b], item_off + n[b]
+ *   are pairwise distinct (the compact [3B, d] batch form) -- the ownership scan is skipped.
  * workspace: arl_bpr_l2_workspace_bytes(B) bytes of device memory.
  * ---------------------------------------------------------------------------------------------- */
 int64_t arl_bpr_l2_workspace_bytes(int64_t B);
 int arl_bpr_l2_fwd_bwd_f32(const float *emb, int64_t d, int64_t item_off, const int32_t *u, const int32_t *p,
                            const int32_t *n, int64_t B, float reg, float upstream, float *loss_out, float *G,
-                           void *workspace, arl_stream_t stream);
+                           void *workspace, int32_t distinct_rows, arl_stream_t stream);
 
 /* User-sharded form of the same loss (one process per GPU holds a block of users): the batch is split by
  * user shard, so the mean (1/B_global) and the two Frobenius norms need the whole batch.
@@ -261,11 +271,19 @@ int arl_sgd_dense_f32(float *p, const float *g, int64_t n, float lr, arl_stream_
 /* ------------------------------------------------------------------------------------------------
  * Row gather / scatter-add helpers (advanced indexing of the propagated tables and its backward).
  *   gather:       dst[t] = src[idx[t]]
- *   scatter_add:  dst[idx[t]] += scale * src[t]   (atomic; duplicates accumulate)
+ *   scatter_add:  dst[idx[t]] += scale * src[t]   (duplicates accumulate in index order -- torch's CPU index_put_(accumulate=True)
+ *                 association, the backward of the reference's advanced-index gathers; ordered, no float atomics, deterministic)
+ *   axpy_unique:  dst[r] += alpha * src[r] once for every DISTINCT row r in idx (src, dst: tables of the same shape)
+ *   shard_batch_prep: user-sharded batch bookkeeping in one launch -- lu[b] = clamp(u[b] - u0, 0, Ul - 1), own [3B] = [(u0 <= u[b] < u1) | 1 | 1]
+ *                 (factors of the batch's user / positive / negative contributions), item_rows = [p | n], rows_l = [lu | Ul + p | Ul + n] with Ul = u1 - u0 (no reference counterpart: main.py:19 pins one device)
  * ---------------------------------------------------------------------------------------------- */
 int arl_gather_rows_f32(const float *src, const int32_t *idx, int64_t n, int64_t d, float *dst, arl_stream_t stream);
 int arl_scatter_add_rows_f32(float *dst, const int32_t *idx, int64_t n, int64_t d, const float *src, float scale,
                              arl_stream_t stream);
+int arl_rows_axpy_unique_f32(float *dst, const float *src, const int32_t *idx, int64_t n, int64_t d, float alpha,
+                             arl_stream_t stream);
+int arl_shard_batch_prep_i32(const int32_t *u, const int32_t *p, const int32_t *n, int64_t B, int64_t u0, int64_t u1,
+                             int32_t *lu, float *own, int32_t *item_rows, int32_t *rows_l, arl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * InfoNCE forward + backward -- replaces util/loss.py:42-49 and its autograd.
@@ -389,6 +407,25 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
  * (attack/White/PGA.py:153-158, CLeaR.py:161-166, DLAttack.py:127-132).  scratch: [rows*cols] fp32. */
 int arl_topn_project_rows_f32(const float *M, int64_t rows, int64_t cols, int64_t n, float *out, int32_t *idx,
                               float *scratch, arl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Item-table exchange of the user-sharded step (no reference counterpart: main.py:19 pins one device).
+ * One process per GPU.  arl_comm_unique_id (rank 0) -> the 128 bytes travel to every rank by any side channel (torch.distributed
+ * broadcast) -> arl_comm_init on every rank.  arl_allreduce_item_f32 sum-all-reduces buf[0, n_elems) IN PLACE, asynchronously on `stream`,
+ * as a direct reduce-scatter + all-gather over the point-to-point xGMI links (every rank owns one shard, sums the P partials of it in rank
+ * order -- deterministic, one writer per element -- and sends the result to every peer), cut into n_chunks chunks (1..64); workspace =
+ * arl_allreduce_item_workspace_bytes(n_elems, world, n_chunks), 16-byte aligned like buf.  RCCL is bound at run time (dlopen of the
+ * instance the process already has, or `rccl_path`); without it the arl_comm_* calls return ARL_E_ARG.  Returns 1000 + ncclResult_t on an
+ * RCCL error.  arl_item_exchange_range: the [lo, hi) element range of chunk `chunk` of shard `shard` (host-side arithmetic, for tests).
+ * ---------------------------------------------------------------------------------------------- */
+typedef void *arl_comm_t;
+int arl_comm_load(const char *rccl_path);
+int arl_comm_unique_id(void *id128);
+int arl_comm_init(const void *id128, int64_t rank, int64_t world, arl_comm_t *out);
+int arl_comm_destroy(arl_comm_t comm);
+int arl_item_exchange_range(int64_t n_elems, int64_t world, int64_t n_chunks, int64_t shard, int64_t chunk, int64_t *lo, int64_t *hi);
+int64_t arl_allreduce_item_workspace_bytes(int64_t n_elems, int64_t world, int64_t n_chunks);
+int arl_allreduce_item_f32(arl_comm_t comm, float *buf, int64_t n_elems, int64_t n_chunks, void *workspace, arl_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,17 @@ def row_err(a, b, floor=1e-3):
     return float((np.sqrt(((a - b) ** 2).sum(1)) / den).max()) if nb.size else 0.0
 
 
+def close(a, b, tol=None, row_tol=None):
+    """The parity bar for forwards, gradients and tables against a reference-captured golden: max-norm (rel_err) AND row-wise (row_err).
+    row_tol: a looser row-wise bar where a caller states why (default: the same 1e-4)."""
+    tol = RTOL if tol is None else tol
+    row_tol = tol if row_tol is None else row_tol
+    e1, e2 = rel_err(a, b), row_err(a, b)
+    if not (e1 < tol and e2 < row_tol):
+        print('close(): max-norm error %.3e (bar %.1e), row-wise error %.3e (bar %.1e)' % (e1, tol, e2, row_tol))      # shown with the failing assertion
+    return e1 < tol and e2 < row_tol
+
+
 # fp32 parity tolerance stated by BASELINE.json north_star ("fp32 embeddings within 1e-4 rel")
 RTOL = 1e-4
 

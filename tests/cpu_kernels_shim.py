@@ -54,11 +54,13 @@ def adam_dense(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8):
 
 
 # ---- sparse-batch primitives (same contracts as arlib_amd.ops)
-def spmm_rows(A, X, rows, layers=(), alpha=1.0, nsplit=16, out=None, workspace=None, check_range=True):
+def spmm_rows(A, X, rows, layers=(), alpha=1.0, nsplit=16, out=None, workspace=None, check_range=True, row_weight=None):
     r = rows.numpy().astype(np.int64)
     y = O.spmm((A.rowptr, A.col, A.val), X.numpy())[r].astype(np.float64)
     for t in layers:
         y += t.numpy()[r]
+    if row_weight is not None:
+        y *= row_weight.numpy().astype(np.float64)[:, None]
     res = torch.from_numpy((alpha * y).astype(np.float32))
     if out is not None:
         out.copy_(res)
@@ -92,7 +94,7 @@ def spmm_adam(A, X, alpha, beta, Z, P, M, V, lr, step, betas=(0.9, 0.999), eps=1
     P.copy_(torch.from_numpy(p)); M.copy_(torch.from_numpy(m)); V.copy_(torch.from_numpy(v))
 
 
-def bpr_l2_fwd_bwd(emb, item_off, u, p, n, reg, G=None, upstream=1.0, workspace=None, loss_out=None, check_range=True):
+def bpr_l2_fwd_bwd(emb, item_off, u, p, n, reg, G=None, upstream=1.0, workspace=None, loss_out=None, check_range=True, distinct_rows=False):
     lb, lr_, Gn = O.bpr_l2(emb.numpy(), item_off, u.numpy(), p.numpy(), n.numpy(), reg)
     if G is not None:
         G.add_(torch.from_numpy(Gn))
@@ -196,13 +198,29 @@ def ngcf_combine_bwd(gST, P, E):
     return gS + gT * E, gS + gT * P
 
 
-def batch_rows_set_(G, flags, bits, idx, src, scale=1.0, check_range=True):
+def rows_axpy_unique_(dst, src, idx, alpha=1.0, check_range=True):
+    r = torch.unique(idx.long())
+    dst[r] += alpha * src[r]
+    return dst
+
+
+def shard_batch_prep(u, p, n, u0, u1, out=None):
+    Ul = u1 - u0
+    lu = (u - u0).clamp(0, max(Ul - 1, 0)).to(torch.int32)
+    own = torch.cat([((u >= u0) & (u < u1)).to(torch.float32), torch.ones(2 * u.numel())])
+    item_rows = torch.cat([p, n]).to(torch.int32)
+    return lu, own, item_rows, torch.cat([lu, item_rows + Ul]).to(torch.int32)
+
+
+def batch_rows_set_(G, flags, bits, idx, src, scale=1.0, check_range=True, row_scale=None, dup_bits=None):
+    if row_scale is not None:
+        src = src * row_scale[:, None]
     scatter_add_rows(G, idx, src, scale)
     mark_rows_(flags, idx, 1)
     mark_bits_(bits, idx, True, G.shape[0])
 
 
-def batch_rows_clear_(G, flags, bits, idx, check_range=True):
+def batch_rows_clear_(G, flags, bits, idx, check_range=True, dup_bits=None):
     zero_rows_(G, idx)
     mark_rows_(flags, idx, 0)
     mark_bits_(bits, idx, False, G.shape[0])

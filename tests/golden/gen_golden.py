@@ -536,6 +536,39 @@ def gen_attacks():
     save('g7_attacks.npz', **out)
 
 # --------------------------------------------------------------------------- BiLevelAttackBatch: CW step, relaxProject
+def gen_fake_rows():
+    """The FINAL fake-user rows of unmodified end-to-end DLAttack / CLeaR runs of the reference (same protocol as the product's end-to-end test:
+    seedSet(2018), LightGCN d = 16 L = 2 trained one epoch, posionDataAttack(deepcopy(rec)); every random draw from the reference's own
+    generators, nothing patched) -- also on an NGCF d = 128 victim for DLAttack (BASELINE config 5's pairing)."""
+    import io, contextlib
+    from copy import deepcopy
+    from attack.White.DLAttack import DLAttack
+    from attack.White.CLeaR import CLeaR
+    from recommender.NGCF import NGCF
+    os.makedirs('data/clean/ml-100k', exist_ok=True)
+    undo_shim = _scipy_torch_index_shim()
+    out = {}
+    try:
+        for tag, cls, F, rec_cls, rkw in (('dl', DLAttack, 2, LightGCN, dict(emb_size=16, n_layers=2)), ('cl', CLeaR, 3, LightGCN, dict(emb_size=16, n_layers=2)),
+                                          ('dl_ngcf128', DLAttack, 2, NGCF, dict(emb_size=128, n_layers=3, model_name='NGCF'))):
+            rargs = rec_args(maxEpoch=1, **rkw)
+            seedSet(2018)
+            data = DataLoader(rargs)
+            rec = rec_cls(rargs, data)
+            with contextlib.redirect_stdout(io.StringIO()):
+                rec.train(Epoch=1, evalNum=5)
+            atk = cls(_attack_args(attackModelName=cls.__name__, maliciousUserSize=F), data)
+            with contextlib.redirect_stdout(io.StringIO()):
+                res = sp.csr_matrix(atk.posionDataAttack(deepcopy(rec)))
+            U = atk.userNum
+            out[tag + '_targets'] = np.array(atk.targetItem, np.int32)
+            out[tag + '_fake_rows'] = np.asarray(res[U:, :].todense(), np.float32)
+            print(tag, 'fake row sums', out[tag + '_fake_rows'].sum(1))
+    finally:
+        undo_shim()
+    save('g20_fake_rows.npz', **out)
+
+
 def gen_bilevel():
     import io, contextlib
     from copy import deepcopy
@@ -1254,6 +1287,8 @@ if __name__ == '__main__':
             gen_ngcf128()
         if 'victims' in only:
             gen_victims()
+        if 'fake_rows' in only:
+            gen_fake_rows()
         sys.exit(0)
     gen_dataset()
     data = gen_sampler()
@@ -1278,4 +1313,5 @@ if __name__ == '__main__':
     gen_gta()
     gen_ngcf128()
     gen_victims()
+    gen_fake_rows()
     print('done; scratch dir', SCRATCH)

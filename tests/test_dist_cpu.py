@@ -64,7 +64,35 @@ def sp_mask(pairs, U, I, u0, u1):
     return rp, np.ascontiguousarray(pairs[sel, 1].astype(np.int32)) if sel.any() else np.zeros(1, np.int32)
 
 
-def _worker(rank, world, port, ret, sparse):
+class DeferredPoisonGloo:
+    """Overlap-hazard double for the CPU suite (the GPU suite has the same one over host-staged gloo): all_reduce_async() sets the partial aside
+    and fills the buffer with NaN; the reduction runs inside wait().  A step that reads or writes a buffer whose all-reduce is in flight cannot
+    produce the oracle's tables."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+
+    class _Work:
+        def __init__(self, dist, t, saved):
+            self.dist, self.t, self.saved = dist, t, saved
+
+        def wait(self):
+            self.dist.all_reduce(self.saved)
+            self.t.copy_(self.saved)
+            return True
+
+    def all_reduce(self, t):
+        self.dist.all_reduce(t)
+        return t
+
+    def all_reduce_async(self, t):
+        saved = t.detach().clone()
+        t.fill_(float('nan'))
+        return self._Work(self.dist, t, saved)
+
+
+def _worker(rank, world, port, ret, sparse, deferred=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import torch.distributed as dist
     import cpu_kernels_shim as shim
@@ -73,7 +101,8 @@ def _worker(rank, world, port, ret, sparse):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.set_num_threads(1)
     U, I, d, L, pairs, E0, batches = small_problem()
-    eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cpu', rank, world, torch.from_numpy(E0), kernels=shim)
+    eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cpu', rank, world, torch.from_numpy(E0), kernels=shim,
+                                              comm=DeferredPoisonGloo() if deferred else None)
     losses = []
     for u, p, n in batches:
         lo = (eng.step_sparse if sparse else eng.step)(torch.from_numpy(u), torch.from_numpy(p), torch.from_numpy(n))
@@ -90,14 +119,14 @@ def _worker(rank, world, port, ret, sparse):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,sparse', [(2, False), (2, True), (3, True)])
-def test_sharded_engine_gloo_matches_single_process_oracle(world, sparse):
+@pytest.mark.parametrize('world,sparse,deferred', [(2, False, False), (2, True, False), (3, True, False), (2, True, True), (3, True, True)])
+def test_sharded_engine_gloo_matches_single_process_oracle(world, sparse, deferred):
     U, I, d, L, pairs, E0, batches = small_problem()
     ref_table, ref_losses = oracle_run(U, I, d, L, pairs, E0, batches)
     mgr = mp.Manager()
     ret = mgr.dict()
     port = free_port()
-    mp.spawn(_worker, args=(world, port, ret, sparse), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, ret, sparse, deferred), nprocs=world, join=True)
     assert np.allclose(ret['losses'], ref_losses, rtol=RTOL, atol=0)
     assert rel_err(ret['table'], ref_table) < RTOL
     # the sharded masked top-10 equals the single-process one on the trained table
@@ -366,3 +395,92 @@ def test_sharded_pga_steps_gloo_match_single_process_oracle(world):
     assert (ret['top'] == ref_idx).mean() > 0.995
     assert np.allclose(ret['losses'], ref_losses, rtol=RTOL, atol=0)
     assert rel_err(ret['S'], ref_S) < RTOL and (ret['S'] != prob[-1]).any()
+
+
+# ---------------------------------------------------------------------------------------------- direct item exchange (arl_allreduce_item_f32)
+def test_item_exchange_partition_tiles_the_buffer():
+    """arl_item_exchange_range (the shard x chunk partition arl_allreduce_item_f32 sends by): every element in exactly one (shard, chunk) range,
+    ranges in order, starts 16-byte aligned -- for ragged sizes, more ranks than 4-element groups, one element, nothing."""
+    import ctypes as C
+    from arlib_amd import _lib
+    L = _lib.lib()
+    for n in (0, 1, 3, 4, 5, 1023, 25_600_000, 1412 * 64, 7):
+        for world in (1, 2, 3, 8):
+            for chunks in (1, 4, 7):
+                pos = 0
+                for q in range(world):
+                    for c in range(chunks):
+                        lo, hi = C.c_int64(), C.c_int64()
+                        assert L.arl_item_exchange_range(n, world, chunks, q, c, C.byref(lo), C.byref(hi)) == 0
+                        assert lo.value == pos and hi.value >= lo.value and (lo.value % 4 == 0 or lo.value == n)
+                        pos = hi.value
+                assert pos == n
+                need = L.arl_allreduce_item_workspace_bytes(n, world, chunks)
+                biggest = max(1, -(-n // world))
+                assert need >= 4 * (world - 1) * -(-biggest // chunks)
+    lo, hi = C.c_int64(), C.c_int64()
+    assert L.arl_item_exchange_range(10, 2, 1, 2, 0, C.byref(lo), C.byref(hi)) == -4          # shard out of range
+
+
+def _direct_worker(rank, world, port, ret, n, chunks):
+    """The schedule of arl_allreduce_item_f32 (direct reduce-scatter, owner sums in rank order, direct all-gather, chunk by chunk) replayed
+    with gloo point-to-point calls over the SAME partition function: the result must equal a plain all-reduce."""
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import torch.distributed as dist
+    from arlib_amd import _lib
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    L = _lib.lib()
+
+    def rng(q, c):
+        lo, hi = C.c_int64(), C.c_int64()
+        assert L.arl_item_exchange_range(n, world, chunks, q, c, C.byref(lo), C.byref(hi)) == 0
+        return lo.value, hi.value
+    g = torch.Generator().manual_seed(100 + rank)
+    buf = torch.randn(n, generator=g)
+    ref = buf.clone(); dist.all_reduce(ref)
+    for c in range(chunks):
+        mlo, mhi = rng(rank, c)
+        reqs, slots = [], {}
+        for q in range(world):
+            if q == rank:
+                continue
+            a, b = rng(q, c)
+            if b > a:
+                reqs.append(dist.isend(buf[a:b].clone(), q))
+            if mhi > mlo:
+                slots[q] = torch.empty(mhi - mlo)
+                reqs.append(dist.irecv(slots[q], q))
+        for r in reqs:
+            r.wait()
+        if mhi > mlo:
+            acc = torch.zeros(mhi - mlo)
+            for r in range(world):                                  # rank order, as shard_sum_kernel
+                acc += buf[mlo:mhi] if r == rank else slots[r]
+            buf[mlo:mhi] = acc
+        reqs = []
+        for q in range(world):
+            if q == rank:
+                continue
+            a, b = rng(q, c)
+            if mhi > mlo:
+                reqs.append(dist.isend(buf[mlo:mhi].clone(), q))
+            if b > a:
+                reqs.append(dist.irecv(buf[a:b], q))
+        for r in reqs:
+            r.wait()
+    gathered = [torch.zeros(n) for _ in range(world)]
+    dist.all_gather(gathered, buf)
+    if rank == 0:
+        ret['err'] = float((buf - ref).abs().max() / ref.abs().max())
+        ret['replicas_equal'] = all(torch.equal(gathered[0], x) for x in gathered)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,n,chunks', [(2, 1412 * 16, 4), (3, 1001, 3), (3, 5, 2)])
+def test_direct_item_exchange_schedule_equals_all_reduce(world, n, chunks):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_direct_worker, args=(world, free_port(), ret, n, chunks), nprocs=world, join=True)
+    assert ret['err'] < 1e-6 and ret['replicas_equal']             # one owner per element: every replica holds the same bits

@@ -11,7 +11,7 @@ from types import SimpleNamespace
 import numpy as np
 import pytest
 import torch
-from conftest import golden, rel_err, row_err, RTOL
+from conftest import golden, rel_err, row_err, close, RTOL
 from test_host_api import make_data
 
 pytestmark = pytest.mark.gpu
@@ -50,13 +50,13 @@ def test_train_two_epochs_matches_reference_run(name):
     assert rec.model._eng is not None and rec.model._eng.t == 44            # the fused device engine ran all 2 x 22 steps (not autograd)
     assert rec.last_train_stats['steps'] == 22 and rec.last_train_stats['fused'] and rec.last_train_stats['loop_seconds'] > 0
     assert random.random() == float(g[name + '_next_random'][0])          # sampler consumed python `random` bit-exactly
-    assert rel_err(rec.model.embedding_dict['user_emb'].detach().cpu().numpy(), g[name + '_user']) < RTOL
-    assert rel_err(rec.model.embedding_dict['item_emb'].detach().cpu().numpy(), g[name + '_item']) < RTOL
-    assert rel_err(rec.best_user_emb.cpu().numpy(), g[name + '_best_user']) < RTOL
+    assert close(rec.model.embedding_dict['user_emb'].detach().cpu().numpy(), g[name + '_user'])
+    assert close(rec.model.embedding_dict['item_emb'].detach().cpu().numpy(), g[name + '_item'])
+    assert close(rec.best_user_emb.cpu().numpy(), g[name + '_best_user'])
     assert rec.bestPerformance[0] == int(g[name + '_best_epoch'][0])
     got = np.array([float(m.strip().split(':')[1]) for m in measure[1:]])
     assert np.allclose(got, g[name + '_measure'], rtol=0, atol=2e-3)       # ranking metrics (a tie can move one hit)
-    assert rel_err(rec.predict(data.id2user[0]), g[name + '_predict0']) < RTOL
+    assert close(rec.predict(data.id2user[0]), g[name + '_predict0'])
     # objects survive deepcopy and pickle (attacks deepcopy recommenders; ARLib torch.save()s them)
     rec2 = copy.deepcopy(rec)
     rec3 = pickle.loads(pickle.dumps(rec))
@@ -85,12 +85,12 @@ def test_autograd_route_with_external_optimizer_matches_golden_steps(ml100k):
         loss = bpr_loss(ue[u], ie[p], ie[n]) + l2_reg_loss(1e-4, ue[u], ie[p])
         opt.zero_grad(); loss.backward()
         if k == 0:
-            assert rel_err(model.embedding_dict['user_emb'].grad.cpu().numpy(), g['grad_user_step0']) < RTOL
-            assert rel_err(model.embedding_dict['item_emb'].grad.cpu().numpy(), g['grad_item_step0']) < RTOL
+            assert close(model.embedding_dict['user_emb'].grad.cpu().numpy(), g['grad_user_step0'])
+            assert close(model.embedding_dict['item_emb'].grad.cpu().numpy(), g['grad_item_step0'])
         opt.step()
         assert abs(loss.item() - g['losses'][k]) <= RTOL * abs(g['losses'][k])
-    assert rel_err(model.embedding_dict['user_emb'].detach().cpu().numpy(), g['user_k3']) < RTOL
-    assert rel_err(model.embedding_dict['item_emb'].detach().cpu().numpy(), g['item_k3']) < RTOL
+    assert close(model.embedding_dict['user_emb'].detach().cpu().numpy(), g['user_k3'])
+    assert close(model.embedding_dict['item_emb'].detach().cpu().numpy(), g['item_k3'])
 
 
 def test_simgcl_step_with_injected_noise_matches_reference():
@@ -113,11 +113,11 @@ def test_simgcl_step_with_injected_noise_matches_reference():
     opt.zero_grad(); loss.backward()
     assert abs(rec_loss.item() - g['rec_loss'][0]) <= RTOL * abs(g['rec_loss'][0])
     assert abs(cl_loss.item() - g['cl_loss'][0]) <= RTOL * abs(g['cl_loss'][0])
-    assert rel_err(model.embedding_dict['user_emb'].grad.cpu().numpy(), g['grad_user']) < RTOL
-    assert rel_err(model.embedding_dict['item_emb'].grad.cpu().numpy(), g['grad_item']) < RTOL
+    assert close(model.embedding_dict['user_emb'].grad.cpu().numpy(), g['grad_user'])
+    assert close(model.embedding_dict['item_emb'].grad.cpu().numpy(), g['grad_item'])
     opt.step()
-    assert rel_err(model.embedding_dict['user_emb'].detach().cpu().numpy(), g['user_k1']) < RTOL
-    assert rel_err(model.embedding_dict['item_emb'].detach().cpu().numpy(), g['item_k1']) < RTOL
+    assert close(model.embedding_dict['user_emb'].detach().cpu().numpy(), g['user_k1'])
+    assert close(model.embedding_dict['item_emb'].detach().cpu().numpy(), g['item_k1'])
     # one epoch through train(): runs, uses device RNG noise, loss finite
     with contextlib.redirect_stdout(io.StringIO()):
         rec.train(Epoch=1, evalNum=1)
@@ -145,17 +145,17 @@ def test_ngcf_forward_and_steps_match_reference(gname, emb, L):
         return model
 
     def check_end(model):
-        assert rel_err(model.embedding_dict['user_emb'].detach().cpu().numpy(), g['user_k3']) < RTOL
-        assert rel_err(model.embedding_dict['item_emb'].detach().cpu().numpy(), g['item_k3']) < RTOL
-        assert rel_err(model.W['w1_0'].detach().cpu().numpy(), g['w1_0_k3']) < RTOL
+        assert close(model.embedding_dict['user_emb'].detach().cpu().numpy(), g['user_k3'])
+        assert close(model.embedding_dict['item_emb'].detach().cpu().numpy(), g['item_k3'])
+        assert close(model.W['w1_0'].detach().cpu().numpy(), g['w1_0_k3'])
 
     def check_grads(model):
-        assert rel_err(model.embedding_dict['user_emb'].grad.cpu().numpy(), g['grad_user']) < RTOL
-        assert rel_err(model.W['w1_0'].grad.cpu().numpy(), g['grad_w1_0']) < RTOL and rel_err(model.W[wl].grad.cpu().numpy(), g['grad_' + wl]) < RTOL
+        assert close(model.embedding_dict['user_emb'].grad.cpu().numpy(), g['grad_user'])
+        assert close(model.W['w1_0'].grad.cpu().numpy(), g['grad_w1_0']) and close(model.W[wl].grad.cpu().numpy(), g['grad_' + wl])
     model = fresh()
     with torch.no_grad():
         u, i = model()
-    assert rel_err(u.cpu().numpy(), g['fwd_user']) < RTOL and rel_err(i.cpu().numpy(), g['fwd_item']) < RTOL
+    assert close(u.cpu().numpy(), g['fwd_user']) and close(i.cpu().numpy(), g['fwd_item'])
     opt = torch.optim.Adam(model.parameters(), lr=0.005)
     for k in range(3):
         bu, bp, bn = (torch.from_numpy(g[x][k].astype(np.int64)).cuda() for x in ('batch_u', 'batch_p', 'batch_n'))
@@ -190,7 +190,7 @@ def test_ngcf_forward_and_steps_match_reference(gname, emb, L):
         assert m3._graph().blocked is not None
         with torch.no_grad():
             u3, i3 = m3()
-        assert rel_err(u3.cpu().numpy(), g['fwd_user']) < RTOL and rel_err(i3.cpu().numpy(), g['fwd_item']) < RTOL
+        assert close(u3.cpu().numpy(), g['fwd_user']) and close(i3.cpu().numpy(), g['fwd_item'])
 
 
 @pytest.mark.parametrize('L', [0, 1, 2, 3])
@@ -267,12 +267,15 @@ def test_ncl_prototype_phase_step_matches_reference(tmp_path, monkeypatch):
     ref = g['losses']
     for got, want in ((rec_loss, ref[0]), (ssl, ref[1]), (proto, ref[2]), (loss, ref[3])):
         assert abs(got.item() - want) <= RTOL * abs(want)
-    assert rel_err(gs[0].cpu().numpy(), g['ssl_grad_user']) < RTOL and rel_err(gs[1].cpu().numpy(), g['ssl_grad_item']) < RTOL
-    assert rel_err(gp[0].cpu().numpy(), g['proto_grad_user']) < RTOL and rel_err(gp[1].cpu().numpy(), g['proto_grad_item']) < RTOL
+    assert close(gs[0].cpu().numpy(), g['ssl_grad_user']) and close(gs[1].cpu().numpy(), g['ssl_grad_item'])
+    # prototype term: softmax over temperature-0.05 logits (|logit| <= 20).  Every entry is within 3e-6 of the table's largest; rows whose
+    # whole gradient is ~1e-2 of the largest row (users already next to their centroid: p - onehot cancels) carry that absolute error at
+    # 6e-4 of their own norm -- hence the row-wise bar of 1e-3 on this term alone
+    assert close(gp[0].cpu().numpy(), g['proto_grad_user'], row_tol=1e-3) and close(gp[1].cpu().numpy(), g['proto_grad_item'], row_tol=1e-3)
     opt.zero_grad(); loss.backward()
-    assert rel_err(ps[0].grad.cpu().numpy(), g['grad_user']) < RTOL and rel_err(ps[1].grad.cpu().numpy(), g['grad_item']) < RTOL
+    assert close(ps[0].grad.cpu().numpy(), g['grad_user']) and close(ps[1].grad.cpu().numpy(), g['grad_item'])
     opt.step()
-    assert rel_err(ps[0].detach().cpu().numpy(), g['user_k1']) < RTOL and rel_err(ps[1].detach().cpu().numpy(), g['item_k1']) < RTOL
+    assert close(ps[0].detach().cpu().numpy(), g['user_k1']) and close(ps[1].detach().cpu().numpy(), g['item_k1'])
     # the class loop: same loss assembled through the hooks (l2_scale, l2_on_negatives, _extra_loss); epochs 0..1 are warm-up (no prototypes)
     with contextlib.redirect_stdout(io.StringIO()):
         rec.train(Epoch=2, evalNum=5)
@@ -296,22 +299,22 @@ def test_xsimgcl_step_with_injected_noise_matches_reference():
     u, p, n = (torch.from_numpy(g[x].astype(np.int64)).cuda() for x in ('batch_u', 'batch_p', 'batch_n'))
     with torch.no_grad():
         u0, i0 = model()
-    assert rel_err(u0.cpu().numpy(), g['fwd_user']) < RTOL and rel_err(i0.cpu().numpy(), g['fwd_item']) < RTOL
+    assert close(u0.cpu().numpy(), g['fwd_user']) and close(i0.cpu().numpy(), g['fwd_item'])
     opt = torch.optim.Adam(model.parameters(), lr=0.005)
     ru, ri, cu, ci = model(True, noises=noise)
     for got, key in ((ru, 'fwdp_user'), (ri, 'fwdp_item'), (cu, 'cl_user'), (ci, 'cl_item')):
-        assert rel_err(got.detach().cpu().numpy(), g[key]) < RTOL, key
+        assert close(got.detach().cpu().numpy(), g[key]), key
     rec_loss = bpr_loss(ru[u], ri[p], ri[n])
     cl_loss = rec.cl_rate * rec.cal_cl_loss([u, p], ru, cu, ri, ci)
     loss = rec_loss + l2_reg_loss(1e-4, ru[u], ri[p]) + cl_loss
     opt.zero_grad(); loss.backward()
     assert abs(rec_loss.item() - g['rec_loss'][0]) <= RTOL * abs(g['rec_loss'][0])
     assert abs(cl_loss.item() - g['cl_loss'][0]) <= RTOL * abs(g['cl_loss'][0])
-    assert rel_err(model.embedding_dict['user_emb'].grad.cpu().numpy(), g['grad_user']) < RTOL
-    assert rel_err(model.embedding_dict['item_emb'].grad.cpu().numpy(), g['grad_item']) < RTOL
+    assert close(model.embedding_dict['user_emb'].grad.cpu().numpy(), g['grad_user'])
+    assert close(model.embedding_dict['item_emb'].grad.cpu().numpy(), g['grad_item'])
     opt.step()
-    assert rel_err(model.embedding_dict['user_emb'].detach().cpu().numpy(), g['user_k1']) < RTOL
-    assert rel_err(model.embedding_dict['item_emb'].detach().cpu().numpy(), g['item_k1']) < RTOL
+    assert close(model.embedding_dict['user_emb'].detach().cpu().numpy(), g['user_k1'])
+    assert close(model.embedding_dict['item_emb'].detach().cpu().numpy(), g['item_k1'])
     # fused engine step from the same start
     U, I = data.user_num, data.item_num
     E0 = torch.from_numpy(np.concatenate([g['user0'], g['item0']])).cuda()
@@ -320,7 +323,7 @@ def test_xsimgcl_step_with_injected_noise_matches_reference():
     assert abs(float(lo[0]) - g['rec_loss'][0]) <= RTOL * abs(g['rec_loss'][0])
     assert abs(cl.item() - g['cl_loss'][0]) <= RTOL * abs(g['cl_loss'][0])
     E = eng.E0.cpu().numpy()
-    assert rel_err(E[:U], g['user_k1']) < RTOL and rel_err(E[U:], g['item_k1']) < RTOL
+    assert close(E[:U], g['user_k1']) and close(E[U:], g['item_k1'])
     assert float(eng.G.abs().max()) == 0.0 and int(eng.flags.max()) == 0       # sparse state left clean
     # layer_cl == L takes the other backward branch: compare fused vs autograd on a second engine
     model.layer_cl = 2
@@ -371,21 +374,21 @@ def test_sgl_views_and_step_match_reference():
     u, p, n = (torch.from_numpy(g[x].astype(np.int64)).cuda() for x in ('batch_u', 'batch_p', 'batch_n'))
     opt = torch.optim.Adam(model.parameters(), lr=0.005)
     ue, ie = model()
-    assert rel_err(ue.detach().cpu().numpy(), g['fwd_user']) < RTOL and rel_err(ie.detach().cpu().numpy(), g['fwd_item']) < RTOL
+    assert close(ue.detach().cpu().numpy(), g['fwd_user']) and close(ie.detach().cpu().numpy(), g['fwd_item'])
     rec_loss = bpr_loss(ue[u], ie[p], ie[n])
     cl_loss = rec.cl_rate * model.cal_cl_loss([u, p], adj1, adj2)
     loss = rec_loss + l2_reg_loss(1e-4, ue[u], ie[p]) + cl_loss
     opt.zero_grad(); loss.backward()
     assert abs(rec_loss.item() - g['rec_loss'][0]) <= RTOL * abs(g['rec_loss'][0])
     assert abs(cl_loss.item() - g['cl_loss'][0]) <= RTOL * abs(g['cl_loss'][0])
-    assert rel_err(model.embedding_dict['user_emb'].grad.cpu().numpy(), g['grad_user']) < RTOL
-    assert rel_err(model.embedding_dict['item_emb'].grad.cpu().numpy(), g['grad_item']) < RTOL
+    assert close(model.embedding_dict['user_emb'].grad.cpu().numpy(), g['grad_user'])
+    assert close(model.embedding_dict['item_emb'].grad.cpu().numpy(), g['grad_item'])
     opt.step()
-    assert rel_err(model.embedding_dict['user_emb'].detach().cpu().numpy(), g['user_k1']) < RTOL
-    assert rel_err(model.embedding_dict['item_emb'].detach().cpu().numpy(), g['item_k1']) < RTOL
+    assert close(model.embedding_dict['user_emb'].detach().cpu().numpy(), g['user_k1'])
+    assert close(model.embedding_dict['item_emb'].detach().cpu().numpy(), g['item_k1'])
     with torch.no_grad():
         v1u, v1i = model(adj1)
-    assert rel_err(v1u.cpu().numpy(), g['view1_user']) < RTOL and rel_err(v1i.cpu().numpy(), g['view1_item']) < RTOL
+    assert close(v1u.cpu().numpy(), g['view1_user']) and close(v1i.cpu().numpy(), g['view1_item'])
     # the fused engine step (sparse-batch schedule over the three graphs) from the same start
     from arlib_amd import engine
     E0 = torch.from_numpy(np.concatenate([g['user0'], g['item0']])).cuda()
@@ -395,7 +398,7 @@ def test_sgl_views_and_step_match_reference():
         assert abs(float(lo[0]) - g['rec_loss'][0]) <= RTOL * abs(g['rec_loss'][0])
         assert abs(cl.item() - g['cl_loss'][0]) <= RTOL * abs(g['cl_loss'][0])
         E = eng.E0.cpu().numpy()
-        assert rel_err(E[:U], g['user_k1']) < RTOL and rel_err(E[U:], g['item_k1']) < RTOL
+        assert close(E[:U], g['user_k1']) and close(E[U:], g['item_k1'])
         assert float(eng.G.abs().max()) == 0.0 and int(eng.flags.max()) == 0
     with contextlib.redirect_stdout(io.StringIO()):
         rec.train(Epoch=1, evalNum=1)
@@ -538,8 +541,8 @@ def test_ngcf_fused_engine_step_matches_reference(gname, emb, L):
     rec, model, opt, eng, cap = run()
     U = data.user_num
     # first step's gradient (captured before Adam consumed it) against the reference's autograd
-    assert rel_err(cap['table'][:U].cpu().numpy(), g['grad_user']) < RTOL and row_err(cap['table'][:U].cpu().numpy(), g['grad_user']) < RTOL
-    assert rel_err(cap['W'][0][:emb].cpu().numpy(), g['grad_w1_0']) < RTOL and rel_err(cap['W'][L - 1][emb:].cpu().numpy(), g['grad_' + wl]) < RTOL
+    assert close(cap['table'][:U].cpu().numpy(), g['grad_user']) and row_err(cap['table'][:U].cpu().numpy(), g['grad_user']) < RTOL
+    assert close(cap['W'][0][:emb].cpu().numpy(), g['grad_w1_0']) and close(cap['W'][L - 1][emb:].cpu().numpy(), g['grad_' + wl])
     # tables and weights after the three steps
     for got, ref in ((model.embedding_dict['user_emb'], g['user_k3']), (model.embedding_dict['item_emb'], g['item_k3']), (model.W['w1_0'], g['w1_0_k3'])):
         got = got.detach().cpu().numpy()

@@ -98,13 +98,16 @@ def test_cfg5_blocked_hop_equals_csr_hop_d128(cfg5):
     zc = ops.spmm(A, X, 0.5, 0.25, Z); zb = ops.spmm(Ab, X, 0.5, 0.25, Z)
     assert float((zb - zc).abs().max() / zc.abs().max()) < 1e-5
     del zc, zb
-    P = torch.randn(N, D, device=DEV, generator=g) * 0.1
-    Pc, Mc, Vc = P.clone(), torch.zeros_like(P), torch.zeros_like(P)
-    Pb, Mb, Vb = P.clone(), torch.zeros_like(P), torch.zeros_like(P)
-    ops.spmm_adam(A, X, 1.0, 1.0, Z, Pc, Mc, Vc, 0.005, 1)
-    ops.spmm_adam(Ab, X, 1.0, 1.0, Z, Pb, Mb, Vb, 0.005, 1)
-    assert float((Pb - Pc).abs().max() / Pc.abs().max()) < 1e-5 and float((Mb - Mc).abs().max() / Mc.abs().max()) < 1e-5
-    del Pc, Mc, Vc, Pb, Mb, Vb, P, Z
+    # (moments well away from zero: with v ~ eps^2 Adam's update g / (|g| + eps) turns rounding differences of g into whole steps)
+    P = torch.randn(N, D, device=DEV, generator=g) * 0.1; M = torch.randn(N, D, device=DEV, generator=g) * 0.01
+    V = torch.rand(N, D, device=DEV, generator=g) * 1e-4 + 1e-6
+    Pc, Mc, Vc = P.clone(), M.clone(), V.clone()
+    Pb, Mb, Vb = P, M, V
+    ops.spmm_adam(A, X, 1.0, 1.0, Z, Pc, Mc, Vc, 0.005, 7)
+    ops.spmm_adam(Ab, X, 1.0, 1.0, Z, Pb, Mb, Vb, 0.005, 7)
+    for xb, xc in ((Pb, Pc), (Mb, Mc), (Vb, Vc)):
+        assert float((xb - xc).abs().max() / xc.abs().max()) < 1e-5
+    del Pc, Mc, Vc, Pb, Mb, Vb, P, M, V, Z
     REPORT['hop_blocked_ms'] = 1e3 * _timed(lambda: ops.spmm(Ab, X, out=yb))
     REPORT['hop_csr_ms'] = 1e3 * _timed(lambda: ops.spmm(A, X, out=yc))
     REPORT['hop_algorithmic_GBps'] = A.spmm_bytes(D) / (REPORT['hop_blocked_ms'] * 1e-3) / 1e9
@@ -163,7 +166,7 @@ def test_cfg5_sampled_rows_against_the_oracle(cfg5):
     for k in (0, len(users) - 1, len(users), len(node) - 1):
         r = int(node[k]); b, e = int(Ar[r]), int(Ar[r + 1])
         assert e - b == rp[k + 1] - rp[k]
-        assert np.allclose(np.sort(Av[b:e].cpu().numpy()), np.sort(val[rp[k]:rp[k + 1]]), rtol=2e-7, atol=0)
+        assert np.allclose(np.sort(Av[b:e].cpu().numpy()), np.sort(val[rp[k]:rp[k + 1]]), rtol=1e-6, atol=0)        # (dinv_r w) dinv_c in fp32 on the device vs one rounding of the float64 value
     REPORT['oracle_rows'] = dict(rows=int(len(node)), edges=int(len(rows)), longest_row=int(deg[node].max()))
 
 

@@ -53,7 +53,33 @@ class HostStagedComm:
         return self._Done()
 
 
-def _worker(rank, world, port, ret, sparse, d=16, schedule='auto'):
+class DeferredPoisonComm(HostStagedComm):
+    """Overlap-hazard double: all_reduce_async() sets the partial aside, fills the buffer with NaN and returns; the reduction happens INSIDE
+    wait() and only then lands in the buffer.  A kernel that reads a buffer whose all-reduce is still in flight reads NaN, and one that writes
+    it loses its data to wait()'s copy -- either way the final tables differ from the oracle.  The pipelined steps (all-reduce of hop h in
+    flight behind A_u(h) and A_i(h+1)) must come out unchanged."""
+
+    class _Work:
+        def __init__(self, comm, t, saved):
+            self.comm, self.t, self.saved = comm, t, saved
+
+        def wait(self):
+            c = self.saved.cpu()
+            self.comm.dist.all_reduce(c)
+            self.t.copy_(c)
+            return True
+
+    def all_reduce_async(self, t):
+        saved = t.detach().clone()
+        t.fill_(float('nan'))
+        return self._Work(self, t, saved)
+
+
+def _comm(kind):
+    return DeferredPoisonComm() if kind == 'deferred' else HostStagedComm()
+
+
+def _worker(rank, world, port, ret, sparse, d=16, schedule='auto', comm='staged'):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import torch.distributed as dist
     from arlib_amd.dist_engine import ShardedPropagationEngine
@@ -61,7 +87,7 @@ def _worker(rank, world, port, ret, sparse, d=16, schedule='auto'):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.cuda.set_device(0)
     U, I, d, L, pairs, E0, batches = small_problem(d)
-    eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cuda:0', rank, world, torch.from_numpy(E0), comm=HostStagedComm(), schedule=schedule)
+    eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cuda:0', rank, world, torch.from_numpy(E0), comm=_comm(comm), schedule=schedule)
     assert (eng.Au.blocked is not None) == (schedule == 'blocked')
     losses = []
     for u, p, n in batches:
@@ -73,18 +99,22 @@ def _worker(rank, world, port, ret, sparse, d=16, schedule='auto'):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('sparse,d,schedule', [(False, 16, 'auto'), (True, 16, 'auto'), (True, 64, 'blocked'), (False, 64, 'blocked')])
-def test_sharded_engine_two_ranks_hip_kernels(sparse, d, schedule):
+@pytest.mark.parametrize('sparse,d,schedule,comm', [(False, 16, 'auto', 'staged'), (True, 16, 'auto', 'staged'), (True, 64, 'blocked', 'staged'),
+                                                   (False, 64, 'blocked', 'staged'), (True, 16, 'auto', 'deferred'), (True, 64, 'blocked', 'deferred'),
+                                                   (False, 16, 'auto', 'deferred')])
+def test_sharded_engine_two_ranks_hip_kernels(sparse, d, schedule, comm):
+    """comm = 'deferred': the reduction completes only inside wait() and the buffer is NaN in between (DeferredPoisonComm) -- proves the
+    pipelined schedule of step_sparse never touches an in-flight buffer."""
     if not torch.cuda.is_available():
         pytest.fail('GPU tests need a GPU')
     U, I, d, L, pairs, E0, batches = small_problem(d)
     ref_table, ref_losses = oracle_run(U, I, d, L, pairs, E0, batches)
-    ret = _spawn(_worker, (sparse, d, schedule))
+    ret = _spawn(_worker, (sparse, d, schedule, comm))
     assert np.allclose(ret['losses'], ref_losses, rtol=RTOL, atol=0)
     assert rel_err(ret['table'], ref_table) < RTOL
 
 
-def _simgcl_worker(rank, world, port, ret):
+def _simgcl_worker(rank, world, port, ret, comm='staged'):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import torch.distributed as dist
     from arlib_amd.dist_engine import ShardedPropagationEngine
@@ -93,7 +123,7 @@ def _simgcl_worker(rank, world, port, ret):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.cuda.set_device(0)
     U, I, d, L, pairs, E0, batch, noise = simgcl_problem()
-    eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cuda:0', rank, world, torch.from_numpy(E0), comm=HostStagedComm(),
+    eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cuda:0', rank, world, torch.from_numpy(E0), comm=_comm(comm),
                                               skip_layer0=True)
     local = lambda a: torch.from_numpy(np.concatenate([a[eng.u0:eng.u1], a[U:]])).cuda()
     lo, cl = eng.step_simgcl(*(torch.from_numpy(x).cuda() for x in batch), noises=[[local(noise[v][h]) for h in range(L)] for v in range(2)])
@@ -109,19 +139,20 @@ def _simgcl_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_sharded_simgcl_two_ranks_hip_kernels():
+@pytest.mark.parametrize('comm', ['staged', 'deferred'])
+def test_sharded_simgcl_two_ranks_hip_kernels(comm):
     if not torch.cuda.is_available():
         pytest.fail('GPU tests need a GPU')
     from test_dist_cpu import simgcl_problem, oracle_simgcl_step
     ref_table, ref_rec, ref_cl = oracle_simgcl_step(*simgcl_problem())
-    ret = _spawn(_simgcl_worker, ())
+    ret = _spawn(_simgcl_worker, (comm,))
     assert abs(ret['rec'] - ref_rec) <= RTOL * abs(ref_rec)
     assert abs(ret['cl'] - ref_cl) <= RTOL * abs(ref_cl)
     assert rel_err(ret['table'], ref_table) < RTOL
     assert ret['replica_diff'] == 0.0
 
 
-def _clear_worker(rank, world, port, ret, skip0):
+def _clear_worker(rank, world, port, ret, skip0, comm='staged'):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import torch.distributed as dist
     from arlib_amd.dist_engine import ShardedPropagationEngine
@@ -130,7 +161,7 @@ def _clear_worker(rank, world, port, ret, skip0):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.cuda.set_device(0)
     U, I, d, L, pairs, E0, n_real, targets, topk, r0, _ = clear_problem(skip0)
-    eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cuda:0', rank, world, torch.from_numpy(E0), comm=HostStagedComm(), skip_layer0=skip0)
+    eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cuda:0', rank, world, torch.from_numpy(E0), comm=_comm(comm), skip_layer0=skip0)
     m = sp_mask(pairs, U, I, eng.u0, eng.u1)
     res, _ = eng.step_clear(targets, n_real, topk, torch.from_numpy(m[0].astype(np.int32)).cuda(), torch.from_numpy(m[1]).cuda(), r0=torch.from_numpy(r0))
     full = eng.gather_full_table().cpu().numpy()
@@ -139,20 +170,20 @@ def _clear_worker(rank, world, port, ret, skip0):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('skip0', [True, False])
-def test_sharded_clear_step_two_ranks_hip_kernels(skip0):
+@pytest.mark.parametrize('skip0,comm', [(True, 'staged'), (False, 'staged'), (True, 'deferred')])
+def test_sharded_clear_step_two_ranks_hip_kernels(skip0, comm):
     """BASELINE config 4 (SimGCL + CLeaR, user-sharded) with the real kernels: masked top-k per shard, staged SFA (arl_sfa_stage1/2/3),
     item-row gradient exchange -- against the single-process oracle composition."""
     if not torch.cuda.is_available():
         pytest.fail('GPU tests need a GPU')
     from test_dist_cpu import clear_problem, oracle_clear_step
     ref_table, ref_cw, ref_sfa = oracle_clear_step(*clear_problem(skip0))
-    ret = _spawn(_clear_worker, (skip0,))
+    ret = _spawn(_clear_worker, (skip0, comm))
     assert abs(ret['cw'] - ref_cw) <= RTOL * abs(ref_cw) and abs(ret['sfa'] - ref_sfa) <= RTOL * abs(ref_sfa)
     assert rel_err(ret['table'], ref_table) < RTOL
 
 
-def _ngcf_worker(rank, world, port, ret):
+def _ngcf_worker(rank, world, port, ret, comm='staged'):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import torch.distributed as dist
     from arlib_amd.dist_engine import ShardedPropagationEngine
@@ -161,7 +192,7 @@ def _ngcf_worker(rank, world, port, ret):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.cuda.set_device(0)
     U, I, d, L, pairs, E0, batches, W1, W2 = ngcf_problem()
-    eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cuda:0', rank, world, torch.from_numpy(E0), comm=HostStagedComm())
+    eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cuda:0', rank, world, torch.from_numpy(E0), comm=_comm(comm))
     eng.init_ngcf(W1, W2)
     losses = []
     for u, p, n in batches:
@@ -173,14 +204,15 @@ def _ngcf_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_sharded_ngcf_two_ranks_hip_kernels():
+@pytest.mark.parametrize('comm', ['staged', 'deferred'])
+def test_sharded_ngcf_two_ranks_hip_kernels(comm):
     """BASELINE config 5's training step (NGCF, user-sharded) with the real kernels against torch autograd on a dense fp64 graph."""
     if not torch.cuda.is_available():
         pytest.fail('GPU tests need a GPU')
     from test_dist_cpu import ngcf_problem, torch_ngcf_steps
     prob = ngcf_problem()
     ref_table, ref_W, ref_losses = torch_ngcf_steps(*prob)
-    ret = _spawn(_ngcf_worker, ())
+    ret = _spawn(_ngcf_worker, (comm,))
     L, d = prob[3], prob[2]
     assert np.allclose(ret['losses'], ref_losses, rtol=RTOL, atol=0)
     assert rel_err(ret['table'], ref_table) < RTOL
@@ -244,3 +276,39 @@ def test_sharded_pga_two_ranks_hip_kernels():
     ret = _spawn(_pga_worker, ())
     assert np.allclose(ret['losses'], ref_losses, rtol=RTOL, atol=0)
     assert rel_err(ret['S'], ref_S) < RTOL
+
+
+def _rccl1_worker(rank, world, port, ret):
+    """One rank on real RCCL: the direct item exchange behind the C ABI (communicator from a unique id, stream hand-over, workspace) and the
+    sharded step routed through it.  With one rank the exchange moves nothing -- what runs here is everything AROUND it."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import torch.distributed as dist
+    from arlib_amd.dist_engine import ShardedPropagationEngine, TorchDistComm
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    comm = TorchDistComm(item_exchange='direct', direct_min_bytes=1024)
+    t = torch.randn(1412 * 64, device='cuda'); ref = t.clone()
+    w = comm.all_reduce_async(t)
+    assert comm._native is not None and comm._native['world'] == 1           # went through arl_comm_init / arl_allreduce_item_f32
+    w.wait(); torch.cuda.synchronize()
+    ok = torch.equal(t, ref)
+    U, I, d, L, pairs, E0, batches = small_problem(64)
+    eng = ShardedPropagationEngine.from_pairs(pairs, U, I, d, L, 1e-4, 0.005, 'cuda:0', 0, 1, torch.from_numpy(E0), comm=comm)
+    losses = []
+    for u, p, n in batches:
+        lo = eng.step_sparse(torch.from_numpy(u).cuda(), torch.from_numpy(p).cuda(), torch.from_numpy(n).cuda())
+        losses.append(float(lo[0] + lo[1]))
+    ret['ok'], ret['table'], ret['losses'] = ok, eng.gather_full_table().cpu().numpy(), losses
+    comm.close()
+    dist.destroy_process_group()
+
+
+def test_direct_item_exchange_one_rank_rccl():
+    if not torch.cuda.is_available():
+        pytest.fail('GPU tests need a GPU')
+    U, I, d, L, pairs, E0, batches = small_problem(64)
+    ref_table, ref_losses = oracle_run(U, I, d, L, pairs, E0, batches)
+    ret = _spawn(_rccl1_worker, (), nprocs=1)
+    assert ret['ok']
+    assert np.allclose(ret['losses'], ref_losses, rtol=RTOL, atol=0) and rel_err(ret['table'], ref_table) < RTOL

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 import torch
-from conftest import golden, rel_err, RTOL
+from conftest import golden, rel_err, close, RTOL
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -42,12 +42,12 @@ def run_golden(mods, ml100k, g, L, lr, opt, snaps):
         if k == 0:
             lo, grad = eng.grad(u, p, n)
             gr = grad.cpu().numpy()
-            assert rel_err(gr[:U], g['grad_user_step0']) < RTOL and rel_err(gr[U:], g['grad_item_step0']) < RTOL
+            assert close(gr[:U], g['grad_user_step0']) and close(gr[U:], g['grad_item_step0'])
         lo = eng.step(u, p, n).cpu().numpy()
         assert abs(lo[0] + lo[1] - g['losses'][k]) <= RTOL * abs(g['losses'][k])
         if (k + 1) in snaps:
             E = eng.E0.cpu().numpy()
-            assert rel_err(E[:U], g['user_k%d' % (k + 1)]) < RTOL and rel_err(E[U:], g['item_k%d' % (k + 1)]) < RTOL
+            assert close(E[:U], g['user_k%d' % (k + 1)]) and close(E[U:], g['item_k%d' % (k + 1)])
     return eng
 
 
@@ -55,14 +55,14 @@ def test_lightgcn_adam_golden_10_steps(mods, ml100k):
     g = golden('g5_lightgcn_adam.npz')
     eng = run_golden(mods, ml100k, g, 3, 0.005, 'adam', {1, 3, 10})
     U = ml100k['U']
-    assert rel_err(eng.m[:U].cpu().numpy(), g['m_user']) < RTOL and rel_err(eng.v[U:].cpu().numpy(), g['v_item']) < RTOL
+    assert close(eng.m[:U].cpu().numpy(), g['m_user']) and close(eng.v[U:].cpu().numpy(), g['v_item'])
 
 
 def test_gmf_adam_golden_25_steps(mods, ml100k):
     g = golden('g5_gmf_adam.npz')
     eng = run_golden(mods, ml100k, g, 0, 0.005, 'adam', {3, 25})
     U = ml100k['U']
-    assert rel_err(eng.m[U:].cpu().numpy(), g['m_item']) < RTOL and rel_err(eng.v[:U].cpu().numpy(), g['v_user']) < RTOL
+    assert close(eng.m[U:].cpu().numpy(), g['m_item']) and close(eng.v[:U].cpu().numpy(), g['v_user'])
 
 
 def test_lightgcn_sgd_golden(mods, ml100k):
@@ -76,7 +76,7 @@ def test_lightgcn_forward_golden(mods, ml100k, L):
     U, I = ml100k['U'], ml100k['I']
     eng = engine.PropagationEngine(ml_graph(ops, ml100k), U, I, 32, L, 1e-4, 0.005, DEV, table=T(np.concatenate([g['lgn_user0'], g['lgn_item0']])))
     out = eng.forward().cpu().numpy()
-    assert rel_err(out[:U], g['lgn_L%d_user' % L]) < RTOL and rel_err(out[U:], g['lgn_L%d_item' % L]) < RTOL
+    assert close(out[:U], g['lgn_L%d_user' % L]) and close(out[U:], g['lgn_L%d_item' % L])
 
 
 def test_simgcl_forward_and_backward_golden(mods, ml100k):
@@ -86,9 +86,9 @@ def test_simgcl_forward_and_backward_golden(mods, ml100k):
     E0 = np.concatenate([g['user0'], g['item0']])
     eng = engine.PropagationEngine(ml_graph(ops, ml100k), U, I, 16, 2, 1e-4, 0.005, DEV, skip_layer0=True, table=T(E0))
     out = eng.forward().cpu().numpy()
-    assert rel_err(out[:U], g['fwd_user']) < RTOL and rel_err(out[U:], g['fwd_item']) < RTOL
+    assert close(out[:U], g['fwd_user']) and close(out[U:], g['fwd_item'])
     outp = eng.forward(noises=[T(g['noise'][0]), T(g['noise'][1])], eps=0.1).cpu().numpy()
-    assert rel_err(outp[:U], g['fwdp_user']) < RTOL and rel_err(outp[U:], g['fwdp_item']) < RTOL
+    assert close(outp[:U], g['fwdp_user']) and close(outp[U:], g['fwdp_item'])
     # backward of the skip-0 mean against the oracle's Horner restatement
     rng = np.random.default_rng(0)
     G = np.zeros_like(E0); rows = rng.integers(0, U + I, 500); G[rows] = rng.standard_normal((500, 16)).astype(np.float32)
@@ -252,7 +252,7 @@ def test_simgcl_fused_step_matches_reference(mods, ml100k):
     assert abs(lo[0] - g['rec_loss'][0]) <= RTOL * abs(g['rec_loss'][0])
     assert abs(cl.item() - g['cl_loss'][0]) <= RTOL * abs(g['cl_loss'][0])
     E = eng.E0.cpu().numpy()
-    assert rel_err(E[:U], g['user_k1']) < RTOL and rel_err(E[U:], g['item_k1']) < RTOL
+    assert close(E[:U], g['user_k1']) and close(E[U:], g['item_k1'])
     assert float(eng.G.abs().max()) == 0.0 and int(eng.flags.max()) == 0
 
 

@@ -360,6 +360,15 @@ def test_ordered_accumulation_is_sequential_and_bit_exact(ops, n, d):
     assert np.array_equal(G.cpu().numpy(), want)
     wantf = np.zeros(N, np.uint8); wantf[idx] = 1
     assert np.array_equal(flags.cpu().numpy(), wantf)
+    # with the duplicate bitmap (only rows named more than once take the ordered scan): same bits, and the bitmap holds exactly those rows
+    G2 = T(base.copy()); flags2 = torch.zeros_like(flags); bits2 = torch.zeros_like(bits); dup = torch.zeros_like(bits)
+    ops.batch_rows_set_(G2, flags2, bits2, T(idx), T(src), 0.37, dup_bits=dup)
+    assert np.array_equal(G2.cpu().numpy(), want) and torch.equal(flags2, flags) and torch.equal(bits2, bits)
+    cnt = np.bincount(idx, minlength=N)
+    dn = dup.cpu().numpy().view(np.uint32)
+    assert np.array_equal(((dn[np.arange(N) >> 5] >> (np.arange(N) & 31)) & 1).astype(bool), cnt > 1)
+    ops.batch_rows_clear_(G2, flags2, bits2, T(idx), dup_bits=dup)
+    assert int(flags2.max()) == 0 and int(bits2.abs().max()) == 0 and int(dup.abs().max()) == 0
 
 
 def test_bpr_backward_ordered(ops):
