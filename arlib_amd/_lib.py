@@ -74,7 +74,7 @@ _SIGS = {
     'arl_sgd_dense_f32': (C.c_int, [_vp, _vp, _i64, _f, _vp]),
     'arl_gather_rows_f32': (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     'arl_scatter_add_rows_f32': (C.c_int, [_vp, _vp, _i64, _i64, _vp, _f, _vp]),
-    'arl_rows_axpy_unique_f32': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _f, _vp]),
+    'arl_rows_axpy_unique_f32': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _f, _vp, _vp]),
     'arl_shard_batch_prep_i32': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     'arl_infonce_workspace_bytes': (_i64, [_i64, _i64]),
     'arl_infonce_fwd_bwd_f32': (C.c_int, [_vp, _vp, _i64, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp]),

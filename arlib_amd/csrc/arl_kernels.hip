@@ -370,6 +370,65 @@ __device__ __forceinline__ bool ordered_scan(int c0, int c1, int t, long long ro
     return true;
 }
 
+// The same scan over a copy of the window's rows in LDS (staged once per workgroup by stage_rows): one dependent global-memory latency per
+// 256 entries becomes an LDS read -- the scan of a 6 144-entry batch list drops from ~10 us to ~1 us per wave.
+template <class OnHit>
+__device__ __forceinline__ bool ordered_scan_lds(const int32_t *srows, int c0, int c1, int t, int row, int lane, OnHit on_hit) {
+    const int n = c1 - c0, tl = t - c0;
+    for (int base = 0; base < n; base += 512) {
+        int v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = base + 64 * i + lane;
+            v[i] = j < n ? srows[j] : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            unsigned long long m = __ballot(v[i] == row);
+            const int b0 = base + 64 * i;
+            if (b0 < tl) {
+                const int lim = tl - b0;
+                if (lim >= 64 ? m != 0ull : (m & ((1ull << lim) - 1ull)) != 0ull) return false;
+            }
+            while (m) {
+                const int tt = c0 + b0 + __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                on_hit(tt);
+            }
+        }
+    }
+    return true;
+}
+// group form: `on_group(m, g0)` receives the 64-bit hit mask of entries g0 .. g0 + 63 (absolute indices), groups in ascending order
+template <class OnGroup>
+__device__ __forceinline__ bool ordered_scan_lds_groups(const int32_t *srows, int c0, int c1, int t, int row, int lane, OnGroup on_group) {
+    const int n = c1 - c0, tl = t - c0;
+    for (int base = 0; base < n; base += 512) {
+        int v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = base + 64 * i + lane;
+            v[i] = j < n ? srows[j] : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned long long m = __ballot(v[i] == row);
+            const int b0 = base + 64 * i;
+            if (b0 < tl) {
+                const int lim = tl - b0;
+                if (lim >= 64 ? m != 0ull : (m & ((1ull << lim) - 1ull)) != 0ull) return false;
+            }
+            if (m) on_group(m, c0 + b0);
+        }
+    }
+    return true;
+}
+template <class RowOf>
+__device__ __forceinline__ void stage_rows(int32_t *srows, int c0, int c1, RowOf rowof) {
+    for (int j = threadIdx.x; j < c1 - c0; j += kBlock) srows[j] = (int32_t)rowof(c0 + j);
+    __syncthreads();
+}
+
 // Which rows does the list name more than once?  One thread per entry sets the row's bit in `bits`; an entry that finds it already set
 // sets the row's bit in `dup`.  WHICH entry arrives second is a race, the resulting SET of duplicated rows is not.  With it the accumulation
 // kernel below scans the list only for the duplicated rows (a few hundred of a 6 144-row batch) -- 44 -> ~10 us per call at cfg2.
@@ -388,12 +447,14 @@ __global__ __launch_bounds__(kBlock) void rows_add_ordered_kernel(float *__restr
                                                                    const int32_t *__restrict__ idx, int c0, int c1, int d,
                                                                    const float *__restrict__ src, float scale, const float *__restrict__ row_scale,
                                                                    const uint32_t *__restrict__ dup) {
+    extern __shared__ int32_t srows[];
     const int lane = threadIdx.x & 63;
     const int t = c0 + blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (t >= c1) return;
-    const long long row = idx[t];
+    const bool valid = t < c1;
+    const int row = valid ? idx[t] : 0;
     float *o = dst + (size_t)row * d;
-    if (dup && !((dup[row >> 5] >> (row & 31)) & 1u)) {               // the list names this row once (rows_mark_dups_kernel): no scan, no order to keep
+    const bool fast = valid && dup && !((dup[row >> 5] >> (row & 31)) & 1u);
+    if (fast) {                                                       // the list names this row once (rows_mark_dups_kernel): no scan, no order to keep
         const float sc = row_scale ? scale * row_scale[t] : scale;
         const float *s = src + (size_t)t * d;
         for (int k = lane; k < d; k += kWave) {
@@ -402,20 +463,39 @@ __global__ __launch_bounds__(kBlock) void rows_add_ordered_kernel(float *__restr
             o[k] = o[k] + c;
         }
         if (MARK && lane == 0) flags[row] = 1;
-        return;
     }
+    if (!__syncthreads_or(valid && !fast)) return;                    // nothing to scan in this workgroup
+    stage_rows(srows, c0, c1, [&](int j) { return idx[j]; });
+    if (!valid || fast) return;
     for (int k0 = 0; k0 < d; k0 += 256) {
         float acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const int k = k0 + 64 * i + lane; acc[i] = k < d ? o[k] : 0.f; }
-        const bool owner = ordered_scan(c0, c1, t, row, lane, [&](int j) { return idx[j]; }, [&](int tt) {
+        // hits of one 64-entry group arrive together (`m`): their rows are loaded four at a time and added in index order -- a row the batch
+        // names 60 times (a popular item) is otherwise 60 dependent load -> add round trips on one wave, the kernel's tail
+        const bool owner = ordered_scan_lds_groups(srows, c0, c1, t, row, lane, [&](unsigned long long m, int g0) {
 #pragma clang fp contract(off)                       // index_put_ adds the ROUNDED product scale * src: no fused multiply-add here
-            const float *s = src + (size_t)tt * d;
-            const float sc = row_scale ? scale * row_scale[tt] : scale;     // optional per-contribution factor (sharded batch: 1 for own samples, 0 for foreign ones)
+            while (m) {
+                int tt[4]; float x[4][4], sc[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = k0 + 64 * i + lane;
-                if (k < d) { const float c = sc * s[k]; acc[i] = acc[i] + c; }
+                for (int q = 0; q < 4; ++q) {
+                    tt[q] = -1;
+                    if (m) { tt[q] = g0 + __ffsll((long long)m) - 1; m &= m - 1ull; }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (tt[q] < 0) continue;
+                    const float *s = src + (size_t)tt[q] * d;
+                    sc[q] = row_scale ? scale * row_scale[tt[q]] : scale;     // optional per-contribution factor (sharded batch: 1 for own samples, 0 for foreign ones)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const int k = k0 + 64 * i + lane; x[q][i] = k < d ? s[k] : 0.f; }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (tt[q] < 0) continue;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const float c = sc[q] * x[q][i]; acc[i] = acc[i] + c; }
+                }
             }
         });
         if (!owner) return;
@@ -873,13 +953,23 @@ __global__ __launch_bounds__(kBlock) void bpr_finalize_kernel(int B, float reg, 
 // dst[r] += alpha * src[r] ONCE for every distinct row r of the list (duplicates in the list are ignored): adds the listed rows of a table that
 // is zero elsewhere (the sparse batch gradient G) into a dense one without a pass over the whole table.
 __global__ __launch_bounds__(kBlock) void rows_axpy_unique_kernel(float *__restrict__ dst, const float *__restrict__ src, const int32_t *__restrict__ idx,
-                                                                   int c0, int c1, int d, float alpha) {
+                                                                   int c0, int c1, int d, float alpha, const uint32_t *__restrict__ dup, int lds_n) {
+    extern __shared__ int32_t srows[];
     const int lane = threadIdx.x & 63;
     const int t = c0 + blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (t >= c1) return;
-    const long long row = idx[t];
-    // first occurrence in the WHOLE list (windows are independent launches, so the scan always starts at 0)
-    if (!ordered_scan(0, t, t, row, lane, [&](int j) { return idx[j]; }, [&](int) {})) return;
+    const bool valid = t < c1;
+    const long long row = valid ? idx[t] : 0;
+    // first occurrence in the WHOLE list (windows are independent launches, so the scan always starts at 0); rows whose bit is clear in
+    // `dup` (a bitmap of the rows some list CONTAINING this one names twice, optional) are named once: no scan
+    const bool scan = valid && (!dup || ((dup[row >> 5] >> (row & 31)) & 1u));
+    if (lds_n > 0) {                                                  // the whole list fits one window: scan a staged copy
+        if (__syncthreads_or(scan)) stage_rows(srows, 0, lds_n, [&](int j) { return idx[j]; });
+        if (!valid) return;
+        if (scan && !ordered_scan_lds(srows, 0, t, t, (int)row, lane, [&](int) {})) return;
+    } else {
+        if (!valid) return;
+        if (scan && !ordered_scan(0, t, t, row, lane, [&](int j) { return idx[j]; }, [&](int) {})) return;
+    }
     float *o = dst + (size_t)row * d;
     const float *x = src + (size_t)row * d;
     for (int k = lane; k < d; k += kWave) o[k] = fmaf(alpha, x[k], o[k]);
@@ -910,12 +1000,13 @@ __global__ __launch_bounds__(kBlock) void bpr_bwd_kernel(const float *__restrict
                                                           const int32_t *__restrict__ ni, int B, float reg, float upstream,
                                                           const float *__restrict__ ws, const float *__restrict__ out,
                                                           float *__restrict__ G, int c0, int c1, int distinct) {
+    extern __shared__ int32_t srows[];
     const int lane = threadIdx.x & 63;
     const int t = c0 + blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (t >= c1) return;
-    if (distinct) { c0 = t; c1 = t + 1; }                           // the caller guarantees 3B distinct rows (compact batch form): every entry owns its row
 #define ARL_ROWOF_BPR(j) ((j) < B ? (long long)ui[j] : ((j) < 2 * B ? item_off + pi[(j) - B] : item_off + ni[(j) - 2 * B]))
-    const long long row = ARL_ROWOF_BPR(t);
+    if (!distinct) stage_rows(srows, c0, c1, [&](int j) { return ARL_ROWOF_BPR(j); });      // the window's rows, once per workgroup
+    if (t >= c1) return;
+    const int row = (int)ARL_ROWOF_BPR(t);
     const float cu = out[2] > 0.f ? upstream * reg / out[2] : 0.f, cp = out[3] > 0.f ? upstream * reg / out[3] : 0.f;
     float *o = G + (size_t)row * d;
     const float *own = emb + (size_t)row * d;
@@ -923,7 +1014,7 @@ __global__ __launch_bounds__(kBlock) void bpr_bwd_kernel(const float *__restrict
         float acc[4], mine[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const int k = k0 + 64 * i + lane; acc[i] = k < d ? o[k] : 0.f; mine[i] = k < d ? own[k] : 0.f; }
-        const bool owner = ordered_scan(c0, c1, t, row, lane, [&](int j) { return ARL_ROWOF_BPR(j); }, [&](int tt) {
+        auto term = [&](int tt) {
             const int kind = tt / B, b = tt - kind * B;
             const float g = ws[b] * upstream;
             const float *x = emb + (size_t)(kind == 0 ? item_off + pi[b] : (long long)ui[b]) * d;   // the other operand: positive row (user term) / user row (item terms)
@@ -939,8 +1030,10 @@ __global__ __launch_bounds__(kBlock) void bpr_bwd_kernel(const float *__restrict
                     acc[i] = __fadd_rn(acc[i], c);
                 }
             }
-        });
-        if (!owner) return;
+        };
+        // distinct: the caller guarantees 3B distinct rows (compact batch form) -- every entry owns its row, nothing to scan
+        if (distinct) term(t);
+        else if (!ordered_scan_lds(srows, c0, c1, t, row, lane, term)) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const int k = k0 + 64 * i + lane; if (k < d) o[k] = acc[i]; }
     }
@@ -2430,7 +2523,7 @@ static int launch_bpr_bwd(const float *emb, int64_t d, int64_t item_off, const i
     const int64_t total = 3 * B;
     for (int64_t c0 = 0; c0 < total; c0 += kOrderedWindow) {
         const int64_t c1 = c0 + kOrderedWindow < total ? c0 + kOrderedWindow : total;
-        hipLaunchKernelGGL(bpr_bwd_kernel, dim3((unsigned)((c1 - c0 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, st, emb, (int)d,
+        hipLaunchKernelGGL(bpr_bwd_kernel, dim3((unsigned)((c1 - c0 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), distinct ? 0 : (size_t)(c1 - c0) * 4, st, emb, (int)d,
                            (long long)item_off, u, p, n, (int)B, reg, upstream, ws, norms, G, (int)c0, (int)c1, distinct);
         ARL_LAUNCH_CHECK();
     }
@@ -2670,7 +2763,7 @@ int arl_batch_rows_set_f32(float *G, uint8_t *flags, uint32_t *bits, const int32
     }
     for (int64_t c0 = 0; c0 < n; c0 += kOrderedWindow) {                 // ordered (atomic-free) accumulation, one window per launch
         const int64_t c1 = c0 + kOrderedWindow < n ? c0 + kOrderedWindow : n;
-        hipLaunchKernelGGL(rows_add_ordered_kernel<true>, dim3((unsigned)((c1 - c0 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
+        hipLaunchKernelGGL(rows_add_ordered_kernel<true>, dim3((unsigned)((c1 - c0 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), (size_t)(c1 - c0) * 4,
                            (hipStream_t)stream, G, flags, bits, idx, (int)c0, (int)c1, (int)d, src, scale, row_scale, (const uint32_t *)dup_bits);
         ARL_LAUNCH_CHECK();
     }
@@ -2806,7 +2899,7 @@ int arl_scatter_add_rows_f32(float *dst, const int32_t *idx, int64_t n, int64_t 
     if (n == 0) return ARL_OK;
     for (int64_t c0 = 0; c0 < n; c0 += kOrderedWindow) {
         const int64_t c1 = c0 + kOrderedWindow < n ? c0 + kOrderedWindow : n;
-        hipLaunchKernelGGL(rows_add_ordered_kernel<false>, dim3((unsigned)((c1 - c0 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
+        hipLaunchKernelGGL(rows_add_ordered_kernel<false>, dim3((unsigned)((c1 - c0 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), (size_t)(c1 - c0) * 4,
                            (hipStream_t)stream, dst, (uint8_t *)nullptr, (uint32_t *)nullptr, idx, (int)c0, (int)c1, (int)d, src, scale, (const float *)nullptr,
                            (const uint32_t *)nullptr);
         ARL_LAUNCH_CHECK();
@@ -2814,13 +2907,15 @@ int arl_scatter_add_rows_f32(float *dst, const int32_t *idx, int64_t n, int64_t 
     return ARL_OK;
 }
 
-int arl_rows_axpy_unique_f32(float *dst, const float *src, const int32_t *idx, int64_t n, int64_t d, float alpha, arl_stream_t stream) {
+int arl_rows_axpy_unique_f32(float *dst, const float *src, const int32_t *idx, int64_t n, int64_t d, float alpha, const uint32_t *dup_bits,
+                             arl_stream_t stream) {
     if (!src || !idx || !dst) return ARL_E_NULL;
     if (n < 0 || d <= 0 || n > 0x7fffffffll || d > 0x7fffffffll || dst == src) return ARL_E_ARG;
     for (int64_t c0 = 0; c0 < n; c0 += kOrderedWindow) {
         const int64_t c1 = c0 + kOrderedWindow < n ? c0 + kOrderedWindow : n;
-        hipLaunchKernelGGL(rows_axpy_unique_kernel, dim3((unsigned)((c1 - c0 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
-                           (hipStream_t)stream, dst, src, idx, (int)c0, (int)c1, (int)d, alpha);
+        const int lds_n = n <= kOrderedWindow ? (int)n : 0;
+        hipLaunchKernelGGL(rows_axpy_unique_kernel, dim3((unsigned)((c1 - c0 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), (size_t)lds_n * 4,
+                           (hipStream_t)stream, dst, src, idx, (int)c0, (int)c1, (int)d, alpha, dup_bits, lds_n);
         ARL_LAUNCH_CHECK();
     }
     return ARL_OK;

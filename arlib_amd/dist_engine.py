@@ -556,7 +556,7 @@ class ShardedPropagationEngine:
             k.spmm_flagged(self.Ai, acc, xf, a, 0.0, None, None, out=dst[Ul:])     # partial item rows (gathers acc's user rows)
             if pending is not None:                                                # complete acc's item rows before A_u reads them
                 pending.wait()
-                k.rows_axpy_unique_(prev_items, self.G, item_rows_packed, prev_a, check_range=False)
+                k.rows_axpy_unique_(prev_items, self.G, item_rows_packed, prev_a, check_range=False, dup_bits=self.dup_bits)
             pending, prev_items, prev_a = self.comm.all_reduce_async(dst[Ul:]), dst, a
             if last:
                 k.spmm_adam(self.Au, acc, a, a, self.G[:Ul], self.E0[:Ul], self.m[:Ul], self.v[:Ul], self.lr, self.t, self.betas, self.eps, zflags=zu)
@@ -564,7 +564,7 @@ class ShardedPropagationEngine:
                 k.spmm_flagged(self.Au, acc, xf, a, a, self.G[:Ul], zu, out=dst[:Ul])
             acc = dst
         pending.wait()
-        k.rows_axpy_unique_(prev_items, self.G, item_rows_packed, prev_a, check_range=False)
+        k.rows_axpy_unique_(prev_items, self.G, item_rows_packed, prev_a, check_range=False, dup_bits=self.dup_bits)
         k.adam_dense(self.E0[Ul:], acc[Ul:], self.m[Ul:], self.v[Ul:], self.lr, self.t, self.betas, self.eps)
         k.batch_rows_clear_(self.G, self.flags, self.bits, rows_l, check_range=False, dup_bits=self.dup_bits)      # clear the sparse state
         return self.loss_out

@@ -843,7 +843,7 @@ def scatter_add_rows(dst, idx, src, scale=1.0, check_range=True):
     return dst
 
 
-def rows_axpy_unique_(dst, src, idx, alpha=1.0, check_range=True):
+def rows_axpy_unique_(dst, src, idx, alpha=1.0, check_range=True, dup_bits=None):
     """dst[r] += alpha * src[r] once per DISTINCT row r listed in idx (src: a table that is zero outside the listed rows, e.g. the sparse
     batch gradient: its rows reach a dense table without a pass over the whole table)."""
     _dev(dst, torch.float32, 'dst', 2); _dev(src, torch.float32, 'src', 2); _dev(idx, torch.int32, 'idx', 1)
@@ -851,7 +851,7 @@ def rows_axpy_unique_(dst, src, idx, alpha=1.0, check_range=True):
         raise ValueError('rows_axpy_unique_: dst and src must be distinct tables of one shape')
     if check_range and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= dst.shape[0]):
         raise IndexError('rows_axpy_unique_: index out of range')
-    check(_lib.lib().arl_rows_axpy_unique_f32(_ptr(dst), _ptr(src), _ptr(idx), idx.numel(), dst.shape[1], float(alpha), _stream()), 'arl_rows_axpy_unique_f32')
+    check(_lib.lib().arl_rows_axpy_unique_f32(_ptr(dst), _ptr(src), _ptr(idx), idx.numel(), dst.shape[1], float(alpha), _ptr(dup_bits), _stream()), 'arl_rows_axpy_unique_f32')
     return dst
 
 

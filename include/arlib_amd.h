@@ -273,7 +273,8 @@ int arl_sgd_dense_f32(float *p, const float *g, int64_t n, float lr, arl_stream_
  *   gather:       dst[t] = src[idx[t]]
  *   scatter_add:  dst[idx[t]] += scale * src[t]   (duplicates accumulate in index order -- torch's CPU index_put_(accumulate=True)
  *                 association, the backward of the reference's advanced-index gathers; ordered, no float atomics, deterministic)
- *   axpy_unique:  dst[r] += alpha * src[r] once for every DISTINCT row r in idx (src, dst: tables of the same shape)
+ *   axpy_unique:  dst[r] += alpha * src[r] once for every DISTINCT row r in idx (src, dst: tables of the same shape); dup_bits: optional bitmap
+ *                 (as filled by arl_batch_rows_set_f32 for a list containing idx) of the rows that may be named twice -- the others skip the scan
  *   shard_batch_prep: user-sharded batch bookkeeping in one launch -- lu[b] = clamp(u[b] - u0, 0, Ul - 1), own [3B] = [(u0 <= u[b] < u1) | 1 | 1]
  *                 (factors of the batch's user / positive / negative contributions), item_rows = [p | n], rows_l = [lu | Ul + p | Ul + n] with Ul = u1 - u0 (no reference counterpart: main.py:19 pins one device)
  * ---------------------------------------------------------------------------------------------- */
@@ -281,7 +282,7 @@ int arl_gather_rows_f32(const float *src, const int32_t *idx, int64_t n, int64_t
 int arl_scatter_add_rows_f32(float *dst, const int32_t *idx, int64_t n, int64_t d, const float *src, float scale,
                              arl_stream_t stream);
 int arl_rows_axpy_unique_f32(float *dst, const float *src, const int32_t *idx, int64_t n, int64_t d, float alpha,
-                             arl_stream_t stream);
+                             const uint32_t *dup_bits, arl_stream_t stream);
 int arl_shard_batch_prep_i32(const int32_t *u, const int32_t *p, const int32_t *n, int64_t B, int64_t u0, int64_t u1,
                              int32_t *lu, float *own, int32_t *item_rows, int32_t *rows_l, arl_stream_t stream);
 

@@ -198,7 +198,7 @@ def ngcf_combine_bwd(gST, P, E):
     return gS + gT * E, gS + gT * P
 
 
-def rows_axpy_unique_(dst, src, idx, alpha=1.0, check_range=True):
+def rows_axpy_unique_(dst, src, idx, alpha=1.0, check_range=True, dup_bits=None):
     r = torch.unique(idx.long())
     dst[r] += alpha * src[r]
     return dst
