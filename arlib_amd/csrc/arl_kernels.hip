@@ -1932,7 +1932,27 @@ constexpr int topk_waves(int D, bool SPLIT) { return (SPLIT && ARL_TOPK_SPLIT_MO
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
 constexpr int kBloomWords = 32;      // 1024 bits per user
-constexpr int kTopkRing = 4;         // staged item tiles in LDS (slots of the ring), a power of two
+// Candidate queues (ARL_TOPK_QUEUE = 1): a pre-filter survivor is APPENDED to its user row's queue in LDS by the lane that found it (one LDS
+// atomic + one 8-byte store, all survivors of a 16-item x 16-user sub-tile in parallel) instead of being broadcast and inserted by the whole
+// wave on the spot; a row's queue is merged into its sorted register list when it holds kQFlush entries (checked once per stage) or is full,
+// and at the end of the stream.  Thresholds move only at a merge -- a threshold that lags admits a few candidates more (they fall off at the
+// merge), it never loses one -- and the per-candidate broadcast / row-select / threshold-select work of the immediate insert is paid once per merge.
+#ifndef ARL_TOPK_QUEUE
+#define ARL_TOPK_QUEUE 1
+#endif
+#ifndef ARL_TOPK_QCAP
+#define ARL_TOPK_QCAP 8
+#endif
+#ifndef ARL_TOPK_QFLUSH
+#define ARL_TOPK_QFLUSH 6
+#endif
+constexpr int kQCap = ARL_TOPK_QCAP;             // queue slots per user row and wave
+constexpr int kQFlush = ARL_TOPK_QFLUSH;         // merge a row's queue at the end of a stage once it holds this many
+constexpr int kQWords = 16 + 16 * kQCap * 2;      // per wave: 16 counters + 16 x kQCap 8-byte keys, in 4-byte words
+#ifndef ARL_TOPK_RING
+#define ARL_TOPK_RING 4
+#endif
+constexpr int kTopkRing = ARL_TOPK_RING;         // staged item tiles in LDS (slots of the ring), a power of two
 constexpr int kTopkLead = 2;         // a wave writes its share of stage s + kTopkLead while it consumes stage s
 #ifndef ARL_TOPK_BOOT_ITEMS
 #define ARL_TOPK_BOOT_ITEMS 4096
@@ -2039,8 +2059,8 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     constexpr int MST = D <= 16 ? 128 : (D <= 64 ? 64 : 32);       // items per stage (one slot of the ring)
     constexpr int NSUB = MST / 16;                                 // 16-item sub-tiles per stage
     constexpr int SPP = NSUB >= 2 ? 2 : 1;                         // sub-tiles per insert phase (at most 32 items)
-    constexpr int NPH = NSUB / SPP;
-    constexpr int NSC = 4 * SPP;                                   // scores per lane and phase
+    [[maybe_unused]] constexpr int NPH = NSUB / SPP;
+    [[maybe_unused]] constexpr int NSC = 4 * SPP;                  // scores per lane and phase
     static_assert(!SPLIT || (D % 32 == 0), "the bf16 path contracts 32 indices per MFMA");
     extern __shared__ unsigned char smem_raw[];
     unsigned char *bt = smem_raw;                                  // two staged item tiles (STAGEB bytes each), then the Bloom filters
@@ -2152,8 +2172,12 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     // survivors with one LDS read; only filter hits pay the binary search in global memory (7 dependent L2 round trips).
     constexpr int STAGEB = 2 * HALF;
     unsigned *ring_ctr = reinterpret_cast<unsigned *>(bt + kTopkRing * STAGEB);                             // fill[kTopkRing], done[kTopkRing]
-    unsigned *bloom = ring_ctr + 2 * kTopkRing + wv * 16 * kBloomWords;                                     // [16][kBloomWords]
+    constexpr int kQAll = ARL_TOPK_QUEUE ? kQWords * (kM16Block / kWave) : 0;
+    unsigned *qcnt = ring_ctr + 2 * kTopkRing + wv * kQWords;                                                // this wave's 16 queue counters ...
+    unsigned long long *qkey = reinterpret_cast<unsigned long long *>(qcnt + 16);                           // ... and its [16][kQCap] keys (8-byte aligned)
+    unsigned *bloom = ring_ctr + 2 * kTopkRing + kQAll + wv * 16 * kBloomWords;                             // [16][kBloomWords]
     if (tid < 2 * kTopkRing) ring_ctr[tid] = 0u;
+    if (ARL_TOPK_QUEUE && lane < 16) qcnt[lane] = 0u;
     if (mrp) {
         for (int t = lane; t < 16 * kBloomWords; t += kWave) bloom[t] = 0u;
         __builtin_amdgcn_wave_barrier();
@@ -2169,6 +2193,7 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
+#if !ARL_TOPK_QUEUE
     // insert `key` into the sorted list of user row `row` (wave-uniform); returns the row's new k-th best score = its threshold
     auto insert_sorted = [&](int row, unsigned long long key) -> float {
         const unsigned Kh = tk_hi[row], Kl = tk_lo[row];
@@ -2245,6 +2270,125 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
             }
         }
     };
+#endif
+#if ARL_TOPK_QUEUE
+#ifndef ARL_TOPK_EXP
+#define ARL_TOPK_EXP 0
+#endif
+    float exp_sink = 0.f;                                              // (developer experiments only: keeps values alive)
+    // merge the queued candidates of user row `row` (wave-uniform) into its sorted list; the row's threshold becomes exact again.  A queue
+    // entry is the raw (score, item) pair; the interacted-item mask and the key packing happen here, one candidate per lane.
+    auto flush_row = [&](int row) {
+        const int cnt = __builtin_amdgcn_readfirstlane((int)*(volatile lds_u32 *)(qcnt + row));
+        const int m = min(cnt, kQCap);
+        unsigned long long cj = 0ull;
+        if (lane < m) {
+            const unsigned long long e = qkey[row * kQCap + lane];
+            float sc = __uint_as_float((unsigned)e);
+            const int item = (int)(unsigned)(e >> 32);
+            if (mrp) {                                                 // interacted -> -10e8 (pre-filter survivors only)
+                const unsigned hb = bloom_hash(item);
+                if ((bloom[row * kBloomWords + (hb >> 5)] >> (hb & 31u)) & 1u) {
+                    const int u = u_base + row;
+                    int lo = mrp[u], hi = mrp[u + 1];
+                    const int end = hi;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (mcol[mid] < item) lo = mid + 1; else hi = mid; }
+                    if (lo < end && mcol[lo] == item) sc = -10e8f * score_scale;      // (-10e8 once scaled back) stays in the list only while it holds fewer than k real items
+                }
+            }
+            cj = pack_cand(sc, item);
+        }
+        if (lane == 0) qcnt[row] = 0u;
+        if (ARL_TOPK_EXP == 4) { exp_sink += (float)(unsigned)cj; return; }       // experiment: appends + queue reads, no list merges (results are wrong)
+        unsigned Kh = tk_hi[row], Kl = tk_lo[row];
+        for (int j = 0; j < m; ++j) {
+            const unsigned ch = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cj >> 32), j);
+            const unsigned cl = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cj, j);
+            const unsigned long long key = ((unsigned long long)ch << 32) | cl, K = ((unsigned long long)Kh << 32) | Kl;
+            const int pos = __popcll(__ballot(K > key));               // keys above the new one: a prefix of the lanes
+            if (pos < k) {                                             // wave-uniform
+                const unsigned sl = __builtin_amdgcn_update_dpp(Kl, Kl, 0x138, 0xf, 0xf, false);            // wave_shr:1
+                const unsigned sh = __builtin_amdgcn_update_dpp(Kh, Kh, 0x138, 0xf, 0xf, false);
+                Kl = lane < pos ? Kl : (lane == pos ? cl : sl);
+                Kh = lane < pos ? Kh : (lane == pos ? ch : sh);
+            }
+        }
+        tk_hi[row] = Kh; tk_lo[row] = Kl;
+        const unsigned th = (unsigned)__builtin_amdgcn_readlane((int)Kh, k - 1);
+        const unsigned tl = (unsigned)__builtin_amdgcn_readlane((int)Kl, k - 1);
+        const float t0 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(thr0v), row));
+        const float nt = (th | tl) ? __builtin_fmaxf(cand_score((unsigned long long)th << 32), t0) : t0;     // t0: the warm-start / bootstrap bound (-inf if none)
+        const bool mine = (g == (row >> 2));
+        const int rj = row & 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) thrf[j] = (mine && rj == j) ? nt : thrf[j];
+    };
+    auto flush_rows_with = [&](unsigned at_least) {                    // every row whose queue holds at least `at_least` candidates
+        const unsigned cn = lane < 16 ? *(volatile lds_u32 *)(qcnt + lane) : 0u;
+        for (unsigned long long need = __ballot(cn >= at_least); need != 0ull; need &= need - 1ull) flush_row(__ffsll((long long)need) - 1);
+    };
+    // Pre-filter + queue appends for the scores of one stage (accumulator ac[sub][reg] <-> item st*MST + 16*sub + c, user row 4g + reg).
+    // Straight line: one compare per score; if any lane of the wave passes anywhere, every passing (sub, reg) appends its lanes' (score, item)
+    // pairs -- an LDS atomic for the slot, one 8-byte store.  A queue that is full sends its lanes to the rare path at the end.
+    auto bookkeeping = [&](const f32x4 (&ac)[NSUB], int st) {
+        if (ARL_TOPK_EXP == 1) {                                       // experiment: scores only, no pre-filter, no lists
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) exp_sink += ac[sub][0] + ac[sub][3];
+            return;
+        }
+        f32x4 sv[NSUB];
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) sv[sub] = ac[sub];
+        if (st == nstages - 1) {                                       // rows past I were staged as copies of item I-1: their scores never pass (NaN)
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub)
+                if (st * MST + 16 * sub + c >= I) sv[sub] = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+        }
+        bool pass[NSUB][4];
+        bool some = false;
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                pass[sub][reg] = sv[sub][reg] >= thrf[reg];            // one compare per score (-inf always passes, +inf and NaN never)
+                some = some || pass[sub][reg];
+            }
+        if (ARL_TOPK_EXP == 2) { exp_sink += some ? 1.f : 0.f; return; }    // experiment: compares only
+        if (ARL_TOPK_EXP == 3) { exp_sink += some ? 1.f : 0.f; flush_rows_with((unsigned)kQFlush); return; }    // experiment: compares + the stage-end queue check (queues stay empty)
+        if (__builtin_amdgcn_ballot_w64(some) != 0ull) {
+            unsigned left = 0u;                                        // bit 4*sub + reg: this lane's candidate found its queue full
+            const int item0 = st * MST + c;
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    if (pass[sub][reg]) {
+                        const int ulw = 4 * g + reg;
+                        const unsigned slot = __hip_atomic_fetch_add((lds_u32 *)(qcnt + ulw), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (slot < (unsigned)kQCap) qkey[ulw * kQCap + slot] = ((unsigned long long)(unsigned)(item0 + 16 * sub) << 32) | __float_as_uint(sv[sub][reg]);
+                        else left |= 1u << (4 * sub + reg);
+                    }
+                }
+            // rare path (cold starts, bursts): merge the full queues, then the lanes left over try again
+            while (__builtin_amdgcn_ballot_w64(left != 0u) != 0ull) {
+                flush_rows_with((unsigned)kQCap);
+                if (left != 0u) {                                      // one candidate per lane and round
+                    const int b = __ffs(left) - 1;
+                    float sc = sv[0][0];
+#pragma unroll
+                    for (int q = 1; q < 4 * NSUB; ++q) sc = (b == q) ? sv[q >> 2][q & 3] : sc;
+                    const int ulw = 4 * g + (b & 3);
+                    const unsigned slot = __hip_atomic_fetch_add((lds_u32 *)(qcnt + ulw), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (slot < (unsigned)kQCap) {
+                        qkey[ulw * kQCap + slot] = ((unsigned long long)(unsigned)(item0 + 16 * (b >> 2)) << 32) | __float_as_uint(sc);
+                        left &= left - 1u;
+                    }
+                }
+            }
+        }
+        flush_rows_with((unsigned)kQFlush);
+    };
+#endif
     // ---- bootstrap pass state: bl[reg][j] = j-th best score this lane has seen for user row 4g + reg (descending)
     float bl[4][4];
 #pragma unroll
@@ -2456,6 +2600,10 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
         step(std::false_type{}, st, nb);
         if (st + 1 < nvirt) step(std::false_type{}, st + 1, nc);
     }
+#if ARL_TOPK_QUEUE
+    flush_rows_with(1u);                                           // whatever is still queued
+    if (ARL_TOPK_EXP && exp_sink == 12345.678f) top_val[0] = exp_sink;
+#endif
 #ifdef ARL_TOPK_PROF
     const long long P_loop = clock64() - P_start;
 #endif
@@ -3283,7 +3431,8 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
         const size_t stageb = 2 * (size_t)mst * ((split ? 2 * kSplitPlanes : 4) * (size_t)d / 2 + 16);     // two half images of mst rows (STAGEB in the kernel)
         const int nwaves = topk_waves((int)d, split);
         const int users_per_wg = 16 * nwaves;
-        const size_t shm_m = kTopkRing * stageb + 2 * kTopkRing * sizeof(unsigned) + (mask_rowptr ? sizeof(unsigned) * users_per_wg * kBloomWords : 0);
+        const size_t shm_m = kTopkRing * stageb + 2 * kTopkRing * sizeof(unsigned) + (ARL_TOPK_QUEUE ? sizeof(unsigned) * kQWords * nwaves : 0) +
+                             (mask_rowptr ? sizeof(unsigned) * users_per_wg * kBloomWords : 0);
         const unsigned grid_m = (unsigned)((U + users_per_wg - 1) / users_per_wg);
         const void *image = Pi;
         const unsigned *max_bits = nullptr;
