@@ -1953,7 +1953,10 @@ constexpr int kQWords = 16 + 16 * kQCap * 2;      // per wave: 16 counters + 16 
 #define ARL_TOPK_RING 4
 #endif
 constexpr int kTopkRing = ARL_TOPK_RING;         // staged item tiles in LDS (slots of the ring), a power of two
-constexpr int kTopkLead = 2;         // a wave writes its share of stage s + kTopkLead while it consumes stage s
+#ifndef ARL_TOPK_LEAD
+#define ARL_TOPK_LEAD 2
+#endif
+constexpr int kTopkLead = ARL_TOPK_LEAD;         // a wave writes its share of stage s + kTopkLead while it consumes stage s (even, < ring)
 #ifndef ARL_TOPK_BOOT_ITEMS
 #define ARL_TOPK_BOOT_ITEMS 4096
 #endif
@@ -2011,16 +2014,22 @@ __device__ __forceinline__ float split_scale(unsigned mbits) {
     const int se = min(max(127 + 13 - (e - 127), 127 - 40), 127 + 40);      // 2^(13 - (e - 127)), kept within 2^+-40 (the product of two scales must not overflow)
     return __uint_as_float((unsigned)se << 23);
 }
+// `order` (optional): image row r holds table row order[r] -- the item stream in another order than the table's (see arl_score_mask_topk_f32)
 __global__ __launch_bounds__(kBlock) void split_f16x2_kernel(const float *__restrict__ X, long long n, int d, const unsigned *__restrict__ mbits,
-                                                              _Float16 *__restrict__ out) {
+                                                              _Float16 *__restrict__ out, const int32_t *__restrict__ order) {
     const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;          // one element each
     if (t >= n) return;
     const long long row = t / d;
     const int kcol = (int)(t - row * d);
-    const float x = X[t] * split_scale(*mbits);
+    const float x = (order ? X[(long long)order[row] * d + kcol] : X[t]) * split_scale(*mbits);
     const _Float16 h = (_Float16)x;
     _Float16 *o = out + row * 2 * d + kcol;
     o[0] = h; o[d] = (_Float16)(x - (float)h);
+}
+
+__global__ __launch_bounds__(kBlock) void invert_perm_kernel(const int32_t *__restrict__ order, int n, int32_t *__restrict__ pos_of) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t < n) pos_of[order[t]] = t;
 }
 
 __global__ __launch_bounds__(kBlock) void split_bf16x3_kernel(const float *__restrict__ X, long long n, int d, __bf16 *__restrict__ out) {
@@ -2042,7 +2051,11 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
                                                                             const int32_t *__restrict__ mrp, const int32_t *__restrict__ mcol, int k,
                                                                             int32_t *__restrict__ top_idx, float *__restrict__ top_val,
                                                                             const float *__restrict__ Pi_f32, const int32_t *__restrict__ warm_idx,
-                                                                            int *__restrict__ underflow, const unsigned *__restrict__ table_max_bits) {
+                                                                            int *__restrict__ underflow, const unsigned *__restrict__ table_max_bits,
+                                                                            const int32_t *__restrict__ item_order, const int32_t *__restrict__ item_pos) {
+    // item_order / item_pos (both or neither): the staged image holds table row item_order[p] at position p (item_pos = the inverse).  Scores,
+    // stages and the bootstrap sample are in POSITIONS; a candidate becomes an item id when it is packed into a key, so masks, keys (ties:
+    // lower item id first) and results are those of the table order -- only the order in which thresholds rise changes.
     constexpr int kM16Block = 64 * topk_waves(D, SPLIT), kMU = 16 * topk_waves(D, SPLIT);       // threads / users per workgroup
     constexpr int Q = D / 4;                                       // contraction indices per lane: [Q*g, Q*g + Q)
     constexpr int SRCB = SPLIT ? kSplitPlanes * D * 2 : D * 4;     // bytes per item row in global memory
@@ -2285,7 +2298,8 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
         if (lane < m) {
             const unsigned long long e = qkey[row * kQCap + lane];
             float sc = __uint_as_float((unsigned)e);
-            const int item = (int)(unsigned)(e >> 32);
+            const int pos = (int)(unsigned)(e >> 32);
+            const int item = item_order ? item_order[pos] : pos;
             if (mrp) {                                                 // interacted -> -10e8 (pre-filter survivors only)
                 const unsigned hb = bloom_hash(item);
                 if ((bloom[row * kBloomWords + (hb >> 5)] >> (hb & 31u)) & 1u) {
@@ -2409,7 +2423,17 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     // the rows' (k + m)-th best of their 64 sample scores -> thr0v (lane r = row r) and thrf
     auto boot_finish = [&]() {
         int m16 = 0;                                               // lane r < 16: interacted items of row r inside the sample
-        if (mrp && lane < 16 && u_base + lane < U) {
+        if (mrp && item_pos) {                                     // permuted stream: count the row's interacted items whose position is in the sample
+            const int lim = NB * MST;
+            for (int r = 0; r < 16; ++r) {
+                const int u = u_base + r;
+                if (u >= U) break;
+                int cntr = 0;
+                for (int e = mrp[u] + lane, end = mrp[u + 1]; __any(e < end); e += kWave)
+                    cntr += __popcll(__ballot(e < end && item_pos[mcol[e]] < lim));
+                if (lane == r) m16 = cntr;
+            }
+        } else if (mrp && lane < 16 && u_base + lane < U) {
             const int b0 = mrp[u_base + lane];
             int lo = b0, hi = mrp[u_base + lane + 1];
             const int lim = NB * MST;
@@ -2567,7 +2591,7 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     };
     unsigned *fill_ctr = ring_ctr, *done_ctr = ring_ctr + kTopkRing;
     constexpr unsigned NWV = kM16Block / kWave;
-    static_assert(kTopkLead == 2 && (kTopkRing & (kTopkRing - 1)) == 0, "the loop below is unrolled by the lead");
+    static_assert(kTopkLead >= 2 && kTopkLead % 2 == 0 && kTopkLead < kTopkRing && (kTopkRing & (kTopkRing - 1)) == 0, "two register sets alternate: the lead is even");
     __syncthreads();                                               // counters zeroed (the only block barrier of the kernel)
     // one step of the pipeline: stage st + 2 goes from register set r to LDS, set r is refilled with stage st + 4, stage st is consumed
     auto step = [&](auto boot_tag, int st, f32x4 (&r)[PER]) {
@@ -2584,13 +2608,15 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
         ARL_PROF_TICK(3)
         compute(boot_tag, slot(st), st, done_ctr + (st & (kTopkRing - 1)));
     };
-    fetch(item_stage(0), nb);
-    if (nvirt > 1) fetch(item_stage(1), nc);
-    stash(slot(0), nb);
-    signal(fill_ctr + 0);
-    if (nvirt > 1) { stash(slot(1), nc); signal(fill_ctr + 1); }
-    if (nvirt > 2) fetch(item_stage(2), nb);
-    if (nvirt > 3) fetch(item_stage(3), nc);
+    // prologue: the first kTopkLead stages go to their slots, the next two are in flight in the two register sets
+    for (int s0 = 0; s0 < kTopkLead; s0 += 2) {
+        if (s0 < nvirt) fetch(item_stage(s0), nb);
+        if (s0 + 1 < nvirt) fetch(item_stage(s0 + 1), nc);
+        if (s0 < nvirt) { stash(slot(s0), nb); signal(fill_ctr + (s0 & (kTopkRing - 1))); }
+        if (s0 + 1 < nvirt) { stash(slot(s0 + 1), nc); signal(fill_ctr + ((s0 + 1) & (kTopkRing - 1))); }
+    }
+    if (nvirt > kTopkLead) fetch(item_stage(kTopkLead), nb);
+    if (nvirt > kTopkLead + 1) fetch(item_stage(kTopkLead + 1), nc);
     for (int st = 0; st < NB; st += 2) {                           // NB is even
         step(std::true_type{}, st, nb);
         step(std::true_type{}, st + 1, nc);
@@ -3417,7 +3443,7 @@ int64_t arl_score_mask_topk_workspace_bytes(int64_t I, int64_t d) { return (I <=
 
 int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t I, int64_t d, const int32_t *mask_rowptr, const int32_t *mask_col,
                             int64_t k, int32_t *top_idx, float *top_val, void *workspace, const int32_t *warm_idx, int32_t *underflow,
-                            arl_stream_t stream) {
+                            const int32_t *item_order, arl_stream_t stream) {
     if (!Pu || !Pi || !top_idx || !top_val) return ARL_E_NULL;
     if (warm_idx && !underflow) return ARL_E_NULL;
     if (mask_rowptr && !mask_col) return ARL_E_NULL;
@@ -3436,6 +3462,8 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
         const unsigned grid_m = (unsigned)((U + users_per_wg - 1) / users_per_wg);
         const void *image = Pi;
         const unsigned *max_bits = nullptr;
+        const int32_t *order_d = nullptr;
+        int32_t *pos_d = nullptr;
         if (split) {
             const long long n = (long long)I * d;
             if (kSplitMode == 2) {
@@ -3446,8 +3474,14 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
                 ARL_LAUNCH_CHECK();
                 hipLaunchKernelGGL(absmax_bits_kernel, dim3(grid_for(U * d / 4 + 1, kBlock, 2048u)), dim3(kBlock), 0, (hipStream_t)stream, Pu, (long long)(U * d), mb + 1);
                 ARL_LAUNCH_CHECK();
+                if (item_order && ARL_TOPK_QUEUE) {                 // the item stream in the caller's order: inverse map behind the two maxima (the 6 I d byte workspace has room)
+                    order_d = item_order;
+                    pos_d = reinterpret_cast<int32_t *>(static_cast<char *>(workspace) + 4 * (size_t)n + 16);
+                    hipLaunchKernelGGL(invert_perm_kernel, dim3((unsigned)((I + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, item_order, (int)I, pos_d);
+                    ARL_LAUNCH_CHECK();
+                }
                 hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, Pi, n, (int)d, mb,
-                                   (_Float16 *)workspace);
+                                   (_Float16 *)workspace, order_d);
                 max_bits = mb;
             } else {
                 hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, Pi, n, (int)d,
@@ -3461,7 +3495,7 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
             hipError_t em = hipFuncSetAttribute((const void *)score_mask_topk_mfma16_kernel<DV, SP, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m); \
             if (em != hipSuccess) return (int)em;                                                                                      \
             hipLaunchKernelGGL((score_mask_topk_mfma16_kernel<DV, SP, WM>), dim3(grid_m), dim3(64 * topk_waves(DV, SP)), shm_m, (hipStream_t)stream, Pu, image, (int)U, (int)I, \
-                               mask_rowptr, mask_col, (int)k, top_idx, top_val, Pi, warm_idx, underflow, max_bits);                    \
+                               mask_rowptr, mask_col, (int)k, top_idx, top_val, Pi, warm_idx, underflow, max_bits, order_d, pos_d);     \
         } while (0)
 #define ARL_TOPK_CASE(DV, SP) do { if (warm_idx) ARL_TOPK_CASE2(DV, SP, true); else ARL_TOPK_CASE2(DV, SP, false); } while (0)
         if (d == 16) ARL_TOPK_CASE(16, false);

@@ -1071,13 +1071,16 @@ def pga_update_(S, grad, dinv_rows=None, dinv_cols=None):
     return S
 
 
-def score_mask_topk(Pu, Pi, k, mask_rowptr=None, mask_col=None, exact=False, warm_idx=None):
+def score_mask_topk(Pu, Pi, k, mask_rowptr=None, mask_col=None, exact=False, warm_idx=None, item_order='norm'):
     """top-k of Pu @ Pi.T per user with an optional interacted-item mask (CSR over users), streamed.
     exact=True: scores are the exact fp32 contraction; default: split-fp16 matrix path (two fp16 pieces of the power-of-two-scaled operands, three products) for d in {64, 128} (scores within
     ~1e-6 relative, faster), exact otherwise.
     warm_idx: optional int32 [U, k] of DISTINCT candidate items per user (e.g. the previous call's result while the tables
     moved little): pre-sets the thresholds, same result, fewer inserts; if a candidate turned out masked the call is repeated
-    cold automatically."""
+    cold automatically.
+    item_order: 'norm' (default) streams the items by descending row norm on the fp16 matrix path when the stream is long enough for a
+    bootstrap pass -- thresholds rise earlier, same result bit for bit (ids, values and tie order are those of the table order); None =
+    table order; or an int32 permutation of [0, I)."""
     _dev(Pu, torch.float32, 'Pu', 2); _dev(Pi, torch.float32, 'Pi', 2)
     U, d = Pu.shape
     I = Pi.shape[0]
@@ -1101,13 +1104,23 @@ def score_mask_topk(Pu, Pi, k, mask_rowptr=None, mask_col=None, exact=False, war
     idx = torch.empty(U, k, dtype=torch.int32, device=Pu.device)
     val = torch.empty(U, k, dtype=torch.float32, device=Pu.device)
     ws = None
+    order = None
     if not exact and d in (64, 128) and k <= 64:
         ws = torch.empty(_lib.lib().arl_score_mask_topk_workspace_bytes(I, d), dtype=torch.uint8, device=Pu.device)
+        if isinstance(item_order, torch.Tensor):
+            order = _dev(item_order, torch.int32, 'item_order', 1)
+            if order.numel() != I:
+                raise ValueError('score_mask_topk: item_order must be a permutation of the I items')
+        elif item_order == 'norm':
+            if I >= 32768:                                 # shorter streams run without a bootstrap pass: nothing to gain
+                order = torch.argsort(torch.linalg.vector_norm(Pi, dim=1), descending=True).to(torch.int32)
+        elif item_order is not None:
+            raise ValueError("score_mask_topk: item_order must be 'norm', None or an int32 permutation")
     check(_lib.lib().arl_score_mask_topk_f32(_ptr(Pu), _ptr(Pi), U, I, d, _ptr(mask_rowptr), _ptr(mask_col), k, _ptr(idx), _ptr(val), _ptr(ws),
-                                             _ptr(warm_idx), _ptr(flag), _stream()), 'arl_score_mask_topk_f32')
+                                             _ptr(warm_idx), _ptr(flag), _ptr(order), _stream()), 'arl_score_mask_topk_f32')
     if flag is not None and int(flag) != 0:                # a warm candidate was masked or repeated: the bound was not valid
         check(_lib.lib().arl_score_mask_topk_f32(_ptr(Pu), _ptr(Pi), U, I, d, _ptr(mask_rowptr), _ptr(mask_col), k, _ptr(idx), _ptr(val), _ptr(ws),
-                                                 None, None, _stream()), 'arl_score_mask_topk_f32')
+                                                 None, None, _ptr(order), _stream()), 'arl_score_mask_topk_f32')
     return idx, val
 
 

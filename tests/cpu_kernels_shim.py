@@ -142,7 +142,7 @@ def infonce_fwd_bwd(v1, v2, tau, want_grad=True, upstream=1.0):
     return torch.tensor([loss], dtype=torch.float32), t(d1), t(d2)
 
 
-def score_mask_topk(Pu, Pi, k, mask_rowptr=None, mask_col=None, exact=False, warm_idx=None):
+def score_mask_topk(Pu, Pi, k, mask_rowptr=None, mask_col=None, exact=False, warm_idx=None, item_order=None):
     mask = None if mask_rowptr is None else (mask_rowptr.numpy().astype(np.int64), mask_col.numpy())
     idx, val = O.score_mask_topk(Pu.numpy(), Pi.numpy(), k, mask)
     return torch.from_numpy(idx.astype(np.int32)), torch.from_numpy(val.astype(np.float32))

@@ -524,6 +524,37 @@ def test_score_mask_topk_bootstrap_threshold(ops, d, k):
         assert rel_err(ex_v.cpu().numpy(), rval.astype(np.float32)) < 1e-5 and (ex_i.cpu().numpy() == ridx).mean() > 0.999
 
 
+@pytest.mark.parametrize('d,k,masked', [(64, 50, False), (64, 50, True), (128, 20, True), (64, 64, True)])
+def test_score_mask_topk_item_stream_order_is_result_neutral(ops, d, k, masked):
+    """item_order only changes the ORDER in which the items are scored (default on long streams: descending row norm, so thresholds rise
+    early); masks, ids, values and tie order are those of the table order.  Same ids and the same value bits as the table-order call for
+    the norm order, a random permutation and its combination with a warm start; users whose interacted items sit inside the permuted
+    bootstrap sample keep a valid bound (the sample's membership goes through the inverse permutation)."""
+    rng = np.random.default_rng(31 * d + k)
+    U, I = 300, 40000
+    Pu = (rng.normal(size=(U, d)) * 0.1).astype(np.float32)
+    Pi = (rng.normal(size=(I, d)) * 0.1 * rng.uniform(0.5, 2.0, size=(I, 1))).astype(np.float32)      # a spread of norms
+    Pi[7] = Pi[11]                                        # two identical items: an exact tie in every user's scores
+    norm_order = np.argsort(-np.linalg.norm(Pi, axis=1), kind='stable')
+    rp = mc = None
+    if masked:
+        cols = []
+        for u in range(U):
+            n_in = int(rng.integers(0, 40))               # interacted items: many of them among the largest-norm items = the permuted sample
+            c = np.concatenate([rng.choice(norm_order[:4096], size=n_in, replace=False), rng.choice(I, size=int(rng.integers(0, 30)), replace=False)])
+            cols.append(np.unique(c).astype(np.int32))
+        rp = T(np.concatenate([[0], np.cumsum([len(c) for c in cols])]).astype(np.int32))
+        mc = T(np.concatenate(cols + [np.zeros(1, np.int32)])[:max(sum(len(c) for c in cols), 1)])
+    base_i, base_v = ops.score_mask_topk(T(Pu), T(Pi), k, rp, mc, item_order=None)
+    for order in ('norm', T(rng.permutation(I).astype(np.int32))):
+        i2, v2 = ops.score_mask_topk(T(Pu), T(Pi), k, rp, mc, item_order=order)
+        assert torch.equal(i2, base_i) and torch.equal(v2, base_v)
+        i3, v3 = ops.score_mask_topk(T(Pu), T(Pi), k, rp, mc, item_order=order, warm_idx=base_i)
+        assert torch.equal(i3, base_i) and torch.equal(v3, base_v)
+    with pytest.raises(ValueError):
+        ops.score_mask_topk(T(Pu), T(Pi), k, item_order=T(np.arange(5, dtype=np.int32)))
+
+
 @pytest.mark.parametrize('F,I,d', [(64, 100000, 64), (5, 777, 32), (130, 301, 128), (64, 1000, 16), (1, 4, 4), (7, 12345, 256)])
 def test_fake_block_products(ops, F, I, d):
     """The F x I fake-user block of the poisoned adjacency as two dense products (attack/White/PGA.py:118-134) against float64."""
