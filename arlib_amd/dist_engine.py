@@ -20,6 +20,8 @@ The BPR batch is global (same bit-exact sampler stream on every rank); a rank ta
 The collective and the kernel set are injected (`comm`, `kernels`) so the shard arithmetic can be exercised with
 world_size-2 gloo processes on CPU in the test-suite; the defaults are RCCL and the HIP kernels, nothing else.
 """
+import contextlib
+
 import numpy as np
 import torch
 
@@ -189,13 +191,15 @@ class ShardedPropagationEngine:
     """Rank-local state + step() of the user-sharded LightGCN (mean of L+1 layers) + BPR/L2 + dense Adam."""
 
     def __init__(self, blocks, n_users, n_items, emb_size, n_layers, reg, lr, device, rank, world, table, chunk=512,
-                 comm=None, kernels=None, betas=(0.9, 0.999), eps=1e-8, skip_layer0=False, schedule='auto'):
+                 comm=None, kernels=None, betas=(0.9, 0.999), eps=1e-8, skip_layer0=False, schedule='auto', two_streams=False):
         if kernels is None:
             from . import ops as kernels         # the HIP kernels; fails loudly if libarlib_amd.so is missing
         self.k = kernels
         self.comm = comm if comm is not None else TorchDistComm()
         self.rank, self.world = rank, world
         self.skip0 = bool(skip_layer0)             # SimGCL: layers 1..L averaged (step_simgcl); LightGCN: 0..L (step / step_sparse)
+        self.two_streams = two_streams             # step_sparse: item-row and user-row kernels of a hop on two compute streams
+        self._side = None
         self.U, self.I, self.d, self.L = int(n_users), int(n_items), int(emb_size), int(n_layers)
         if self.L < 1:
             raise ValueError('the sharded engine is for graph models (n_layers >= 1)')
@@ -226,6 +230,11 @@ class ShardedPropagationEngine:
         self.ws = None
         self.sums = torch.zeros(3, dtype=torch.float32, device=self.device)
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=self.device)
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     @classmethod
     def from_pairs(cls, pairs, n_users, n_items, emb_size, n_layers, reg, lr, device, rank, world, table, **kw):
@@ -506,16 +515,35 @@ class ShardedPropagationEngine:
         item_rows_packed = rows_l[B:]
         # forward.  Software pipeline over hops: the item-row all-reduce of hop h runs behind A_u(h) AND A_i(h+1) -- the
         # item-side kernel of the next hop only gathers USER rows, which are local and already final.
+        # Optional (two_streams=True; measured on one rank's share of cfg2: 1.26 -> 1.34 ms wall per step, so OFF by default): A_i(h) on the
+        # main stream and A_u(h) on a side stream -- they read the same operand and write disjoint row blocks.  Events order exactly what depends:
+        #   A_i(h+1) after A_u(h) (user rows of the new layer);  A_u(h) after the all-reduce of hop h-1 (item rows of its operand).
+        two = self.two_streams and self.device.type == 'cuda'
+        if two:
+            main, side = torch.cuda.current_stream(), self._side_stream()
+            side.wait_stream(main)                             # the previous step's updates of E0 / the sparse state
+        on_side = (lambda: torch.cuda.stream(side)) if two else contextlib.nullcontext
         layers = [self.E0]
-        pending = None
+        pending = ev_u = ev_ar = None
         for h in range(L - 1):
             src, dst = layers[-1], self.hops[h]
+            if two and ev_u is not None:
+                main.wait_event(ev_u)                          # src's user rows come from the side stream
             k.spmm(self.Ai, src, out=dst[Ul:])                 # partial item rows (gathers user rows of src)
-            if pending is not None:
-                pending.wait()                                 # src's item rows are complete from here on
+            with on_side():
+                if pending is not None:
+                    if two:
+                        side.wait_event(ev_ar)
+                    pending.wait()                             # src's item rows are complete from here on
+                k.spmm(self.Au, src, out=dst[:Ul])             # exact user rows (gathers item rows of src)
+                if two:
+                    ev_u = side.record_event()
             pending = self.comm.all_reduce_async(dst[Ul:])
-            k.spmm(self.Au, src, out=dst[:Ul])                 # exact user rows (gathers item rows of src)
+            if two:
+                ev_ar = main.record_event()
             layers.append(dst)
+        if two and ev_u is not None:
+            main.wait_event(ev_u)                              # the row-subset hops below read the last layer's user rows
         X = layers[-1]
         # compact batch rows, already scaled by 1/(L+1): item rows = per-rank partial of the last hop + the layers' own rows, which are
         # replicas: layer j is contributed by rank j % world alone (its rows ride in the row-subset hop's epilogue); user rows = complete on the
@@ -546,6 +574,8 @@ class ShardedPropagationEngine:
         zu = self.flags[:Ul]
         acc = self.G
         pending, prev_items, prev_a = None, None, 1.0
+        ev_u = ev_ar = None
+        ev_g = main.record_event() if two else None                                # G, flags and bits are set (main stream)
         for h in range(L):
             last = h == L - 1
             a = s if last else 1.0
@@ -553,19 +583,32 @@ class ShardedPropagationEngine:
             if dst is acc:
                 dst = self.hops[(h + 1) % len(self.hops)]
             xf = self.bits if h == 0 else None
+            if two and ev_u is not None:
+                main.wait_event(ev_u)                                              # acc's user rows come from the side stream
             k.spmm_flagged(self.Ai, acc, xf, a, 0.0, None, None, out=dst[Ul:])     # partial item rows (gathers acc's user rows)
-            if pending is not None:                                                # complete acc's item rows before A_u reads them
-                pending.wait()
-                k.rows_axpy_unique_(prev_items, self.G, item_rows_packed, prev_a, check_range=False, dup_bits=self.dup_bits)
+            with on_side():
+                if pending is not None:                                            # complete acc's item rows before A_u reads them
+                    if two:
+                        side.wait_event(ev_ar)
+                    pending.wait()
+                    k.rows_axpy_unique_(prev_items, self.G, item_rows_packed, prev_a, check_range=False, dup_bits=self.dup_bits)
+                elif two:
+                    side.wait_event(ev_g)
+                if last:
+                    k.spmm_adam(self.Au, acc, a, a, self.G[:Ul], self.E0[:Ul], self.m[:Ul], self.v[:Ul], self.lr, self.t, self.betas, self.eps, zflags=zu)
+                else:
+                    k.spmm_flagged(self.Au, acc, xf, a, a, self.G[:Ul], zu, out=dst[:Ul])
+                if two:
+                    ev_u = side.record_event()
             pending, prev_items, prev_a = self.comm.all_reduce_async(dst[Ul:]), dst, a
-            if last:
-                k.spmm_adam(self.Au, acc, a, a, self.G[:Ul], self.E0[:Ul], self.m[:Ul], self.v[:Ul], self.lr, self.t, self.betas, self.eps, zflags=zu)
-            else:
-                k.spmm_flagged(self.Au, acc, xf, a, a, self.G[:Ul], zu, out=dst[:Ul])
+            if two:
+                ev_ar = main.record_event()
             acc = dst
         pending.wait()
         k.rows_axpy_unique_(prev_items, self.G, item_rows_packed, prev_a, check_range=False, dup_bits=self.dup_bits)
         k.adam_dense(self.E0[Ul:], acc[Ul:], self.m[Ul:], self.v[Ul:], self.lr, self.t, self.betas, self.eps)
+        if two:
+            main.wait_event(ev_u)                                                  # the user block's fused Adam hop (side stream) reads G / flags
         k.batch_rows_clear_(self.G, self.flags, self.bits, rows_l, check_range=False, dup_bits=self.dup_bits)      # clear the sparse state
         return self.loss_out
 
