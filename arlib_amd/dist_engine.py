@@ -216,7 +216,9 @@ class ShardedPropagationEngine:
         if schedule not in ('auto', 'csr', 'blocked'):
             raise ValueError("schedule must be 'auto', 'csr' or 'blocked'")
         if schedule != 'csr' and hasattr(kernels, 'auto_blocked') and (schedule == 'blocked' or self.Au.nnz + self.Ai.nnz >= kernels.BLOCKED_MIN_NNZ):
-            kernels.auto_blocked(self.Au, self.d, force=True); kernels.auto_blocked(self.Ai, self.d, force=True)
+            import os
+            rpw = int(os.environ.get('ARL_SHARD_RPW', 32))             # developer knob (rows per wave of the shard plans)
+            kernels.auto_blocked(self.Au, self.d, force=True, rows_per_wave=rpw); kernels.auto_blocked(self.Ai, self.d, force=True, rows_per_wave=rpw)
         for gph in (self.Au, self.Ai):                       # flag-masked hops take the rows sorted by length (ops.CSRGraph.enable_masked_order)
             if hasattr(gph, 'enable_masked_order') and gph.nnz >= 1_000_000:
                 gph.enable_masked_order()

@@ -355,13 +355,13 @@ BLOCKED_MIN_NNZ = 6_000_000      # measured cross-over (tools/blocked_bench.py):
 BLOCKED_MIN_WAVES = 1024         # a row set with fewer waves stays with the CSR kernel
 
 
-def auto_blocked(graph, d, split=None, force=False):
+def auto_blocked(graph, d, split=None, force=False, rows_per_wave=32):
     """Attach the register-blocked plan to `graph` when it pays (d = 64 or 128, >= BLOCKED_MIN_NNZ edges) or when forced; no-op if the
     graph already has one or cannot take one (other widths, 2^24 columns or more).  Returns the graph."""
     if graph is None or graph.blocked is not None or int(d) not in (64, 128) or graph.n_cols >= (1 << 24):
         return graph
     if force or graph.nnz >= BLOCKED_MIN_NNZ:
-        graph.enable_blocked(split=split, min_waves=0 if force else BLOCKED_MIN_WAVES)
+        graph.enable_blocked(split=split, rows_per_wave=rows_per_wave, min_waves=0 if force else BLOCKED_MIN_WAVES)
     return graph
 
 
