@@ -22,6 +22,7 @@ import scipy.sparse as sp
 import torch
 import torch.nn.functional as F
 
+from ... import ops
 from ...util.metrics import AttackMetric
 from .._common import init_graph, with_fake_rows
 from .BiLevelAttackByBatchInject import _CwLoss
@@ -40,6 +41,20 @@ class _ItemInfoNCE(torch.autograd.Function):
             v2 = Pi / nrm
             I = Pi.shape[0]
             k = (I + bs - 1) // bs
+            if Pi.is_cuda and Pi.shape[1] in ops.NCE_ALLROWS_WIDTHS and Pi.dtype == torch.float32:
+                # fused form (arl_nce_allrows_*): ttl_j = sum_i exp(<v2_j, v1_i>/T) over ALL items i is a log-sum-exp with v2 as the batch side;
+                # only v2 carries gradient.  Batch j // bs has n_j items: weight of item j = 1 / (n_j k).
+                v1c, v2c = v1.contiguous(), v2.contiguous()
+                lse, dA, _ = ops.nce_allrows(v2c, v1c, temperature, want_dV=False)
+                n_of = torch.full((I,), float(bs), device=Pi.device)
+                if I % bs:
+                    n_of[(I // bs) * bs:] = float(I % bs)
+                w = 1.0 / (n_of * k)
+                loss = (w * (lse - (v1c * v2c).sum(-1) / temperature)).sum()
+                g = (dA - v1c) * (w / temperature)[:, None]                # d loss / d v2
+                G = (g - v2c * (v2c * g).sum(-1, keepdim=True)) / nrm      # through x / |x|
+                ctx.save_for_backward(G)
+                return loss
             loss = torch.zeros((), dtype=torch.float32, device=Pi.device)
             G = torch.empty_like(Pi)
             for b in range(0, I, bs):

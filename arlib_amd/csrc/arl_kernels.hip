@@ -1188,6 +1188,139 @@ __global__ __launch_bounds__(kBlock) void nce_grad_kernel(const float *__restric
 }
 
 // ================================================================================================
+// All-rows InfoNCE (recommender/NCL.py:96-115 ssl_layer_loss; attack/White/InfoAttack.py:214-230): for normalised rows A [nA, d] (the batch)
+// and a normalised table V [nV, d] (ALL users or items),
+//     lse_b = log sum_j exp(<a_b, v_j> / T),   dA_b = sum_j P_bj v_j,   dV_j = sum_b P_bj a_b,   P_bj = exp(<a_b, v_j>/T - lse_b)
+// with nA x nV logits (2 048 x 10^6 at cfg2) that are never stored.  The reference materialises them; the round-2 form walked the table in
+// panels with two library GEMMs per panel and pass.  Here one kernel, three uses, exact fp32 on v_mfma_f32_16x16x4_f32:
+//   * a wave keeps 16 rows of the RESIDENT side in registers (B operand; lane (c, g) holds row c, columns [16g, 16g + 16) -- a permutation
+//     of the contraction index both operands share) and its output for them (a sum of exponentials, or a 16 x d gradient tile);
+//   * the STREAMED side goes through LDS 64 rows at a time (double-buffered, one block barrier per stage);
+//   * scores come out as C[t = 4g + reg][r = c]; exp() of them is already in A-operand layout for the second product
+//     out[r][:] += sum_t P[t][r] X_t[t][:]  (MFMA j contracts t = 4g + j), so no transposition through LDS;
+//   * |<a, v>| <= 1 for normalised rows: exp((s - 1)/T) cannot overflow, so the log-sum-exp needs no running maximum.
+// Uses: lse and dA with A resident and V streamed in `gridDim.y` splits (partials summed in split order: deterministic), dV with V resident and
+// A streamed whole.  LSE_ON_R: the log-sum-exp subtracted from a score belongs to the resident row (A resident) or to the streamed row.
+template <int D, bool GRAD, bool LSE_ON_R>
+__global__ __launch_bounds__(kBlock) void nce_allrows_kernel(const float *__restrict__ Xr, int nR, const float *__restrict__ Xt, int nT, int split_len,
+                                                              float inv_tau, const float *__restrict__ lse, float *__restrict__ out) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    constexpr int Q = D / 4, LD = D + 4, NT = D / 16;
+    __shared__ float tile[2][64 * LD];
+    __shared__ float tlse[2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int r0 = (blockIdx.x * kWavesPerBlock + wv) * 16;
+    const int t_begin = blockIdx.y * split_len, t_end = min(nT, t_begin + split_len);
+    float br[Q];
+    {
+        const int r = r0 + c;
+#pragma unroll
+        for (int i = 0; i < Q; i += 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < nR) v = *reinterpret_cast<const float4 *>(Xr + (size_t)r * D + Q * g + i);
+            br[i] = v.x; br[i + 1] = v.y; br[i + 2] = v.z; br[i + 3] = v.w;
+        }
+    }
+    const float lse_r = (GRAD && LSE_ON_R && r0 + c < nR) ? lse[r0 + c] : 0.f;
+    v4f o[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) o[n] = v4f{0.f, 0.f, 0.f, 0.f};
+    float sum = 0.f;
+    const int nst = (t_end - t_begin + 63) / 64;
+    // staging: a stage is 64 x D floats = 16 D float4s over 256 threads; the NEXT stage is fetched into registers before the current one
+    // is consumed and goes to the other LDS buffer afterwards (its last readers passed the barrier of the stage before)
+    constexpr int PF = 64 * (D / 4) / kBlock;
+    float4 pre[PF];
+    float pre_lse = 0.f;
+    auto fetch = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int f = tid + i * kBlock, row = f / (D / 4), q4 = f % (D / 4);
+            const int t = min(t_begin + st * 64 + row, nT - 1);         // clamped; rows past t_end are masked below
+            pre[i] = *reinterpret_cast<const float4 *>(Xt + (size_t)t * D + q4 * 4);
+        }
+        if (GRAD && !LSE_ON_R && tid < 64) pre_lse = lse[min(t_begin + st * 64 + tid, nT - 1)];
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int f = tid + i * kBlock, row = f / (D / 4), q4 = f % (D / 4);
+            *reinterpret_cast<float4 *>(&tile[buf][row * LD + q4 * 4]) = pre[i];
+        }
+        if (GRAD && !LSE_ON_R && tid < 64) tlse[buf][tid] = pre_lse;
+    };
+    if (nst > 0) { fetch(0); stash(0); }
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nst) fetch(st + 1);
+        const float *T = tile[buf];
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            v4f sc = v4f{0.f, 0.f, 0.f, 0.f};
+            const float *arow = T + (sub * 16 + c) * LD + Q * g;
+#pragma unroll
+            for (int i = 0; i < Q; i += 4) {
+                const float4 a = *reinterpret_cast<const float4 *>(arow + i);
+                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, br[i], sc, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, br[i + 1], sc, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, br[i + 2], sc, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, br[i + 3], sc, 0, 0, 0);
+            }
+            const int tb = t_begin + st * 64 + sub * 16 + 4 * g;        // streamed row of register 0
+            float pj[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = tb + j < t_end;
+                if (!GRAD) pj[j] = ok ? __expf((sc[j] - 1.f) * inv_tau) : 0.f;
+                else pj[j] = ok ? __expf(sc[j] * inv_tau - (LSE_ON_R ? lse_r : tlse[buf][sub * 16 + 4 * g + j])) : 0.f;
+            }
+            if (!GRAD) {
+                sum += (pj[0] + pj[1]) + (pj[2] + pj[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float *brow = T + (sub * 16 + 4 * g + j) * LD + c;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(pj[j], brow[16 * n], o[n], 0, 0, 0);
+                }
+            }
+        }
+        if (st + 1 < nst) stash(buf ^ 1);
+        __syncthreads();
+    }
+    if (!GRAD) {
+        sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);         // over the four lane groups (fixed order)
+        if (g == 0 && r0 + c < nR) out[(size_t)blockIdx.y * nR + r0 + c] = sum;
+    } else {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = r0 + 4 * g + reg;
+                if (r < nR) out[((size_t)blockIdx.y * nR + r) * D + 16 * n + c] = o[n][reg];
+            }
+    }
+}
+
+// lse[b] = 1/T + log(sum over splits of the partial sums), splits added in order
+__global__ __launch_bounds__(kBlock) void nce_allrows_lse_finish_kernel(const float *__restrict__ part, int n_splits, int nA, float inv_tau, float *__restrict__ lse) {
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= nA) return;
+    float s = 0.f;
+    for (int k = 0; k < n_splits; ++k) s += part[(size_t)k * nA + b];
+    lse[b] = inv_tau + logf(s);
+}
+// out[i] = sum over splits of part[k][i], in split order
+__global__ __launch_bounds__(kBlock) void nce_allrows_fold_kernel(const float4 *__restrict__ part, int n_splits, long long n4, float4 *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (long long)gridDim.x * kBlock) {
+        float4 a = part[i];
+        for (int k = 1; k < n_splits; ++k) a = add4(a, part[(size_t)k * n4 + i]);
+        out[i] = a;
+    }
+}
+
+// ================================================================================================
 // NGCF layer glue (recommender/NGCF.py:200-208): E' = leaky_relu((P + E) W1 + (P * E) W2), P = A E.
 // The two d x d products run as ONE rocBLAS GEMM on [S | T] (N x 2d) by [W1; W2]; these kernels are the element-wise passes
 // around it, each touching every operand once (the ATen expression graph makes ~18 passes forward, ~30 backward).
@@ -3103,6 +3236,72 @@ int arl_shard_batch_prep_i32(const int32_t *u, const int32_t *p, const int32_t *
     hipLaunchKernelGGL(shard_batch_prep_kernel, dim3((unsigned)((B + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, u, p, n, (int)B, (int)u0,
                        (int)u1, lu, own, item_rows, rows_l);
     ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+// number of splits of the streamed table when the batch is the resident side: enough workgroups to fill the chip several times over
+static int nce_allrows_splits(int64_t nA, int64_t nV) {
+    const int64_t row_blocks = (nA + 63) / 64;
+    int64_t s = (2048 + row_blocks - 1) / row_blocks;
+    const int64_t max_s = (nV + 4095) / 4096;                          // at least 4 096 streamed rows per split
+    if (s > max_s) s = max_s;
+    if (s > 512) s = 512;
+    return (int)(s < 1 ? 1 : s);
+}
+
+int64_t arl_nce_allrows_workspace_bytes(int64_t nA, int64_t nV, int64_t d) {
+    if (nA <= 0 || nV <= 0 || d <= 0) return 0;
+    return (int64_t)sizeof(float) * nce_allrows_splits(nA, nV) * nA * (d > 1 ? d : 1);
+}
+
+#define ARL_NCE_DISPATCH(DV, GRADV, LSERV, GRID, ...)                                                                              \
+    do {                                                                                                                          \
+        hipLaunchKernelGGL((nce_allrows_kernel<DV, GRADV, LSERV>), GRID, dim3(kBlock), 0, st, __VA_ARGS__);                       \
+        ARL_LAUNCH_CHECK();                                                                                                       \
+    } while (0)
+#define ARL_NCE_BY_WIDTH(GRADV, LSERV, GRID, ...)                                                                                 \
+    do {                                                                                                                          \
+        if (d == 16) ARL_NCE_DISPATCH(16, GRADV, LSERV, GRID, __VA_ARGS__);                                                       \
+        else if (d == 32) ARL_NCE_DISPATCH(32, GRADV, LSERV, GRID, __VA_ARGS__);                                                  \
+        else if (d == 64) ARL_NCE_DISPATCH(64, GRADV, LSERV, GRID, __VA_ARGS__);                                                  \
+        else ARL_NCE_DISPATCH(128, GRADV, LSERV, GRID, __VA_ARGS__);                                                              \
+    } while (0)
+
+int arl_nce_allrows_lse_f32(const float *A, int64_t nA, const float *V, int64_t nV, int64_t d, float tau, float *lse, void *workspace,
+                            arl_stream_t stream) {
+    if (!A || !V || !lse || !workspace) return ARL_E_NULL;
+    if (d != 16 && d != 32 && d != 64 && d != 128) return ARL_E_DIM;
+    if (nA <= 0 || nV <= 0 || nA > 0x7fffffffll / 128 || nV > 0x7fffffffll / 128 || !(tau > 0.f)) return ARL_E_ARG;
+    if (((uintptr_t)A | (uintptr_t)V) & 15) return ARL_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int ns = nce_allrows_splits(nA, nV);
+    const int split_len = (int)((nV + ns - 1) / ns);
+    float *part = (float *)workspace;
+    ARL_NCE_BY_WIDTH(false, true, dim3((unsigned)((nA + 63) / 64), (unsigned)ns), A, (int)nA, V, (int)nV, split_len, 1.0f / tau, (const float *)nullptr, part);
+    hipLaunchKernelGGL(nce_allrows_lse_finish_kernel, dim3((unsigned)((nA + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, part, ns, (int)nA, 1.0f / tau, lse);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_nce_allrows_grad_f32(const float *A, int64_t nA, const float *V, int64_t nV, int64_t d, float tau, const float *lse, float *dA, float *dV,
+                             void *workspace, arl_stream_t stream) {
+    if (!A || !V || !lse || !workspace || (!dA && !dV)) return ARL_E_NULL;
+    if (d != 16 && d != 32 && d != 64 && d != 128) return ARL_E_DIM;
+    if (nA <= 0 || nV <= 0 || nA > 0x7fffffffll / 128 || nV > 0x7fffffffll / 128 || !(tau > 0.f)) return ARL_E_ARG;
+    if (((uintptr_t)A | (uintptr_t)V | (uintptr_t)dA | (uintptr_t)dV | (uintptr_t)workspace) & 15) return ARL_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int ns = nce_allrows_splits(nA, nV);
+    const int split_len = (int)((nV + ns - 1) / ns);
+    float *part = (float *)workspace;
+    if (dA) {       // the batch resident, the table streamed in splits, partial tiles folded in split order
+        ARL_NCE_BY_WIDTH(true, true, dim3((unsigned)((nA + 63) / 64), (unsigned)ns), A, (int)nA, V, (int)nV, split_len, 1.0f / tau, lse, part);
+        const long long n4 = nA * d / 4;
+        hipLaunchKernelGGL(nce_allrows_fold_kernel, dim3(grid_for(n4, kBlock)), dim3(kBlock), 0, st, (const float4 *)part, ns, n4, (float4 *)dA);
+        ARL_LAUNCH_CHECK();
+    }
+    if (dV) {       // the table resident (16 rows per wave), the whole batch streamed
+        ARL_NCE_BY_WIDTH(true, false, dim3((unsigned)((nV + 63) / 64), 1u), V, (int)nV, A, (int)nA, (int)nA, 1.0f / tau, lse, dV);
+    }
     return ARL_OK;
 }
 

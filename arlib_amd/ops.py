@@ -888,6 +888,30 @@ def infonce_fwd_bwd(v1, v2, tau, want_grad=True, upstream=1.0):
     return loss, d1, d2
 
 
+NCE_ALLROWS_WIDTHS = (16, 32, 64, 128)
+
+
+def nce_allrows(A, V, tau, want_grad=True, want_dV=True):
+    """All-rows InfoNCE pieces for row-NORMALISED A [nA, d] (the batch) and V [nV, d] (all users or items), d in {16, 32, 64, 128}, without an nA x nV logit
+    matrix: returns lse [nA] = log sum_j exp(<a_b, v_j>/tau) and, with want_grad, (dA, dV) = (sum_j P_bj v_j, sum_b P_bj a_b) with
+    P = exp(<a, v>/tau - lse); want_dV=False skips the table-side sum (dV = None).  The caller applies 1/tau, the positive pairs' terms and
+    the upstream gradient (recommender/NCL.py:96-115, attack/White/InfoAttack.py:96-101)."""
+    _dev(A, torch.float32, 'A', 2); _dev(V, torch.float32, 'V', 2)
+    nA, d = A.shape
+    nV = V.shape[0]
+    if V.shape[1] != d or d not in NCE_ALLROWS_WIDTHS or nA == 0 or nV == 0:
+        raise ValueError('nce_allrows: A [nA, d], V [nV, d] with d in %s' % (NCE_ALLROWS_WIDTHS,))
+    L = _lib.lib()
+    ws = torch.empty(max(L.arl_nce_allrows_workspace_bytes(nA, nV, d) // 4, 4), dtype=torch.float32, device=A.device)
+    lse = torch.empty(nA, dtype=torch.float32, device=A.device)
+    check(L.arl_nce_allrows_lse_f32(_ptr(A), nA, _ptr(V), nV, d, float(tau), _ptr(lse), _ptr(ws), _stream()), 'arl_nce_allrows_lse_f32')
+    if not want_grad:
+        return lse
+    dA, dV = torch.empty_like(A), (torch.empty_like(V) if want_dV else None)
+    check(L.arl_nce_allrows_grad_f32(_ptr(A), nA, _ptr(V), nV, d, float(tau), _ptr(lse), _ptr(dA), _ptr(dV), _ptr(ws), _stream()), 'arl_nce_allrows_grad_f32')
+    return lse, dA, dV
+
+
 def simgcl_perturb_rng(src, eps, seed, stream_id, out=None, row_ids=None):
     """out = src + sign(src) * normalize(u) * eps with u ~ uniform[0,1) drawn inside the kernel from (seed, stream_id, row, column): the
     SimGCL perturbation (SimGCL.py:203-205) without a noise table or a clone.  out may be src (in place).  row_ids (int32, optional): src holds

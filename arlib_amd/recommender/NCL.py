@@ -11,7 +11,8 @@ As executed by the reference:
 * both phases step the optimiser (the commented `optimizer.step()` lines sit above the live one).
 
 The structure loss has B x U and B x I logits (2048 x 10^6 at cfg2): `_AllRowsNCE` walks the table in panels, twice (log-sum-exp,
-then gradients), so nothing of that size is kept -- two library GEMMs per panel and pass.
+then gradients), so nothing of that size is kept; at d = 64 on the GPU it runs as the fused all-rows kernels (ops.nce_allrows: exact
+fp32 MFMA, no logits stored, no library GEMM), other widths keep two library GEMMs per panel and pass.
 """
 import numpy as np
 import torch
@@ -39,9 +40,22 @@ class _AllRowsNCE(torch.autograd.Function):
     """sum_b -log( exp(<A_b, V_idx_b>/T) / sum_j exp(<A_b, V_j>/T) ) for normalised rows A [B, d] and the normalised table V [N, d]
     (ssl_layer_loss, NCL.py:96-103 / :109-115), with the gradients w.r.t. A and V, panel by panel."""
     PANEL = 65536
+    FUSED = True          # False: the panel form (library GEMMs) also where the fused kernels apply -- A/B and tests
 
     @staticmethod
     def forward(ctx, A, V, idx, T):
+        if _AllRowsNCE.FUSED and A.is_cuda and A.shape[1] in ops.NCE_ALLROWS_WIDTHS and A.dtype == torch.float32:
+            # the fused form (arl_nce_allrows_*): no B x N logits, no library GEMM; exact fp32 products on the matrix cores
+            with torch.no_grad():
+                A_, V_ = A.contiguous(), V.contiguous()
+                lse, dA, dV = ops.nce_allrows(A_, V_, T)
+                Vi = V_[idx]
+                loss = (lse - (A_ * Vi).sum(1) / T).sum()
+                dA -= Vi
+                dA /= T; dV /= T
+                ops.scatter_add_rows(dV, idx.to(torch.int32).contiguous(), A_, -1.0 / T, check_range=False)
+            ctx.save_for_backward(dA, dV)
+            return loss
         with torch.no_grad():
             B, N = A.shape[0], V.shape[0]
             m = torch.full((B,), -float('inf'), device=A.device); s = torch.zeros(B, device=A.device)

@@ -414,6 +414,24 @@ int arl_topn_project_rows_f32(const float *M, int64_t rows, int64_t cols, int64_
                               float *scratch, arl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * All-rows InfoNCE -- replaces the nA x nV logit matrices of recommender/NCL.py:96-115 (ssl_layer_loss: F.normalize, two
+ * torch.matmul against ALL users / items, exp, sum, log) and attack/White/InfoAttack.py:214-230, forward and backward, without ever
+ * storing a logit.  A [nA, d] and V [nV, d] are row-NORMALISED fp32 tables (|<a, v>| <= 1 is what makes the fixed shift of the
+ * log-sum-exp safe), d in {16, 32, 64, 128}.
+ *   arl_nce_allrows_lse_f32   lse[b] = log sum_j exp(<a_b, v_j> / tau)
+ *   arl_nce_allrows_grad_f32  dA[b] = sum_j P_bj v_j,  dV[j] = sum_b P_bj a_b  with  P_bj = exp(<a_b, v_j>/tau - lse[b])
+ *                             (the caller applies 1/tau, the positive pairs' -v_idx / -a_b terms and the upstream gradient);
+ *                             dA or dV may be NULL when only one side is differentiated (InfoAttack: the other view is a constant)
+ * Exact fp32 products on the matrix cores (v_mfma_f32_16x16x4_f32); partial results are combined in a fixed order (deterministic).
+ * workspace: arl_nce_allrows_workspace_bytes(nA, nV, d) bytes, 16-byte aligned like A, V and dA.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t arl_nce_allrows_workspace_bytes(int64_t nA, int64_t nV, int64_t d);
+int arl_nce_allrows_lse_f32(const float *A, int64_t nA, const float *V, int64_t nV, int64_t d, float tau, float *lse,
+                            void *workspace, arl_stream_t stream);
+int arl_nce_allrows_grad_f32(const float *A, int64_t nA, const float *V, int64_t nV, int64_t d, float tau, const float *lse,
+                             float *dA, float *dV, void *workspace, arl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Item-table exchange of the user-sharded step (no reference counterpart: main.py:19 pins one device).
  * One process per GPU.  arl_comm_unique_id (rank 0) -> the 128 bytes travel to every rank by any side channel (torch.distributed
  * broadcast) -> arl_comm_init on every rank.  arl_allreduce_item_f32 sum-all-reduces buf[0, n_elems) IN PLACE, asynchronously on `stream`,

@@ -328,6 +328,28 @@ def test_gather_scatter_rows(ops):
     assert rel_err(dst.cpu().numpy(), ref) < 1e-5
 
 
+@pytest.mark.parametrize('nA,nV,d', [(2048, 20000, 64), (77, 333, 64), (16, 64, 64), (1000, 4097, 64), (500, 3000, 16), (300, 1412, 32), (260, 2000, 128)])
+def test_nce_allrows_against_float64(ops, nA, nV, d):
+    """All-rows InfoNCE (recommender/NCL.py:96-115): log-sum-exp over the whole table and both gradient sums against float64 torch; ragged
+    sizes (rows past the last full 16 / 64 tile on both sides), temperature 0.05 (logits up to 20), two runs bit-identical."""
+    g = torch.Generator().manual_seed(nA + nV)
+    A = torch.nn.functional.normalize(torch.randn(nA, d, generator=g), dim=1).to(DEV)
+    V = torch.nn.functional.normalize(torch.randn(nV, d, generator=g) + 0.3, dim=1).to(DEV)
+    tau = 0.05
+    lse, dA, dV = ops.nce_allrows(A, V, tau)
+    S = (A.double() @ V.double().T) / tau
+    lse_ref = torch.logsumexp(S, dim=1)
+    P = torch.exp(S - lse_ref[:, None])
+    assert float((lse.double() - lse_ref).abs().max()) < 1e-5
+    assert rel_err(dA.cpu().numpy(), (P @ V.double()).cpu().numpy()) < 1e-5
+    assert rel_err(dV.cpu().numpy(), (P.T @ A.double()).cpu().numpy()) < 1e-5
+    lse2, dA2, dV2 = ops.nce_allrows(A, V, tau)
+    assert torch.equal(lse, lse2) and torch.equal(dA, dA2) and torch.equal(dV, dV2)
+    assert torch.equal(ops.nce_allrows(A, V, tau, want_grad=False), lse)
+    with pytest.raises(ValueError):
+        ops.nce_allrows(A[:, :8].contiguous(), V[:, :8].contiguous(), tau)
+
+
 def _seq_add(dst, idx, src, scale):
     """CPU index_put_(accumulate) association: contributions added one after the other in index order, fp32, product rounded first."""
     out = dst.copy()
