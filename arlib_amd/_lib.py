@@ -101,9 +101,11 @@ _SIGS = {
     'arl_fake_block_cols_f32': (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, C.c_float, _vp, _vp]),
     'arl_score_mask_topk_workspace_bytes': (_i64, [_i64, _i64]),
     'arl_score_mask_topk_f32': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'arl_normalize_rows_f32': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    'arl_normalize_rows_bwd_f32': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _f, _vp, _vp, _vp]),
     'arl_nce_allrows_workspace_bytes': (_i64, [_i64, _i64, _i64]),
     'arl_nce_allrows_lse_f32': (C.c_int, [_vp, _i64, _vp, _i64, _i64, _f, _vp, _vp, _vp]),
-    'arl_nce_allrows_grad_f32': (C.c_int, [_vp, _i64, _vp, _i64, _i64, _f, _vp, _vp, _vp, _vp, _vp]),
+    'arl_nce_allrows_grad_f32': (C.c_int, [_vp, _i64, _vp, _i64, _i64, _f, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
     'arl_comm_load': (C.c_int, [C.c_char_p]),
     'arl_comm_unique_id': (C.c_int, [_vp]),
     'arl_comm_init': (C.c_int, [_vp, _i64, _i64, C.POINTER(C.c_void_p)]),

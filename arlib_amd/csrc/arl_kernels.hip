@@ -1201,9 +1201,11 @@ __global__ __launch_bounds__(kBlock) void nce_grad_kernel(const float *__restric
 //   * |<a, v>| <= 1 for normalised rows: exp((s - 1)/T) cannot overflow, so the log-sum-exp needs no running maximum.
 // Uses: lse and dA with A resident and V streamed in `gridDim.y` splits (partials summed in split order: deterministic), dV with V resident and
 // A streamed whole.  LSE_ON_R: the log-sum-exp subtracted from a score belongs to the resident row (A resident) or to the streamed row.
-template <int D, bool GRAD, bool LSE_ON_R>
+// FUSED (with GRAD, LSE_ON_R): no log-sum-exp comes in; the tile accumulates the UNNORMALISED sum_t exp((s - 1)/T) x_t and the row sums go to
+// `sums` as in the GRAD = false form -- the fold divides (one pass over the table less than log-sum-exp first, gradient second).
+template <int D, bool GRAD, bool LSE_ON_R, bool FUSED = false>
 __global__ __launch_bounds__(kBlock) void nce_allrows_kernel(const float *__restrict__ Xr, int nR, const float *__restrict__ Xt, int nT, int split_len,
-                                                              float inv_tau, const float *__restrict__ lse, float *__restrict__ out) {
+                                                              float inv_tau, const float *__restrict__ lse, float *__restrict__ out, float *__restrict__ sums) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     constexpr int Q = D / 4, LD = D + 4, NT = D / 16;
     __shared__ float tile[2][64 * LD];
@@ -1221,7 +1223,7 @@ __global__ __launch_bounds__(kBlock) void nce_allrows_kernel(const float *__rest
             br[i] = v.x; br[i + 1] = v.y; br[i + 2] = v.z; br[i + 3] = v.w;
         }
     }
-    const float lse_r = (GRAD && LSE_ON_R && r0 + c < nR) ? lse[r0 + c] : 0.f;
+    const float lse_r = (GRAD && LSE_ON_R && !FUSED && r0 + c < nR) ? lse[r0 + c] : 0.f;
     v4f o[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) o[n] = v4f{0.f, 0.f, 0.f, 0.f};
@@ -1229,31 +1231,31 @@ __global__ __launch_bounds__(kBlock) void nce_allrows_kernel(const float *__rest
     const int nst = (t_end - t_begin + 63) / 64;
     // staging: a stage is 64 x D floats = 16 D float4s over 256 threads; the NEXT stage is fetched into registers before the current one
     // is consumed and goes to the other LDS buffer afterwards (its last readers passed the barrier of the stage before)
+    // (macros, not lambdas: an array captured by reference stays in scratch memory and every load is waited for at once)
     constexpr int PF = 64 * (D / 4) / kBlock;
-    float4 pre[PF];
+    v4f pre[PF];
     float pre_lse = 0.f;
-    auto fetch = [&](int st) {
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int f = tid + i * kBlock, row = f / (D / 4), q4 = f % (D / 4);
-            const int t = min(t_begin + st * 64 + row, nT - 1);         // clamped; rows past t_end are masked below
-            pre[i] = *reinterpret_cast<const float4 *>(Xt + (size_t)t * D + q4 * 4);
-        }
-        if (GRAD && !LSE_ON_R && tid < 64) pre_lse = lse[min(t_begin + st * 64 + tid, nT - 1)];
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int f = tid + i * kBlock, row = f / (D / 4), q4 = f % (D / 4);
-            *reinterpret_cast<float4 *>(&tile[buf][row * LD + q4 * 4]) = pre[i];
-        }
-        if (GRAD && !LSE_ON_R && tid < 64) tlse[buf][tid] = pre_lse;
-    };
-    if (nst > 0) { fetch(0); stash(0); }
+    const int frow = tid / (D / 4), fq = (tid % (D / 4)) * 4;               // this thread's row (+ i * kBlock / (D/4)) and column of a stage
+    constexpr int FSTEP = kBlock / (D / 4);
+#define ARL_NCE_FETCH(ST)                                                                                                          \
+    do {                                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < PF; ++i) {                                                                           \
+            const int t = min(t_begin + (ST) * 64 + frow + i * FSTEP, nT - 1);     /* clamped; rows past t_end are masked below */ \
+            pre[i] = *reinterpret_cast<const v4f *>(Xt + (size_t)t * D + fq);                                                      \
+        }                                                                                                                          \
+        if (GRAD && !LSE_ON_R && tid < 64) pre_lse = lse[min(t_begin + (ST) * 64 + tid, nT - 1)];                                  \
+    } while (0)
+#define ARL_NCE_STASH(BUF)                                                                                                         \
+    do {                                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < PF; ++i) *reinterpret_cast<v4f *>(&tile[BUF][(frow + i * FSTEP) * LD + fq]) = pre[i]; \
+        if (GRAD && !LSE_ON_R && tid < 64) tlse[BUF][tid] = pre_lse;                                                               \
+    } while (0)
+    if (nst > 0) { ARL_NCE_FETCH(0); ARL_NCE_STASH(0); }
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): the resident rows have landed on every path into the loop (else the in-loop wait is vmcnt(0) too)
     __syncthreads();
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1;
-        if (st + 1 < nst) fetch(st + 1);
+        if (st + 1 < nst) ARL_NCE_FETCH(st + 1);
         const float *T = tile[buf];
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
@@ -1272,12 +1274,11 @@ __global__ __launch_bounds__(kBlock) void nce_allrows_kernel(const float *__rest
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool ok = tb + j < t_end;
-                if (!GRAD) pj[j] = ok ? __expf((sc[j] - 1.f) * inv_tau) : 0.f;
+                if (!GRAD || FUSED) pj[j] = ok ? __expf((sc[j] - 1.f) * inv_tau) : 0.f;
                 else pj[j] = ok ? __expf(sc[j] * inv_tau - (LSE_ON_R ? lse_r : tlse[buf][sub * 16 + 4 * g + j])) : 0.f;
             }
-            if (!GRAD) {
-                sum += (pj[0] + pj[1]) + (pj[2] + pj[3]);
-            } else {
+            if (!GRAD || FUSED) sum += (pj[0] + pj[1]) + (pj[2] + pj[3]);
+            if (GRAD) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float *brow = T + (sub * 16 + 4 * g + j) * LD + c;
@@ -1286,13 +1287,16 @@ __global__ __launch_bounds__(kBlock) void nce_allrows_kernel(const float *__rest
                 }
             }
         }
-        if (st + 1 < nst) stash(buf ^ 1);
+        if (st + 1 < nst) ARL_NCE_STASH(buf ^ 1);
         __syncthreads();
     }
-    if (!GRAD) {
+#undef ARL_NCE_FETCH
+#undef ARL_NCE_STASH
+    if (!GRAD || FUSED) {
         sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);         // over the four lane groups (fixed order)
-        if (g == 0 && r0 + c < nR) out[(size_t)blockIdx.y * nR + r0 + c] = sum;
-    } else {
+        if (g == 0 && r0 + c < nR) (GRAD ? sums : out)[(size_t)blockIdx.y * nR + r0 + c] = sum;
+    }
+    if (GRAD) {
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -1311,12 +1315,57 @@ __global__ __launch_bounds__(kBlock) void nce_allrows_lse_finish_kernel(const fl
     for (int k = 0; k < n_splits; ++k) s += part[(size_t)k * nA + b];
     lse[b] = inv_tau + logf(s);
 }
+// fused form: lse[b] = 1/T + log Z_b, dA[b][:] = (sum over splits of the unnormalised tiles) / Z_b, Z_b = sum over splits of the row sums
+__global__ __launch_bounds__(kBlock) void nce_allrows_fold_norm_kernel(const float4 *__restrict__ part, const float *__restrict__ sums, int n_splits, int nA, int d4,
+                                                                        float inv_tau, float *__restrict__ lse, float4 *__restrict__ out) {
+    const long long n4 = (long long)nA * d4;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (long long)gridDim.x * kBlock) {
+        const int b = (int)(i / d4);
+        float z = 0.f;
+        for (int k = 0; k < n_splits; ++k) z += sums[(size_t)k * nA + b];
+        float4 a = part[i];
+        for (int k = 1; k < n_splits; ++k) a = add4(a, part[(size_t)k * n4 + i]);
+        out[i] = make_float4(a.x / z, a.y / z, a.z / z, a.w / z);
+        if (i - (long long)b * d4 == 0) lse[b] = inv_tau + logf(z);
+    }
+}
 // out[i] = sum over splits of part[k][i], in split order
 __global__ __launch_bounds__(kBlock) void nce_allrows_fold_kernel(const float4 *__restrict__ part, int n_splits, long long n4, float4 *__restrict__ out) {
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (long long)gridDim.x * kBlock) {
         float4 a = part[i];
         for (int k = 1; k < n_splits; ++k) a = add4(a, part[(size_t)k * n4 + i]);
         out[i] = a;
+    }
+}
+
+// F.normalize(x, dim=1) and its autograd on whole tables (recommender/NCL.py:98-99, 110-111: the four normalisations around each all-rows
+// InfoNCE), one pass each: LPR = d/4 rounded up to a power of two lanes hold a row as float4s, 64 / LPR rows per wave.
+//   forward : y = x / max(||x||, 1e-12), nrm = max(||x||, 1e-12)
+//   backward: dx = scale * (dy - y <y, dy>) / nrm      (dx = scale * dy / nrm for a row at the eps clamp: torch's clamp_min passes no gradient there)
+template <bool BWD>
+__global__ __launch_bounds__(kBlock) void rows_normalize_kernel(const float *__restrict__ X, const float *__restrict__ dY, float *__restrict__ nrm, long long n, int d,
+                                                                int lpr, float scale, const float *__restrict__ scale_dev, float *__restrict__ out) {
+    if (BWD && scale_dev) scale *= *scale_dev;
+    const int lane = threadIdx.x & 63, sub = lane % lpr, rows_per_wave = 64 / lpr;
+    const long long wave0 = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    for (long long w = wave0; w * rows_per_wave < n; w += (long long)gridDim.x * kWavesPerBlock) {
+        const long long r = w * rows_per_wave + lane / lpr;
+        const bool live = r < n && sub * 4 < d;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f), g = x;
+        if (live) x = *reinterpret_cast<const float4 *>(X + r * d + sub * 4);
+        if (BWD && live) g = *reinterpret_cast<const float4 *>(dY + r * d + sub * 4);
+        float s = BWD ? (x.x * g.x + x.y * g.y) + (x.z * g.z + x.w * g.w) : (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+        for (int o = 1; o < lpr; o <<= 1) s += __shfl_xor(s, o);
+        if (!BWD) {
+            const float m = fmaxf(sqrtf(s), 1e-12f);
+            if (live) *reinterpret_cast<float4 *>(out + r * d + sub * 4) = make_float4(x.x / m, x.y / m, x.z / m, x.w / m);
+            if (r < n && sub == 0) nrm[r] = m;
+        } else if (live) {
+            const float m = nrm[r];
+            const float dot = m > 1e-12f ? s : 0.f;
+            *reinterpret_cast<float4 *>(out + r * d + sub * 4) = make_float4(scale * (g.x - x.x * dot) / m, scale * (g.y - x.y * dot) / m,
+                                                                              scale * (g.z - x.z * dot) / m, scale * (g.w - x.w * dot) / m);
+        }
     }
 }
 
@@ -3251,20 +3300,20 @@ static int nce_allrows_splits(int64_t nA, int64_t nV) {
 
 int64_t arl_nce_allrows_workspace_bytes(int64_t nA, int64_t nV, int64_t d) {
     if (nA <= 0 || nV <= 0 || d <= 0) return 0;
-    return (int64_t)sizeof(float) * nce_allrows_splits(nA, nV) * nA * (d > 1 ? d : 1);
+    return (int64_t)sizeof(float) * nce_allrows_splits(nA, nV) * nA * (d + 4);      // per split: an nA x d tile block + nA row sums (padded)
 }
 
-#define ARL_NCE_DISPATCH(DV, GRADV, LSERV, GRID, ...)                                                                              \
+#define ARL_NCE_DISPATCH(DV, GRADV, LSERV, FUSEDV, GRID, ...)                                                                      \
     do {                                                                                                                          \
-        hipLaunchKernelGGL((nce_allrows_kernel<DV, GRADV, LSERV>), GRID, dim3(kBlock), 0, st, __VA_ARGS__);                       \
+        hipLaunchKernelGGL((nce_allrows_kernel<DV, GRADV, LSERV, FUSEDV>), GRID, dim3(kBlock), 0, st, __VA_ARGS__);               \
         ARL_LAUNCH_CHECK();                                                                                                       \
     } while (0)
-#define ARL_NCE_BY_WIDTH(GRADV, LSERV, GRID, ...)                                                                                 \
+#define ARL_NCE_BY_WIDTH(GRADV, LSERV, FUSEDV, GRID, ...)                                                                         \
     do {                                                                                                                          \
-        if (d == 16) ARL_NCE_DISPATCH(16, GRADV, LSERV, GRID, __VA_ARGS__);                                                       \
-        else if (d == 32) ARL_NCE_DISPATCH(32, GRADV, LSERV, GRID, __VA_ARGS__);                                                  \
-        else if (d == 64) ARL_NCE_DISPATCH(64, GRADV, LSERV, GRID, __VA_ARGS__);                                                  \
-        else ARL_NCE_DISPATCH(128, GRADV, LSERV, GRID, __VA_ARGS__);                                                              \
+        if (d == 16) ARL_NCE_DISPATCH(16, GRADV, LSERV, FUSEDV, GRID, __VA_ARGS__);                                               \
+        else if (d == 32) ARL_NCE_DISPATCH(32, GRADV, LSERV, FUSEDV, GRID, __VA_ARGS__);                                          \
+        else if (d == 64) ARL_NCE_DISPATCH(64, GRADV, LSERV, FUSEDV, GRID, __VA_ARGS__);                                          \
+        else ARL_NCE_DISPATCH(128, GRADV, LSERV, FUSEDV, GRID, __VA_ARGS__);                                                      \
     } while (0)
 
 int arl_nce_allrows_lse_f32(const float *A, int64_t nA, const float *V, int64_t nV, int64_t d, float tau, float *lse, void *workspace,
@@ -3277,15 +3326,17 @@ int arl_nce_allrows_lse_f32(const float *A, int64_t nA, const float *V, int64_t 
     const int ns = nce_allrows_splits(nA, nV);
     const int split_len = (int)((nV + ns - 1) / ns);
     float *part = (float *)workspace;
-    ARL_NCE_BY_WIDTH(false, true, dim3((unsigned)((nA + 63) / 64), (unsigned)ns), A, (int)nA, V, (int)nV, split_len, 1.0f / tau, (const float *)nullptr, part);
+    ARL_NCE_BY_WIDTH(false, true, false, dim3((unsigned)((nA + 63) / 64), (unsigned)ns), A, (int)nA, V, (int)nV, split_len, 1.0f / tau, (const float *)nullptr, part,
+                     (float *)nullptr);
     hipLaunchKernelGGL(nce_allrows_lse_finish_kernel, dim3((unsigned)((nA + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, part, ns, (int)nA, 1.0f / tau, lse);
     ARL_LAUNCH_CHECK();
     return ARL_OK;
 }
 
-int arl_nce_allrows_grad_f32(const float *A, int64_t nA, const float *V, int64_t nV, int64_t d, float tau, const float *lse, float *dA, float *dV,
-                             void *workspace, arl_stream_t stream) {
+int arl_nce_allrows_grad_f32(const float *A, int64_t nA, const float *V, int64_t nV, int64_t d, float tau, float *lse, int32_t lse_given, float *dA,
+                             float *dV, void *workspace, arl_stream_t stream) {
     if (!A || !V || !lse || !workspace || (!dA && !dV)) return ARL_E_NULL;
+    if (!lse_given && !dA) return ARL_E_ARG;                          // the log-sum-exp comes out of the dA pass
     if (d != 16 && d != 32 && d != 64 && d != 128) return ARL_E_DIM;
     if (nA <= 0 || nV <= 0 || nA > 0x7fffffffll / 128 || nV > 0x7fffffffll / 128 || !(tau > 0.f)) return ARL_E_ARG;
     if (((uintptr_t)A | (uintptr_t)V | (uintptr_t)dA | (uintptr_t)dV | (uintptr_t)workspace) & 15) return ARL_E_ARG;
@@ -3294,15 +3345,53 @@ int arl_nce_allrows_grad_f32(const float *A, int64_t nA, const float *V, int64_t
     const int split_len = (int)((nV + ns - 1) / ns);
     float *part = (float *)workspace;
     if (dA) {       // the batch resident, the table streamed in splits, partial tiles folded in split order
-        ARL_NCE_BY_WIDTH(true, true, dim3((unsigned)((nA + 63) / 64), (unsigned)ns), A, (int)nA, V, (int)nV, split_len, 1.0f / tau, lse, part);
         const long long n4 = nA * d / 4;
-        hipLaunchKernelGGL(nce_allrows_fold_kernel, dim3(grid_for(n4, kBlock)), dim3(kBlock), 0, st, (const float4 *)part, ns, n4, (float4 *)dA);
+        const dim3 grid((unsigned)((nA + 63) / 64), (unsigned)ns);
+        if (lse_given) {
+            ARL_NCE_BY_WIDTH(true, true, false, grid, A, (int)nA, V, (int)nV, split_len, 1.0f / tau, (const float *)lse, part, (float *)nullptr);
+            hipLaunchKernelGGL(nce_allrows_fold_kernel, dim3(grid_for(n4, kBlock)), dim3(kBlock), 0, st, (const float4 *)part, ns, n4, (float4 *)dA);
+        } else {
+            float *sums = part + (size_t)ns * nA * d;
+            ARL_NCE_BY_WIDTH(true, true, true, grid, A, (int)nA, V, (int)nV, split_len, 1.0f / tau, (const float *)nullptr, part, sums);
+            hipLaunchKernelGGL(nce_allrows_fold_norm_kernel, dim3(grid_for(n4, kBlock)), dim3(kBlock), 0, st, (const float4 *)part, (const float *)sums, ns, (int)nA,
+                               (int)(d / 4), 1.0f / tau, lse, (float4 *)dA);
+        }
         ARL_LAUNCH_CHECK();
     }
     if (dV) {       // the table resident (16 rows per wave), the whole batch streamed
-        ARL_NCE_BY_WIDTH(true, false, dim3((unsigned)((nV + 63) / 64), 1u), V, (int)nV, A, (int)nA, (int)nA, 1.0f / tau, lse, dV);
+        ARL_NCE_BY_WIDTH(true, false, false, dim3((unsigned)((nV + 63) / 64), 1u), V, (int)nV, A, (int)nA, (int)nA, 1.0f / tau, (const float *)lse, dV, (float *)nullptr);
     }
     return ARL_OK;
+}
+
+static int normalize_rows_launch(bool bwd, const float *X, const float *dY, float *nrm, int64_t n, int64_t d, float scale, const float *scale_dev, float *out,
+                                 hipStream_t st) {
+    int lpr = 1;
+    while (lpr * 4 < d) lpr <<= 1;
+    const long long waves = (n + 64 / lpr - 1) / (64 / lpr);
+    const long long blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    const unsigned grid = (unsigned)(blocks < 16384 ? blocks : 16384);
+    if (bwd) hipLaunchKernelGGL((rows_normalize_kernel<true>), dim3(grid), dim3(kBlock), 0, st, X, dY, nrm, (long long)n, (int)d, lpr, scale, scale_dev, out);
+    else hipLaunchKernelGGL((rows_normalize_kernel<false>), dim3(grid), dim3(kBlock), 0, st, X, dY, nrm, (long long)n, (int)d, lpr, scale, scale_dev, out);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_normalize_rows_f32(const float *X, int64_t n, int64_t d, float *Y, float *nrm, arl_stream_t stream) {
+    if (!X || !Y || !nrm) return ARL_E_NULL;
+    if (n < 0 || d <= 0 || d > 256 || (d & 3)) return ARL_E_DIM;
+    if (((uintptr_t)X | (uintptr_t)Y) & 15) return ARL_E_ARG;
+    if (n == 0) return ARL_OK;
+    return normalize_rows_launch(false, X, nullptr, nrm, n, d, 1.f, nullptr, Y, (hipStream_t)stream);
+}
+
+int arl_normalize_rows_bwd_f32(const float *Y, const float *nrm, const float *dY, int64_t n, int64_t d, float scale, const float *scale_dev, float *dX,
+                               arl_stream_t stream) {
+    if (!Y || !nrm || !dY || !dX) return ARL_E_NULL;
+    if (n < 0 || d <= 0 || d > 256 || (d & 3)) return ARL_E_DIM;
+    if (((uintptr_t)Y | (uintptr_t)dY | (uintptr_t)dX) & 15) return ARL_E_ARG;
+    if (n == 0) return ARL_OK;
+    return normalize_rows_launch(true, Y, dY, const_cast<float *>(nrm), n, d, scale, scale_dev, dX, (hipStream_t)stream);
 }
 
 int64_t arl_infonce_workspace_bytes(int64_t n, int64_t d) { return (n < 0 || d < 0) ? 0 : (int64_t)sizeof(float) * (4 * n * d + 4 * n); }

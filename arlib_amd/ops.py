@@ -891,11 +891,12 @@ def infonce_fwd_bwd(v1, v2, tau, want_grad=True, upstream=1.0):
 NCE_ALLROWS_WIDTHS = (16, 32, 64, 128)
 
 
-def nce_allrows(A, V, tau, want_grad=True, want_dV=True):
+def nce_allrows(A, V, tau, want_grad=True, want_dV=True, lse=None):
     """All-rows InfoNCE pieces for row-NORMALISED A [nA, d] (the batch) and V [nV, d] (all users or items), d in {16, 32, 64, 128}, without an nA x nV logit
     matrix: returns lse [nA] = log sum_j exp(<a_b, v_j>/tau) and, with want_grad, (dA, dV) = (sum_j P_bj v_j, sum_b P_bj a_b) with
     P = exp(<a, v>/tau - lse); want_dV=False skips the table-side sum (dV = None).  The caller applies 1/tau, the positive pairs' terms and
-    the upstream gradient (recommender/NCL.py:96-115, attack/White/InfoAttack.py:96-101)."""
+    the upstream gradient (recommender/NCL.py:96-115, attack/White/InfoAttack.py:96-101).  lse: a log-sum-exp from an earlier want_grad=False
+    call (forward and backward at different times); without it the gradient call produces it on the way."""
     _dev(A, torch.float32, 'A', 2); _dev(V, torch.float32, 'V', 2)
     nA, d = A.shape
     nV = V.shape[0]
@@ -903,13 +904,42 @@ def nce_allrows(A, V, tau, want_grad=True, want_dV=True):
         raise ValueError('nce_allrows: A [nA, d], V [nV, d] with d in %s' % (NCE_ALLROWS_WIDTHS,))
     L = _lib.lib()
     ws = torch.empty(max(L.arl_nce_allrows_workspace_bytes(nA, nV, d) // 4, 4), dtype=torch.float32, device=A.device)
-    lse = torch.empty(nA, dtype=torch.float32, device=A.device)
-    check(L.arl_nce_allrows_lse_f32(_ptr(A), nA, _ptr(V), nV, d, float(tau), _ptr(lse), _ptr(ws), _stream()), 'arl_nce_allrows_lse_f32')
+    given = lse is not None
+    if given:
+        _dev(lse, torch.float32, 'lse', 1)
+        if lse.numel() != nA or not want_grad:
+            raise ValueError('nce_allrows: lse [nA] goes with want_grad=True')
+    else:
+        lse = torch.empty(nA, dtype=torch.float32, device=A.device)
     if not want_grad:
+        check(L.arl_nce_allrows_lse_f32(_ptr(A), nA, _ptr(V), nV, d, float(tau), _ptr(lse), _ptr(ws), _stream()), 'arl_nce_allrows_lse_f32')
         return lse
     dA, dV = torch.empty_like(A), (torch.empty_like(V) if want_dV else None)
-    check(L.arl_nce_allrows_grad_f32(_ptr(A), nA, _ptr(V), nV, d, float(tau), _ptr(lse), _ptr(dA), _ptr(dV), _ptr(ws), _stream()), 'arl_nce_allrows_grad_f32')
+    # lse_given = 0: the log-sum-exp comes out of the dA pass (two passes over V instead of three)
+    check(L.arl_nce_allrows_grad_f32(_ptr(A), nA, _ptr(V), nV, d, float(tau), _ptr(lse), 1 if given else 0, _ptr(dA), _ptr(dV), _ptr(ws), _stream()), 'arl_nce_allrows_grad_f32')
     return lse, dA, dV
+
+
+def normalize_rows(X):
+    """(Y, nrm) = (F.normalize(X, dim=1), max(||X_r||, 1e-12)) in one pass (recommender/NCL.py:98-99)."""
+    _dev(X, torch.float32, 'X', 2)
+    Y, nrm = torch.empty_like(X), torch.empty(X.shape[0], dtype=torch.float32, device=X.device)
+    check(_lib.lib().arl_normalize_rows_f32(_ptr(X), X.shape[0], X.shape[1], _ptr(Y), _ptr(nrm), _stream()), 'arl_normalize_rows_f32')
+    return Y, nrm
+
+
+def normalize_rows_bwd(Y, nrm, dY, scale=1.0, out=None, scale_dev=None):
+    """Autograd of normalize_rows: scale * (dY - Y <Y, dY>) / nrm; out may be dY (in place); scale_dev: a one-element GPU tensor multiplied into scale."""
+    _dev(Y, torch.float32, 'Y', 2); _dev(dY, torch.float32, 'dY', 2); _dev(nrm, torch.float32, 'nrm', 1)
+    if out is None:
+        out = torch.empty_like(dY)
+    _dev(out, torch.float32, 'out', 2)
+    if dY.shape != Y.shape or out.shape != Y.shape or nrm.numel() != Y.shape[0]:
+        raise ValueError('normalize_rows_bwd: shape mismatch')
+    if scale_dev is not None:
+        _dev(scale_dev, torch.float32, 'scale_dev')
+    check(_lib.lib().arl_normalize_rows_bwd_f32(_ptr(Y), _ptr(nrm), _ptr(dY), Y.shape[0], Y.shape[1], float(scale), _ptr(scale_dev), _ptr(out), _stream()), 'arl_normalize_rows_bwd_f32')
+    return out
 
 
 def simgcl_perturb_rng(src, eps, seed, stream_id, out=None, row_ids=None):

@@ -85,6 +85,39 @@ class _AllRowsNCE(torch.autograd.Function):
         return g * dA, g * dV, None, None
 
 
+class _AllRowsNCEOfRaw(torch.autograd.Function):
+    """_AllRowsNCE.apply(F.normalize(Xa), F.normalize(Xv), idx, T) with the four normalisation passes (forward and autograd) inside:
+    arl_normalize_rows_f32 / _bwd_f32 around arl_nce_allrows_grad_f32; 1/T and the upstream gradient ride in the backward kernel."""
+
+    @staticmethod
+    def forward(ctx, Xa, Xv, idx, T):
+        with torch.no_grad():
+            Ya, na = ops.normalize_rows(Xa.contiguous())
+            Yv, nv = ops.normalize_rows(Xv.contiguous())
+            lse, dA, dV = ops.nce_allrows(Ya, Yv, T)
+            Vi = Yv[idx]
+            loss = (lse - (Ya * Vi).sum(1) / T).sum()
+            dA -= Vi
+            ops.scatter_add_rows(dV, idx.to(torch.int32).contiguous(), Ya, -1.0, check_range=False)
+        ctx.save_for_backward(Ya, na, Yv, nv, dA, dV)
+        ctx.T = T
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        Ya, na, Yv, nv, dA, dV = ctx.saved_tensors
+        g1 = g.reshape(1).to(torch.float32).contiguous()
+        # (not in place: the graph may be walked again, retain_graph=True)
+        return ops.normalize_rows_bwd(Ya, na, dA, 1.0 / ctx.T, scale_dev=g1), ops.normalize_rows_bwd(Yv, nv, dV, 1.0 / ctx.T, scale_dev=g1), None, None
+
+
+def all_rows_nce(Xa, Xv, idx, T):
+    """sum_b -log softmax_j(<F.normalize(Xa)_b, F.normalize(Xv)_j>/T)[idx_b]  (ssl_layer_loss, NCL.py:96-103 / :109-115)."""
+    if _AllRowsNCE.FUSED and Xa.is_cuda and Xa.shape[1] in ops.NCE_ALLROWS_WIDTHS and Xa.dtype == torch.float32:
+        return _AllRowsNCEOfRaw.apply(Xa, Xv, idx, T)
+    return _AllRowsNCE.apply(F.normalize(Xa), F.normalize(Xv), idx, T)
+
+
 def InfoNCE(view1, view2, temperature, b_cos=True):
     """The module-local InfoNCE of the reference's NCL.py (:320-334): -mean(diag(log_softmax(v1 v2^T / T)))."""
     if b_cos:
@@ -144,8 +177,8 @@ class NCL(Recommender):
         U, I = self.data.user_num, self.data.item_num
         ctx_u, ctx_i = torch.split(context_emb, [U, I])
         ini_u, ini_i = torch.split(initial_emb, [U, I])
-        loss_u = _AllRowsNCE.apply(F.normalize(ctx_u[user]), F.normalize(ini_u), user, self.ssl_temp)
-        loss_i = _AllRowsNCE.apply(F.normalize(ctx_i[item]), F.normalize(ini_i), item, self.ssl_temp)
+        loss_u = all_rows_nce(ctx_u[user], ini_u, user, self.ssl_temp)
+        loss_i = all_rows_nce(ctx_i[item], ini_i, item, self.ssl_temp)
         return self.ssl_reg * (loss_u + self.alpha * loss_i)
 
     def _clean_graph(self):

@@ -421,15 +421,26 @@ int arl_topn_project_rows_f32(const float *M, int64_t rows, int64_t cols, int64_
  *   arl_nce_allrows_lse_f32   lse[b] = log sum_j exp(<a_b, v_j> / tau)
  *   arl_nce_allrows_grad_f32  dA[b] = sum_j P_bj v_j,  dV[j] = sum_b P_bj a_b  with  P_bj = exp(<a_b, v_j>/tau - lse[b])
  *                             (the caller applies 1/tau, the positive pairs' -v_idx / -a_b terms and the upstream gradient);
- *                             dA or dV may be NULL when only one side is differentiated (InfoAttack: the other view is a constant)
+ *                             dA or dV may be NULL when only one side is differentiated (InfoAttack: the other view is a constant).
+ *                             lse_given != 0: lse is an input (from arl_nce_allrows_lse_f32).  lse_given == 0: lse is an OUTPUT of the
+ *                             dA pass (dA required), which then accumulates unnormalised exp((s - 1)/tau) terms and divides in the fold:
+ *                             forward + backward in two passes over the table instead of three.
  * Exact fp32 products on the matrix cores (v_mfma_f32_16x16x4_f32); partial results are combined in a fixed order (deterministic).
  * workspace: arl_nce_allrows_workspace_bytes(nA, nV, d) bytes, 16-byte aligned like A, V and dA.
  * ---------------------------------------------------------------------------------------------- */
 int64_t arl_nce_allrows_workspace_bytes(int64_t nA, int64_t nV, int64_t d);
 int arl_nce_allrows_lse_f32(const float *A, int64_t nA, const float *V, int64_t nV, int64_t d, float tau, float *lse,
                             void *workspace, arl_stream_t stream);
-int arl_nce_allrows_grad_f32(const float *A, int64_t nA, const float *V, int64_t nV, int64_t d, float tau, const float *lse,
+int arl_nce_allrows_grad_f32(const float *A, int64_t nA, const float *V, int64_t nV, int64_t d, float tau, float *lse, int32_t lse_given,
                              float *dA, float *dV, void *workspace, arl_stream_t stream);
+
+/* F.normalize(x, dim=1) of a whole table and its autograd in one pass each (the normalisations around the all-rows InfoNCE,
+ * recommender/NCL.py:98-99, 110-111; d % 4 == 0, d <= 256, 16-byte aligned tables):
+ *   Y = X / max(||X_r||, 1e-12), nrm[r] = max(||X_r||, 1e-12);   dX = scale * (dY - Y <Y, dY>) / nrm  (dX may alias dY;
+ *   scale_dev, optional: a device scalar multiplied into scale -- the upstream gradient without a host round trip). */
+int arl_normalize_rows_f32(const float *X, int64_t n, int64_t d, float *Y, float *nrm, arl_stream_t stream);
+int arl_normalize_rows_bwd_f32(const float *Y, const float *nrm, const float *dY, int64_t n, int64_t d, float scale, const float *scale_dev,
+                               float *dX, arl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Item-table exchange of the user-sharded step (no reference counterpart: main.py:19 pins one device).

@@ -346,8 +346,62 @@ def test_nce_allrows_against_float64(ops, nA, nV, d):
     lse2, dA2, dV2 = ops.nce_allrows(A, V, tau)
     assert torch.equal(lse, lse2) and torch.equal(dA, dA2) and torch.equal(dV, dV2)
     assert torch.equal(ops.nce_allrows(A, V, tau, want_grad=False), lse)
+    # the three-pass form (log-sum-exp given): same sums with the normalisation inside the exponent instead of after the sum
+    _, dA3, dV3 = ops.nce_allrows(A, V, tau, lse=lse, want_dV=True)
+    assert rel_err(dA3.cpu().numpy(), (P @ V.double()).cpu().numpy()) < 1e-5 and torch.equal(dV3, dV)
     with pytest.raises(ValueError):
         ops.nce_allrows(A[:, :8].contiguous(), V[:, :8].contiguous(), tau)
+
+
+@pytest.mark.parametrize('n,d', [(1000, 64), (37, 16), (513, 128), (90, 100), (5, 256)])
+def test_normalize_rows_forward_and_autograd(ops, n, d):
+    """arl_normalize_rows_f32 / _bwd_f32 against F.normalize and torch's autograd of it (recommender/NCL.py:98-99), incl. a zero row (eps clamp)."""
+    g = torch.Generator().manual_seed(n * d)
+    X = (torch.randn(n, d, generator=g) * 3).to(DEV)
+    X[n // 2] = 0
+    dY = torch.randn(n, d, generator=g).to(DEV)
+    Xr = X.clone().requires_grad_(True)
+    Yr = torch.nn.functional.normalize(Xr, dim=1)
+    Yr.backward(dY * 0.7)
+    Y, nrm = ops.normalize_rows(X)
+    assert rel_err(Y.cpu().numpy(), Yr.detach().cpu().numpy()) < 1e-6
+    sc = torch.tensor([0.35], device=DEV)
+    dX = ops.normalize_rows_bwd(Y, nrm, dY, 2.0, scale_dev=sc)
+    live = torch.ones(n, dtype=torch.bool); live[n // 2] = False
+    assert rel_err(dX[live].cpu().numpy(), Xr.grad[live].cpu().numpy()) < 1e-5
+    assert torch.equal(dX[n // 2], dY[n // 2] * 0.7 / 1e-12) or torch.allclose(dX[n // 2], dY[n // 2] * 0.7 / 1e-12, rtol=1e-6)
+    dY2 = dY.clone()
+    assert ops.normalize_rows_bwd(Y, nrm, dY2, 0.7, out=dY2) is dY2 and rel_err(dY2[live].cpu().numpy(), Xr.grad[live].cpu().numpy()) < 1e-5
+
+
+def test_all_rows_nce_fused_equals_panel_form():
+    """recommender/NCL.py:96-115: the fused route (normalisation kernels + arl_nce_allrows_*) against the panel route (F.normalize + library GEMMs)
+    on raw rows: loss and both gradients."""
+    from arlib_amd.recommender import NCL as M
+    g = torch.Generator().manual_seed(7)
+    Xv0 = torch.randn(3000, 64, generator=g).to(DEV)
+    idx = torch.randint(0, 3000, (500,), generator=g).to(DEV)
+    Xc0 = (Xv0 + 2.0 * torch.randn(3000, 64, generator=g).to(DEV))          # contexts at an angle to their own rows: lse - pos does not cancel
+    out = []
+    for fused in (True, False):
+        M._AllRowsNCE.FUSED = fused
+        try:
+            Xv = Xv0.clone().requires_grad_(True)
+            Xc = Xc0.clone().requires_grad_(True)
+            loss = 1e-3 * M.all_rows_nce(Xc[idx], Xv, idx, 0.05)
+            loss.backward()
+            out.append((loss.item(), Xc.grad.cpu().numpy(), Xv.grad.cpu().numpy()))
+        finally:
+            M._AllRowsNCE.FUSED = True
+    # float64 autograd of the reference's expression as the arbiter
+    Xv = Xv0.double().cpu().requires_grad_(True); Xc = Xc0.double().cpu().requires_grad_(True)
+    a, v = torch.nn.functional.normalize(Xc[idx.cpu()]), torch.nn.functional.normalize(Xv)
+    l64 = 1e-3 * -torch.log(torch.exp((a * v[idx.cpu()]).sum(1) / 0.05) / torch.exp(a @ v.T / 0.05).sum(1)).sum()
+    l64.backward()
+    for name, (l, gc, gv) in zip(('fused', 'panel'), out):
+        errs = (abs(l - l64.item()) / abs(l64.item()), rel_err(gc, Xc.grad.numpy()), rel_err(gv, Xv.grad.numpy()))
+        print('all_rows_nce %s vs float64: loss %.2e, context grad %.2e, table grad %.2e' % ((name,) + errs))
+        assert errs[0] < 1e-5 and errs[1] < 2e-5 and errs[2] < 2e-5
 
 
 def _seq_add(dst, idx, src, scale):
