@@ -1125,6 +1125,9 @@ def pga_update_(S, grad, dinv_rows=None, dinv_cols=None):
     return S
 
 
+TOPK_STATS = {'calls': 0, 'warm': 0, 'cold_repeats': 0}     # counters for benches: warm-started calls and how many of them had to be repeated cold
+
+
 def score_mask_topk(Pu, Pi, k, mask_rowptr=None, mask_col=None, exact=False, warm_idx=None, item_order='norm'):
     """top-k of Pu @ Pi.T per user with an optional interacted-item mask (CSR over users), streamed.
     exact=True: scores are the exact fp32 contraction; default: split-fp16 matrix path (two fp16 pieces of the power-of-two-scaled operands, three products) for d in {64, 128} (scores within
@@ -1172,7 +1175,10 @@ def score_mask_topk(Pu, Pi, k, mask_rowptr=None, mask_col=None, exact=False, war
             raise ValueError("score_mask_topk: item_order must be 'norm', None or an int32 permutation")
     check(_lib.lib().arl_score_mask_topk_f32(_ptr(Pu), _ptr(Pi), U, I, d, _ptr(mask_rowptr), _ptr(mask_col), k, _ptr(idx), _ptr(val), _ptr(ws),
                                              _ptr(warm_idx), _ptr(flag), _ptr(order), _stream()), 'arl_score_mask_topk_f32')
+    TOPK_STATS['calls'] += 1
+    TOPK_STATS['warm'] += flag is not None
     if flag is not None and int(flag) != 0:                # a warm candidate was masked or repeated: the bound was not valid
+        TOPK_STATS['cold_repeats'] += 1
         check(_lib.lib().arl_score_mask_topk_f32(_ptr(Pu), _ptr(Pi), U, I, d, _ptr(mask_rowptr), _ptr(mask_col), k, _ptr(idx), _ptr(val), _ptr(ws),
                                                  None, None, _ptr(order), _stream()), 'arl_score_mask_topk_f32')
     return idx, val

@@ -200,9 +200,12 @@ def attack_leg(torch, ops, data, E0_dev, args):
     for k in range(L):
         E = _hop(graph, E); out += E
     out /= (L + 1)
+    Pu_all, Pi_all = out[:U + F].contiguous(), out[U + F:].contiguous()
+    ops.score_mask_topk(Pu_all[:256].contiguous(), Pi_all, 50)      # first call of the process: code-object load of the kernel and of torch's sort (not timed)
     torch.cuda.synchronize(); t1 = time.perf_counter()
-    top_idx, _ = ops.score_mask_topk(out[:U + F].contiguous(), out[U + F:].contiguous(), 50)
+    top_idx, _ = ops.score_mask_topk(Pu_all, Pi_all, 50)
     torch.cuda.synchronize(); topk_s = time.perf_counter() - t1
+    del Pu_all, Pi_all
     M = cw_operator(U + F + I, U + F, *cw_pairs(top_idx, U, targets, pop=True), device=E0.device)
 
     def step():
@@ -290,9 +293,10 @@ def clear_leg(torch, ops, data, A, E0_dev, args):
         lossall.backward()
         opt.step()
         return float(cw.detach()), float(sfa.detach())
-    step(); torch.cuda.synchronize()
+    step(); step(); torch.cuda.synchronize()                 # a cold-started step and the first warm-started one (its own kernel instantiation: code-object load) are not timed
     n = max(1, args.clear_steps)
     per = []
+    rep0 = ops.TOPK_STATS['cold_repeats']
     t0 = time.perf_counter()
     for _ in range(n):
         ts = time.perf_counter()
@@ -302,9 +306,38 @@ def clear_leg(torch, ops, data, A, E0_dev, args):
     dt = (time.perf_counter() - t0) / n
     return {'metric': 'attack-grad steps/sec (CLeaR surrogate step: CW + SFA, LightGCN d=%d L=%d)' % (d, L), 'value': 1.0 / dt, 'unit': 'steps/s',
             'ms_per_step': 1e3 * dt, 'steps_timed': n, 'ms_per_step_median': 1e3 * float(np.median(per)), 'ms_per_step_min': 1e3 * min(per), 'ms_per_step_max': 1e3 * max(per),
+            'ms_per_step_all': [round(1e3 * x, 2) for x in per], 'topk_cold_repeats': ops.TOPK_STATS['cold_repeats'] - rep0,
             'ms_forward_topk_loss': 1e3 * parts['forward+topk+loss'] / n, 'targets': 5, 'pairs': U * 5,
             'cw_loss': cw, 'sfa_loss': sfa, 'score_flops_per_step': 2.0 * U * I * d,
             'note': 'dominated by the U x I scoring pass (compute-bound line item, SURVEY 8d); peak memory %.1f GB' % (torch.cuda.max_memory_allocated() / 1e9)}
+
+
+def ncl_structure_leg(torch, E0_dev, args, reps=10):
+    """NCL's structure-contrastive term at cfg2 sizes (recommender/NCL.py:96-115): the batch's 2 048 rows against ALL user rows and ALL item
+    rows, forward + backward (row normalisation, log-sum-exp over the table, gradients to both sides), no B x N logit matrix."""
+    from arlib_amd.recommender.NCL import all_rows_nce
+    U, B, d = args.users, args.batch, args.emb
+    g = torch.Generator().manual_seed(args.seed)
+    out = {}
+    for name, tab in (('users', E0_dev[:U]), ('items', E0_dev[U:])):
+        N = tab.shape[0]
+        V0 = tab.clone().requires_grad_(True)
+        C0 = (tab + 0.05 * torch.randn(tab.shape, generator=g).to(tab.device)).requires_grad_(True)
+        idx = torch.randint(0, N, (B,), generator=g).to(tab.device)
+
+        def run():
+            all_rows_nce(C0[idx], V0, idx, 0.05).backward()
+            V0.grad = None; C0.grad = None
+        for _ in range(2):
+            run()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps):
+            run()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / reps
+        out[name] = {'rows': N, 'ms': ms, 'tflops_fp32': 4 * 2.0 * B * N * d / (ms * 1e-3) / 1e12}
+    out['what'] = 'all-rows InfoNCE of a %d-row batch, d=%d, temperature 0.05: forward + backward, 4 exact-fp32 MFMA passes of 2*B*N*d flop each' % (B, d)
+    return out
 
 
 def class_api_leg(torch, data, args, engine_ms):
@@ -569,6 +602,9 @@ def main():
             # DLAttack's inner step (attack/White/DLAttack.py:86-113) is the BPR/Adam step of the headline metric on the
             # surrogate (its CW term is a detached constant); the scoring pass above runs once per outer epoch
             res['attack_dlattack_inner'] = {'value': 1e3 / ms, 'unit': 'steps/s', 'note': 'same fused step as `value` (B=%d)' % B}
+        if not sharded and args.attack_steps > 0 and d in (16, 32, 64, 128):
+            torch.cuda.empty_cache()
+            res['ncl_structure_term'] = ncl_structure_leg(torch, E0_snapshot, args)
         if not sharded and args.api_steps > 0:
             torch.cuda.empty_cache()
             res['class_api'] = class_api_leg(torch, data, args, float(np.median(region_s)) * 1e3 / args.steps)
