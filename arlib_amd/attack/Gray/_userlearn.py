@@ -19,6 +19,7 @@ from ...util.metrics import AttackMetric
 from .._common import init_graph, with_fake_rows
 from ..White.CLeaR import CLeaR
 from ..White.DLAttack import device_mask
+from ...util.optim import Adam        # torch.optim.Adam, stepped by arl_adam_dense_f32
 
 
 class UserLearningBiLevel(CLeaR):
@@ -41,7 +42,7 @@ class UserLearningBiLevel(CLeaR):
             tmpRecommender = deepcopy(recommender)
             uiAdj2 = uiAdj.copy()
             init_graph(tmpRecommender.model, uiAdj2, Up, self.itemNum, n_real=self.userNum)
-            optimizer_attack = torch.optim.Adam(tmpRecommender.model.parameters(), lr=recommender.args.lRate)
+            optimizer_attack = Adam(tmpRecommender.model.parameters(), lr=recommender.args.lRate)
             mask = device_mask(uiAdj2)
             Pu = Pi = None
             self.last_top_idx = None

@@ -17,6 +17,7 @@ import torch
 from ... import ops
 from ...util.metrics import AttackMetric
 from .._common import AttackBase, DEVICE, symmetric_adjacency, init_graph, rebuild_interaction_matrix, reinit_with_tables, cw_pairs, with_fake_rows, append_rows
+from ...util.optim import Adam        # torch.optim.Adam, stepped by arl_adam_dense_f32
 from .DLAttack import masked_topk, device_mask
 from .PGA import cw_operator_from_topk
 
@@ -90,7 +91,7 @@ class CLeaR(AttackBase):
             tmpRecommender = deepcopy(recommender)
             uiAdj2 = uiAdj.copy()
             init_graph(tmpRecommender.model, uiAdj2, Up, self.itemNum, n_real=self.userNum)
-            optimizer_attack = torch.optim.Adam(tmpRecommender.model.parameters(), lr=recommender.args.lRate)
+            optimizer_attack = Adam(tmpRecommender.model.parameters(), lr=recommender.args.lRate)
             Pu = Pi = None
             mask = device_mask(uiAdj2)          # the poisoned pattern is fixed while the surrogate is trained
             warm = None

@@ -25,6 +25,7 @@ import torch.nn.functional as F
 from ... import ops
 from ...util.metrics import AttackMetric
 from .._common import init_graph, with_fake_rows
+from ...util.optim import Adam        # torch.optim.Adam, stepped by arl_adam_dense_f32
 from .BiLevelAttackByBatchInject import _CwLoss
 from .CLeaR import CLeaR
 from .DLAttack import masked_topk
@@ -117,7 +118,7 @@ class InfoAttack(CLeaR):
             tmpRecommender = deepcopy(recommender)
             uiAdj2 = uiAdj.copy()
             init_graph(tmpRecommender.model, uiAdj2, Up, self.itemNum, n_real=self.userNum)
-            optimizer_attack = torch.optim.Adam(tmpRecommender.model.parameters(), lr=recommender.args.lRate)
+            optimizer_attack = Adam(tmpRecommender.model.parameters(), lr=recommender.args.lRate)
             mask = self.single_element_mask(uiAdj2, view1.device)
             for _ in range(self.outerEpoch):
                 loss, _, _ = self.surrogate_loss(tmpRecommender.model, mask, topk, view1)

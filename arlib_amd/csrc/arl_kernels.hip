@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "arlib_amd.h"
 #include <type_traits>
 
@@ -65,7 +67,7 @@ struct Epi {
     const float *S_in;       // LAYERSUM
     float *S;
     float *P, *M, *V;        // ADAM
-    float step_size, inv_bc2_sqrt, b1, b2, eps;
+    float step_size, bc2_sqrt, w1, b2, w2, eps;   // ADAM: lr/(1-b1^t), sqrt(1-b2^t), 1-b1, b2, 1-b2 as torch rounds them (adam_scalars)
     const float *rscale;     // AXPBY, optional: y = alpha * rscale[row] * (A x)[row] + beta * z (a diagonal factor applied to the product)
     int ld;                  // split-row combine only: row stride (floats) of the tables when it is not the kernel's width (0 = dense)
 };
@@ -154,9 +156,9 @@ __device__ __forceinline__ void spmm_epilogue(const Epi &ep, int row, int d, int
         float p[4] = {p4.x, p4.y, p4.z, p4.w}, m[4] = {m4.x, m4.y, m4.z, m4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            m[k] = m[k] + (g[k] - m[k]) * (1.0f - ep.b1);
-            v[k] = v[k] * ep.b2 + (1.0f - ep.b2) * g[k] * g[k];
-            const float denom = sqrtf(v[k]) * ep.inv_bc2_sqrt + ep.eps;
+            m[k] = m[k] + (g[k] - m[k]) * ep.w1;
+            v[k] = v[k] * ep.b2 + ep.w2 * g[k] * g[k];
+            const float denom = sqrtf(v[k]) / ep.bc2_sqrt + ep.eps;
             p[k] = p[k] - ep.step_size * (m[k] / denom);
         }
         *reinterpret_cast<float4 *>(ep.P + o) = make_float4(p[0], p[1], p[2], p[3]);
@@ -726,9 +728,9 @@ __device__ __forceinline__ void spmm_epilogue1(const Epi &ep, int row, int lane,
             float g = ep.alpha * a[c];
             if (zr) g = fmaf(ep.beta, ep.Z[o + c], g);
             float p = ep.P[o + c], m = ep.M[o + c], v = ep.V[o + c];
-            m = m + (g - m) * (1.0f - ep.b1);
-            v = v * ep.b2 + (1.0f - ep.b2) * g * g;
-            const float denom = sqrtf(v) * ep.inv_bc2_sqrt + ep.eps;
+            m = m + (g - m) * ep.w1;
+            v = v * ep.b2 + ep.w2 * g * g;
+            const float denom = sqrtf(v) / ep.bc2_sqrt + ep.eps;
             p = p - ep.step_size * (m / denom);
             ep.P[o + c] = p; ep.M[o + c] = m; ep.V[o + c] = v;
         }
@@ -1044,40 +1046,51 @@ __global__ __launch_bounds__(kBlock) void bpr_bwd_kernel(const float *__restrict
 // Dense optimisers (torch.optim.Adam / SGD)
 // ================================================================================================
 __global__ __launch_bounds__(kBlock) void adam_kernel(float4 *__restrict__ p, const float4 *__restrict__ g, float4 *__restrict__ m,
-                                                       float4 *__restrict__ v, long long n4, float step_size, float inv_bc2_sqrt,
-                                                       float b1, float b2, float eps) {
+                                                       float4 *__restrict__ v, long long n4, float step_size, float bc2_sqrt,
+                                                       float w1, float b2, float w2, float eps) {
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (long long)gridDim.x * kBlock) {
         const float4 g4 = g[i];
         float4 p4 = p[i], m4 = m[i], v4 = v[i];
         float gg[4] = {g4.x, g4.y, g4.z, g4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            mm[k] = mm[k] + (gg[k] - mm[k]) * (1.0f - b1);
-            vv[k] = vv[k] * b2 + (1.0f - b2) * gg[k] * gg[k];
-            pp[k] = pp[k] - step_size * (mm[k] / (sqrtf(vv[k]) * inv_bc2_sqrt + eps));
+            mm[k] = mm[k] + (gg[k] - mm[k]) * w1;
+            vv[k] = vv[k] * b2 + w2 * gg[k] * gg[k];
+            pp[k] = pp[k] - step_size * (mm[k] / (sqrtf(vv[k]) / bc2_sqrt + eps));
         }
         p[i] = make_float4(pp[0], pp[1], pp[2], pp[3]); m[i] = make_float4(mm[0], mm[1], mm[2], mm[3]); v[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
     }
 }
 // scalar form for the <= 3 trailing elements (or a whole table whose base is not 16-byte aligned)
 __global__ __launch_bounds__(kBlock) void adam_scalar_kernel(float *p, const float *g, float *m, float *v, long long from, long long n,
-                                                              float step_size, float inv_bc2_sqrt, float b1, float b2, float eps) {
+                                                              float step_size, float bc2_sqrt, float w1, float b2, float w2, float eps) {
     for (long long i = from + (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
         const float gi = g[i];
-        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
-        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+        const float mi = m[i] + (gi - m[i]) * w1;
+        const float vi = v[i] * b2 + w2 * gi * gi;
         m[i] = mi; v[i] = vi;
-        p[i] = p[i] - step_size * (mi / (sqrtf(vi) * inv_bc2_sqrt + eps));
+        p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
     }
 }
 __global__ __launch_bounds__(kBlock) void sgd_kernel(float *__restrict__ p, const float *__restrict__ g, long long n, float lr) {
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) p[i] = p[i] - lr * g[i];
 }
 
-inline void adam_scalars(float lr, float b1, float b2, int64_t step, float *step_size, float *inv_bc2_sqrt) {
-    const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
-    *step_size = (float)((double)lr / bc1);
-    *inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+// torch.optim.Adam holds lr, betas and eps as Python doubles and rounds DERIVED quantities to fp32 (torch/optim/adam.py _single_tensor_adam:
+// lerp weight 1 - beta1, addcmul value 1 - beta2, step_size = lr / (1 - beta1^t), sqrt(1 - beta2^t)): (float)(1 - 0.999) = 0.001f, whereas
+// 1.0f - 0.999f = 0.00100005 (4.7e-5 off in every second-moment update).  The C ABI carries floats, so the double the caller typed is recovered
+// as the shortest decimal that rounds to the float (0.999f -> 0.999); a float that is no short decimal is taken as it is.
+inline double typed_double(float x) {
+    char buf[32];
+    snprintf(buf, sizeof buf, "%.7g", (double)x);
+    const double d = strtod(buf, nullptr);
+    return (float)d == x ? d : (double)x;
+}
+struct AdamScalars { float step_size, bc2_sqrt, w1, b2, w2; };
+inline AdamScalars adam_scalars(float lr, float b1, float b2, int64_t step) {
+    const double B1 = typed_double(b1), B2 = typed_double(b2), LR = typed_double(lr);
+    const double bc1 = 1.0 - pow(B1, (double)step), bc2 = 1.0 - pow(B2, (double)step);
+    return {(float)(LR / bc1), (float)sqrt(bc2), (float)(1.0 - B1), (float)B2, (float)(1.0 - B2)};
 }
 
 // ================================================================================================
@@ -3000,8 +3013,10 @@ int arl_spmm_blocked_adam_f32(const arl_blocked *P, const float *X, int64_t d, f
     if (step < 1 || Pm == X) return ARL_E_ARG;
     Epi ep = {};
     ep.alpha = alpha; ep.beta = beta; ep.Z = (beta != 0.f) ? Z : nullptr; ep.zflags = zflags; ep.P = Pm; ep.M = M; ep.V = V;
-    ep.b1 = beta1; ep.b2 = beta2; ep.eps = eps;
-    adam_scalars(lr, beta1, beta2, step, &ep.step_size, &ep.inv_bc2_sqrt);
+    {
+        const AdamScalars a = adam_scalars(lr, beta1, beta2, step);
+        ep.step_size = a.step_size; ep.bc2_sqrt = a.bc2_sqrt; ep.w1 = a.w1; ep.b2 = a.b2; ep.w2 = a.w2; ep.eps = (float)typed_double(eps);
+    }
     return launch_spmm_blocked<EPI_ADAM>(P, X, d, ep, (hipStream_t)stream);
 }
 
@@ -3022,8 +3037,10 @@ int arl_spmm_tiled_adam_f32(const arl_tiled *T, const float *X, int64_t d, float
     if (step < 1 || P == X) return ARL_E_ARG;
     Epi ep = {};
     ep.alpha = alpha; ep.beta = beta; ep.Z = (beta != 0.f) ? Z : nullptr; ep.zflags = zflags; ep.P = P; ep.M = M; ep.V = V;
-    ep.b1 = beta1; ep.b2 = beta2; ep.eps = eps;
-    adam_scalars(lr, beta1, beta2, step, &ep.step_size, &ep.inv_bc2_sqrt);
+    {
+        const AdamScalars a = adam_scalars(lr, beta1, beta2, step);
+        ep.step_size = a.step_size; ep.bc2_sqrt = a.bc2_sqrt; ep.w1 = a.w1; ep.b2 = a.b2; ep.w2 = a.w2; ep.eps = (float)typed_double(eps);
+    }
     return launch_spmm_tiled<EPI_ADAM>(T, X, d, ep, (hipStream_t)stream);
 }
 
@@ -3045,8 +3062,10 @@ int arl_spmm_csr_adam_f32(const arl_csr *A, const float *X, int64_t d, float alp
     if (P == X) return ARL_E_ARG;
     Epi ep = {};
     ep.alpha = alpha; ep.beta = beta; ep.Z = (beta != 0.f) ? Z : nullptr; ep.zflags = zflags; ep.P = P; ep.M = M; ep.V = V;
-    ep.b1 = beta1; ep.b2 = beta2; ep.eps = eps;
-    adam_scalars(lr, beta1, beta2, step, &ep.step_size, &ep.inv_bc2_sqrt);
+    {
+        const AdamScalars a = adam_scalars(lr, beta1, beta2, step);
+        ep.step_size = a.step_size; ep.bc2_sqrt = a.bc2_sqrt; ep.w1 = a.w1; ep.b2 = a.b2; ep.w2 = a.w2; ep.eps = (float)typed_double(eps);
+    }
     return launch_spmm<EPI_ADAM>(A, X, d, ep, (hipStream_t)stream);
 }
 
@@ -3199,19 +3218,18 @@ int arl_adam_dense_f32(float *p, const float *g, float *m, float *v, int64_t n, 
     if (!p || !g || !m || !v) return ARL_E_NULL;
     if (n < 0 || step < 1) return ARL_E_ARG;
     if (n == 0) return ARL_OK;
-    float step_size, inv_bc2_sqrt;
-    adam_scalars(lr, beta1, beta2, step, &step_size, &inv_bc2_sqrt);
+    const AdamScalars a = adam_scalars(lr, beta1, beta2, step);
     hipStream_t st = (hipStream_t)stream;
     const bool al = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15u) == 0;
     const long long n4 = al ? n / 4 : 0;
     if (n4 > 0) {
         hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n4, kBlock)), dim3(kBlock), 0, st, (float4 *)p, (const float4 *)g, (float4 *)m, (float4 *)v, n4,
-                           step_size, inv_bc2_sqrt, beta1, beta2, eps);
+                           a.step_size, a.bc2_sqrt, a.w1, a.b2, a.w2, eps);
         ARL_LAUNCH_CHECK();
     }
     if (n4 * 4 < n) {
-        hipLaunchKernelGGL(adam_scalar_kernel, dim3(grid_for(n - n4 * 4, kBlock)), dim3(kBlock), 0, st, p, g, m, v, n4 * 4, (long long)n, step_size,
-                           inv_bc2_sqrt, beta1, beta2, eps);
+        hipLaunchKernelGGL(adam_scalar_kernel, dim3(grid_for(n - n4 * 4, kBlock)), dim3(kBlock), 0, st, p, g, m, v, n4 * 4, (long long)n, a.step_size,
+                           a.bc2_sqrt, a.w1, a.b2, a.w2, eps);
         ARL_LAUNCH_CHECK();
     }
     return ARL_OK;

@@ -155,7 +155,7 @@ class NGCF(Recommender):
 
     def _fusable(self, optimizer):
         g = optimizer.param_groups[0] if len(optimizer.param_groups) == 1 else None
-        if (type(optimizer) is not torch.optim.Adam or g is None or self.model.layers < 1 or self.model.latent_size not in ops.NGCF_DENSE_WIDTHS
+        if (not isinstance(optimizer, torch.optim.Adam) or g is None or self.model.layers < 1 or self.model.latent_size not in ops.NGCF_DENSE_WIDTHS
                 or g.get('weight_decay', 0) != 0 or g.get('amsgrad', False) or g.get('maximize', False) or g.get('capturable', False)):
             return None
         mine = self._params() + self._weight_params()

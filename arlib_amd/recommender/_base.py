@@ -22,6 +22,7 @@ from ..engine import PropagationEngine
 from ..util.sampler import next_batch_pairwise, device_epoch
 from ..util.loss import bpr_l2_loss, l2_reg_loss, InfoNCE
 from ..util.metrics import ranking_evaluation, ranking_evaluation_topk
+from ..util.optim import Adam as FusedAdam
 
 DEVICE = 'cuda'
 
@@ -339,7 +340,7 @@ class Recommender:
 
     def _fusable(self, optimizer):
         """The fused engine may stand in for `optimizer` iff it is a stock Adam/SGD over exactly this model's two tables."""
-        if type(optimizer) not in (torch.optim.Adam, torch.optim.SGD) or len(optimizer.param_groups) != 1:
+        if type(optimizer) not in (torch.optim.Adam, FusedAdam, torch.optim.SGD) or len(optimizer.param_groups) != 1:
             return None
         g = optimizer.param_groups[0]
         ps = g['params']
@@ -347,7 +348,7 @@ class Recommender:
         # nn.ParameterDict sorts plain-dict keys, so parameters() yields item_emb before user_emb: compare as a set
         if len(ps) != 2 or {id(ps[0]), id(ps[1])} != {id(mine[0]), id(mine[1])} or g.get('weight_decay', 0) != 0 or g.get('maximize', False):
             return None
-        if type(optimizer) is torch.optim.Adam:
+        if type(optimizer) in (torch.optim.Adam, FusedAdam):
             if g.get('amsgrad', False) or g.get('capturable', False):
                 return None
             return 'adam'

@@ -277,7 +277,8 @@ def clear_leg(torch, ops, data, A, E0_dev, args):
     deg_i = np.bincount(data.pairs0[:, 1], minlength=I)
     atk = CLeaR.__new__(CLeaR)
     atk.userNum, atk.itemNum, atk.targetItem = U, I, [int(t) for t in np.argsort(deg_i, kind='stable')[:5]]
-    opt = torch.optim.Adam(enc.parameters(), lr=0.005)
+    from arlib_amd.util.optim import Adam                     # what CLeaR.posionDataAttack builds for its surrogate (torch.optim.Adam, stepped by arl_adam_dense_f32)
+    opt = Adam(enc.parameters(), lr=0.005)
     r0 = torch.randn(d, generator=torch.Generator().manual_seed(args.seed)).to(dev)
     parts = {}
 

@@ -15,6 +15,7 @@
  */
 #include <stdint.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 #include <math.h>
 
@@ -251,17 +252,29 @@ void orc_bpr_l2_fwd_bwd(const float *emb, int64_t d, int64_t item_off, const int
  * no weight decay, amsgrad off.  Restates torch/optim/adam.py _single_tensor_adam:
  *   m.lerp_(g, 1-b1); v = v*b2 + (1-b2) g*g; step_size = lr/(1-b1^t); denom = sqrt(v)/sqrt(1-b2^t) + eps;
  *   p -= step_size * m/denom.      SGD (attack/White/PGA.py:59): p -= lr * g.
+ * torch keeps lr and the betas as Python doubles and rounds the DERIVED weights to fp32: (float)(1 - 0.999) = 0.001f, not 1.0f - 0.999f
+ * = 0.00100005.  This interface carries floats; the double the caller typed is recovered as the shortest decimal that rounds to the float.
  * ------------------------------------------------------------------------------------------ */
+static double orc_typed_double(float x)
+{
+    char buf[32];
+    snprintf(buf, sizeof buf, "%.7g", (double)x);
+    double d = strtod(buf, NULL);
+    return (float)d == x ? d : (double)x;
+}
+
 void orc_adam_step(float *p, const float *g, float *m, float *v, int64_t n, float lr, float b1, float b2, float eps, int64_t t)
 {
-    double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
-    float step_size = (float)((double)lr / bc1);
+    double B1 = orc_typed_double(b1), B2 = orc_typed_double(b2), LR = orc_typed_double(lr);
+    double bc1 = 1.0 - pow(B1, (double)t), bc2 = 1.0 - pow(B2, (double)t);
+    float step_size = (float)(LR / bc1);
     float bc2_sqrt = (float)sqrt(bc2);
+    float w1 = (float)(1.0 - B1), w2 = (float)(1.0 - B2), b2f = (float)B2;
 #pragma omp parallel for
     for (int64_t i = 0; i < n; i++) {
         float gi = g[i];
-        float mi = m[i] + (gi - m[i]) * (1.0f - b1);
-        float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+        float mi = m[i] + (gi - m[i]) * w1;
+        float vi = v[i] * b2f + w2 * gi * gi;
         m[i] = mi; v[i] = vi;
         float denom = sqrtf(vi) / bc2_sqrt + eps;
         p[i] = p[i] - step_size * (mi / denom);

@@ -404,6 +404,30 @@ def test_all_rows_nce_fused_equals_panel_form():
         assert errs[0] < 1e-5 and errs[1] < 2e-5 and errs[2] < 2e-5
 
 
+def test_fused_adam_optimizer_equals_torch_adam():
+    """util/optim.Adam (arl_adam_dense_f32 behind torch.optim.Adam's interface) against the stock class: 4 steps on a table and an odd-sized
+    vector, parameters and both moments; a non-default flag falls through to the stock step."""
+    from arlib_amd.util.optim import Adam
+    g = torch.Generator().manual_seed(3)
+    base = [torch.randn(1000, 64, generator=g).to(DEV), torch.randn(37, generator=g).to(DEV)]
+    grads = [[torch.randn(b.shape, generator=g).to(DEV) * (0.1 ** s) for b in base] for s in range(4)]
+    runs = []
+    for cls, kw in ((torch.optim.Adam, {}), (Adam, {}), (Adam, {'amsgrad': True}), (torch.optim.Adam, {'amsgrad': True})):
+        ps = [torch.nn.Parameter(b.clone()) for b in base]
+        opt = cls(ps, lr=0.005, **kw)
+        for s in range(4):
+            for p, gr in zip(ps, grads[s]):
+                p.grad = gr.clone()
+            opt.step()
+        runs.append(([p.detach().cpu().numpy() for p in ps], [opt.state[p]['exp_avg'].cpu().numpy() for p in ps], [opt.state[p]['exp_avg_sq'].cpu().numpy() for p in ps],
+                     [float(opt.state[p]['step']) for p in ps]))
+    for a, b in ((runs[0], runs[1]), (runs[3], runs[2])):
+        for x, y in zip(a[:3], b[:3]):
+            for u, v in zip(x, y):
+                assert rel_err(v, u) < 1e-6
+        assert a[3] == b[3] == [4.0, 4.0]
+
+
 def _seq_add(dst, idx, src, scale):
     """CPU index_put_(accumulate) association: contributions added one after the other in index order, fp32, product rounded first."""
     out = dst.copy()
