@@ -184,9 +184,10 @@ def cw_operator_from_topk(n_nodes, Up, n_real, targets, neg, device):
     dev = neg.device
     tg = torch.as_tensor(targets, device=dev, dtype=torch.int64)
     ar_u = torch.arange(n_real, device=dev, dtype=torch.int64)
-    flat = neg.reshape(-1)
+    flat = neg.reshape(-1).to(torch.int32)                   # 32-bit keys: half the radix passes of an int64 sort
     sorted_items, order = torch.sort(flat, stable=True)
-    neg_ptr = torch.searchsorted(sorted_items, torch.arange(I + 1, device=dev, dtype=torch.int64))
+    neg_ptr = torch.searchsorted(sorted_items, torch.arange(I + 1, device=dev, dtype=torch.int32))
+    sorted_items = sorted_items.long()
     neg_cnt = neg_ptr[1:] - neg_ptr[:-1]
     item_len = neg_cnt.clone()
     item_len[tg] += n_real
