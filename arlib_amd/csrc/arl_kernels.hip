@@ -2247,7 +2247,11 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
                                                                             int32_t *__restrict__ top_idx, float *__restrict__ top_val,
                                                                             const float *__restrict__ Pi_f32, const int32_t *__restrict__ warm_idx,
                                                                             int *__restrict__ underflow, const unsigned *__restrict__ table_max_bits,
-                                                                            const int32_t *__restrict__ item_order, const int32_t *__restrict__ item_pos) {
+                                                                            const int32_t *__restrict__ item_order, const int32_t *__restrict__ item_pos,
+                                                                            const int *__restrict__ gate) {
+    // gate (optional): the launch is the cold repeat of a warm-started call and runs only if that call raised its underflow flag -- decided here,
+    // on the device, so that the host never waits for the flag (every thread of the grid takes the same branch)
+    if (gate != nullptr && *gate == 0) return;
     // item_order / item_pos (both or neither): the staged image holds table row item_order[p] at position p (item_pos = the inverse).  Scores,
     // stages and the bootstrap sample are in POSITIONS; a candidate becomes an item id when it is packed into a key, so masks, keys (ties:
     // lower item id first) and results are those of the table order -- only the order in which thresholds rise changes.
@@ -3796,14 +3800,19 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
             ARL_LAUNCH_CHECK();
             image = workspace;
         }
-#define ARL_TOPK_CASE2(DV, SP, WM)                                                                                                     \
+#define ARL_TOPK_CASE2(DV, SP, WM, WARMP, GATE)                                                                                        \
         do {                                                                                                                           \
             hipError_t em = hipFuncSetAttribute((const void *)score_mask_topk_mfma16_kernel<DV, SP, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m); \
             if (em != hipSuccess) return (int)em;                                                                                      \
             hipLaunchKernelGGL((score_mask_topk_mfma16_kernel<DV, SP, WM>), dim3(grid_m), dim3(64 * topk_waves(DV, SP)), shm_m, (hipStream_t)stream, Pu, image, (int)U, (int)I, \
-                               mask_rowptr, mask_col, (int)k, top_idx, top_val, Pi, warm_idx, underflow, max_bits, order_d, pos_d);     \
+                               mask_rowptr, mask_col, (int)k, top_idx, top_val, Pi, WARMP, underflow, max_bits, order_d, pos_d, GATE);  \
         } while (0)
-#define ARL_TOPK_CASE(DV, SP) do { if (warm_idx) ARL_TOPK_CASE2(DV, SP, true); else ARL_TOPK_CASE2(DV, SP, false); } while (0)
+        /* a warm-started call is followed by its own cold repeat, gated on the underflow flag on the device: valid results without a host round trip */
+#define ARL_TOPK_CASE(DV, SP)                                                                                                          \
+        do {                                                                                                                           \
+            if (warm_idx) { ARL_TOPK_CASE2(DV, SP, true, warm_idx, (const int *)nullptr); ARL_TOPK_CASE2(DV, SP, false, (const int32_t *)nullptr, (const int *)underflow); } \
+            else ARL_TOPK_CASE2(DV, SP, false, (const int32_t *)nullptr, (const int *)nullptr);                                         \
+        } while (0)
         if (d == 16) ARL_TOPK_CASE(16, false);
         else if (d == 32) ARL_TOPK_CASE(32, false);
         else if (d == 64) { if (split) ARL_TOPK_CASE(64, true); else ARL_TOPK_CASE(64, false); }

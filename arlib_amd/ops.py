@@ -6,6 +6,8 @@ the whole GPU host), then passes raw pointers + sizes + the current HIP stream t
 No op has a CPU fallback.
 """
 import ctypes as C
+import os
+import time
 import numpy as np
 import torch
 
@@ -1173,14 +1175,24 @@ def score_mask_topk(Pu, Pi, k, mask_rowptr=None, mask_col=None, exact=False, war
                 order = torch.argsort(torch.linalg.vector_norm(Pi, dim=1), descending=True).to(torch.int32)
         elif item_order is not None:
             raise ValueError("score_mask_topk: item_order must be 'norm', None or an int32 permutation")
+    timed = os.environ.get('ARL_TOPK_TIME') == '1'          # diagnostics: wall time of the pass itself, between device synchronisations
+    evs = None
+    if TOPK_STATS.get('record_events') or os.environ.get('ARL_TOPK_TIME') == '2':       # diagnostics: device-side span (events on the launch stream, no host synchronisation)
+        evs = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        evs[0].record()
+    if timed:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
     check(_lib.lib().arl_score_mask_topk_f32(_ptr(Pu), _ptr(Pi), U, I, d, _ptr(mask_rowptr), _ptr(mask_col), k, _ptr(idx), _ptr(val), _ptr(ws),
                                              _ptr(warm_idx), _ptr(flag), _ptr(order), _stream()), 'arl_score_mask_topk_f32')
+    if timed:
+        torch.cuda.synchronize(); TOPK_STATS.setdefault('ms', []).append(1e3 * (time.perf_counter() - t0))
+    if evs is not None:
+        evs[1].record(); TOPK_STATS.setdefault('events', []).append(evs)
     TOPK_STATS['calls'] += 1
     TOPK_STATS['warm'] += flag is not None
-    if flag is not None and int(flag) != 0:                # a warm candidate was masked or repeated: the bound was not valid
-        TOPK_STATS['cold_repeats'] += 1
-        check(_lib.lib().arl_score_mask_topk_f32(_ptr(Pu), _ptr(Pi), U, I, d, _ptr(mask_rowptr), _ptr(mask_col), k, _ptr(idx), _ptr(val), _ptr(ws),
-                                                 None, None, _ptr(order), _stream()), 'arl_score_mask_topk_f32')
+    # (a warm-started call repeats itself cold on the device when its flag is raised: nothing to wait for here; benches that count the repeats keep the flags)
+    if flag is not None and TOPK_STATS.get('record_events'):
+        TOPK_STATS.setdefault('flags', []).append(flag)
     return idx, val
 
 

@@ -280,37 +280,49 @@ def clear_leg(torch, ops, data, A, E0_dev, args):
     from arlib_amd.util.optim import Adam                     # what CLeaR.posionDataAttack builds for its surrogate (torch.optim.Adam, stepped by arl_adam_dense_f32)
     opt = Adam(enc.parameters(), lr=0.005)
     r0 = torch.randn(d, generator=torch.Generator().manual_seed(args.seed)).to(dev)
-    parts = {}
-
     warm = [None]
 
-    def step(timed=False):
-        t = time.perf_counter()
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
         lossall, _, _, cw, sfa = atk.surrogate_loss(enc, mask, 50, r0=r0, warm=warm[0])       # steps after the first reuse the previous lists
         warm[0] = atk.last_top_idx
-        if timed:
-            torch.cuda.synchronize(); parts['forward+topk+loss'] = parts.get('forward+topk+loss', 0.0) + time.perf_counter() - t
+        if ev is not None:
+            ev[1].record()
         opt.zero_grad()
         lossall.backward()
         opt.step()
-        return float(cw.detach()), float(sfa.detach())
+        if ev is not None:
+            ev[2].record()
+        if os.environ.get('ARL_CLEAR_TRACE') == '1':                # diagnostics (synchronising): loss terms and table magnitudes per step
+            trace.append((float(cw.detach()), float(sfa.detach()), float(enc.embedding_dict['user_emb'].detach().abs().max()), float(enc.embedding_dict['item_emb'].detach().abs().max())))
+        return cw.detach(), sfa.detach()
+    trace = []
     step(); step(); torch.cuda.synchronize()                 # a cold-started step and the first warm-started one (its own kernel instantiation: code-object load) are not timed
     n = max(1, args.clear_steps)
-    per = []
-    rep0 = ops.TOPK_STATS['cold_repeats']
-    t0 = time.perf_counter()
-    for _ in range(n):
-        ts = time.perf_counter()
-        cw, sfa = step(True)                                 # synchronises after the forward; the float() reads of the losses end the step
-        torch.cuda.synchronize()
-        per.append(time.perf_counter() - ts)
+    # The timed loop never waits for the device (as the attack's own loop, CLeaR.py:73-129 / attack/White/CLeaR.py): step boundaries are HIP events on
+    # the launch stream, the wall clock brackets all n steps between two synchronisations.  (Waiting for every step made the figure depend on how fast the
+    # host thread wakes up after a 45 ms kernel: 58 ms per step on some boxes, 80-100 ms in 10 ms quanta on others, with the same device-side spans.)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
+    ops.TOPK_STATS['record_events'], ops.TOPK_STATS['events'], ops.TOPK_STATS['flags'] = True, [], []      # device-side span of every scoring pass of the timed steps
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for k in range(n):
+        cw, sfa = step(evs[k])
+    torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
+    ops.TOPK_STATS['record_events'] = False
+    topk_dev = [a.elapsed_time(b) for a, b in ops.TOPK_STATS.pop('events', [])]
+    cold_repeats = int(sum(int(f) != 0 for f in ops.TOPK_STATS.pop('flags', [])))
+    per = [evs[k][0].elapsed_time(evs[k + 1][0]) * 1e-3 for k in range(n - 1)] + [evs[n - 1][0].elapsed_time(evs[n - 1][2]) * 1e-3]      # step start to next step start
+    fwd = [e[0].elapsed_time(e[1]) for e in evs]
     return {'metric': 'attack-grad steps/sec (CLeaR surrogate step: CW + SFA, LightGCN d=%d L=%d)' % (d, L), 'value': 1.0 / dt, 'unit': 'steps/s',
             'ms_per_step': 1e3 * dt, 'steps_timed': n, 'ms_per_step_median': 1e3 * float(np.median(per)), 'ms_per_step_min': 1e3 * min(per), 'ms_per_step_max': 1e3 * max(per),
-            'ms_per_step_all': [round(1e3 * x, 2) for x in per], 'topk_cold_repeats': ops.TOPK_STATS['cold_repeats'] - rep0,
-            'ms_forward_topk_loss': 1e3 * parts['forward+topk+loss'] / n, 'targets': 5, 'pairs': U * 5,
-            'cw_loss': cw, 'sfa_loss': sfa, 'score_flops_per_step': 2.0 * U * I * d,
-            'note': 'dominated by the U x I scoring pass (compute-bound line item, SURVEY 8d); peak memory %.1f GB' % (torch.cuda.max_memory_allocated() / 1e9)}
+            'ms_per_step_all': [round(1e3 * x, 2) for x in per], 'topk_device_ms_all': [round(x, 2) for x in topk_dev], 'topk_device_ms_median': float(np.median(topk_dev)) if topk_dev else None,
+            **({'trace_cw_sfa_umax_imax': trace} if trace else {}), 'topk_cold_repeats': cold_repeats,
+            'ms_forward_topk_loss': float(np.mean(fwd)), 'targets': 5, 'pairs': U * 5,
+            'cw_loss': float(cw), 'sfa_loss': float(sfa), 'score_flops_per_step': 2.0 * U * I * d,
+            'timing': '`ms_per_step` = wall clock over the %d steps between two device synchronisations / %d; per-step figures = HIP events at the step boundaries on the launch stream' % (n, n),
+            'note': 'dominated by the U x I scoring pass (compute-bound line item, SURVEY 8d): `topk_device_ms_all` is its device-side span per step; peak memory %.1f GB' % (torch.cuda.max_memory_allocated() / 1e9)}
 
 
 def ncl_structure_leg(torch, E0_dev, args, reps=10):

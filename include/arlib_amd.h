@@ -398,7 +398,9 @@ int arl_pga_update_f32(float *S, const float *grad, const float *dinv_rows, cons
  * warm_idx (optional, matrix-core path only): [U, k] DISTINCT candidate items per user, e.g. the previous call's top_idx when
  * the tables moved little; it only pre-sets each user's threshold (same result, ~6x fewer list inserts).  If a candidate has
  * become masked the threshold may exclude too much: *underflow (int32, zeroed by the caller) is then set non-zero and the
- * caller must repeat the call with warm_idx == NULL.
+ * same call repeats the pass cold -- a second launch that every workgroup leaves at once unless the flag is set, decided on
+ * the device: top_idx / top_val are valid in stream order either way and the host never has to read the flag (it stays
+ * readable as a statistic).
  * item_order (optional, used on the fp16 matrix path; a permutation of [0, I)): the items are STREAMED in this order instead of table
  * order -- typically by descending row norm, so that the items most users rank high come first and the thresholds rise early (6-20 %
  * less time at 1 M x 100 K).  Masks, warm_idx, top_idx and the tie order (lower item id first) are in item ids as always: the result is

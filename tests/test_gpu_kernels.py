@@ -760,7 +760,7 @@ def test_score_mask_topk_warm_start_is_result_neutral(ops, d, masked):
         guess[:, ::2] = cold_i.flip(1)[:, ::2]   # same sets, other order
     g_i, g_v = ops.score_mask_topk(T(Pu2), T(Pi), k, rp, mc, warm_idx=guess)
     assert torch.equal(g_i, ref_i) and torch.equal(g_v, ref_v)
-    # (c) invalid candidates (a repeated item): the bound over-excludes, the wrapper repeats cold
+    # (c) invalid candidates (a repeated item): the bound over-excludes, the call repeats itself cold (second launch, gated on the flag on the device)
     bad = cold_i.clone(); bad[:, 1:] = bad[:, :1]
     b_i, b_v = ops.score_mask_topk(T(Pu2), T(Pi), k, rp, mc, warm_idx=bad)
     assert torch.equal(b_i, ref_i) and torch.equal(b_v, ref_v)
