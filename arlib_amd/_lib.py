@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ARLIB_AMD_LIB') or os.path.join(_HERE, 'lib', 'libarlib_amd.so')      # override: developer builds (e.g. `make prof`)
-ABI_VERSION = 20
+ABI_VERSION = 21
 _lib = None
 
 
@@ -93,6 +93,7 @@ _SIGS = {
     'arl_sfa_stage1_f32': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     'arl_sfa_stage2_f32': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     'arl_sfa_stage3_f32': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, C.c_int32, _vp, _vp, _vp, _vp]),
+    'arl_sddmm_csr_f32': (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _f, _vp, _vp]),
     'arl_sddmm_rows_dense_f32': (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp]),
     'arl_pga_update_f32': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     'arl_tables_sum_f32': (C.c_int, [_vp, _i64, _i64, C.c_float, _vp, _vp]),

@@ -1382,6 +1382,32 @@ __global__ __launch_bounds__(kBlock) void rows_normalize_kernel(const float *__r
     }
 }
 
+// Gradient of a scalar loss with respect to the STORED entries of the adjacency, given dL/d(A X) = dY (the autograd of torch.sparse.mm with
+// respect to its sparse argument, which recommender/LightGCN.py:41-43,58-59 accumulates when requires_adjgrad is set):
+//     gval[e] += alpha * <dY[row(e)], X[col[e]]>      for every stored entry e, CSR order.
+// One wave per row; LPR = d/4 (rounded up to a power of two) lanes hold an edge's operand row as float4s, 64 / LPR edges per round.
+// Each entry has one writer: no atomics.
+__global__ __launch_bounds__(kBlock) void sddmm_csr_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, long long n_rows, int d, int lpr,
+                                                           const float *__restrict__ dY, const float *__restrict__ X, float alpha, float *__restrict__ gval) {
+    const int lane = threadIdx.x & 63, sub = lane % lpr, slot = lane / lpr, per_round = 64 / lpr;
+    const bool qact = sub * 4 < d;
+    for (long long r = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); r < n_rows; r += (long long)gridDim.x * kWavesPerBlock) {
+        const int e0 = rowptr[r], e1 = rowptr[r + 1];
+        if (e0 == e1) continue;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (qact) g = *reinterpret_cast<const float4 *>(dY + r * d + sub * 4);
+        for (int e = e0 + slot; __any(e < e1); e += per_round) {
+            float s = 0.f;
+            if (e < e1 && qact) {
+                const float4 x = *reinterpret_cast<const float4 *>(X + (long long)col[e] * d + sub * 4);
+                s = (g.x * x.x + g.y * x.y) + (g.z * x.z + g.w * x.w);
+            }
+            for (int o = 1; o < lpr; o <<= 1) s += __shfl_xor(s, o);
+            if (e < e1 && sub == 0) gval[e] = fmaf(alpha, s, gval[e]);
+        }
+    }
+}
+
 // ================================================================================================
 // NGCF layer glue (recommender/NGCF.py:200-208): E' = leaky_relu((P + E) W1 + (P * E) W2), P = A E.
 // The two d x d products run as ONE rocBLAS GEMM on [S | T] (N x 2d) by [W1; W2]; these kernels are the element-wise passes
@@ -3701,6 +3727,21 @@ int arl_sddmm_rows_dense_f32(const float *dY, const float *X, int64_t d, const i
     }
     hipLaunchKernelGGL(sddmm_rows_dense_kernel, dim3((unsigned)((n_cols + 63) / 64)), dim3(kBlock), shm, (hipStream_t)stream, dY, X, (int)d, rows,
                        (int)n_rows_sel, (long long)col_off, (int)n_cols, out);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
+int arl_sddmm_csr_f32(const int32_t *rowptr, const int32_t *col, int64_t n_rows, int64_t d, const float *dY, const float *X, float alpha, float *gval,
+                      arl_stream_t stream) {
+    if (!rowptr || !col || !dY || !X || !gval) return ARL_E_NULL;
+    if (d <= 0 || d > 256 || (d & 3)) return ARL_E_DIM;
+    if (n_rows < 0 || n_rows > 0x7fffffffll) return ARL_E_RANGE;
+    if (((uintptr_t)dY | (uintptr_t)X) & 15) return ARL_E_ARG;
+    if (n_rows == 0) return ARL_OK;
+    int lpr = 1;
+    while (lpr * 4 < d) lpr <<= 1;
+    hipLaunchKernelGGL(sddmm_csr_kernel, dim3(grid_for(n_rows, kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, rowptr, col, (long long)n_rows, (int)d, lpr, dY, X,
+                       alpha, gval);
     ARL_LAUNCH_CHECK();
     return ARL_OK;
 }

@@ -125,6 +125,28 @@ class PropagationEngine:
             acc = dst
         return acc
 
+    def adjacency_gradient(self, G, out=None):
+        """dL/d(values of A) from dL/d(out) = G for out = mean(E_0 .. E_L), E_{k+1} = A E_k: what autograd leaves in `sparse_norm_adj.grad` when the
+        reference sets `sparse_norm_adj.requires_grad = True` (recommender/LightGCN.py:41-43,58-59).  With dE_L = G/(L+1), dE_k = G/(L+1) + A dE_{k+1}
+        (A symmetric) the gradient on a stored entry (i, j) is sum_k <dE_{k+1}[i], E_k[j]>: L - 1 forward hops, L - 1 backward hops and L products
+        over the pattern (ops.sddmm_csr), accumulated into `out` ([nnz] fp32, CSR order)."""
+        L, A = self.L, self.A
+        if self.skip0:
+            raise NotImplementedError('adjacency_gradient: the layer mean that skips layer 0 (SimGCL family) is not covered')
+        if out is None:
+            out = torch.zeros(A.col.numel(), dtype=torch.float32, device=G.device)
+        if L == 0:
+            return out
+        E = [self.E0]
+        for k in range(L - 1):
+            E.append(ops.spmm(A, E[-1]))
+        acc = G.contiguous()
+        for j in range(L):
+            ops.sddmm_csr(A, acc, E[L - 1 - j], 1.0 / (L + 1), out=out)
+            if j < L - 1:
+                acc = ops.spmm(A, acc, 1.0, 1.0, G)
+        return out
+
     # ---- the propagated mean on a row subset, with its backward: the sparse-batch schedule of step() for callers that keep autograd and
     # their own optimiser (an extra loss term, an optimiser over one table only, gradient capture)
     def forward_rows(self, rows):

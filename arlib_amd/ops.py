@@ -1049,6 +1049,21 @@ def sddmm_rows_dense(dY, X, rows, col_off, n_cols, out=None):
     return out
 
 
+def sddmm_csr(A, dY, X, alpha=1.0, out=None):
+    """out[e] += alpha * <dY[row(e)], X[col[e]]> over the stored entries of the CSR graph A: the gradient of a loss with respect to the adjacency's values
+    given dL/d(A X) = dY (recommender/LightGCN.py:41-43,58-59, requires_adjgrad).  out: [nnz] fp32 (zeros when omitted)."""
+    _dev(dY, torch.float32, 'dY', 2); _dev(X, torch.float32, 'X', 2)
+    if dY.shape[0] != A.n_rows or dY.shape[1] != X.shape[1] or X.shape[0] < A.n_cols:
+        raise ValueError('sddmm_csr: dY [n_rows, d], X [n_cols, d]')
+    if out is None:
+        out = torch.zeros(A.col.numel(), dtype=torch.float32, device=X.device)
+    _dev(out, torch.float32, 'out', 1)
+    if out.numel() != A.col.numel():
+        raise ValueError('sddmm_csr: one output per stored entry')
+    check(_lib.lib().arl_sddmm_csr_f32(_ptr(A.rowptr), _ptr(A.col), A.n_rows, X.shape[1], _ptr(dY), _ptr(X), float(alpha), _ptr(out), _stream()), 'arl_sddmm_csr_f32')
+    return out
+
+
 def tables_sum(tables, alpha=1.0, out=None):
     """alpha * sum of up to 8 equally shaped fp32 tables in one pass (the LightGCN layer mean with alpha = 1/(L+1))."""
     if not 1 <= len(tables) <= 8:

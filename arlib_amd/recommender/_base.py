@@ -407,9 +407,15 @@ class Recommender:
             if self.has_extra_loss and not (fused_kind == 'adam' and self.fused_extra_loss):
                 fused_kind = None
         self.optimizer = optimizer
+        adj = None
         if requires_adjgrad:
-            raise NotImplementedError('requires_adjgrad accumulates a dense N x N matrix in the reference (LightGCN.py:42-43, dead from the CLI); '
-                                      'use attack.White.PGA which computes the fake-user block directly')
+            # recommender/LightGCN.py:41-43: sparse_norm_adj.requires_grad = True, Matgrad = zeros(N, N).  The gradient of a sparse operand lives on its
+            # stored entries, so Matgrad is kept as one value per entry of the pattern (CSR order) instead of N x N.
+            if type(model).forward is not GraphEncoder.forward or getattr(model, 'skip_layer0', False) or self.has_extra_loss:
+                raise NotImplementedError('requires_adjgrad is implemented for the LightGCN propagation (mean over layers 0..L, BPR + L2 loss)')
+            adj = model.sparse_norm_adj
+            adj.requires_grad = True
+            self.Matgrad = torch.zeros(adj.values.numel(), dtype=torch.float32, device=DEVICE)
         if requires_embgrad:
             model.requires_grad = True
             self.usergrad = torch.zeros((self.data.user_num, self.args.emb_size), device=DEVICE)
@@ -453,7 +459,7 @@ class Recommender:
                     continue
                 model.train()
                 ul, pl, nl = u.long(), p.long(), ng.long()
-                if (self.rows_forward and self._rows_capable(model) and not self.train_forward_perturbed
+                if (self.rows_forward and self._rows_capable(model) and not self.train_forward_perturbed and adj is None
                         and not (self.has_extra_loss and self.extra_loss_takes_outputs)):
                     # the loss reads the output on the batch rows only: encoders that can evaluate just those rows do (NGCF's last layer)
                     B = u.numel()
@@ -462,6 +468,8 @@ class Recommender:
                 else:
                     outs = model(True) if self.train_forward_perturbed else model()
                     rec_user_emb, rec_item_emb = outs[0], outs[1]
+                    if adj is not None:
+                        rec_user_emb.retain_grad(); rec_item_emb.retain_grad()
                     user_emb, pos_item_emb, neg_item_emb = rec_user_emb[ul], rec_item_emb[pl], rec_item_emb[nl]
                 batch_loss = bpr_l2_loss(user_emb, pos_item_emb, neg_item_emb, self.args.reg * self.l2_scale)
                 if self.l2_on_negatives:
@@ -471,6 +479,13 @@ class Recommender:
                                                else self._extra_loss(model, ul, pl))
                 optimizer.zero_grad()
                 batch_loss.backward()
+                if adj is not None:
+                    # what autograd would add to sparse_norm_adj.grad; the reference never zeroes it (it is no optimizer parameter, so
+                    # optimizer.zero_grad() passes it by): .grad is the running sum over the steps so far, and Matgrad adds THAT (LightGCN.py:58-59)
+                    g_vals = model._engine().adjacency_gradient(torch.cat([rec_user_emb.grad, rec_item_emb.grad], 0))
+                    adj.values.grad = g_vals if adj.values.grad is None else adj.values.grad + g_vals
+                    if maxEpoch - epoch < gradIterationNum:
+                        self.Matgrad += adj.values.grad
                 if requires_embgrad and maxEpoch - epoch < gradIterationNum:
                     self.usergrad += model.embedding_dict['user_emb'].grad
                     self.itemgrad += model.embedding_dict['item_emb'].grad
@@ -489,8 +504,35 @@ class Recommender:
             if epoch % evalNum == 0:
                 self.evaluate(epoch)
         self.user_emb, self.item_emb = self.best_user_emb, self.best_item_emb
+        if requires_adjgrad:
+            block = self._adjgrad_block(adj)
+            if requires_embgrad:
+                return block, self.user_emb, self.item_emb, self.usergrad, self.itemgrad
+            return block
         if requires_embgrad:
             return self.user_emb, self.item_emb, self.usergrad, self.itemgrad
+
+    def _adjgrad_block(self, adj):
+        """(Matgrad + Matgrad.T)[:U, U:] of recommender/LightGCN.py:74-80 from the per-entry Matgrad: the value on (u, U + i) plus the value on its
+        mirror entry (U + i, u).  Dense [U, I] like the reference's while that is at most 2^27 elements, a sparse COO tensor beyond."""
+        U, I = self.data.user_num, self.data.item_num
+        indptr, indices = adj.indptr, adj.indices
+        n = len(indices)
+        pos = sp.csr_matrix((np.arange(1, n + 1, dtype=np.int64), indices, indptr), shape=adj.shape)
+        mirror = pos.T.tocsr()
+        mirror.sort_indices()
+        if mirror.nnz != n or not np.array_equal(mirror.indices, indices):
+            raise ValueError('requires_adjgrad: the adjacency pattern is not symmetric')
+        m = self.Matgrad
+        nu = int(indptr[U])                                              # the user rows' entries come first in CSR order
+        vals = m[:nu] + m[torch.from_numpy(mirror.data[:nu] - 1).to(m.device)]
+        rows = torch.from_numpy(np.repeat(np.arange(U, dtype=np.int64), np.diff(indptr[:U + 1]))).to(m.device)
+        cols = torch.from_numpy(indices[:nu].astype(np.int64) - U).to(m.device)
+        if U * I <= 2 ** 27:
+            block = torch.zeros(U, I, dtype=torch.float32, device=m.device)
+            block[rows, cols] = vals
+            return block
+        return torch.sparse_coo_tensor(torch.stack([rows, cols]), vals, (U, I)).coalesce()
 
     def train_batches(self, batches, optimizer):
         """Run the BPR + L2 training step on an iterable of (u, p, n) batches with `optimizer` and no evaluation -- the

@@ -363,6 +363,11 @@ int arl_sfa_stage3_f32(const float *X, const float *w, const float *r0, const fl
  *   out[t, j] += <dY[rows[t]], X[col_off + j]> ,  0 <= j < n_cols.   out: [n_rows_sel, n_cols]. */
 int arl_sddmm_rows_dense_f32(const float *dY, const float *X, int64_t d, const int32_t *rows, int64_t n_rows_sel,
                              int64_t col_off, int64_t n_cols, float *out, arl_stream_t stream);
+/* Gradient w.r.t. EVERY stored entry of the adjacency (CSR order): gval[e] += alpha * <dY[row(e)], X[col[e]]> -- the autograd of
+ * torch.sparse.mm with respect to its sparse argument, as accumulated by train(requires_adjgrad=True) (recommender/LightGCN.py:41-43,58-59);
+ * d % 4 == 0, d <= 256, 16-byte aligned tables.  One writer per entry (deterministic). */
+int arl_sddmm_csr_f32(const int32_t *rowptr, const int32_t *col, int64_t n_rows, int64_t d, const float *dY, const float *X, float alpha,
+                      float *gval, arl_stream_t stream);
 /* out = alpha * (tables[0] + ... + tables[n_tables-1]), element-wise over n_elems floats (n_elems % 4 == 0, 1 <= n_tables <= 8): the mean
  * over the propagated layers (recommender/LightGCN.py:236-240: torch.stack(...).mean) in one pass.  tables: HOST array of device pointers;
  * out may alias one of them. */

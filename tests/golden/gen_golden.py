@@ -1262,6 +1262,25 @@ def gen_sgl(data):
     save('g12_sgl.npz', **o)
 
 
+def gen_adjgrad():
+    """Reference `LightGCN.train(requires_adjgrad=True)` (recommender/LightGCN.py:29-80): the gradient of the batch losses with respect to the
+    normalised adjacency's stored entries, accumulated the reference's way -- `sparse_norm_adj.grad` is never zeroed (it is not an optimizer
+    parameter), and `Matgrad += sparse_norm_adj.grad` adds that running sum after every step -- and returned as (Matgrad + Matgrad.T)[:U, U:]."""
+    import io, contextlib
+    args = rec_args(emb_size=16, n_layers=2)
+    seedSet(2018)
+    data = DataLoader(args)
+    rec = LightGCN(args, data)
+    u0 = rec.model.embedding_dict['user_emb'].detach().numpy().copy(); i0 = rec.model.embedding_dict['item_emb'].detach().numpy().copy()
+    with contextlib.redirect_stdout(io.StringIO()):
+        block = rec.train(requires_adjgrad=True, Epoch=2, gradIterationNum=10, evalNum=1)
+    block = block.detach().numpy()
+    r, c = np.nonzero(block)
+    save('g21_adjgrad.npz', user0=u0, item0=i0, block_row=r.astype(np.int32), block_col=c.astype(np.int32), block_val=block[r, c].astype(np.float32),
+         block_shape=np.array(block.shape, np.int64), user=rec.model.embedding_dict['user_emb'].detach().numpy().copy(),
+         item=rec.model.embedding_dict['item_emb'].detach().numpy().copy(), next_random=np.array([random.random()], np.float64))
+
+
 if __name__ == '__main__':
     only = set(sys.argv[1:])                          # e.g. `gen_golden.py xsimgcl` regenerates that fixture alone
     if only:
@@ -1289,6 +1308,8 @@ if __name__ == '__main__':
             gen_victims()
         if 'fake_rows' in only:
             gen_fake_rows()
+        if 'adjgrad' in only:
+            gen_adjgrad()
         sys.exit(0)
     gen_dataset()
     data = gen_sampler()
@@ -1314,4 +1335,5 @@ if __name__ == '__main__':
     gen_ngcf128()
     gen_victims()
     gen_fake_rows()
+    gen_adjgrad()
     print('done; scratch dir', SCRATCH)

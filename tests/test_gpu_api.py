@@ -65,6 +65,49 @@ def test_train_two_epochs_matches_reference_run(name):
         assert rel_err(u.detach().cpu().numpy(), rec.model()[0].detach().cpu().numpy()) < 1e-6
 
 
+@pytest.mark.parametrize('array_native', [False, True])
+def test_train_requires_adjgrad_matches_reference_run(array_native):
+    """LightGCN.train(requires_adjgrad=True, Epoch=2) against the reference's own run (g21, recommender/LightGCN.py:29-80): the returned
+    (Matgrad + Matgrad.T)[:U, U:] block -- the reference's accumulation included (sparse_norm_adj.grad is never zeroed; Matgrad adds the running
+    sum after every step) --, the tables after the 44 steps and the random stream.  The gradient lives on the pattern's entries
+    (arl_sddmm_csr_f32) instead of a dense N x N matrix."""
+    from arlib_amd.util.tool import seedSet
+    from arlib_amd.recommender.LightGCN import LightGCN
+    g = golden('g21_adjgrad.npz')
+    seedSet(2018)
+    data = make_data(array_native)
+    rec = LightGCN(rec_args(emb_size=16, n_layers=2), data)
+    assert close(rec.model.embedding_dict['user_emb'].detach().cpu().numpy(), g['user0'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        block = rec.train(requires_adjgrad=True, Epoch=2, gradIterationNum=10, evalNum=1)
+    assert random.random() == float(g['next_random'][0])
+    assert tuple(block.shape) == tuple(int(x) for x in g['block_shape'])
+    got = block.cpu().numpy()
+    ref = np.zeros_like(got)
+    ref[g['block_row'], g['block_col']] = g['block_val']
+    assert close(got, ref)                                             # max-norm and row-wise, 1e-4
+    assert np.count_nonzero(got) <= len(data.training_data)            # nothing outside the interaction pattern
+    assert close(rec.model.embedding_dict['user_emb'].detach().cpu().numpy(), g['user'])
+    assert close(rec.model.embedding_dict['item_emb'].detach().cpu().numpy(), g['item'])
+
+
+def test_sddmm_csr_against_float64(ml100k):
+    """arl_sddmm_csr_f32: gval[e] += alpha <dY[row(e)], X[col[e]]> on every stored entry, d in {16, 64, 100}, accumulation into existing values."""
+    from arlib_amd import ops
+    from oracle import oracle as O
+    p = ml100k['pairs0']
+    rowptr, col, w = O.bipartite_csr(p[:, 0], p[:, 1], ml100k['U'], ml100k['I'])
+    A = ops.CSRGraph(rowptr, col, w, 'cuda:0')
+    rows = np.repeat(np.arange(len(rowptr) - 1), np.diff(rowptr))
+    rng = np.random.default_rng(5)
+    for d in (16, 64, 100):
+        dY = rng.standard_normal((len(rowptr) - 1, d)).astype(np.float32); X = rng.standard_normal((len(rowptr) - 1, d)).astype(np.float32)
+        base = rng.standard_normal(len(col)).astype(np.float32)
+        out = ops.sddmm_csr(A, torch.from_numpy(dY).cuda(), torch.from_numpy(X).cuda(), 0.25, out=torch.from_numpy(base.copy()).cuda())
+        ref = base.astype(np.float64) + 0.25 * np.einsum('ed,ed->e', dY[rows].astype(np.float64), X[col].astype(np.float64))
+        assert rel_err(out.cpu().numpy(), ref) < 1e-6
+
+
 def test_autograd_route_with_external_optimizer_matches_golden_steps(ml100k):
     """A caller-owned SGD over a *subset view* cannot be fused: the generic autograd route must give the same numbers."""
     from arlib_amd.recommender.LightGCN import LightGCN
