@@ -46,6 +46,9 @@ class _Layer(torch.autograd.Function):
             gZ = ops.ngcf_act_bwd(g_out.contiguous(), out, ctx.slope)
             gW = torch.mm(ST.t(), gZ)
             gP, gE = ops.ngcf_combine_bwd(torch.mm(gZ, Wcat.t()), P, ego)
+        sink = getattr(ctx.graph, 'grad_sink', None)
+        if sink is not None:                                       # P = A ego: the adjacency's stored entries receive <gP[row], ego[col]> (train(requires_adjgrad=True))
+            ops.sddmm_csr(ctx.graph, gP.contiguous(), ego, 1.0, out=sink)
         g_ego = ops.spmm(ctx.graph, gP, 1.0, 1.0, gE)
         return g_ego, gW[:d], gW[d:], None, None
 
@@ -189,6 +192,20 @@ class NGCF(Recommender):
         super()._sync_optimizer_step(eng, optimizer, kind)
         for q in self._weight_params():
             optimizer.state[q]['step'] = torch.tensor(float(eng.t))
+
+    def _adjgrad_begin(self, model):
+        # recommender/NGCF.py:39-42: every layer's P = A E is a product with the adjacency; their backward passes add into this buffer (_Layer.backward)
+        g = model._graph()
+        g.grad_sink = torch.zeros(g.col.numel(), dtype=torch.float32, device=g.col.device)
+
+    def _adjgrad_end(self, model):
+        model._graph().grad_sink = None
+
+    def _adjgrad_step(self, model, g_user, g_item):
+        sink = model._graph().grad_sink
+        out = sink.clone()
+        sink.zero_()
+        return out
 
     def train(self, requires_adjgrad=False, requires_embgrad=False, gradIterationNum=10, Epoch=0, optimizer=None, evalNum=5):
         return self._train_loop(Epoch, optimizer, evalNum, requires_embgrad=requires_embgrad, requires_adjgrad=requires_adjgrad,

@@ -411,8 +411,9 @@ class Recommender:
         if requires_adjgrad:
             # recommender/LightGCN.py:41-43: sparse_norm_adj.requires_grad = True, Matgrad = zeros(N, N).  The gradient of a sparse operand lives on its
             # stored entries, so Matgrad is kept as one value per entry of the pattern (CSR order) instead of N x N.
-            if type(model).forward is not GraphEncoder.forward or getattr(model, 'skip_layer0', False) or self.has_extra_loss:
-                raise NotImplementedError('requires_adjgrad is implemented for the LightGCN propagation (mean over layers 0..L, BPR + L2 loss)')
+            if self.has_extra_loss:
+                raise NotImplementedError('requires_adjgrad is implemented for the BPR + L2 loss (LightGCN, NGCF)')
+            self._adjgrad_begin(model)
             adj = model.sparse_norm_adj
             adj.requires_grad = True
             self.Matgrad = torch.zeros(adj.values.numel(), dtype=torch.float32, device=DEVICE)
@@ -482,7 +483,7 @@ class Recommender:
                 if adj is not None:
                     # what autograd would add to sparse_norm_adj.grad; the reference never zeroes it (it is no optimizer parameter, so
                     # optimizer.zero_grad() passes it by): .grad is the running sum over the steps so far, and Matgrad adds THAT (LightGCN.py:58-59)
-                    g_vals = model._engine().adjacency_gradient(torch.cat([rec_user_emb.grad, rec_item_emb.grad], 0))
+                    g_vals = self._adjgrad_step(model, rec_user_emb.grad, rec_item_emb.grad)
                     adj.values.grad = g_vals if adj.values.grad is None else adj.values.grad + g_vals
                     if maxEpoch - epoch < gradIterationNum:
                         self.Matgrad += adj.values.grad
@@ -505,12 +506,25 @@ class Recommender:
                 self.evaluate(epoch)
         self.user_emb, self.item_emb = self.best_user_emb, self.best_item_emb
         if requires_adjgrad:
+            self._adjgrad_end(model)
             block = self._adjgrad_block(adj)
             if requires_embgrad:
                 return block, self.user_emb, self.item_emb, self.usergrad, self.itemgrad
             return block
         if requires_embgrad:
             return self.user_emb, self.item_emb, self.usergrad, self.itemgrad
+
+    def _adjgrad_begin(self, model):
+        """Prepare the encoder for train(requires_adjgrad=True); the base form covers the LightGCN propagation (mean over layers 0..L)."""
+        if type(model).forward is not GraphEncoder.forward or getattr(model, 'skip_layer0', False):
+            raise NotImplementedError('requires_adjgrad is implemented for the LightGCN and NGCF propagations')
+
+    def _adjgrad_end(self, model):
+        pass
+
+    def _adjgrad_step(self, model, g_user, g_item):
+        """One step's gradient on the adjacency's stored entries (CSR order) from the gradient of the loss w.r.t. the propagated tables."""
+        return model._engine().adjacency_gradient(torch.cat([g_user, g_item], 0))
 
     def _adjgrad_block(self, adj):
         """(Matgrad + Matgrad.T)[:U, U:] of recommender/LightGCN.py:74-80 from the per-entry Matgrad: the value on (u, U + i) plus the value on its

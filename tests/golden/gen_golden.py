@@ -1263,22 +1263,47 @@ def gen_sgl(data):
 
 
 def gen_adjgrad():
-    """Reference `LightGCN.train(requires_adjgrad=True)` (recommender/LightGCN.py:29-80): the gradient of the batch losses with respect to the
+    """Reference `X.train(requires_adjgrad=True)` (recommender/LightGCN.py:29-80, NGCF.py:31-79): the gradient of the batch losses with respect to the
     normalised adjacency's stored entries, accumulated the reference's way -- `sparse_norm_adj.grad` is never zeroed (it is not an optimizer
-    parameter), and `Matgrad += sparse_norm_adj.grad` adds that running sum after every step -- and returned as (Matgrad + Matgrad.T)[:U, U:]."""
+    parameter), and `Matgrad += sparse_norm_adj.grad` adds that running sum after every step -- and returned as (Matgrad + Matgrad.T)[:U, U:].
+    NOTE: the NGCF run is not reproducible from one generation to the next (tables after the 44 steps: two outcomes 3.8e-3 / 7.4e-3 apart; the first
+    step agrees to 1e-7); tests/test_gpu_api.py::test_ngcf_train_requires_adjgrad_matches_reference_run holds the 44-step figures to bars that cover both."""
     import io, contextlib
-    args = rec_args(emb_size=16, n_layers=2)
-    seedSet(2018)
-    data = DataLoader(args)
-    rec = LightGCN(args, data)
-    u0 = rec.model.embedding_dict['user_emb'].detach().numpy().copy(); i0 = rec.model.embedding_dict['item_emb'].detach().numpy().copy()
-    with contextlib.redirect_stdout(io.StringIO()):
-        block = rec.train(requires_adjgrad=True, Epoch=2, gradIterationNum=10, evalNum=1)
-    block = block.detach().numpy()
-    r, c = np.nonzero(block)
-    save('g21_adjgrad.npz', user0=u0, item0=i0, block_row=r.astype(np.int32), block_col=c.astype(np.int32), block_val=block[r, c].astype(np.float32),
-         block_shape=np.array(block.shape, np.int64), user=rec.model.embedding_dict['user_emb'].detach().numpy().copy(),
-         item=rec.model.embedding_dict['item_emb'].detach().numpy().copy(), next_random=np.array([random.random()], np.float64))
+    from recommender.NGCF import NGCF
+    for fname, cls, kw in (('g21_adjgrad.npz', LightGCN, dict(emb_size=16, n_layers=2)), ('g22_adjgrad_ngcf.npz', NGCF, dict(emb_size=32, n_layers=2, model_name='NGCF'))):
+        args = rec_args(**kw)
+        seedSet(2018)
+        data = DataLoader(args)
+        rec = cls(args, data)
+        init = {k: v.detach().numpy().copy() for k, v in rec.model.state_dict().items()}
+        u0 = rec.model.embedding_dict['user_emb'].detach().numpy().copy(); i0 = rec.model.embedding_dict['item_emb'].detach().numpy().copy()
+        # the first step alone (a 44-step trajectory amplifies rounding differences, NGCF's by a lot): sparse_norm_adj.grad after the first backward
+        first = {}
+        orig_backward = torch.Tensor.backward
+
+        def backward_and_capture(self, *a, **k):
+            out = orig_backward(self, *a, **k)
+            if not first:
+                gr = rec.model.sparse_norm_adj.grad.coalesce()
+                first['idx'], first['val'] = gr.indices().numpy().copy(), gr.values().numpy().copy()
+            return out
+        torch.Tensor.backward = backward_and_capture
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                block = rec.train(requires_adjgrad=True, Epoch=2, gradIterationNum=10, evalNum=1)
+        finally:
+            torch.Tensor.backward = orig_backward
+        U = data.user_num
+        N = U + data.item_num
+        M1 = sp.coo_matrix((first['val'], (first['idx'][0], first['idx'][1])), shape=(N, N)).tocsr()
+        B1 = (M1 + M1.T).tocsr()[:U, U:].tocoo()
+        block = block.detach().numpy()
+        r, c = np.nonzero(block)
+        extra = {'init_' + k.replace('.', '__'): v for k, v in init.items() if 'embedding_dict' not in k}
+        save(fname, user0=u0, item0=i0, block_row=r.astype(np.int32), block_col=c.astype(np.int32), block_val=block[r, c].astype(np.float32),
+             first_row=B1.row.astype(np.int32), first_col=B1.col.astype(np.int32), first_val=B1.data.astype(np.float32),
+             block_shape=np.array(block.shape, np.int64), user=rec.model.embedding_dict['user_emb'].detach().numpy().copy(),
+             item=rec.model.embedding_dict['item_emb'].detach().numpy().copy(), next_random=np.array([random.random()], np.float64), **extra)
 
 
 if __name__ == '__main__':
