@@ -296,6 +296,7 @@ class PGA(AttackBase):
             S2 = S.clone()
             for _ in range(self.innerEpoch):
                 pairs = None
+                losses = []                                  # printed after the loop: reading each loss as it is produced would stall the launch queue once per step
                 for batch in range(0, I, self.batchSize):
                     graph = fg.set_block(S2)
                     if L == 0:
@@ -311,7 +312,9 @@ class PGA(AttackBase):
                         pairs = cw_operator(U + F + I, U + F, *cw_pairs(top_idx, U, self.targetItem, pop=True), device=E0.device)
                     block, loss = pga_step_block(graph, fg.fake_rows, U + F, I, E0, L, pairs)
                     ops.pga_update_(S2, block, fg.dinv[U:U + F].contiguous(), fg.dinv[U + F:].contiguous())
-                    print('>> batchNum:{} Loss:{}'.format(int(batch / self.batchSize), loss.item()))
+                    losses.append(loss)
+                for b, lo in enumerate(torch.stack(losses).tolist() if losses else []):      # the reference's lines (PGA.py:140), same order, one device read
+                    print('>> batchNum:{} Loss:{}'.format(b, lo))
             proj, _ = ops.topn_project_rows(S2, int(self.maliciousFeedbackSize * I))
             proj[:, self.targetItem] = 1
             S = proj
