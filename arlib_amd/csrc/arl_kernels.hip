@@ -2143,7 +2143,7 @@ __global__ __launch_bounds__(kBlock) void score_mask_topk_kernel(const float *__
 #endif
 constexpr int topk_waves(int D, bool SPLIT) { return (SPLIT && ARL_TOPK_SPLIT_MODE == 2) ? (D == 64 ? ARL_TOPK_D64_WAVES : (D == 128 ? ARL_TOPK_D128_WAVES : 8)) : 8; }
 #ifdef ARL_TOPK_PROF
-#define ARL_PROF_DECL long long P_acc[4] = {0, 0, 0, 0}, P_t0 = clock64(); const long long P_start = P_t0;
+#define ARL_PROF_DECL long long P_acc[7] = {0, 0, 0, 0, 0, 0, 0}, P_t0 = clock64(); const long long P_start = P_t0;
 #define ARL_PROF_TICK(SLOT) { const long long P_t = clock64(); P_acc[SLOT] += P_t - P_t0; P_t0 = P_t; }
 #else
 #define ARL_PROF_DECL
@@ -2176,6 +2176,21 @@ constexpr int kQWords = 16 + 16 * kQCap * 2;      // per wave: 16 counters + 16 
 constexpr int kTopkRing = ARL_TOPK_RING;         // staged item tiles in LDS (slots of the ring), a power of two
 #ifndef ARL_TOPK_LEAD
 #define ARL_TOPK_LEAD 2
+#endif
+#ifndef ARL_TOPK_SUBSKIP
+#define ARL_TOPK_SUBSKIP 1
+#endif
+#ifndef ARL_TOPK_POLL8
+#define ARL_TOPK_POLL8 0
+#endif
+#ifndef ARL_TOPK_SIGNAL_WAIT
+#define ARL_TOPK_SIGNAL_WAIT 1
+#endif
+#ifndef ARL_TOPK_QCHK
+#define ARL_TOPK_QCHK 2                          // the per-row queue counts are looked at every ARL_TOPK_QCHK-th stage (full queues are merged when they fill, whatever this is)
+#endif
+#ifndef ARL_TOPK_PIPE
+#define ARL_TOPK_PIPE 1
 #endif
 constexpr int kTopkLead = ARL_TOPK_LEAD;         // a wave writes its share of stage s + kTopkLead while it consumes stage s (even, < ring)
 #ifndef ARL_TOPK_BOOT_ITEMS
@@ -2570,7 +2585,7 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     // Straight line: one compare per score; if any lane of the wave passes anywhere, every passing (sub, reg) appends its lanes' (score, item)
     // pairs -- an LDS atomic for the slot, one 8-byte store.  A queue that is full sends its lanes to the rare path at the end.
     auto bookkeeping = [&](const f32x4 (&ac)[NSUB], int st) {
-        if (ARL_TOPK_EXP == 1) {                                       // experiment: scores only, no pre-filter, no lists
+        if (ARL_TOPK_EXP == 1 || ARL_TOPK_EXP >= 5) {                  // experiment: scores only, no pre-filter, no lists
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub) exp_sink += ac[sub][0] + ac[sub][3];
             return;
@@ -2583,22 +2598,27 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
             for (int sub = 0; sub < NSUB; ++sub)
                 if (st * MST + 16 * sub + c >= I) sv[sub] = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
         }
-        bool pass[NSUB][4];
+        bool pass[NSUB][4], psub[NSUB];
         bool some = false;
 #pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub)
+        for (int sub = 0; sub < NSUB; ++sub) {
+            psub[sub] = false;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 pass[sub][reg] = sv[sub][reg] >= thrf[reg];            // one compare per score (-inf always passes, +inf and NaN never)
-                some = some || pass[sub][reg];
+                psub[sub] = psub[sub] || pass[sub][reg];
             }
+            some = some || psub[sub];
+        }
         if (ARL_TOPK_EXP == 2) { exp_sink += some ? 1.f : 0.f; return; }    // experiment: compares only
         if (ARL_TOPK_EXP == 3) { exp_sink += some ? 1.f : 0.f; flush_rows_with((unsigned)kQFlush); return; }    // experiment: compares + the stage-end queue check (queues stay empty)
         if (__builtin_amdgcn_ballot_w64(some) != 0ull) {
             unsigned left = 0u;                                        // bit 4*sub + reg: this lane's candidate found its queue full
             const int item0 = st * MST + c;
 #pragma unroll
-            for (int sub = 0; sub < NSUB; ++sub)
+            for (int sub = 0; sub < NSUB; ++sub) {
+                // two levels of skipping: a wave sees ~2 survivors per stage, so most sub-tiles have none (one branch instead of four)
+                if (ARL_TOPK_SUBSKIP && __builtin_amdgcn_ballot_w64(psub[sub]) == 0ull) continue;
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     if (pass[sub][reg]) {
@@ -2608,6 +2628,7 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
                         else left |= 1u << (4 * sub + reg);
                     }
                 }
+            }
             // rare path (cold starts, bursts): merge the full queues, then the lanes left over try again
             while (__builtin_amdgcn_ballot_w64(left != 0u) != 0ull) {
                 flush_rows_with((unsigned)kQCap);
@@ -2625,7 +2646,7 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
                 }
             }
         }
-        flush_rows_with((unsigned)kQFlush);
+        if (ARL_TOPK_QCHK == 1 || (st % ARL_TOPK_QCHK) == 0) flush_rows_with((unsigned)kQFlush);
     };
 #endif
     // ---- bootstrap pass state: bl[reg][j] = j-th best score this lane has seen for user row 4g + reg (descending)
@@ -2701,6 +2722,61 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
             // fragments of GRP sub-tiles at a time (all of the stage, or two when the workgroup runs four waves per SIMD on 128 registers)
             constexpr int GRP = (topk_waves(D, SPLIT) >= 16 && NSUB > 2) ? 2 : ((D >= 128 && topk_waves(D, SPLIT) >= 12) ? 1 : NSUB);
             constexpr int TA[3] = {0, 1, 0}, TB[3] = {1, 0, 0};    // ah*bl, al*bh, ah*bh: smallest products first
+            if constexpr (ARL_TOPK_EXP == 5) {                     // probe: ring + staging only (no fragment reads, no MFMAs)
+            } else if constexpr (ARL_TOPK_EXP == 6) {              // probe: MFMAs on whatever the registers hold (fragments read in the first stage only)
+                f16x8 pb[2][KS];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) { pb[pl][ks] = ah[pl][ks]; asm volatile("" : "+v"(pb[pl][ks])); }
+#pragma unroll
+                for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+                    for (int term = 0; term < 3; ++term)
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks)
+                            accs[sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[TA[term]][ks], pb[TB[term]][ks], accs[sub], 0, 0, 0);
+            } else if constexpr (ARL_TOPK_EXP == 7) {              // probe: fragment reads only (kept alive through an empty asm), no MFMAs
+#pragma unroll
+                for (int s0 = 0; s0 < NSUB; s0 += 2) {
+                    f16x8 v[2][2][KS];
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                            for (int ks = 0; ks < KS; ++ks)
+                                v[sub][pl][ks] = *reinterpret_cast<const f16x8 *>(buf + (g & 1) * HALF + ((s0 + sub) * 16 + c) * RH + ((pl * 2 + (g >> 1)) * PPG + ks) * 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("" ::"v"(v[0][0][0]), "v"(v[0][0][1]), "v"(v[0][1][0]), "v"(v[0][1][1]), "v"(v[1][0][0]), "v"(v[1][0][1]), "v"(v[1][1][0]), "v"(v[1][1][1]));
+                }
+            } else if constexpr (ARL_TOPK_PIPE && GRP == 2 && NSUB > 2) {
+                // Software-pipelined form: the fragments of sub-tile s + 1 are requested BEFORE the six MFMAs of sub-tile s are issued (two
+                // 16-register buffers = the registers of the two-sub-tile group form), so a wave's LDS latency runs behind its own matrix
+                // work instead of behind the other three waves' of its SIMD only.
+                f16x8 pb[2][2][KS];
+                auto rd = [&](int sub, int b) {
+#pragma unroll
+                    for (int plo = 0; plo < 2; ++plo)
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            const int pl = 1 - plo;
+                            pb[b][pl][ks] = *reinterpret_cast<const f16x8 *>(buf + (g & 1) * HALF + (sub * 16 + c) * RH + ((pl * 2 + (g >> 1)) * PPG + ks) * 16);
+                        }
+                };
+                rd(0, 0);
+#pragma unroll
+                for (int sub = 0; sub < NSUB; ++sub) {
+                    if (sub + 1 < NSUB) rd(sub + 1, (sub + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int term = 0; term < 3; ++term)
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks)
+                            accs[sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[TA[term]][ks], pb[sub & 1][TB[term]][ks], accs[sub], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else
 #pragma unroll
             for (int s0 = 0; s0 < NSUB; s0 += GRP) {
                 f16x8 bfr[GRP][2][KS];
@@ -2803,16 +2879,25 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     };
     auto slot = [&](int st) { return bt + (st & (kTopkRing - 1)) * STAGEB; };
     auto signal = [&](unsigned *ctr) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the LDS executes one wave's operations in issue order: the counter's atomic lands after the tile writes issued before it, no wait
+        // for their completion needed (ARL_TOPK_SIGNAL_WAIT = 1: the round-3 form, which waited for them first -- one exposed LDS round trip per stage)
+        if (ARL_TOPK_SIGNAL_WAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add((lds_u32 *)ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
-    auto wait_ge = [&](unsigned *ctr, unsigned want) {             // explicit LDS loads: a flat load would also wait for the global prefetch
+    [[maybe_unused]] auto wait_ge = [&](unsigned *ctr, unsigned want) {             // explicit LDS loads: a flat load would also wait for the global prefetch
+        if (ARL_TOPK_EXP == 8) return;                             // probe (scores only, racy): no waits at all -- what the ring's synchronisation costs
         int spins = 0;
         while ((unsigned)__builtin_amdgcn_readfirstlane((int)*(volatile lds_u32 *)ctr) < want) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1 << 26)) __builtin_trap();             // never reached: every wave signals every stage; a trap beats a hang
         }
         asm volatile("" ::: "memory");
+    };
+    [[maybe_unused]] auto poll_all = [&]() -> unsigned {
+        const unsigned v = *(volatile lds_u32 *)(ring_ctr + min(lane, 2 * kTopkRing - 1));
+        asm volatile("" ::: "memory");
+        return v;
     };
     unsigned *fill_ctr = ring_ctr, *done_ctr = ring_ctr + kTopkRing;
     constexpr unsigned NWV = kM16Block / kWave;
@@ -2822,14 +2907,41 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     auto step = [&](auto boot_tag, int st, f32x4 (&r)[PER]) {
         const int t = st + kTopkLead;
 
+#if ARL_TOPK_POLL8
+        // one LDS round trip reads all 2 * ring counters (lane l < 2 * ring holds counter l); in the steady state both conditions of the step
+        // (the slot to refill has been read by every wave; the stage to consume is complete) hold in that one snapshot
+        unsigned snap = poll_all();
+        if (t < nvirt) {
+            for (int spins = 0; (unsigned)__builtin_amdgcn_readlane((int)snap, kTopkRing + (t & (kTopkRing - 1))) < NWV * (unsigned)(t / kTopkRing); snap = poll_all()) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 26)) __builtin_trap();
+            }
+#else
         if (t < nvirt) {
             wait_ge(done_ctr + (t & (kTopkRing - 1)), NWV * (unsigned)(t / kTopkRing));          // stage t - ring has been read by every wave
+#endif
+#ifdef ARL_TOPK_PROF
+            ARL_PROF_TICK(4)
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");          // (profiling build: the older of the two loads in flight, timed apart)
+            ARL_PROF_TICK(5)
+#endif
             stash(slot(t), r);
             signal(fill_ctr + (t & (kTopkRing - 1)));
+#ifdef ARL_TOPK_PROF
+            ARL_PROF_TICK(6)
+#endif
             if (t + 2 < nvirt) fetch(item_stage(t + 2), r);
         }
         ARL_PROF_TICK(0)
+#if ARL_TOPK_POLL8
+        for (int spins = 0; (unsigned)__builtin_amdgcn_readlane((int)snap, st & (kTopkRing - 1)) < NWV * (unsigned)(st / kTopkRing + 1); snap = poll_all()) {
+            if (spins) __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 26)) __builtin_trap();
+        }
+        asm volatile("" ::: "memory");
+#else
         wait_ge(fill_ctr + (st & (kTopkRing - 1)), NWV * (unsigned)(st / kTopkRing + 1));
+#endif
         ARL_PROF_TICK(3)
         compute(boot_tag, slot(st), st, done_ctr + (st & (kTopkRing - 1)));
     };
@@ -2872,6 +2984,7 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     if (lane == 0 && u_base < U) {
         float *o = top_val + (size_t)u_base * k;
         o[0] = (float)P_acc[0]; o[1] = (float)P_acc[1]; o[2] = (float)P_acc[2]; o[3] = (float)P_acc[3]; o[4] = (float)P_loop; o[5] = (float)(clock64() - P_start);
+        o[6] = (float)P_acc[4]; o[7] = (float)P_acc[5]; o[8] = (float)P_acc[6];
     }
 #endif
 }

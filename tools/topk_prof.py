@@ -16,7 +16,7 @@ idx, val = ops.score_mask_topk(Pu, Pi, k, exact=os.environ.get('EXACT', '0') == 
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 NW = int(os.environ.get('NW', 16 if d == 64 and os.environ.get('EXACT', '0') != '1' else 8))
-v = val.view(U // (16 * NW), NW, 16 * k)[:, :, :6].double().mean(0).cpu().numpy()      # [wave, section]
+v = val.view(U // (16 * NW), NW, 16 * k)[:, :, :9].double().mean(0).cpu().numpy()      # [wave, section]
 print('k=%d d=%d: %.1f ms' % (k, d, dt * 1e3))
 for w in range(NW):
-    print('  wave %d: refill(wait done + stash) %.0f  wait fill %.0f  mfma %.0f  book %.0f | loop %.0f total %.0f' % (w, v[w, 0], v[w, 3], v[w, 1], v[w, 2], v[w, 4], v[w, 5]))
+    print('  wave %d: wait done %.0f  load wait %.0f  stash+signal %.0f  fetch issue %.0f  wait fill %.0f  mfma %.0f  book %.0f | loop %.0f total %.0f' % (w, v[w, 6], v[w, 7], v[w, 8], v[w, 0], v[w, 3], v[w, 1], v[w, 2], v[w, 4], v[w, 5]))
