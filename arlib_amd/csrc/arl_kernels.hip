@@ -2162,10 +2162,10 @@ constexpr int kBloomWords = 32;      // 1024 bits per user
 #define ARL_TOPK_QUEUE 1
 #endif
 #ifndef ARL_TOPK_QCAP
-#define ARL_TOPK_QCAP 8
+#define ARL_TOPK_QCAP 16
 #endif
 #ifndef ARL_TOPK_QFLUSH
-#define ARL_TOPK_QFLUSH 6
+#define ARL_TOPK_QFLUSH 12
 #endif
 constexpr int kQCap = ARL_TOPK_QCAP;             // queue slots per user row and wave
 constexpr int kQFlush = ARL_TOPK_QFLUSH;         // merge a row's queue at the end of a stage once it holds this many
@@ -2176,6 +2176,18 @@ constexpr int kQWords = 16 + 16 * kQCap * 2;      // per wave: 16 counters + 16 
 constexpr int kTopkRing = ARL_TOPK_RING;         // staged item tiles in LDS (slots of the ring), a power of two
 #ifndef ARL_TOPK_LEAD
 #define ARL_TOPK_LEAD 2
+#endif
+#ifndef ARL_TOPK_ESCALE
+#define ARL_TOPK_ESCALE 1.05f                    // (probes only: anything below 1.05 voids the bound)
+#endif
+#ifndef ARL_TOPK_RGRP
+#define ARL_TOPK_RGRP 2
+#endif
+#ifndef ARL_TOPK_PAIRS
+#define ARL_TOPK_PAIRS 0
+#endif
+#ifndef ARL_TOPK_REFINE
+#define ARL_TOPK_REFINE 1                        // fp16 split form: stream scores from the high pieces only, exact three-product scores for queued candidates (see the kernel)
 #endif
 #ifndef ARL_TOPK_SUBSKIP
 #define ARL_TOPK_SUBSKIP 1
@@ -2333,6 +2345,8 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     }
     constexpr int KS = SPLIT ? Q / 8 : 1;                          // 16-bit MFMAs (8 indices per lane each) per operand pair
     constexpr bool F16 = SPLIT && kSplitMode == 2;
+    constexpr bool REFINE = F16 && ARL_TOPK_REFINE && ARL_TOPK_QUEUE;      // see the staging constants below
+    float Ereg[4] = {0.f, 0.f, 0.f, 0.f};                          // REFINE: the bound E of user rows 4g + reg (scaled domain)
     bf16x8 af[3][KS];
     f16x8 ah[2][KS];
     // scaled domain of the fp16 form: scores = true scores * score_scale (a power of two); 1 otherwise
@@ -2340,11 +2354,23 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     if constexpr (F16) {
         const float su = split_scale(table_max_bits[1]), si = split_scale(table_max_bits[0]);
         score_scale = su * si; score_unscale = (1.f / su) * (1.f / si);
+        float n2 = 0.f;
 #pragma unroll
         for (int t = 0; t < Q; ++t) {
             const float x = a[t] * su;
             const _Float16 h = (_Float16)x;
             ah[0][t / 8][t % 8] = h; ah[1][t / 8][t % 8] = (_Float16)(x - (float)h);
+            n2 = fmaf(x, x, n2);
+        }
+        if constexpr (REFINE) {
+            n2 += __shfl_xor(n2, 16); n2 += __shfl_xor(n2, 32);   // |a'|^2 of user c (the four k-groups of a column hold a quarter each)
+            // max |b'| <= sqrt(D) * (largest element of the item table, scaled)
+            // (+ two absolute terms for pieces that are subnormal fp16 numbers -- elements 2^27 below their table's maximum: rounding error <= 2^-25
+            // instead of 2^-11 relative; they matter only for user rows that are zero to fp32 precision next to the rest of the table)
+            const float na = sqrtf(n2), bm = __uint_as_float(table_max_bits[0]) * si, sd = sqrtf((float)D);
+            const float Ec = ARL_TOPK_ESCALE * 0.0009765625f * na * sd * bm + 1.1920929e-7f * (float)D * bm + 5.9604645e-8f * sd * na;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) Ereg[reg] = __shfl(Ec, 4 * g + reg);
         }
     } else if constexpr (SPLIT) {
 #pragma unroll
@@ -2355,8 +2381,13 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
             af[0][t / 8][t % 8] = h; af[1][t / 8][t % 8] = m; af[2][t / 8][t % 8] = (__bf16)(r1 - (float)m);
         }
     }
+    // REFINE: the stream contracts the HIGH fp16 pieces only (one product instead of three, half the staged bytes and fragment reads); that score
+    // differs from the three-product score by at most E = 1.05 * 2^-10 * |a| * max|b| (each piece keeps 11 bits; Cauchy-Schwarz), so the pre-filter
+    // runs against threshold - E and every queued candidate gets its three-product score -- the same MFMA sequence on the same operands as
+    // the one-pass form, bit for bit -- when its row's queue is merged (up to 8 candidates per 16 x 16 tile, fragments gathered from the image).
     constexpr int C16 = SRCB / 16;                                 // 16-byte pieces per item row
-    constexpr int F4 = MST * C16;
+    constexpr int C16S = REFINE ? C16 / kSplitPlanes : C16;        // ... of which the stream stages these (the first plane)
+    constexpr int F4 = MST * C16S;
     constexpr int PER = (F4 + kM16Block - 1) / kM16Block;
     static_assert(PER >= 1 && PER <= 6, "staging assumes one to six 16-byte pieces per thread");
     const int nstages = (I + MST - 1) / MST;                       // item stages
@@ -2373,12 +2404,12 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     auto item_stage = [&](int v) { return v < NB ? v : v - NB; };
     auto stage_ptr = [&](int st, int p) {
         const int f = tid + p * kM16Block;
-        const int item = min(st * MST + f / C16, I - 1);           // clamped, never selected on: rows past I are masked out of pm
-        return reinterpret_cast<const float4 *>(Pi + (size_t)item * SRCB + (f % C16) * 16);
+        const int item = min(st * MST + f / C16S, I - 1);          // clamped, never selected on: rows past I are masked out of pm
+        return reinterpret_cast<const float4 *>(Pi + (size_t)item * SRCB + (f % C16S) * 16);
     };
     auto lds_ptr = [&](unsigned char *buf, int p) {
         const int f = tid + p * kM16Block;
-        const int row = f / C16, piece = f % C16;                  // piece = plane * (4*PPG) + j, j-th 16-B run of the plane
+        const int row = f / C16S, piece = f % C16S;                // piece = plane * (4*PPG) + j, j-th 16-B run of the plane
         const int pl = piece / (4 * PPG), j = piece % (4 * PPG), gq = j / PPG, ks = j % PPG;
         return reinterpret_cast<float4 *>(buf + (gq & 1) * HALF + row * RH + ((pl * 2 + (gq >> 1)) * PPG + ks) * 16);
     };
@@ -2413,7 +2444,7 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const float t0 = WARM ? __shfl(thr0v, 4 * g + reg) : -INFINITY;
-        thrf[reg] = (u_base + 4 * g + reg < U) ? t0 : INFINITY;    // users past U never insert (cold calls: reset after the bootstrap)
+        thrf[reg] = (u_base + 4 * g + reg < U) ? t0 - Ereg[reg] : INFINITY;    // users past U never insert (cold calls: reset after the bootstrap)
     }
     // The running top-k of each of the wave's 16 users is a SORTED list held in registers: lane j of tk[r] is the j-th largest key
     // of user row r (k <= 64 = one key per lane; 0 = empty, below every real key).  An insert is one 64-bit compare + ballot for
@@ -2535,9 +2566,32 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
         const int cnt = __builtin_amdgcn_readfirstlane((int)*(volatile lds_u32 *)(qcnt + row));
         const int m = min(cnt, kQCap);
         unsigned long long cj = 0ull;
+        unsigned long long e = 0ull;
+        if (lane < m) e = qkey[row * kQCap + lane];
+        float sc_exact = 0.f;
+        if constexpr (REFINE) {
+            // three-product scores of the queued candidates: candidate j is column j of one 16 x 16 tile (fragments gathered from the staged
+            // image at its stream position), the wave's own user fragments are the rows; the row's scores sit in the lanes of k-group row / 4
+            static_assert(kQCap <= 16, "a queue's candidates are the columns of one tile");
+            const int pos_c = __shfl((int)(unsigned)(e >> 32), c);             // 0 for columns without a candidate: row 0 of the image, never read back
+            const unsigned char *src = Pi + (size_t)pos_c * SRCB + (size_t)(g * PPG) * 16;
+            f16x8 fb[2][KS];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) fb[pl][ks] = *reinterpret_cast<const f16x8 *>(src + pl * (D * 2) + ks * 16);
+            constexpr int TA[3] = {0, 1, 0}, TB[3] = {1, 0, 0};                 // the one-pass form's order: ah*bl, al*bh, ah*bh
+            f32x4 ca = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) ca = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[TA[term]][ks], fb[TB[term]][ks], ca, 0, 0, 0);
+            const int rr = row & 3;
+            const float pick = rr == 0 ? ca[0] : (rr == 1 ? ca[1] : (rr == 2 ? ca[2] : ca[3]));
+            sc_exact = __shfl(pick, c + 16 * (row >> 2));
+        }
         if (lane < m) {
-            const unsigned long long e = qkey[row * kQCap + lane];
-            float sc = __uint_as_float((unsigned)e);
+            float sc = REFINE ? sc_exact : __uint_as_float((unsigned)e);
             const int pos = (int)(unsigned)(e >> 32);
             const int item = item_order ? item_order[pos] : pos;
             if (mrp) {                                                 // interacted -> -10e8 (pre-filter survivors only)
@@ -2555,7 +2609,10 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
         if (lane == 0) qcnt[row] = 0u;
         if (ARL_TOPK_EXP == 4) { exp_sink += (float)(unsigned)cj; return; }       // experiment: appends + queue reads, no list merges (results are wrong)
         unsigned Kh = tk_hi[row], Kl = tk_lo[row];
-        for (int j = 0; j < m; ++j) {
+        // only candidates above the list's k-th key as it stands can enter (the queue's thresholds lag, and REFINE's are lowered by E)
+        const unsigned long long Kk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)Kh, k - 1) << 32) | (unsigned)__builtin_amdgcn_readlane((int)Kl, k - 1);
+        for (unsigned long long todo = __ballot(lane < m && cj > Kk); todo != 0ull; todo &= todo - 1ull) {
+            const int j = __ffsll((long long)todo) - 1;
             const unsigned ch = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cj >> 32), j);
             const unsigned cl = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cj, j);
             const unsigned long long key = ((unsigned long long)ch << 32) | cl, K = ((unsigned long long)Kh << 32) | Kl;
@@ -2575,7 +2632,7 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
         const bool mine = (g == (row >> 2));
         const int rj = row & 3;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) thrf[j] = (mine && rj == j) ? nt : thrf[j];
+        for (int j = 0; j < 4; ++j) thrf[j] = (mine && rj == j) ? nt - Ereg[j] : thrf[j];
     };
     auto flush_rows_with = [&](unsigned at_least) {                    // every row whose queue holds at least `at_least` candidates
         const unsigned cn = lane < 16 ? *(volatile lds_u32 *)(qcnt + lane) : 0u;
@@ -2704,9 +2761,9 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
             float gm = bl[reg][3];
 #pragma unroll
             for (int off = 1; off < 16; off <<= 1) gm = fminf(gm, __shfl_xor(gm, off, 16));
-            float t0 = (nrem >= 0 && u_base + 4 * g + reg < U) ? gm : -INFINITY;
+            float t0 = (nrem >= 0 && u_base + 4 * g + reg < U) ? gm - Ereg[reg] : -INFINITY;      // (REFINE: the sample's scores are high-piece scores, each within E of the true one)
             if constexpr (WARM) t0 = fmaxf(t0, __shfl(thr0v, 4 * g + reg));       // both are valid lower bounds: keep the better one
-            thrf[reg] = (u_base + 4 * g + reg < U) ? t0 : INFINITY;
+            thrf[reg] = (u_base + 4 * g + reg < U) ? t0 - Ereg[reg] : INFINITY;
             const float bc = __shfl(t0, 16 * (lane >> 2) + 0);     // lane r < 16 reads group r / 4 ...
             if (lane < 16 && (lane & 3) == reg) t0v = bc;          // ... when this is row r's register
         }
@@ -2722,7 +2779,25 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
             // fragments of GRP sub-tiles at a time (all of the stage, or two when the workgroup runs four waves per SIMD on 128 registers)
             constexpr int GRP = (topk_waves(D, SPLIT) >= 16 && NSUB > 2) ? 2 : ((D >= 128 && topk_waves(D, SPLIT) >= 12) ? 1 : NSUB);
             constexpr int TA[3] = {0, 1, 0}, TB[3] = {1, 0, 0};    // ah*bl, al*bh, ah*bh: smallest products first
-            if constexpr (ARL_TOPK_EXP == 5) {                     // probe: ring + staging only (no fragment reads, no MFMAs)
+            if constexpr (REFINE) {                                // high pieces only: the fragments of RG sub-tiles at a time, then their products
+                constexpr int RG = ARL_TOPK_RGRP < NSUB ? ARL_TOPK_RGRP : NSUB;
+#pragma unroll
+                for (int s0 = 0; s0 < NSUB; s0 += RG) {
+                    f16x8 pb[RG][KS];
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                        for (int sub = 0; sub < RG; ++sub)
+                            pb[sub][ks] = *reinterpret_cast<const f16x8 *>(buf + (g & 1) * HALF + ((s0 + sub) * 16 + c) * RH + ((g >> 1) * PPG + ks) * 16);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                        for (int sub = 0; sub < RG; ++sub)
+                            accs[s0 + sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0][ks], pb[sub][ks], accs[s0 + sub], 0, 0, 0);
+                    if constexpr (RG < NSUB) __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if constexpr (ARL_TOPK_EXP == 5) {              // probe: ring + staging only (no fragment reads, no MFMAs)
             } else if constexpr (ARL_TOPK_EXP == 6) {              // probe: MFMAs on whatever the registers hold (fragments read in the first stage only)
                 f16x8 pb[2][KS];
 #pragma unroll
@@ -2844,7 +2919,7 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
         }
         // the tile's fragments are in registers: the slot can be refilled while this wave does its bookkeeping
         asm volatile("" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add((lds_u32 *)done_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (done_slot != nullptr && lane == 0) __hip_atomic_fetch_add((lds_u32 *)done_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifdef ARL_TOPK_PROF
         { float sink = accs[0][0] + accs[NSUB - 1][3]; asm volatile("" ::"v"(sink)); ARL_PROF_TICK(1) }
 #endif
@@ -2904,7 +2979,7 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     static_assert(kTopkLead >= 2 && kTopkLead % 2 == 0 && kTopkLead < kTopkRing && (kTopkRing & (kTopkRing - 1)) == 0, "two register sets alternate: the lead is even");
     __syncthreads();                                               // counters zeroed (the only block barrier of the kernel)
     // one step of the pipeline: stage st + 2 goes from register set r to LDS, set r is refilled with stage st + 4, stage st is consumed
-    auto step = [&](auto boot_tag, int st, f32x4 (&r)[PER]) {
+    [[maybe_unused]] auto step = [&](auto boot_tag, int st, f32x4 (&r)[PER]) {
         const int t = st + kTopkLead;
 
 #if ARL_TOPK_POLL8
@@ -2945,6 +3020,43 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
         ARL_PROF_TICK(3)
         compute(boot_tag, slot(st), st, done_ctr + (st & (kTopkRing - 1)));
     };
+#if ARL_TOPK_PAIRS
+    // Stages are synchronised in PAIRS (slots {0,1} and {2,3} of the ring; one fill and one done counter per pair): half the counter polls, tile-write
+    // waits and signals per item of the per-stage form -- with REFINE a stage is eight MFMAs per wave and those round trips were most of the loop.
+    static_assert(kTopkLead == 2 && kTopkRing == 4, "pairs: two stages of lead in a ring of four");
+    auto pair_step = [&](auto boot_tag, int st) {                  // st even: stages st + 2, st + 3 go to LDS, st + 4, st + 5 are requested, st and st + 1 are consumed
+        const int t = st + 2;
+        if (t < nvirt) {
+            const int ps = (t >> 1) & 1;
+            wait_ge(done_ctr + ps, NWV * (unsigned)(t / 4));        // the pair that held these two slots has been read by every wave
+            ARL_PROF_TICK(4)
+            stash(slot(t), nb);
+            if (t + 1 < nvirt) stash(slot(t + 1), nc);
+            signal(fill_ctr + ps);
+            ARL_PROF_TICK(6)
+            if (t + 2 < nvirt) fetch(item_stage(t + 2), nb);
+            if (t + 3 < nvirt) fetch(item_stage(t + 3), nc);
+        }
+        ARL_PROF_TICK(0)
+        const int pc = (st >> 1) & 1;
+        wait_ge(fill_ctr + pc, NWV * (unsigned)(st / 4 + 1));
+        ARL_PROF_TICK(3)
+        const int last = min(st + 1, nvirt - 1);
+#pragma nounroll
+        for (int sx = st; sx <= last; ++sx)                        // (a loop, not two calls: one copy of the stage body in the instruction cache)
+            compute(boot_tag, slot(sx), sx, sx == last ? done_ctr + pc : (unsigned *)nullptr);
+    };
+    if (0 < nvirt) fetch(item_stage(0), nb);
+    if (1 < nvirt) fetch(item_stage(1), nc);
+    if (0 < nvirt) stash(slot(0), nb);
+    if (1 < nvirt) stash(slot(1), nc);
+    signal(fill_ctr + 0);
+    if (2 < nvirt) fetch(item_stage(2), nb);
+    if (3 < nvirt) fetch(item_stage(3), nc);
+    for (int st = 0; st < NB; st += 2) pair_step(std::true_type{}, st);      // NB is even
+    if (NB > 0) boot_finish();
+    for (int st = NB; st < nvirt; st += 2) pair_step(std::false_type{}, st);
+#else
     // prologue: the first kTopkLead stages go to their slots, the next two are in flight in the two register sets
     for (int s0 = 0; s0 < kTopkLead; s0 += 2) {
         if (s0 < nvirt) fetch(item_stage(s0), nb);
@@ -2963,6 +3075,7 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
         step(std::false_type{}, st, nb);
         if (st + 1 < nvirt) step(std::false_type{}, st + 1, nc);
     }
+#endif
 #if ARL_TOPK_QUEUE
     flush_rows_with(1u);                                           // whatever is still queued
     if (ARL_TOPK_EXP && exp_sink == 12345.678f) top_val[0] = exp_sink;
