@@ -2155,7 +2155,7 @@ typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
 constexpr int kBloomWords = 32;      // 1024 bits per user
 // Candidate queues (ARL_TOPK_QUEUE = 1): a pre-filter survivor is APPENDED to its user row's queue in LDS by the lane that found it (one LDS
 // atomic + one 8-byte store, all survivors of a 16-item x 16-user sub-tile in parallel) instead of being broadcast and inserted by the whole
-// wave on the spot; a row's queue is merged into its sorted register list when it holds kQFlush entries (checked once per stage) or is full,
+// wave on the spot; a row's queue is merged into its sorted register list when it holds kQFlush entries (looked at every ARL_TOPK_QCHK-th stage) or is full,
 // and at the end of the stream.  Thresholds move only at a merge -- a threshold that lags admits a few candidates more (they fall off at the
 // merge), it never loses one -- and the per-candidate broadcast / row-select / threshold-select work of the immediate insert is paid once per merge.
 #ifndef ARL_TOPK_QUEUE
@@ -2294,6 +2294,29 @@ __global__ __launch_bounds__(kBlock) void split_bf16x3_kernel(const float *__res
     o[0] = h; o[d] = m; o[2 * d] = l;
 }
 
+// largest scaled row norm |b * scale| of every stage of the item stream (positions [st * mst, st * mst + mst) of the staged image) and, behind
+// them, of the whole table (float bits, an atomic maximum: zeroed first): the per-stage factor of the high-piece stream's bound E
+__global__ __launch_bounds__(kWave) void stage_norm_kernel(const float *__restrict__ X, int I, int d, int mst, const unsigned *__restrict__ mbits,
+                                                            const int32_t *__restrict__ order, int nstages, float *__restrict__ out) {
+    const int st = blockIdx.x, lane = threadIdx.x;
+    const int p = st * mst + lane;
+    float n2 = 0.f;
+    if (lane < mst && p < I) {
+        const float *x = X + (size_t)(order ? order[p] : p) * d;
+        for (int t = 0; t < d; t += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + t);
+            n2 = fmaf(v.x, v.x, n2); n2 = fmaf(v.y, v.y, n2); n2 = fmaf(v.z, v.z, n2); n2 = fmaf(v.w, v.w, n2);
+        }
+    }
+    float nm = sqrtf(n2) * split_scale(*mbits);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nm = fmaxf(nm, __shfl_xor(nm, off));
+    if (lane == 0) {
+        out[st] = nm;
+        atomicMax(reinterpret_cast<unsigned *>(out + nstages), __float_as_uint(nm));
+    }
+}
+
 template <int D, bool SPLIT, bool WARM>
 __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfma16_kernel(const float *__restrict__ Pu, const void *__restrict__ Pi_image, int U, int I,
                                                                             const int32_t *__restrict__ mrp, const int32_t *__restrict__ mcol, int k,
@@ -2301,7 +2324,7 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
                                                                             const float *__restrict__ Pi_f32, const int32_t *__restrict__ warm_idx,
                                                                             int *__restrict__ underflow, const unsigned *__restrict__ table_max_bits,
                                                                             const int32_t *__restrict__ item_order, const int32_t *__restrict__ item_pos,
-                                                                            const int *__restrict__ gate) {
+                                                                            const int *__restrict__ gate, const float *__restrict__ stage_norm) {
     // gate (optional): the launch is the cold repeat of a warm-started call and runs only if that call raised its underflow flag -- decided here,
     // on the device, so that the host never waits for the flag (every thread of the grid takes the same branch)
     if (gate != nullptr && *gate == 0) return;
@@ -2346,7 +2369,8 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     constexpr int KS = SPLIT ? Q / 8 : 1;                          // 16-bit MFMAs (8 indices per lane each) per operand pair
     constexpr bool F16 = SPLIT && kSplitMode == 2;
     constexpr bool REFINE = F16 && ARL_TOPK_REFINE && ARL_TOPK_QUEUE;      // see the staging constants below
-    float Ereg[4] = {0.f, 0.f, 0.f, 0.f};                          // REFINE: the bound E of user rows 4g + reg (scaled domain)
+    float Ereg[4] = {0.f, 0.f, 0.f, 0.f};                          // REFINE: E of user rows 4g + reg for an item of scaled norm n is Ereg * n + Eabs
+    float Eabs = 0.f;
     bf16x8 af[3][KS];
     f16x8 ah[2][KS];
     // scaled domain of the fp16 form: scores = true scores * score_scale (a power of two); 1 otherwise
@@ -2364,11 +2388,13 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
         }
         if constexpr (REFINE) {
             n2 += __shfl_xor(n2, 16); n2 += __shfl_xor(n2, 32);   // |a'|^2 of user c (the four k-groups of a column hold a quarter each)
-            // max |b'| <= sqrt(D) * (largest element of the item table, scaled)
-            // (+ two absolute terms for pieces that are subnormal fp16 numbers -- elements 2^27 below their table's maximum: rounding error <= 2^-25
-            // instead of 2^-11 relative; they matter only for user rows that are zero to fp32 precision next to the rest of the table)
-            const float na = sqrtf(n2), bm = __uint_as_float(table_max_bits[0]) * si, sd = sqrtf((float)D);
-            const float Ec = ARL_TOPK_ESCALE * 0.0009765625f * na * sd * bm + 1.1920929e-7f * (float)D * bm + 5.9604645e-8f * sd * na;
+            // E(user c, item) = 1.05 * 2^-10 * |a'| * |b'|: the stream takes |b'| per STAGE (stage_norm, the largest scaled row norm of the stage's
+            // items -- decreasing along a norm-ordered stream), the bootstrap and the warm start the table's largest.
+            // (+ an absolute term for pieces that are subnormal fp16 numbers -- elements 2^27 below their table's maximum: rounding error <= 2^-25
+            // instead of 2^-11 relative; it matters only for rows that are zero to fp32 precision next to the rest of their table)
+            const float bm = __uint_as_float(table_max_bits[0]) * si, am = __uint_as_float(table_max_bits[1]) * su;
+            Eabs = 1.1920929e-7f * (float)D * (bm + am);
+            const float Ec = ARL_TOPK_ESCALE * 0.0009765625f * sqrtf(n2);
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) Ereg[reg] = __shfl(Ec, 4 * g + reg);
         }
@@ -2444,7 +2470,7 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const float t0 = WARM ? __shfl(thr0v, 4 * g + reg) : -INFINITY;
-        thrf[reg] = (u_base + 4 * g + reg < U) ? t0 - Ereg[reg] : INFINITY;    // users past U never insert (cold calls: reset after the bootstrap)
+        thrf[reg] = (u_base + 4 * g + reg < U) ? t0 : INFINITY;    // users past U never insert (cold calls: reset after the bootstrap)
     }
     // The running top-k of each of the wave's 16 users is a SORTED list held in registers: lane j of tk[r] is the j-th largest key
     // of user row r (k <= 64 = one key per lane; 0 = empty, below every real key).  An insert is one 64-bit compare + ballot for
@@ -2632,7 +2658,7 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
         const bool mine = (g == (row >> 2));
         const int rj = row & 3;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) thrf[j] = (mine && rj == j) ? nt - Ereg[j] : thrf[j];
+        for (int j = 0; j < 4; ++j) thrf[j] = (mine && rj == j) ? nt : thrf[j];
     };
     auto flush_rows_with = [&](unsigned at_least) {                    // every row whose queue holds at least `at_least` candidates
         const unsigned cn = lane < 16 ? *(volatile lds_u32 *)(qcnt + lane) : 0u;
@@ -2641,7 +2667,7 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     // Pre-filter + queue appends for the scores of one stage (accumulator ac[sub][reg] <-> item st*MST + 16*sub + c, user row 4g + reg).
     // Straight line: one compare per score; if any lane of the wave passes anywhere, every passing (sub, reg) appends its lanes' (score, item)
     // pairs -- an LDS atomic for the slot, one 8-byte store.  A queue that is full sends its lanes to the rare path at the end.
-    auto bookkeeping = [&](const f32x4 (&ac)[NSUB], int st) {
+    auto bookkeeping = [&](const f32x4 (&ac)[NSUB], int st, float sn) {      // sn: the stage's largest scaled item norm (REFINE)
         if (ARL_TOPK_EXP == 1 || ARL_TOPK_EXP >= 5) {                  // experiment: scores only, no pre-filter, no lists
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub) exp_sink += ac[sub][0] + ac[sub][3];
@@ -2655,6 +2681,9 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
             for (int sub = 0; sub < NSUB; ++sub)
                 if (st * MST + 16 * sub + c >= I) sv[sub] = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
         }
+        float tf[4];                                                   // the stage's pre-filter thresholds: exact thresholds lowered by the stage's E
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) tf[reg] = REFINE ? thrf[reg] - fmaf(Ereg[reg], sn, Eabs) : thrf[reg];
         bool pass[NSUB][4], psub[NSUB];
         bool some = false;
 #pragma unroll
@@ -2662,7 +2691,7 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
             psub[sub] = false;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                pass[sub][reg] = sv[sub][reg] >= thrf[reg];            // one compare per score (-inf always passes, +inf and NaN never)
+                pass[sub][reg] = sv[sub][reg] >= tf[reg];              // one compare per score (-inf always passes, +inf and NaN never)
                 psub[sub] = psub[sub] || pass[sub][reg];
             }
             some = some || psub[sub];
@@ -2761,9 +2790,9 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
             float gm = bl[reg][3];
 #pragma unroll
             for (int off = 1; off < 16; off <<= 1) gm = fminf(gm, __shfl_xor(gm, off, 16));
-            float t0 = (nrem >= 0 && u_base + 4 * g + reg < U) ? gm - Ereg[reg] : -INFINITY;      // (REFINE: the sample's scores are high-piece scores, each within E of the true one)
+            float t0 = (nrem >= 0 && u_base + 4 * g + reg < U) ? gm - (REFINE ? fmaf(Ereg[reg], stage_norm[nstages], Eabs) : 0.f) : -INFINITY;      // (REFINE: the sample's scores are high-piece scores, each within E of the true one)
             if constexpr (WARM) t0 = fmaxf(t0, __shfl(thr0v, 4 * g + reg));       // both are valid lower bounds: keep the better one
-            thrf[reg] = (u_base + 4 * g + reg < U) ? t0 - Ereg[reg] : INFINITY;
+            thrf[reg] = (u_base + 4 * g + reg < U) ? t0 : INFINITY;
             const float bc = __shfl(t0, 16 * (lane >> 2) + 0);     // lane r < 16 reads group r / 4 ...
             if (lane < 16 && (lane & 3) == reg) t0v = bc;          // ... when this is row r's register
         }
@@ -2772,6 +2801,8 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     ARL_PROF_DECL
     // Scores of one staged tile + their bookkeeping.
     auto compute = [&](auto boot_tag, const unsigned char *buf, int st, unsigned *done_slot) {
+        float sn = 0.f;
+        if constexpr (REFINE && !decltype(boot_tag)::value) sn = stage_norm[st - NB];      // wave-uniform (a scalar load, long done when the products are)
         f32x4 accs[NSUB];
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) accs[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -2924,7 +2955,7 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
         { float sink = accs[0][0] + accs[NSUB - 1][3]; asm volatile("" ::"v"(sink)); ARL_PROF_TICK(1) }
 #endif
         if constexpr (decltype(boot_tag)::value) boot_book(accs);  // bootstrap stage (its own loop below, so `bl` is dead in the stream's)
-        else bookkeeping(accs, st - NB);
+        else bookkeeping(accs, st - NB, sn);
         ARL_PROF_TICK(2)
     };
     // Staging: global -> registers (one stage of lead: the loads of stage t + 1 are issued right after stage t went to LDS) -> a RING
@@ -4041,6 +4072,7 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
         const unsigned *max_bits = nullptr;
         const int32_t *order_d = nullptr;
         int32_t *pos_d = nullptr;
+        float *snorm_d = nullptr;
         if (split) {
             const long long n = (long long)I * d;
             if (kSplitMode == 2) {
@@ -4060,6 +4092,13 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
                 hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, Pi, n, (int)d, mb,
                                    (_Float16 *)workspace, order_d);
                 max_bits = mb;
+                {   // per-stage and whole-table largest scaled row norms (the factor of the high-piece stream's bound), behind the inverse map's room
+                    const int nst = (int)((I + mst - 1) / mst);
+                    snorm_d = reinterpret_cast<float *>(static_cast<char *>(workspace) + 4 * (size_t)n + 16 + 4 * (size_t)I);
+                    if (hipMemsetAsync(snorm_d + nst, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return ARL_E_ARG;
+                    hipLaunchKernelGGL(stage_norm_kernel, dim3((unsigned)nst), dim3(kWave), 0, (hipStream_t)stream, Pi, (int)I, (int)d, mst, mb, order_d, nst, snorm_d);
+                    ARL_LAUNCH_CHECK();
+                }
             } else {
                 hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, Pi, n, (int)d,
                                    (__bf16 *)workspace);
@@ -4072,7 +4111,7 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
             hipError_t em = hipFuncSetAttribute((const void *)score_mask_topk_mfma16_kernel<DV, SP, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m); \
             if (em != hipSuccess) return (int)em;                                                                                      \
             hipLaunchKernelGGL((score_mask_topk_mfma16_kernel<DV, SP, WM>), dim3(grid_m), dim3(64 * topk_waves(DV, SP)), shm_m, (hipStream_t)stream, Pu, image, (int)U, (int)I, \
-                               mask_rowptr, mask_col, (int)k, top_idx, top_val, Pi, WARMP, underflow, max_bits, order_d, pos_d, GATE);  \
+                               mask_rowptr, mask_col, (int)k, top_idx, top_val, Pi, WARMP, underflow, max_bits, order_d, pos_d, GATE, (const float *)snorm_d);  \
         } while (0)
         /* a warm-started call is followed by its own cold repeat, gated on the underflow flag on the device: valid results without a host round trip */
 #define ARL_TOPK_CASE(DV, SP)                                                                                                          \

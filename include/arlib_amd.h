@@ -399,7 +399,9 @@ int arl_pga_update_f32(float *S, const float *grad, const float *dinv_rows, cons
  * the 16-bit matrix path with every fp32 operand (scaled by a power of two chosen per table on the device) split in
  * two fp16 pieces, three partial products accumulated in fp32 -- scores within ~1e-6 relative of the exact ones
  * (the size of fp32 summation-order differences), 3x faster; the workspace receives the split image of Pi and the
- * two tables' largest magnitudes.  Other d ignore the workspace.
+ * two tables' largest magnitudes.  Other d ignore the workspace.  (How the three products are scheduled is internal: the
+ * stream contracts the high pieces only, filters against threshold - E with E a rigorous bound on the two other products,
+ * and every candidate that reaches a list is scored with all three -- the scores returned are those of the three-product form.)
  * warm_idx (optional, matrix-core path only): [U, k] DISTINCT candidate items per user, e.g. the previous call's top_idx when
  * the tables moved little; it only pre-sets each user's threshold (same result, ~6x fewer list inserts).  If a candidate has
  * become masked the threshold may exclude too much: *underflow (int32, zeroed by the caller) is then set non-zero and the
