@@ -624,6 +624,52 @@ def test_score_mask_topk_bootstrap_threshold(ops, d, k):
         assert rel_err(ex_v.cpu().numpy(), rval.astype(np.float32)) < 1e-5 and (ex_i.cpu().numpy() == ridx).mean() > 0.999
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('d,k,masked', [(64, 50, False), (64, 50, True), (128, 50, False)])
+def test_score_mask_topk_high_piece_bound_worst_case(ops, d, k, masked):
+    """The fp16 matrix path streams scores of the HIGH pieces only and filters against threshold - E (E = 1.05 * 2^-10 |a| |b|), then scores
+    every queued candidate with all three products (arl_kernels.hip, REFINE).  Worst case for that bound: every element sits just under the
+    midpoint between two fp16 values (its high piece rounds down by almost half an ulp) and all signs agree, so the high-piece score of every
+    pair is LOW by almost 2^-10 of the score, coherently -- an item that beats a user's k-th best by less than that has a high-piece score
+    below the threshold.  A bound that is too small drops such items; the lists must still be those of the float64 scores."""
+    rng = np.random.default_rng(77 * d + k + masked)
+    U, I = 300, 40000
+
+    def worst(shape, lo_exp):
+        j = rng.integers(0, 1024, size=shape).astype(np.float64)
+        e = rng.integers(lo_exp, 1, size=shape).astype(np.float64)
+        return ((1.0 + (j + 0.4995) / 1024.0) * 2.0 ** e).astype(np.float32)       # mantissa just below a rounding midpoint of the 11-bit grid
+
+    Pu, Pi = worst((U, d), -2), worst((I, d), -3)
+    Pi *= (2.0 ** rng.integers(-2, 1, size=(I, 1))).astype(np.float32)             # a spread of norms (powers of two keep the mantissas)
+    scores = Pu.astype(np.float64) @ Pi.astype(np.float64).T
+    rp = mc = None
+    if masked:
+        cols = [np.unique(np.concatenate([np.argsort(-scores[u])[:int(rng.integers(0, 30))], rng.choice(I, size=20, replace=False)])).astype(np.int32) for u in range(U)]
+        for u in range(U):
+            scores[u, cols[u]] = -10e8
+        rp = T(np.concatenate([[0], np.cumsum([len(c) for c in cols])]).astype(np.int32))
+        mc = T(np.concatenate(cols))
+    ridx = np.argsort(-scores, axis=1, kind='stable')[:, :k]
+    rval = np.take_along_axis(scores, ridx, 1)
+    first = None
+    for order in ('norm', None):
+        idx, val = ops.score_mask_topk(T(Pu), T(Pi), k, rp, mc, item_order=order)
+        if first is None:
+            first = (idx, val)
+        else:
+            assert torch.equal(idx, first[0]) and torch.equal(val, first[1])
+        idx, val = idx.cpu().numpy(), val.cpu().numpy()
+        assert rel_err(val, rval.astype(np.float32)) < 1e-5
+        same = idx == ridx
+        assert same.mean() > 0.995, same.mean()                                     # (dense scores: many last-ulp near-ties)
+        for r, c in np.argwhere(~same):
+            assert abs(rval[r, c] - val[r, c]) <= 2e-6 * abs(rval[r, c])            # a mismatch is a near-tie, never a dropped item
+        assert np.abs(val[:, -1] - rval[:, -1]).max() <= 2e-6 * np.abs(rval[:, -1]).max()      # every user's k-th best score: nothing above it was lost
+    wi, wv = ops.score_mask_topk(T(Pu), T(Pi), k, rp, mc, warm_idx=first[0])
+    assert torch.equal(wi, first[0]) and torch.equal(wv, first[1])
+
+
 @pytest.mark.parametrize('d,k,masked', [(64, 50, False), (64, 50, True), (128, 20, True), (64, 64, True)])
 def test_score_mask_topk_item_stream_order_is_result_neutral(ops, d, k, masked):
     """item_order only changes the ORDER in which the items are scored (default on long streams: descending row norm, so thresholds rise
