@@ -50,7 +50,8 @@ class _CwSfaLoss(torch.autograd.Function):
         w = torch.zeros(Up + I, dtype=torch.float32, device=X.device)
         w[:n_real] = float(T)
         w[Up:] = neg_cnt.to(torch.float32)
-        w.index_add_(0, torch.as_tensor(targets, device=X.device, dtype=torch.int64) + Up, torch.full((T,), float(n_real), device=X.device))
+        tg = targets.to(X.device, torch.int64) if isinstance(targets, torch.Tensor) else torch.as_tensor(targets, device=X.device, dtype=torch.int64)
+        w.index_add_(0, tg + Up, torch.full((T,), float(n_real), device=X.device))
         sfa, G_sfa = ops.sfa_l1(X, w, r0.to(X.device, torch.float32).contiguous(), 3 * n_real * T * d)
         ctx.save_for_backward(G_cw, G_sfa)
         ctx.Up = Up
@@ -68,6 +69,37 @@ class CLeaR(AttackBase):
         super().__init__(arg, data)
         self.batchSize = 2048
 
+    # The surrogate step must not make the host wait for the device: a blocking copy in the middle of a step drains the stream, exposes the host's
+    # wake-up latency (tens of ms on some boxes) and stops the host from queueing ahead.  Small host data therefore travels through pinned
+    # staging slots with asynchronous copies, and the target ids live on the device.
+    _RING = 8
+
+    def _targets_on(self, device):
+        t = getattr(self, '_tg_dev', None)
+        if t is None or t.device != device or t.numel() != len(self.targetItem):
+            t = self._tg_dev = torch.as_tensor(self.targetItem, device=device, dtype=torch.int64)
+        return t
+
+    def _upload(self, host, device):
+        """Device copy of a small CPU tensor without a stream synchronisation (pinned slot + asynchronous copy; a slot is reused after
+        _RING uploads, once the copy that read it has completed)."""
+        if device.type != 'cuda':
+            return host.to(device)
+        ring = getattr(self, '_up_ring', None)
+        if ring is None or ring['pin'].shape[1] != host.numel() or ring['pin'].dtype != host.dtype or ring['dev'].device != device:
+            ring = self._up_ring = {'pin': torch.empty(self._RING, host.numel(), dtype=host.dtype).pin_memory(),
+                                    'dev': torch.empty(self._RING, host.numel(), dtype=host.dtype, device=device), 'ev': [None] * self._RING, 'n': 0}
+        i = ring['n'] % self._RING
+        ring['n'] += 1
+        if ring['ev'][i] is not None:
+            ring['ev'][i].synchronize()
+        ring['pin'][i].copy_(host.reshape(-1))
+        ring['dev'][i].copy_(ring['pin'][i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        ring['ev'][i] = ev
+        return ring['dev'][i].view(host.shape)
+
     def surrogate_loss(self, model, uiAdj2, topk, r0=None, warm=None):
         """One evaluation of lossall = CWloss + sfaloss (CLeaR.py:74-126); returns (lossall, Pu, Pi, cw, sfa).
         `uiAdj2`: the poisoned U' x I interactions (scipy) or their device_mask()."""
@@ -76,8 +108,8 @@ class CLeaR(AttackBase):
             top_idx, _ = masked_topk(Pu.detach(), Pi.detach(), uiAdj2, min(topk, self.itemNum), warm=warm)
             self.last_top_idx = top_idx                                    # next step's warm start (same users, same mask)
         if r0 is None:
-            r0 = torch.randn(Pu.size(1))                                   # CLeaR.py:100-103: CPU generator, then moved
-        cw, sfa = _CwSfaLoss.apply(Pu, Pi, top_idx, self.userNum, self.targetItem, r0)
+            r0 = self._upload(torch.randn(Pu.size(1)), Pu.device)          # CLeaR.py:100-103: CPU generator, then moved
+        cw, sfa = _CwSfaLoss.apply(Pu, Pi, top_idx, self.userNum, self._targets_on(Pu.device), r0)
         return cw + sfa, Pu, Pi, cw, sfa
 
     def posionDataAttack(self, recommender):

@@ -182,7 +182,8 @@ def cw_operator_from_topk(n_nodes, Up, n_real, targets, neg, device):
     I = n_nodes - Up
     c = 1.0 / (n_real * T)
     dev = neg.device
-    tg = torch.as_tensor(targets, device=dev, dtype=torch.int64)
+    # (a device tensor is taken as it is: building one from a Python list is a pageable host-to-device copy, i.e. a stream synchronisation per call)
+    tg = targets.to(dev, torch.int64) if isinstance(targets, torch.Tensor) else torch.as_tensor(targets, device=dev, dtype=torch.int64)
     ar_u = torch.arange(n_real, device=dev, dtype=torch.int64)
     flat = neg.reshape(-1).to(torch.int32)                   # 32-bit keys: half the radix passes of an int64 sort
     sorted_items, order = torch.sort(flat, stable=True)

@@ -216,9 +216,12 @@ def attack_leg(torch, ops, data, E0_dev, args):
     out /= (L + 1)
     Pu_all, Pi_all = out[:U + F].contiguous(), out[U + F:].contiguous()
     ops.score_mask_topk(Pu_all[:256].contiguous(), Pi_all, 50)      # first call of the process: code-object load of the kernel and of torch's sort (not timed)
-    torch.cuda.synchronize(); t1 = time.perf_counter()
-    top_idx, _ = ops.score_mask_topk(Pu_all, Pi_all, 50)
-    torch.cuda.synchronize(); topk_s = time.perf_counter() - t1
+    topk_all = []
+    for _ in range(3):                               # three passes (the GPU has idled through the host-side set-up above: the first one also pays the clock ramp)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        top_idx, _ = ops.score_mask_topk(Pu_all, Pi_all, 50)
+        torch.cuda.synchronize(); topk_all.append(time.perf_counter() - t1)
+    topk_s = sorted(topk_all)[1]                     # the median is the figure
     del Pu_all, Pi_all
     M = cw_operator(U + F + I, U + F, *cw_pairs(top_idx, U, targets, pop=True), device=E0.device)
 
@@ -256,7 +259,7 @@ def attack_leg(torch, ops, data, E0_dev, args):
             'value': 1.0 / dt, 'unit': 'steps/s', 'ms_per_step': 1e3 * dt, 'fake_users': F, 'targets': 5, 'cw_loss': float(loss),
             'algorithmic_bytes_per_step': step_bytes, 'hbm_frac': step_bytes / dt / 1e9 / HBM_PEAK_GBS,
             'cpu_baseline': cpu,
-            'score_topk_pass': {'seconds': topk_s, 'tflops': 2.0 * (U + F) * I * d / topk_s / 1e12,
+            'score_topk_pass': {'seconds': topk_s, 'seconds_all': topk_all, 'tflops': 2.0 * (U + F) * I * d / topk_s / 1e12,
                                 'roofline': {'bound': 'mfma', 'achieved': 2.0 * (U + F) * I * d / topk_s / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s',
                                              'frac': 2.0 * (U + F) * I * d / topk_s / 1e12 / 2500.0,
                                              'note': 'fp16 matrix flops executed by the stream: ONE fp16 product per (user, item, k) -- the high pieces; the two other products of '
