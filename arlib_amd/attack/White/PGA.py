@@ -209,6 +209,10 @@ def cw_operator_from_topk(n_nodes, Up, n_real, targets, neg, device):
     tpos = ((item_start[tg] + neg_cnt[tg])[:, None] + ar_u[None, :]).reshape(-1)
     col[tpos] = ar_u.to(torch.int32).repeat(T)
     val[tpos] = -c
+    if n_real > ops.DEFAULT_CHUNK and rowptr.is_cuda:
+        # every target's row holds its n_real dense entries: at least one long row, so the plan can be built on the device -- no host read,
+        # the step that rebuilds this operator (CLeaR) never waits for the stream
+        return ops.CSRGraph.from_device(rowptr, col, val, nnz, long_entries=n_user_entries if 2 * T <= ops.DEFAULT_CHUNK else None), neg_cnt      # user rows hold 2T entries: only item rows can be long
     return ops.CSRGraph(rowptr, col, val, device, validate=False), neg_cnt
 
 

@@ -99,6 +99,52 @@ class CSRGraph:
         self.dinv = None
         self.blocked = None
 
+    @classmethod
+    def from_device(cls, rowptr, col, val, nnz, chunk=DEFAULT_CHUNK, n_cols=None, long_entries=None):
+        """CSR graph from DEVICE arrays without any host read (the constructor copies rowptr to the host for its long-row plan: a stream
+        synchronisation plus milliseconds of host work -- too much for an operator rebuilt inside an attack step, attack/White/CLeaR.py).
+        The long-row plan is built on the device with static shapes: room for nnz / chunk long rows and 2 nnz / chunk chunks, the unused
+        tail filled with copies of the LAST real long row (same partial range: it is recomputed with the same value) and with empty chunks.
+        The caller guarantees at least one row longer than `chunk`, trusts rowptr / col (no validation), passes nnz = rowptr[-1] as a
+        Python int, and uses the graph only for SpMMs whose output does not alias an input (the duplicated long rows are written twice)."""
+        dev = rowptr.device
+        n = rowptr.numel() - 1
+        g = object.__new__(cls)
+        g.device, g.n_rows, g.nnz, g.chunk = dev, n, int(nnz), int(chunk)
+        g.n_cols = n if n_cols is None else int(n_cols)
+        rp = rowptr.to(torch.int64)
+        g.rowptr = rowptr.to(torch.int32).contiguous()
+        g.col, g.val = col.to(torch.int32).contiguous(), val.to(torch.float32).contiguous()
+        deg = rp[1:] - rp[:-1]
+        is_long = deg > g.chunk
+        # a long row holds more than `chunk` entries; `long_entries` (optional) = an upper bound on the entries that can sit in long rows
+        NL = max(1, (g.nnz if long_entries is None else int(long_entries)) // g.chunk)
+        NC = 2 * NL                                            # ceil(deg / chunk) <= deg / chunk + 1 per long row
+        n_long = is_long.sum()
+        order = torch.argsort((~is_long).to(torch.int8), stable=True)[:NL]      # the long rows in ascending order, then filler
+        slot = torch.minimum(torch.arange(NL, device=dev), n_long - 1).clamp_(min=0)
+        rows = order[slot]                                     # entries past n_long repeat the last real long row
+        nch = (deg[rows] + g.chunk - 1) // g.chunk
+        real = torch.arange(NL, device=dev) < n_long
+        cum = torch.cumsum(torch.where(real, nch, torch.zeros_like(nch)), 0)     # chunks before and including long row l
+        first = cum - nch
+        first = torch.where(real, first, first[slot])          # the copies share the original's partial range
+        c = torch.arange(NC, device=dev)
+        l = torch.searchsorted(cum, c, right=True).clamp_(max=NL - 1)
+        l = torch.minimum(l, (n_long - 1).clamp(min=0))
+        crow = rows[l]
+        k = c - first[l]
+        cbeg = torch.minimum(rp[crow] + k * g.chunk, rp[crow + 1])              # chunks past the real ones come out empty (begin = end = row end)
+        cend = torch.minimum(cbeg + g.chunk, rp[crow + 1])
+        i32 = lambda a: a.to(torch.int32).contiguous()
+        g.chunk_row, g.chunk_begin, g.chunk_end = i32(crow), i32(cbeg), i32(cend)
+        g.long_row, g.long_first, g.long_count = i32(rows), i32(first), i32(nch)
+        g.n_chunks, g.n_long = NC, NL
+        g._partial = None
+        g.dinv = None
+        g.blocked = None
+        return g
+
     def enable_blocked(self, split=None, rows_per_wave=32, hub=None, col_block=1024, min_waves=0, unroll=None, split_hubs=True, piece=None, wpg=None, wave_multiple=None, col_order=None):
         """Attach a register-blocked plan (BlockedPlan): full-table SpMMs at d = 64 then run through arl_spmm_blocked_*.
         `split` = number of users of a bipartite adjacency: user rows and item rows get separate launches (they gather from

@@ -48,3 +48,13 @@ def weights():
 
 w = timed('row weights', weights)
 timed('sfa_l1', lambda: ops.sfa_l1(X, w, r0, 3 * U * T * d))
+
+# the step's own pieces as attack/White/CLeaR.py runs them (structured operator, packed table)
+from arlib_amd.attack.White.PGA import cw_operator_from_topk
+tg = torch.as_tensor(targets, device=dev, dtype=torch.int64)
+ranks = top_idx.shape[1] - 1 - torch.arange(T, device=dev)
+negs = timed('neg = top_idx[:, ranks]', lambda: top_idx[:U][:, ranks].long())
+Mn = timed('cw_operator_from_topk', lambda: cw_operator_from_topk(U + I, U, U, tg, negs, dev))
+timed('spmm(M, X) structured', lambda: ops.spmm(Mn[0], X))
+timed('row norms + argsort (item_order)', lambda: torch.argsort(torch.linalg.vector_norm(X[U:], dim=1), descending=True))
+timed('warm-started masked pass', lambda: ops.score_mask_topk(X[:U].contiguous(), X[U:].contiguous(), k, *mask, warm_idx=top_idx))
