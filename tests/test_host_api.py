@@ -458,3 +458,27 @@ def test_syn_v1_native_generator_equals_numpy_generator():
         assert np.array_equal(a, b)
         assert S.graph_digest(a) == S.graph_digest_native(b) == S.graph_digest_native(a)
     assert S.graph_digest_native(a[::-1].copy()) != S.graph_digest_native(a)           # order-sensitive
+
+
+def test_csrgraph_device_side_long_row_plan_equals_host_plan():
+    """CSRGraph.from_device builds the long-row plan with static shapes and no host read (the CW operator CLeaR rebuilds every step):
+    its real part must equal the host constructor's plan; the padding repeats the last real long row and holds only empty chunks."""
+    import torch
+    from arlib_amd import ops
+    rng = np.random.default_rng(5)
+    for n, chunk, longs in ((2000, 16, {5: 40, 77: 16, 1999: 100, 1000: 17}), (300, 8, {0: 9}), (50, 4, {49: 50, 48: 5, 3: 33})):
+        deg = rng.integers(0, chunk, n)
+        for r, v in longs.items():
+            deg[r] = v
+        rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        nnz = int(rp[-1])
+        col, val = torch.zeros(nnz, dtype=torch.int32), torch.ones(nnz)
+        g = ops.CSRGraph.from_device(torch.from_numpy(rp), col, val, nnz, chunk=chunk)
+        h = ops.CSRGraph(rp, col.numpy(), val.numpy(), 'cpu', chunk=chunk, validate=False)
+        nl, nc = h.n_long, h.n_chunks
+        assert nl >= 1 and g.n_long >= nl and g.n_chunks >= nc
+        for a, b in ((g.long_row, h.long_row), (g.long_first, h.long_first), (g.long_count, h.long_count)):
+            assert torch.equal(a[:nl], b) and bool((a[nl:] == b[-1]).all())
+        assert torch.equal(g.chunk_begin[:nc], h.chunk_begin) and torch.equal(g.chunk_end[:nc], h.chunk_end)
+        assert bool((g.chunk_begin[nc:] == g.chunk_end[nc:]).all())
+        assert torch.equal(g.rowptr, h.rowptr)
