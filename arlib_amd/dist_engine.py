@@ -532,17 +532,23 @@ class ShardedPropagationEngine:
             if two and ev_u is not None:
                 main.wait_event(ev_u)                          # src's user rows come from the side stream
             k.spmm(self.Ai, src, out=dst[Ul:])                 # partial item rows (gathers user rows of src)
+            if not two:
+                # one compute stream: a collective's stream waits, at enqueue time, for everything the caller's stream holds -- so the exchange
+                # of hop h is enqueued right after A_i(h), BEFORE A_u(h) is, and runs behind A_u(h) and A_i(h+1)
+                if pending is not None:
+                    pending.wait()                             # src's item rows are complete from here on
+                pending = self.comm.all_reduce_async(dst[Ul:])
+                k.spmm(self.Au, src, out=dst[:Ul])             # exact user rows (gathers item rows of src)
+                layers.append(dst)
+                continue
             with on_side():
                 if pending is not None:
-                    if two:
-                        side.wait_event(ev_ar)
-                    pending.wait()                             # src's item rows are complete from here on
-                k.spmm(self.Au, src, out=dst[:Ul])             # exact user rows (gathers item rows of src)
-                if two:
-                    ev_u = side.record_event()
-            pending = self.comm.all_reduce_async(dst[Ul:])
-            if two:
-                ev_ar = main.record_event()
+                    side.wait_event(ev_ar)
+                    pending.wait()
+                k.spmm(self.Au, src, out=dst[:Ul])
+                ev_u = side.record_event()
+            pending = self.comm.all_reduce_async(dst[Ul:])     # (main stream: after A_i(h) only -- A_u(h) is on the side stream)
+            ev_ar = main.record_event()
             layers.append(dst)
         if two and ev_u is not None:
             main.wait_event(ev_u)                              # the row-subset hops below read the last layer's user rows
@@ -588,23 +594,33 @@ class ShardedPropagationEngine:
             if two and ev_u is not None:
                 main.wait_event(ev_u)                                              # acc's user rows come from the side stream
             k.spmm_flagged(self.Ai, acc, xf, a, 0.0, None, None, out=dst[Ul:])     # partial item rows (gathers acc's user rows)
-            with on_side():
-                if pending is not None:                                            # complete acc's item rows before A_u reads them
-                    if two:
-                        side.wait_event(ev_ar)
+            if not two:
+                # same order as in the forward: complete acc's item rows, enqueue THIS hop's exchange, then launch A_u -- the exchange of the
+                # last hop runs behind the user block's fused Adam hop
+                if pending is not None:
                     pending.wait()
                     k.rows_axpy_unique_(prev_items, self.G, item_rows_packed, prev_a, check_range=False, dup_bits=self.dup_bits)
-                elif two:
+                pending, prev_items, prev_a = self.comm.all_reduce_async(dst[Ul:]), dst, a
+                if last:
+                    k.spmm_adam(self.Au, acc, a, a, self.G[:Ul], self.E0[:Ul], self.m[:Ul], self.v[:Ul], self.lr, self.t, self.betas, self.eps, zflags=zu)
+                else:
+                    k.spmm_flagged(self.Au, acc, xf, a, a, self.G[:Ul], zu, out=dst[:Ul])
+                acc = dst
+                continue
+            with on_side():
+                if pending is not None:                                            # complete acc's item rows before A_u reads them
+                    side.wait_event(ev_ar)
+                    pending.wait()
+                    k.rows_axpy_unique_(prev_items, self.G, item_rows_packed, prev_a, check_range=False, dup_bits=self.dup_bits)
+                else:
                     side.wait_event(ev_g)
                 if last:
                     k.spmm_adam(self.Au, acc, a, a, self.G[:Ul], self.E0[:Ul], self.m[:Ul], self.v[:Ul], self.lr, self.t, self.betas, self.eps, zflags=zu)
                 else:
                     k.spmm_flagged(self.Au, acc, xf, a, a, self.G[:Ul], zu, out=dst[:Ul])
-                if two:
-                    ev_u = side.record_event()
+                ev_u = side.record_event()
             pending, prev_items, prev_a = self.comm.all_reduce_async(dst[Ul:]), dst, a
-            if two:
-                ev_ar = main.record_event()
+            ev_ar = main.record_event()
             acc = dst
         pending.wait()
         k.rows_axpy_unique_(prev_items, self.G, item_rows_packed, prev_a, check_range=False, dup_bits=self.dup_bits)

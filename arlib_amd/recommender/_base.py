@@ -408,6 +408,10 @@ class Recommender:
                 fused_kind = None
         self.optimizer = optimizer
         adj = None
+        if requires_adjgrad and requires_embgrad and not hasattr(self, 'Matgrad'):
+            # recommender/LightGCN.py:36-44: `if requires_embgrad: ... elif requires_adjgrad:` allocates Matgrad only when requires_embgrad is off, and
+            # the loop's `self.Matgrad += ...` (:58-59) then fails: same error, raised before any work is spent
+            raise AttributeError("'%s' object has no attribute 'Matgrad'" % type(self).__name__)
         if requires_adjgrad:
             # recommender/LightGCN.py:41-43: sparse_norm_adj.requires_grad = True, Matgrad = zeros(N, N).  The gradient of a sparse operand lives on its
             # stored entries, so Matgrad is kept as one value per entry of the pattern (CSR order) instead of N x N.
@@ -427,7 +431,7 @@ class Recommender:
         # nothing -- it only consumes the sampler's random stream and runs the per-epoch evaluation.  Same here,
         # without spending the forward/backward.
         mine = self._params()
-        inert = not requires_embgrad and not any(p is q for g in optimizer.param_groups for p in g['params'] for q in mine)
+        inert = not requires_embgrad and not requires_adjgrad and not any(p is q for g in optimizer.param_groups for p in g['params'] for q in mine)
         eng = None
         if fused_kind:
             eng = model._engine(self.args.reg, self.args.lRate, fused_kind)

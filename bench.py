@@ -409,6 +409,48 @@ def class_api_leg(torch, data, args, engine_ms):
             'train_call_wall_seconds': epoch_wall, 'note': 'train() wall also holds the epoch shuffle + all negatives of the epoch (host, one native call) and the epoch-end full forward'}
 
 
+def self_launch(n, result_out):
+    """Run `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <same argv>` as a child and return its exit code.  The rendezvous
+    is 127.0.0.1 on a free port.  stdout of the children is the saved descriptor (one JSON line from rank 0)."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    result_out.flush()
+    p = subprocess.Popen(cmd, stdout=result_out.fileno(), env=env)
+    try:
+        return p.wait()
+    except KeyboardInterrupt:
+        p.terminate()
+        return p.wait()
+
+
+def comm_evidence(torch, dist, backend, world, rank, dev, eng):
+    """What a reader needs to answer "did RCCL see N ranks": backend as torch.distributed reports it, the RCCL version torch runs on, and per rank the
+    process id, device index, device name / uuid / PCI bus id (all-gathered through the group itself)."""
+    try:
+        ver = '.'.join(str(x) for x in torch.cuda.nccl.version())
+    except Exception as e:                                   # gloo-only builds
+        ver = 'unavailable (%s)' % type(e).__name__
+    pr = torch.cuda.get_device_properties(dev)
+    mine = {'rank': rank, 'pid': os.getpid(), 'device_index': dev.index, 'visible_devices': torch.cuda.device_count(), 'name': pr.name,
+            'uuid': str(getattr(pr, 'uuid', None)), 'pci_bus_id': getattr(pr, 'pci_bus_id', None), 'arch': getattr(pr, 'gcnArchName', None)}
+    allr = [None] * world
+    dist.all_gather_object(allr, mine)
+    # one element per rank summed through the SAME collective the item exchange uses: world*(world+1)/2 only if every rank took part
+    probe = torch.full((1,), float(rank + 1), device=dev)
+    dist.all_reduce(probe)
+    return {'backend': dist.get_backend(), 'is_rccl': dist.get_backend() == 'nccl', 'world_size': dist.get_world_size(), 'rccl_version': ver,
+            'item_exchange': getattr(eng.comm, 'item_exchange', None), 'ranks': allr,
+            'distinct_devices': len({(r['uuid'], r['pci_bus_id'], r['device_index']) for r in allr}),
+            'allreduce_probe': {'sum_of_rank_plus_1': float(probe[0]), 'expected': world * (world + 1) / 2.0}}
+
+
 def main():
     args = parse()
     # stdout carries exactly one line, the JSON: whatever libraries print there (RCCL's version banner at communicator start-up, the classes'
@@ -416,13 +458,16 @@ def main():
     sys.stdout.flush()
     result_out = os.fdopen(os.dup(1), 'w')
     os.dup2(2, 1)
-    import torch
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU, BEFORE this process imports torch or touches the GPU
+        # (children, never an exec of a GPU-initialised process); the parent only forwards the exit code.  Rank 0 of the children writes the
+        # JSON line to the descriptor they inherit.
+        sys.exit(self_launch(args.gpus, result_out))
+    import torch
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
         raise SystemExit('WORLD_SIZE %d != --gpus %d' % (world, args.gpus))
     # test hook (1-GPU boxes): ARL_BENCH_BACKEND=gloo + ARL_BENCH_SINGLE_DEVICE=1 runs the N>1 code path with every rank on cuda:0
     backend = os.environ.get('ARL_BENCH_BACKEND', 'nccl')
@@ -490,7 +535,7 @@ def main():
                (lambda k: eng.step_sparse(dev_batches[k, 0], dev_batches[k, 1], dev_batches[k, 2]))
         import torch.distributed as dist
         barrier = dist.barrier
-        parallelism = 'user-sharded x%d, item partial sums all-reduced (RCCL) per hop' % world
+        parallelism = 'user-sharded x%d, item partial sums all-reduced (%s) per hop' % (world, 'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend())
     setup_s = time.perf_counter() - t_setup
 
     ev = SpmmEvents(torch)
@@ -511,7 +556,7 @@ def main():
     ev.on = False
     ops.EVENT_HOOK = None
     loss = float(lo[0] + lo[1])
-    comm_diag = None
+    comm_diag = comm_info = None
     if sharded:
         # diagnostic region (not part of any reported time): the same steps with an event pair around every wait on a collective -- per rank,
         # how long the compute stream stood still for communication in one step
@@ -531,6 +576,7 @@ def main():
         allr = [None] * world
         dist.all_gather_object(allr, mine)
         comm_diag = allr
+        comm_info = comm_evidence(torch, dist, backend, world, rank, dev, eng)
     # further timed regions of the same K steps (same batches again: the step's cost does not depend on the table values), each bracketed
     # like the first; `value` stays the first region (the contract), the list shows how repeatable it is
     region_s = [dt]
@@ -612,6 +658,8 @@ def main():
                                    'gather_model_bytes_per_launch': E * (8 + 4 * d) + 4 * N * d}
             else:
                 res['spmm_events_ms'] = {k: v[0] for k, v in evs.items()}
+        if comm_info is not None:
+            res['comm'] = comm_info
         if comm_diag is not None:
             res['communication'] = {'per_rank': comm_diag, 'note': 'separate diagnostic region: event pairs around every wait on an all-reduce; exposed = time the '
                                     'compute stream was blocked by the collective (0 = fully hidden behind the SpMM kernels)'}

@@ -39,3 +39,31 @@ def test_bench_json_contract_small_instance():
     assert r['cpu_baseline_torch']['value'] > 0 and r['cpu_baseline_torch']['steps_timed'] >= 1      # reference-shaped stock-PyTorch step, on by default
     assert 'traffic_source' in roof
     assert r['class_api']['steps'] == 5 and r['class_api']['fused_engine'] and r['class_api']['ms_per_step'] > 0
+
+
+def test_bench_gpus2_plain_invocation_self_launches():
+    """`python bench.py --gpus 2` started the way the driver starts `--gpus 1` (no launcher, no WORLD_SIZE): bench.py starts its two ranks itself
+    (child processes, before the parent touches the GPU) and prints the one JSON line with n_gpus 2 and the communication evidence.  On a 1-GPU
+    box both ranks share cuda:0 over gloo (the documented test hooks); on a multi-GPU node the same invocation runs RCCL, one rank per GPU."""
+    if not torch.cuda.is_available():
+        pytest.fail('GPU tests need a GPU')
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    single = torch.cuda.device_count() < 2
+    if single:
+        env['ARL_BENCH_SINGLE_DEVICE'] = '1'; env['ARL_BENCH_BACKEND'] = 'gloo'
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--users', '30000', '--items', '3000', '--steps', '3', '--warmup', '1']
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and r['steps'] == 3 and r['value'] > 0 and r['scaling'] == 'strong'
+    c = r['comm']
+    assert c['world_size'] == 2 and len(c['ranks']) == 2 and {x['rank'] for x in c['ranks']} == {0, 1}
+    assert len({x['pid'] for x in c['ranks']}) == 2                                           # two processes
+    assert c['allreduce_probe']['sum_of_rank_plus_1'] == c['allreduce_probe']['expected'] == 3.0
+    assert c['backend'] == ('gloo' if single else 'nccl') and c['is_rccl'] == (not single)
+    assert ('RCCL' in r['config']['parallelism']) == (not single)                             # the label follows the backend that ran
+    assert c['distinct_devices'] == (1 if single else 2)
+    assert 'projected_ceiling_8gpu' not in r or r['projected_ceiling_8gpu'] is None or r['projected_ceiling_8gpu'] > 0
