@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ARLIB_AMD_LIB') or os.path.join(_HERE, 'lib', 'libarlib_amd.so')      # override: developer builds (e.g. `make prof`)
-ABI_VERSION = 21
+ABI_VERSION = 22
 _lib = None
 
 
@@ -101,6 +101,7 @@ _SIGS = {
     'arl_fake_block_rows_f32': (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, C.c_float, _vp, _vp, _vp]),
     'arl_fake_block_cols_f32': (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, C.c_float, _vp, _vp]),
     'arl_score_mask_topk_workspace_bytes': (_i64, [_i64, _i64]),
+    'arl_score_mask_topk_stats_offset': (_i64, [_i64, _i64]),
     'arl_score_mask_topk_f32': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'arl_normalize_rows_f32': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     'arl_normalize_rows_bwd_f32': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _f, _vp, _vp, _vp]),
@@ -109,7 +110,7 @@ _SIGS = {
     'arl_nce_allrows_grad_f32': (C.c_int, [_vp, _i64, _vp, _i64, _i64, _f, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
     'arl_comm_load': (C.c_int, [C.c_char_p]),
     'arl_comm_unique_id': (C.c_int, [_vp]),
-    'arl_comm_init': (C.c_int, [_vp, _i64, _i64, C.POINTER(C.c_void_p)]),
+    'arl_comm_init': (C.c_int, [_vp, _i64, _i64, _i64, C.POINTER(C.c_void_p)]),
     'arl_comm_destroy': (C.c_int, [_vp]),
     'arl_item_exchange_range': (C.c_int, [_i64, _i64, _i64, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
     'arl_allreduce_item_workspace_bytes': (_i64, [_i64, _i64, _i64]),

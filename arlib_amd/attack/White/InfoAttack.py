@@ -42,7 +42,7 @@ class _ItemInfoNCE(torch.autograd.Function):
             v2 = Pi / nrm
             I = Pi.shape[0]
             k = (I + bs - 1) // bs
-            if Pi.is_cuda and Pi.shape[1] in ops.NCE_ALLROWS_WIDTHS and Pi.dtype == torch.float32:
+            if Pi.is_cuda and Pi.shape[1] in ops.NCE_ALLROWS_WIDTHS and Pi.dtype == torch.float32 and temperature >= ops.NCE_ALLROWS_MIN_TAU:
                 # fused form (arl_nce_allrows_*): ttl_j = sum_i exp(<v2_j, v1_i>/T) over ALL items i is a log-sum-exp with v2 as the batch side;
                 # only v2 carries gradient.  Batch j // bs has n_j items: weight of item j = 1 / (n_j k).
                 v1c, v2c = v1.contiguous(), v2.contiguous()

@@ -14,7 +14,20 @@
 #include <dlfcn.h>
 #include <stdint.h>
 #include <string.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// A box without the RCCL headers still builds the library (the functions are bound by dlopen at run time): the few declarations used here, with the
+// values of nccl.h (ncclFloat32 = 7, ncclSum = 0, a 128-byte unique id).
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclFloat = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+}
+#endif
 #include "arlib_amd.h"
 
 namespace {
@@ -98,14 +111,22 @@ int arl_comm_unique_id(void *id128) {
     return ARL_OK;
 }
 
-int arl_comm_init(const void *id128, int64_t rank, int64_t world, arl_comm_t *out) {
+int arl_comm_init(const void *id128, int64_t rank, int64_t world, int64_t device, arl_comm_t *out) {
     if (!id128 || !out) return ARL_E_NULL;
     if (world < 1 || rank < 0 || rank >= world) return ARL_E_ARG;
     if (!load_rccl(nullptr)) return ARL_E_ARG;
     ncclUniqueId id;
     memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    // the communicator binds to the CURRENT device of the calling thread: make it the caller's device for the call (device < 0: leave it alone)
+    int prev = -1;
+    if (device >= 0) {
+        if (hipGetDevice(&prev) != hipSuccess) return ARL_E_ARG;
+        const hipError_t e = hipSetDevice((int)device);
+        if (e != hipSuccess) return (int)e;
+    }
     Comm *c = new Comm{nullptr, (int)rank, (int)world};
     const ncclResult_t r = g_rccl.CommInitRank(&c->nc, (int)world, id, (int)rank);
+    if (device >= 0 && prev >= 0 && prev != (int)device) (void)hipSetDevice(prev);
     if (r != ncclSuccess) { delete c; return 1000 + (int)r; }
     *out = (arl_comm_t)c;
     return ARL_OK;
@@ -152,6 +173,8 @@ int arl_allreduce_item_f32(arl_comm_t comm, float *buf, int64_t n_elems, int64_t
     int64_t mlo, mhi;
     shard_range(n_elems, P, me, &mlo, &mhi);
 #define ARL_NCCL(CALL) do { const ncclResult_t r__ = (CALL); if (r__ != ncclSuccess) return 1000 + (int)r__; } while (0)
+    // inside a GroupStart / GroupEnd pair: close the group before leaving, an open group would swallow every later RCCL call of the thread
+#define ARL_NCCL_G(CALL) do { const ncclResult_t r__ = (CALL); if (r__ != ncclSuccess) { (void)g_rccl.GroupEnd(); return 1000 + (int)r__; } } while (0)
     for (int ch = 0; ch < (int)n_chunks; ++ch) {
         float *tmp = ws + (int64_t)(ch & 1) * (P - 1) * slot;
         int64_t clo, chi;
@@ -163,8 +186,8 @@ int arl_allreduce_item_f32(arl_comm_t comm, float *buf, int64_t n_elems, int64_t
             int64_t qlo, qhi, a, b;
             shard_range(n_elems, P, q, &qlo, &qhi);
             chunk_range(qlo, qhi, (int)n_chunks, ch, &a, &b);
-            if (b > a) ARL_NCCL(g_rccl.Send(buf + a, (size_t)(b - a), ncclFloat, q, c->nc, st));
-            if (chi > clo) ARL_NCCL(g_rccl.Recv(tmp + (int64_t)(q < me ? q : q - 1) * slot, (size_t)(chi - clo), ncclFloat, q, c->nc, st));
+            if (b > a) ARL_NCCL_G(g_rccl.Send(buf + a, (size_t)(b - a), ncclFloat, q, c->nc, st));
+            if (chi > clo) ARL_NCCL_G(g_rccl.Recv(tmp + (int64_t)(q < me ? q : q - 1) * slot, (size_t)(chi - clo), ncclFloat, q, c->nc, st));
         }
         ARL_NCCL(g_rccl.GroupEnd());
         if (chi > clo) {
@@ -181,12 +204,13 @@ int arl_allreduce_item_f32(arl_comm_t comm, float *buf, int64_t n_elems, int64_t
             int64_t qlo, qhi, a, b;
             shard_range(n_elems, P, q, &qlo, &qhi);
             chunk_range(qlo, qhi, (int)n_chunks, ch, &a, &b);
-            if (chi > clo) ARL_NCCL(g_rccl.Send(buf + clo, (size_t)(chi - clo), ncclFloat, q, c->nc, st));
-            if (b > a) ARL_NCCL(g_rccl.Recv(buf + a, (size_t)(b - a), ncclFloat, q, c->nc, st));
+            if (chi > clo) ARL_NCCL_G(g_rccl.Send(buf + clo, (size_t)(chi - clo), ncclFloat, q, c->nc, st));
+            if (b > a) ARL_NCCL_G(g_rccl.Recv(buf + a, (size_t)(b - a), ncclFloat, q, c->nc, st));
         }
         ARL_NCCL(g_rccl.GroupEnd());
     }
 #undef ARL_NCCL
+#undef ARL_NCCL_G
     return ARL_OK;
 }
 

@@ -434,9 +434,11 @@ __device__ __forceinline__ void stage_rows(int32_t *srows, int c0, int c1, RowOf
 // Which rows does the list name more than once?  One thread per entry sets the row's bit in `bits`; an entry that finds it already set
 // sets the row's bit in `dup`.  WHICH entry arrives second is a race, the resulting SET of duplicated rows is not.  With it the accumulation
 // kernel below scans the list only for the duplicated rows (a few hundred of a 6 144-row batch) -- 44 -> ~10 us per call at cfg2.
-__global__ __launch_bounds__(kBlock) void rows_mark_dups_kernel(uint32_t *__restrict__ bits, uint32_t *__restrict__ dup, const int32_t *__restrict__ idx, int n) {
+__global__ __launch_bounds__(kBlock) void rows_mark_dups_kernel(uint32_t *__restrict__ bits, uint32_t *__restrict__ dup, const int32_t *__restrict__ idx, int n,
+                                                                 const float *__restrict__ row_scale) {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     if (t >= n) return;
+    if (row_scale && row_scale[t] == 0.f) return;                     // an entry with factor 0 is ABSENT (see rows_add_ordered_kernel)
     const int row = idx[t];
     const uint32_t m = 1u << (row & 31);
     if (atomicOr(bits + (row >> 5), m) & m) atomicOr(dup + (row >> 5), m);
@@ -452,7 +454,10 @@ __global__ __launch_bounds__(kBlock) void rows_add_ordered_kernel(float *__restr
     extern __shared__ int32_t srows[];
     const int lane = threadIdx.x & 63;
     const int t = c0 + blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    const bool valid = t < c1;
+    // An entry whose per-contribution factor is exactly 0 is ABSENT: it adds nothing, marks nothing and never takes part in a scan.  The user-sharded
+    // step keeps static shapes by giving every foreign sample factor 0 on a clamped local row (shard_batch_prep_kernel): at 8 ranks ~7/8 of the
+    // batch's user entries would otherwise pile up on two rows -- hundreds of dependent add trips of zeros on one wave, and two marked rows more
+    const bool valid = t < c1 && !(row_scale && row_scale[t] == 0.f);
     const int row = valid ? idx[t] : 0;
     float *o = dst + (size_t)row * d;
     const bool fast = valid && dup && !((dup[row >> 5] >> (row & 31)) & 1u);
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(kBlock) void rows_add_ordered_kernel(float *__restr
         if (MARK && lane == 0) flags[row] = 1;
     }
     if (!__syncthreads_or(valid && !fast)) return;                    // nothing to scan in this workgroup
-    stage_rows(srows, c0, c1, [&](int j) { return idx[j]; });
+    stage_rows(srows, c0, c1, [&](int j) { return (row_scale && row_scale[j] == 0.f) ? -1 : idx[j]; });      // absent entries match no row
     if (!valid || fast) return;
     for (int k0 = 0; k0 < d; k0 += 256) {
         float acc[4];
@@ -699,6 +704,9 @@ int launch_spmm(const arl_csr *A, const float *X, int64_t d, const Epi &ep, hipS
 // atomics, deterministic.  Rows longer than the plan's hub threshold are not in the plan (chunked CSR kernel).
 // ================================================================================================
 typedef float f32x32v __attribute__((ext_vector_type(32)));
+#ifndef ARL_SPMM_EXP_NOVAL
+#define ARL_SPMM_EXP_NOVAL 0                     // 1 = developer timing probe of a value-free record stream (`make variant`); never the product library
+#endif
 
 struct BlockedDev {
     int n_waves;
@@ -752,10 +760,10 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked64_kernel(BlockedDev P, co
     const int begin = P.wave_ptr[w], end = P.wave_ptr[w + 1];
     const float *xl = X + lane * CPL;
     int rc = 0; float rv = 0.f;
-    if (begin < end) { rc = __builtin_nontemporal_load(P.rec_col + begin + lane); rv = __builtin_nontemporal_load(P.rec_val + begin + lane); }
+    if (begin < end) { rc = __builtin_nontemporal_load(P.rec_col + begin + lane); if (!ARL_SPMM_EXP_NOVAL) rv = __builtin_nontemporal_load(P.rec_val + begin + lane); }
     for (int base = begin; base < end; base += 64) {
         const int c_cur = rc; const float v_cur = rv;
-        if (base + 64 < end) { rc = __builtin_nontemporal_load(P.rec_col + base + 64 + lane); rv = __builtin_nontemporal_load(P.rec_val + base + 64 + lane); }       // next batch in flight
+        if (base + 64 < end) { rc = __builtin_nontemporal_load(P.rec_col + base + 64 + lane); if (!ARL_SPMM_EXP_NOVAL) rv = __builtin_nontemporal_load(P.rec_val + base + 64 + lane); }       // next batch in flight
 #pragma unroll
         for (int j = 0; j < 64; j += UNR) {
             float x[UNR][CPL]; int cs[UNR];
@@ -768,8 +776,13 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked64_kernel(BlockedDev P, co
             }
 #pragma unroll
             for (int t = 0; t < UNR; ++t) {
-                const float v = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v_cur), j + t));
                 const int slot = ((unsigned)cs[t] >> 24) & 31;
+                if (ARL_SPMM_EXP_NOVAL) {                          // timing probe only (profiles/r04_experiments.md): no value stream, plain adds -- results are wrong
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) acc[c][slot] += x[t][c];
+                    continue;
+                }
+                const float v = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v_cur), j + t));
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) acc[c][slot] = fmaf(v, x[t][c], acc[c][slot]);
             }
@@ -2317,6 +2330,34 @@ __global__ __launch_bounds__(kWave) void stage_norm_kernel(const float *__restri
     }
 }
 
+// suffix maxima of the per-stage norms: out[s] = max(sn[s..nst)), out[nst] = 0 -- the largest scaled item norm any LATER stage of the stream can hold
+// (the early exit's bound; for a norm-ordered stream it equals sn).  One wave.
+__global__ __launch_bounds__(kWave) void stage_sufmax_kernel(const float *__restrict__ sn, int nst, float *__restrict__ out) {
+    const int lane = threadIdx.x;
+    float carry = 0.f;
+    for (int base = ((nst - 1) / kWave) * kWave; base >= 0; base -= kWave) {
+        const int s = base + lane;
+        float v = s < nst ? sn[s] : 0.f;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const float o = __shfl_down(v, off);
+            if (lane + off < kWave) v = fmaxf(v, o);
+        }
+        v = fmaxf(v, carry);
+        if (s < nst) out[s] = v;
+        carry = __shfl(v, 0);
+    }
+    if (lane == 0) out[nst] = 0.f;
+}
+
+#ifndef ARL_TOPK_EXIT
+#define ARL_TOPK_EXIT 1                          // exact early exit of the norm-ordered stream (see the kernel); 0 = the round-3 form
+#endif
+#ifndef ARL_TOPK_EXIT_EVERY
+#define ARL_TOPK_EXIT_EVERY 4                    // a wave tests its 16 users' bound every this-many stages (a power of two)
+#endif
+constexpr int kExitWords = 4;                    // LDS words behind the ring counters: [0] stop stage, [1] votes
+
 template <int D, bool SPLIT, bool WARM>
 __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfma16_kernel(const float *__restrict__ Pu, const void *__restrict__ Pi_image, int U, int I,
                                                                             const int32_t *__restrict__ mrp, const int32_t *__restrict__ mcol, int k,
@@ -2324,7 +2365,8 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
                                                                             const float *__restrict__ Pi_f32, const int32_t *__restrict__ warm_idx,
                                                                             int *__restrict__ underflow, const unsigned *__restrict__ table_max_bits,
                                                                             const int32_t *__restrict__ item_order, const int32_t *__restrict__ item_pos,
-                                                                            const int *__restrict__ gate, const float *__restrict__ stage_norm) {
+                                                                            const int *__restrict__ gate, const float *__restrict__ stage_norm,
+                                                                            unsigned long long *__restrict__ stats) {
     // gate (optional): the launch is the cold repeat of a warm-started call and runs only if that call raised its underflow flag -- decided here,
     // on the device, so that the host never waits for the flag (every thread of the grid takes the same branch)
     if (gate != nullptr && *gate == 0) return;
@@ -2370,6 +2412,7 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     constexpr bool F16 = SPLIT && kSplitMode == 2;
     constexpr bool REFINE = F16 && ARL_TOPK_REFINE && ARL_TOPK_QUEUE;      // see the staging constants below
     float Ereg[4] = {0.f, 0.f, 0.f, 0.f};                          // REFINE: E of user rows 4g + reg for an item of scaled norm n is Ereg * n + Eabs
+    [[maybe_unused]] float Nreg[4] = {0.f, 0.f, 0.f, 0.f};         // early exit: no later item passes row 4g + reg's pre-filter once Nreg * (largest later norm) + 2 Eabs < threshold
     float Eabs = 0.f;
     bf16x8 af[3][KS];
     f16x8 ah[2][KS];
@@ -2397,6 +2440,14 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
             const float Ec = ARL_TOPK_ESCALE * 0.0009765625f * sqrtf(n2);
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) Ereg[reg] = __shfl(Ec, 4 * g + reg);
+            // Early exit.  A high-piece score is <ah, bh> accumulated in fp32: |score| <= |ah| |bh| (1 + 2^-18) (Cauchy-Schwarz; 64 or 128 exact
+            // products, fp32 adds) <= |a'| |b'| (1 + 2^-10 + 2^-17) + Eabs (each piece within 2^-11 relative of its element, or 2^-25 absolute when
+            // subnormal: that part is what Eabs bounds).  With the 1.05 below covering the roundings of the two norms themselves, an item of
+            // scaled norm n cannot pass the pre-filter `score >= threshold - (Ereg n + Eabs)` of a row with
+            //     (|a'| (1 + 1.05 * 2^-10) + Ereg) * n + 2 Eabs < threshold.
+            const float Nc = fmaf(sqrtf(n2), 1.f + 1.05f * 0.0009765625f, Ec);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) Nreg[reg] = __shfl(Nc, 4 * g + reg);
         }
     } else if constexpr (SPLIT) {
 #pragma unroll
@@ -2483,10 +2534,12 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     constexpr int STAGEB = 2 * HALF;
     unsigned *ring_ctr = reinterpret_cast<unsigned *>(bt + kTopkRing * STAGEB);                             // fill[kTopkRing], done[kTopkRing]
     constexpr int kQAll = ARL_TOPK_QUEUE ? kQWords * (kM16Block / kWave) : 0;
-    unsigned *qcnt = ring_ctr + 2 * kTopkRing + wv * kQWords;                                                // this wave's 16 queue counters ...
+    unsigned *exit_st = ring_ctr + 2 * kTopkRing;                                                            // [0] stop stage (virtual index), [1] waves that voted
+    unsigned *qcnt = ring_ctr + 2 * kTopkRing + kExitWords + wv * kQWords;                                                // this wave's 16 queue counters ...
     unsigned long long *qkey = reinterpret_cast<unsigned long long *>(qcnt + 16);                           // ... and its [16][kQCap] keys (8-byte aligned)
-    unsigned *bloom = ring_ctr + 2 * kTopkRing + kQAll + wv * 16 * kBloomWords;                             // [16][kBloomWords]
+    unsigned *bloom = ring_ctr + 2 * kTopkRing + kExitWords + kQAll + wv * 16 * kBloomWords;                             // [16][kBloomWords]
     if (tid < 2 * kTopkRing) ring_ctr[tid] = 0u;
+    if (tid == 0) { exit_st[0] = 0x7fffffffu; exit_st[1] = 0u; }
     if (ARL_TOPK_QUEUE && lane < 16) qcnt[lane] = 0u;
     if (mrp) {
         for (int t = lane; t < 16 * kBloomWords; t += kWave) bloom[t] = 0u;
@@ -3007,10 +3060,47 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     };
     unsigned *fill_ctr = ring_ctr, *done_ctr = ring_ctr + kTopkRing;
     constexpr unsigned NWV = kM16Block / kWave;
+    // ---- Exact early exit (REFINE, with per-stage norms; pays on a norm-ordered stream).  Row r is FINISHED at stage s when no item of a later
+    // stage can pass its pre-filter: Nreg_r * sufmax[s + 1] + 2 Eabs < threshold_r (Cauchy-Schwarz, see Nreg).  Thresholds only rise and the suffix
+    // maxima only fall, so a finished row stays finished.  A wave whose 16 rows are finished VOTES once; the wave casting the last of the
+    // workgroup's votes, in its step s, publishes stop = s + lead + 1; every wave reads `stop` in the same LDS instruction as the fill counter it
+    // waits for before consuming a stage, and leaves the loop at stage `stop` without consuming it.  Why that stage is safe: the fill counter of
+    // stage t completes only when every wave has run step t - lead, so (1) no wave has consumed stage s + lead + 1 when the last vote is cast in step s,
+    // and (2) a wave that sees stage `stop` filled sees a counter the voter raised in its step s + 1, after it stored `stop` (one wave's LDS operations
+    // execute in order).  All waves leave at the same stage, the counters of every stage below it complete as before; the stages skipped could
+    // not have produced a candidate, so lists, values and tie order are those of the full stream, bit for bit.
+    constexpr bool EXIT = REFINE && ARL_TOPK_EXIT && !ARL_TOPK_POLL8 && !ARL_TOPK_PAIRS;
+    [[maybe_unused]] const float *sufmax = stage_norm ? stage_norm + nstages + 1 : nullptr;      // [nstages + 1], behind the stage norms and the table's maximum
+    [[maybe_unused]] bool voted = false;                               // wave-uniform
+    [[maybe_unused]] int stop_seen = 0x7fffffff;
+    [[maybe_unused]] auto wait_fill_stop = [&](unsigned *ctr, unsigned want) -> int {      // wait_ge(ctr, want); returns the stop stage read with the counter
+        const lds_u32 *p = (const lds_u32 *)(lane < 32 ? ctr : exit_st);                   // (different banks: one pass of the LDS)
+        unsigned v;
+        int spins = 0;
+        while (v = *(volatile const lds_u32 *)p, (unsigned)__builtin_amdgcn_readfirstlane((int)v) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 26)) __builtin_trap();
+        }
+        asm volatile("" ::: "memory");
+        return __builtin_amdgcn_readlane((int)v, 32);
+    };
+    [[maybe_unused]] auto vote = [&](int st) {                         // after stage st (virtual index, a stream stage) has been consumed
+        const float sx = sufmax[st - NB + 1];                          // wave-uniform scalar load
+        bool fin = true;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) fin = fin && (fmaf(Nreg[reg], sx, 2.f * Eabs) < thrf[reg]);       // (+inf for rows past U; NaN never finishes)
+        if (__builtin_amdgcn_ballot_w64(!fin) == 0ull) {
+            voted = true;
+            if (lane == 0) {
+                const unsigned before = __hip_atomic_fetch_add((lds_u32 *)(exit_st + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (before == NWV - 1u) __hip_atomic_store((lds_u32 *)exit_st, (unsigned)(st + kTopkLead + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    };
     static_assert(kTopkLead >= 2 && kTopkLead % 2 == 0 && kTopkLead < kTopkRing && (kTopkRing & (kTopkRing - 1)) == 0, "two register sets alternate: the lead is even");
     __syncthreads();                                               // counters zeroed (the only block barrier of the kernel)
     // one step of the pipeline: stage st + 2 goes from register set r to LDS, set r is refilled with stage st + 4, stage st is consumed
-    [[maybe_unused]] auto step = [&](auto boot_tag, int st, f32x4 (&r)[PER]) {
+    [[maybe_unused]] auto step = [&](auto boot_tag, int st, f32x4 (&r)[PER]) -> bool {
         const int t = st + kTopkLead;
 
 #if ARL_TOPK_POLL8
@@ -3046,10 +3136,19 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
         }
         asm volatile("" ::: "memory");
 #else
-        wait_ge(fill_ctr + (st & (kTopkRing - 1)), NWV * (unsigned)(st / kTopkRing + 1));
+        if constexpr (EXIT) {
+            if (sufmax != nullptr) {
+                stop_seen = wait_fill_stop(fill_ctr + (st & (kTopkRing - 1)), NWV * (unsigned)(st / kTopkRing + 1));
+                if (st >= stop_seen) return true;                      // wave-uniform; every wave of the workgroup leaves at this stage
+            } else wait_ge(fill_ctr + (st & (kTopkRing - 1)), NWV * (unsigned)(st / kTopkRing + 1));
+        } else wait_ge(fill_ctr + (st & (kTopkRing - 1)), NWV * (unsigned)(st / kTopkRing + 1));
 #endif
         ARL_PROF_TICK(3)
         compute(boot_tag, slot(st), st, done_ctr + (st & (kTopkRing - 1)));
+        if constexpr (EXIT && !decltype(boot_tag)::value) {
+            if (sufmax != nullptr && !voted && (st & (ARL_TOPK_EXIT_EVERY - 1)) == ARL_TOPK_EXIT_EVERY - 1) vote(st);
+        }
+        return false;
     };
 #if ARL_TOPK_PAIRS
     // Stages are synchronised in PAIRS (slots {0,1} and {2,3} of the ring; one fill and one done counter per pair): half the counter polls, tile-write
@@ -3103,8 +3202,12 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     }
     if (NB > 0) boot_finish();
     for (int st = NB; st < nvirt; st += 2) {
-        step(std::false_type{}, st, nb);
-        if (st + 1 < nvirt) step(std::false_type{}, st + 1, nc);
+        if (step(std::false_type{}, st, nb)) break;
+        if (st + 1 < nvirt && step(std::false_type{}, st + 1, nc)) break;
+    }
+    if (stats != nullptr && tid == 0) {                            // stream stages this workgroup consumed (all of them without an exit), and one workgroup
+        atomicAdd(stats, (unsigned long long)(min(stop_seen, nvirt) - NB));
+        atomicAdd(stats + 1, 1ull);
     }
 #endif
 #if ARL_TOPK_QUEUE
@@ -3420,7 +3523,7 @@ int arl_batch_rows_set_f32(float *G, uint8_t *flags, uint32_t *bits, const int32
     if (n < 0 || n > 0x7fffffffll || d <= 0 || d > 0x7fffffffll) return ARL_E_ARG;
     if (n == 0) return ARL_OK;
     if (dup_bits) {
-        hipLaunchKernelGGL(rows_mark_dups_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, bits, dup_bits, idx, (int)n);
+        hipLaunchKernelGGL(rows_mark_dups_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, bits, dup_bits, idx, (int)n, row_scale);
         ARL_LAUNCH_CHECK();
     }
     for (int64_t c0 = 0; c0 < n; c0 += kOrderedWindow) {                 // ordered (atomic-free) accumulation, one window per launch
@@ -4047,7 +4150,14 @@ int arl_fake_block_cols_f32(const float *S, int64_t F, int64_t I, const float *X
     return ARL_OK;
 }
 
-int64_t arl_score_mask_topk_workspace_bytes(int64_t I, int64_t d) { return (I <= 0 || d <= 0) ? 0 : 6 * I * d; }
+int64_t arl_score_mask_topk_workspace_bytes(int64_t I, int64_t d) { return (I <= 0 || d <= 0) ? 0 : 6 * I * d + 64; }
+// byte offset, inside the workspace, of the pass's two 8-byte counters [stream stages consumed summed over workgroups, workgroups] (fp16 split path,
+// d = 64 / 128): consumed / (workgroups * ceil(I / stage items)) is the share of the item stream the early exit did not skip
+int64_t arl_score_mask_topk_stats_offset(int64_t I, int64_t d) {
+    if (I <= 0 || d <= 0) return 0;
+    const int64_t mst = d <= 16 ? 128 : (d <= 64 ? 64 : 32), nst = (I + mst - 1) / mst;
+    return (4 * I * d + 16 + 4 * I + 4 * (2 * nst + 2) + 7) / 8 * 8;
+}
 
 int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t I, int64_t d, const int32_t *mask_rowptr, const int32_t *mask_col,
                             int64_t k, int32_t *top_idx, float *top_val, void *workspace, const int32_t *warm_idx, int32_t *underflow,
@@ -4065,7 +4175,7 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
         const size_t stageb = 2 * (size_t)mst * ((split ? 2 * kSplitPlanes : 4) * (size_t)d / 2 + 16);     // two half images of mst rows (STAGEB in the kernel)
         const int nwaves = topk_waves((int)d, split);
         const int users_per_wg = 16 * nwaves;
-        const size_t shm_m = kTopkRing * stageb + 2 * kTopkRing * sizeof(unsigned) + (ARL_TOPK_QUEUE ? sizeof(unsigned) * kQWords * nwaves : 0) +
+        const size_t shm_m = kTopkRing * stageb + (2 * kTopkRing + kExitWords) * sizeof(unsigned) + (ARL_TOPK_QUEUE ? sizeof(unsigned) * kQWords * nwaves : 0) +
                              (mask_rowptr ? sizeof(unsigned) * users_per_wg * kBloomWords : 0);
         const unsigned grid_m = (unsigned)((U + users_per_wg - 1) / users_per_wg);
         const void *image = Pi;
@@ -4073,6 +4183,7 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
         const int32_t *order_d = nullptr;
         int32_t *pos_d = nullptr;
         float *snorm_d = nullptr;
+        unsigned long long *stats_d = nullptr;
         if (split) {
             const long long n = (long long)I * d;
             if (kSplitMode == 2) {
@@ -4098,6 +4209,11 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
                     if (hipMemsetAsync(snorm_d + nst, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return ARL_E_ARG;
                     hipLaunchKernelGGL(stage_norm_kernel, dim3((unsigned)nst), dim3(kWave), 0, (hipStream_t)stream, Pi, (int)I, (int)d, mst, mb, order_d, nst, snorm_d);
                     ARL_LAUNCH_CHECK();
+                    // behind them: the suffix maxima [nst + 1] (the early exit's bound) and two 8-byte counters (stream stages consumed, workgroups)
+                    hipLaunchKernelGGL(stage_sufmax_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)stream, snorm_d, nst, snorm_d + nst + 1);
+                    ARL_LAUNCH_CHECK();
+                    stats_d = reinterpret_cast<unsigned long long *>(static_cast<char *>(workspace) + arl_score_mask_topk_stats_offset(I, d));
+                    if (hipMemsetAsync(stats_d, 0, 2 * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess) return ARL_E_ARG;
                 }
             } else {
                 hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, Pi, n, (int)d,
@@ -4111,7 +4227,7 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
             hipError_t em = hipFuncSetAttribute((const void *)score_mask_topk_mfma16_kernel<DV, SP, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m); \
             if (em != hipSuccess) return (int)em;                                                                                      \
             hipLaunchKernelGGL((score_mask_topk_mfma16_kernel<DV, SP, WM>), dim3(grid_m), dim3(64 * topk_waves(DV, SP)), shm_m, (hipStream_t)stream, Pu, image, (int)U, (int)I, \
-                               mask_rowptr, mask_col, (int)k, top_idx, top_val, Pi, WARMP, underflow, max_bits, order_d, pos_d, GATE, (const float *)snorm_d);  \
+                               mask_rowptr, mask_col, (int)k, top_idx, top_val, Pi, WARMP, underflow, max_bits, order_d, pos_d, GATE, (const float *)snorm_d, stats_d);  \
         } while (0)
         /* a warm-started call is followed by its own cold repeat, gated on the underflow flag on the device: valid results without a host round trip */
 #define ARL_TOPK_CASE(DV, SP)                                                                                                          \

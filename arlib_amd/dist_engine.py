@@ -90,7 +90,8 @@ class TorchDistComm:
             box = [bytes(ident.raw)]
             self.dist.broadcast_object_list(box, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
             handle = C.c_void_p()
-            _lib.check(L.arl_comm_init(box[0], rank, world, C.byref(handle)), 'arl_comm_init')
+            dev_index = device.index if device.index is not None else torch.cuda.current_device()
+            _lib.check(L.arl_comm_init(box[0], rank, world, dev_index, C.byref(handle)), 'arl_comm_init')
             self._native = dict(L=L, handle=handle, world=world, stream=torch.cuda.Stream(device=device), ws=None)
         return self._native
 
@@ -100,9 +101,12 @@ class TorchDistComm:
         nat = self._native_comm(t.device)
         L, n = nat['L'], t.numel()
         need = L.arl_allreduce_item_workspace_bytes(n, nat['world'], self.n_chunks)
-        if nat['ws'] is None or nat['ws'].numel() * 4 < need:
-            nat['ws'] = torch.empty(max(need // 4, 4), dtype=torch.float32, device=t.device)
         side = nat['stream']
+        if nat['ws'] is None or nat['ws'].numel() * 4 < need:
+            # the receive workspace is used on the communication stream only: tell the allocator, so that a replaced workspace is not handed out
+            # again while an exchange enqueued on that stream still reads it
+            nat['ws'] = torch.empty(max(need // 4, 4), dtype=torch.float32, device=t.device)
+            nat['ws'].record_stream(side)
         side.wait_event(torch.cuda.current_stream().record_event())          # the producer of `t` runs on the caller's stream
         _lib.check(L.arl_allreduce_item_f32(nat['handle'], C.c_void_p(t.data_ptr()), n, self.n_chunks, C.c_void_p(nat['ws'].data_ptr()),
                                             C.c_void_p(side.cuda_stream)), 'arl_allreduce_item_f32')

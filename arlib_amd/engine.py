@@ -125,24 +125,29 @@ class PropagationEngine:
             acc = dst
         return acc
 
-    def adjacency_gradient(self, G, out=None):
-        """dL/d(values of A) from dL/d(out) = G for out = mean(E_0 .. E_L), E_{k+1} = A E_k: what autograd leaves in `sparse_norm_adj.grad` when the
-        reference sets `sparse_norm_adj.requires_grad = True` (recommender/LightGCN.py:41-43,58-59).  With dE_L = G/(L+1), dE_k = G/(L+1) + A dE_{k+1}
-        (A symmetric) the gradient on a stored entry (i, j) is sum_k <dE_{k+1}[i], E_k[j]>: L - 1 forward hops, L - 1 backward hops and L products
-        over the pattern (ops.sddmm_csr), accumulated into `out` ([nnz] fp32, CSR order)."""
+    def adjacency_gradient(self, G, out=None, noises=None, eps=0.1):
+        """dL/d(values of A) from dL/d(out) = G for out = mean of the layers E_k, E_{k+1} = A E_k (+ a perturbation that carries no gradient when
+        `noises` is given: the SimGCL views, recommender/SimGCL.py:198-210): what autograd leaves in `sparse_norm_adj.grad` when the reference sets
+        `sparse_norm_adj.requires_grad = True` (recommender/LightGCN.py:41-43,58-59; SimGCL.py:44-47,62-63).  With s = 1/(L+1) (layers 0..L) or
+        1/L (skip_layer0: layers 1..L), dE_L = s G, dE_k = s G + A dE_{k+1} (A symmetric; k >= 1 is in the mean either way), the gradient on a
+        stored entry (i, j) is sum_k <dE_{k+1}[i], E_k[j]>: L - 1 forward hops, L - 1 backward hops and L products over the pattern
+        (ops.sddmm_csr), ACCUMULATED into `out` ([nnz] fp32, CSR order).  noises: the [hop] tables of the forward this gradient belongs to."""
         L, A = self.L, self.A
-        if self.skip0:
-            raise NotImplementedError('adjacency_gradient: the layer mean that skips layer 0 (SimGCL family) is not covered')
         if out is None:
             out = torch.zeros(A.col.numel(), dtype=torch.float32, device=G.device)
         if L == 0:
             return out
+        s = 1.0 / L if self.skip0 else 1.0 / (L + 1)
         E = [self.E0]
         for k in range(L - 1):
-            E.append(ops.spmm(A, E[-1]))
-        acc = G.contiguous()
+            nxt = ops.spmm(A, E[-1])
+            if noises is not None:
+                ops.simgcl_perturb_(nxt, noises[k], eps)
+            E.append(nxt)
+        G = G.contiguous()
+        acc = G
         for j in range(L):
-            ops.sddmm_csr(A, acc, E[L - 1 - j], 1.0 / (L + 1), out=out)
+            ops.sddmm_csr(A, acc, E[L - 1 - j], s, out=out)
             if j < L - 1:
                 acc = ops.spmm(A, acc, 1.0, 1.0, G)
         return out

@@ -937,10 +937,15 @@ def infonce_fwd_bwd(v1, v2, tau, want_grad=True, upstream=1.0):
 
 
 NCE_ALLROWS_WIDTHS = (16, 32, 64, 128)
+# The all-rows kernels compute exp((s - 1) / tau) with the constant 1 as the shift -- exact for row-NORMALISED operands (|s| <= 1), no running maximum.
+# fp32 exp underflows below ~ -87, so a row whose best cosine is under 1 - 87 tau would sum to 0 (lse = -inf, NaN gradients); with tau >= 2 / 87 no
+# cosine in [-1, 1] can underflow.  Smaller temperatures take the callers' panel form (running maximum).
+NCE_ALLROWS_MIN_TAU = 0.023
 
 
 def nce_allrows(A, V, tau, want_grad=True, want_dV=True, lse=None):
-    """All-rows InfoNCE pieces for row-NORMALISED A [nA, d] (the batch) and V [nV, d] (all users or items), d in {16, 32, 64, 128}, without an nA x nV logit
+    """All-rows InfoNCE pieces for row-NORMALISED A [nA, d] (the batch) and V [nV, d] (all users or items; PRECONDITION: unit rows -- the kernel shifts by the
+    constant 1 = the largest possible cosine, it keeps no running maximum), tau >= NCE_ALLROWS_MIN_TAU, d in {16, 32, 64, 128}, without an nA x nV logit
     matrix: returns lse [nA] = log sum_j exp(<a_b, v_j>/tau) and, with want_grad, (dA, dV) = (sum_j P_bj v_j, sum_b P_bj a_b) with
     P = exp(<a, v>/tau - lse); want_dV=False skips the table-side sum (dV = None).  The caller applies 1/tau, the positive pairs' terms and
     the upstream gradient (recommender/NCL.py:96-115, attack/White/InfoAttack.py:96-101).  lse: a log-sum-exp from an earlier want_grad=False
@@ -950,6 +955,9 @@ def nce_allrows(A, V, tau, want_grad=True, want_dV=True, lse=None):
     nV = V.shape[0]
     if V.shape[1] != d or d not in NCE_ALLROWS_WIDTHS or nA == 0 or nV == 0:
         raise ValueError('nce_allrows: A [nA, d], V [nV, d] with d in %s' % (NCE_ALLROWS_WIDTHS,))
+    if not float(tau) >= NCE_ALLROWS_MIN_TAU:
+        raise ValueError('nce_allrows: tau %g < %g -- exp((s - 1) / tau) of a row-normalised pair can underflow to 0 for every term of a row '
+                         '(see NCE_ALLROWS_MIN_TAU); use the panel form' % (float(tau), NCE_ALLROWS_MIN_TAU))
     L = _lib.lib()
     ws = torch.empty(max(L.arl_nce_allrows_workspace_bytes(nA, nV, d) // 4, 4), dtype=torch.float32, device=A.device)
     given = lse is not None
@@ -1251,10 +1259,26 @@ def score_mask_topk(Pu, Pi, k, mask_rowptr=None, mask_col=None, exact=False, war
         evs[1].record(); TOPK_STATS.setdefault('events', []).append(evs)
     TOPK_STATS['calls'] += 1
     TOPK_STATS['warm'] += flag is not None
+    if ws is not None and TOPK_STATS.get('record_exit'):      # diagnostics: the pass's early-exit counters (a 16-byte device copy, no synchronisation)
+        off = _lib.lib().arl_score_mask_topk_stats_offset(I, d)
+        mst = 128 if d <= 16 else (64 if d <= 64 else 32)
+        TOPK_STATS.setdefault('exit', []).append((ws[off:off + 16].clone(), (I + mst - 1) // mst))
     # (a warm-started call repeats itself cold on the device when its flag is raised: nothing to wait for here; benches that count the repeats keep the flags)
     if flag is not None and TOPK_STATS.get('record_events'):
         TOPK_STATS.setdefault('flags', []).append(flag)
     return idx, val
+
+
+def topk_exit_fractions(reset=True):
+    """Per recorded pass (TOPK_STATS['record_exit'] = True): the share of (workgroup, stage) pairs of the item stream the early exit skipped.
+    Synchronises (reads the counters)."""
+    out = []
+    for t, nst in TOPK_STATS.get('exit', []):
+        consumed, wgs = (int(x) for x in t.view(torch.int64).tolist())
+        out.append(1.0 - consumed / float(max(1, wgs * nst)) if wgs else 0.0)
+    if reset:
+        TOPK_STATS['exit'] = []
+    return out
 
 
 def topn_project_rows(M, n):

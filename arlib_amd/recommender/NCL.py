@@ -44,7 +44,7 @@ class _AllRowsNCE(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, A, V, idx, T):
-        if _AllRowsNCE.FUSED and A.is_cuda and A.shape[1] in ops.NCE_ALLROWS_WIDTHS and A.dtype == torch.float32:
+        if _AllRowsNCE.FUSED and A.is_cuda and A.shape[1] in ops.NCE_ALLROWS_WIDTHS and A.dtype == torch.float32 and T >= ops.NCE_ALLROWS_MIN_TAU:
             # the fused form (arl_nce_allrows_*): no B x N logits, no library GEMM; exact fp32 products on the matrix cores
             with torch.no_grad():
                 A_, V_ = A.contiguous(), V.contiguous()
@@ -113,7 +113,7 @@ class _AllRowsNCEOfRaw(torch.autograd.Function):
 
 def all_rows_nce(Xa, Xv, idx, T):
     """sum_b -log softmax_j(<F.normalize(Xa)_b, F.normalize(Xv)_j>/T)[idx_b]  (ssl_layer_loss, NCL.py:96-103 / :109-115)."""
-    if _AllRowsNCE.FUSED and Xa.is_cuda and Xa.shape[1] in ops.NCE_ALLROWS_WIDTHS and Xa.dtype == torch.float32:
+    if _AllRowsNCE.FUSED and Xa.is_cuda and Xa.shape[1] in ops.NCE_ALLROWS_WIDTHS and Xa.dtype == torch.float32 and T >= ops.NCE_ALLROWS_MIN_TAU:
         return _AllRowsNCEOfRaw.apply(Xa, Xv, idx, T)
     return _AllRowsNCE.apply(F.normalize(Xa), F.normalize(Xv), idx, T)
 

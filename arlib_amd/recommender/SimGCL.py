@@ -32,6 +32,7 @@ class SimGCL(Recommender):
     print_every = 100
     has_extra_loss = True
     fused_extra_loss = True
+    adjgrad_through_views = True
 
     def __init__(self, args, data):
         self._common_init(args, data, 'SimGCL')

@@ -123,7 +123,7 @@ class _Propagate(torch.autograd.Function):
         eng = enc._engine()
         out = torch.empty_like(eng.E0)
         eng.forward(noises=noises, eps=enc.eps, out=out)
-        ctx.enc = enc
+        ctx.enc, ctx.noises = enc, noises
         U = user_emb.shape[0]
         return out[:U], out[U:]
 
@@ -131,6 +131,9 @@ class _Propagate(torch.autograd.Function):
     def backward(ctx, g_user, g_item):
         eng = ctx.enc._engine()
         G = torch.cat([g_user, g_item], 0).contiguous()
+        sink = getattr(ctx.enc, '_adj_sink', None)
+        if sink is not None:            # train(requires_adjgrad=True): every forward through the adjacency leaves its share of sparse_norm_adj.grad here
+            eng.adjacency_gradient(G, out=sink, noises=ctx.noises, eps=ctx.enc.eps)
         dE0 = eng.backward_to_table(G).clone()
         U = g_user.shape[0]
         return dE0[:U], dE0[U:], None, None
@@ -305,6 +308,7 @@ class GraphEncoder(nn.Module):
         st = dict(self.__dict__)
         st['_eng'] = None
         st.pop('_arl_inc', None)
+        st.pop('_adj_sink', None)
         return st
 
 
@@ -313,6 +317,7 @@ class Recommender:
     print_every = 1000
     has_extra_loss = False
     fused_extra_loss = False      # the model's extra loss has a fused engine step (SimGCL)
+    adjgrad_through_views = False # train(requires_adjgrad=True) is covered although the loss has an extra term: that term's forwards also run through _Propagate (SimGCL)
     train_forward_perturbed = False   # the training forward is model(True) and hands extra outputs to _extra_loss (XSimGCL)
 
     @staticmethod
@@ -415,8 +420,8 @@ class Recommender:
         if requires_adjgrad:
             # recommender/LightGCN.py:41-43: sparse_norm_adj.requires_grad = True, Matgrad = zeros(N, N).  The gradient of a sparse operand lives on its
             # stored entries, so Matgrad is kept as one value per entry of the pattern (CSR order) instead of N x N.
-            if self.has_extra_loss:
-                raise NotImplementedError('requires_adjgrad is implemented for the BPR + L2 loss (LightGCN, NGCF)')
+            if self.has_extra_loss and not self.adjgrad_through_views:
+                raise NotImplementedError('requires_adjgrad is implemented for LightGCN, NGCF and SimGCL')
             self._adjgrad_begin(model)
             adj = model.sparse_norm_adj
             adj.requires_grad = True
@@ -447,9 +452,12 @@ class Recommender:
                     pass
                 batches = ()
             else:
-                batches = device_epoch(self.data, self.args.batch_size, DEVICE, U, I)
+                samp = {}
+                batches = device_epoch(self.data, self.args.batch_size, DEVICE, U, I, stats=samp)
             it = iter(batches)
-            first = next(it, None)                                   # the epoch's shuffle + negatives are drawn here (host), before the loop clock starts
+            t_first = time.perf_counter()
+            first = next(it, None)                                   # the epoch's shuffle + the first chunk of negatives (host); later chunks are drawn behind the GPU steps
+            t_first = time.perf_counter() - t_first
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
             t_loop, n_done = time.perf_counter(), 0
@@ -500,7 +508,13 @@ class Recommender:
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
             # wall clock of the epoch's batch loop alone (sampler draw, evaluation and the epoch-end forward excluded)
-            self.last_train_stats = {'steps': n_done, 'loop_seconds': time.perf_counter() - t_loop, 'fused': eng is not None}
+            # wall clock of the epoch's batch loop (evaluation and the epoch-end forward excluded).  The loop INCLUDES whatever time it waited for the
+            # sampler's producer thread; the serial prologue (epoch shuffle + first chunk) is reported beside it
+            self.last_train_stats = {'steps': n_done, 'loop_seconds': time.perf_counter() - t_loop, 'fused': eng is not None, 'first_batch_seconds': t_first}
+            if hasattr(batches, 'close'):
+                batches.close()                                      # lets the producer finish the epoch's RNG stream and writes Python's `random` state back
+            if not inert:
+                self.last_train_stats.update({'sampler_' + k: v for k, v in samp.items()})
             if eng is not None:
                 self._sync_optimizer_step(eng, optimizer, fused_kind)
             model.eval()
@@ -519,16 +533,22 @@ class Recommender:
             return self.user_emb, self.item_emb, self.usergrad, self.itemgrad
 
     def _adjgrad_begin(self, model):
-        """Prepare the encoder for train(requires_adjgrad=True); the base form covers the LightGCN propagation (mean over layers 0..L)."""
-        if type(model).forward is not GraphEncoder.forward or getattr(model, 'skip_layer0', False):
-            raise NotImplementedError('requires_adjgrad is implemented for the LightGCN and NGCF propagations')
+        """Prepare the encoder for train(requires_adjgrad=True).  The base form covers every encoder whose forwards all run through _Propagate
+        (GraphEncoder.forward: LightGCN's mean over layers 0..L, SimGCL's clean pass and perturbed views over layers 1..L): each backward of such a
+        forward adds its share of the adjacency's gradient to the encoder's sink (engine.adjacency_gradient)."""
+        if type(model).forward is not GraphEncoder.forward:
+            raise NotImplementedError('requires_adjgrad is implemented for the LightGCN, NGCF and SimGCL propagations')
+        nnz = model._engine().A.col.numel()
+        model._adj_sink = torch.zeros(nnz, dtype=torch.float32, device=DEVICE)
 
     def _adjgrad_end(self, model):
-        pass
+        model._adj_sink = None
 
     def _adjgrad_step(self, model, g_user, g_item):
-        """One step's gradient on the adjacency's stored entries (CSR order) from the gradient of the loss w.r.t. the propagated tables."""
-        return model._engine().adjacency_gradient(torch.cat([g_user, g_item], 0))
+        """One step's gradient on the adjacency's stored entries (CSR order): what the step's backward passes left in the sink."""
+        out = model._adj_sink.clone()
+        model._adj_sink.zero_()
+        return out
 
     def _adjgrad_block(self, adj):
         """(Matgrad + Matgrad.T)[:U, U:] of recommender/LightGCN.py:74-80 from the per-entry Matgrad: the value on (u, U + i) plus the value on its

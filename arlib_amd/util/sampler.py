@@ -185,15 +185,9 @@ def _shadow(data):
     return sh
 
 
-def next_batch_pairwise(data, batch_size, whole_epoch=False):
-    """Generator with the reference's signature and semantics (util/sampler.py:4-30): shuffles
-    data.training_data in place, then yields (u_idx, i_idx, j_idx) per batch -- here int32 numpy arrays
-    (index a tensor with them exactly as with the reference's Python lists).
-
-    whole_epoch=True draws the negatives of ALL batches in one native call right after the shuffle.  The numbers are the
-    same (the stream is consumed sample by sample either way); what changes is WHEN Python's `random` state advances -- at
-    once instead of batch by batch -- so it is only for loops that do not touch `random` between batches (our own training
-    loops).  It removes the per-batch getstate/setstate round trip (~0.2 ms per batch)."""
+def _begin_epoch(data):
+    """The epoch's in-place shuffle (util/sampler.py:9) on the int image, with the Python list / ratings kept in the same order.  Returns
+    (sampler, mt): `mt` = the RNG state AFTER the shuffle, not yet written back to Python's `random`."""
     track = None
     if hasattr(data, 'pair_sampler'):               # array-native data (synthetic.InteractionData, DataLoader.ArrayDataLoader)
         sh = data.pair_sampler
@@ -207,15 +201,28 @@ def next_batch_pairwise(data, batch_size, whole_epoch=False):
     sh.shuffle(mt, also=order if track is None else track)
     if track is not None:
         data._permute_ratings(track[:, 0])
-    if whole_epoch and sh.nnz:
-        allb = sh.batch(mt, 0, sh.nnz)
-    mt.to_python()
     if order is not None:                            # keep the Python list in the same (shuffled) order: in-place carry-over
         if hasattr(data, '_defer_td_permutation'):
             data._defer_td_permutation(order[:, 0])  # applied when somebody reads data.training_data
         else:
             td = data.training_data
             td[:] = [td[k] for k in order[:, 0]]
+    return sh, mt
+
+
+def next_batch_pairwise(data, batch_size, whole_epoch=False):
+    """Generator with the reference's signature and semantics (util/sampler.py:4-30): shuffles
+    data.training_data in place, then yields (u_idx, i_idx, j_idx) per batch -- here int32 numpy arrays
+    (index a tensor with them exactly as with the reference's Python lists).
+
+    whole_epoch=True draws the negatives of ALL batches in one native call right after the shuffle.  The numbers are the
+    same (the stream is consumed sample by sample either way); what changes is WHEN Python's `random` state advances -- at
+    once instead of batch by batch -- so it is only for loops that do not touch `random` between batches (our own training
+    loops).  It removes the per-batch getstate/setstate round trip (~0.2 ms per batch)."""
+    sh, mt = _begin_epoch(data)
+    if whole_epoch and sh.nnz:
+        allb = sh.batch(mt, 0, sh.nnz)
+    mt.to_python()
     b = 0
     while b < sh.nnz:
         cnt = min(batch_size, sh.nnz - b)
@@ -231,22 +238,115 @@ def next_batch_pairwise(data, batch_size, whole_epoch=False):
         yield out[0], out[1], out[2]
 
 
-def device_epoch(data, batch_size, device, n_users=None, n_items=None):
-    """One epoch of next_batch_pairwise(whole_epoch=True) as DEVICE int32 tensors: the epoch's [3, nnz] index image is range-
-    checked and uploaded once, the batches are views of it (three small pageable host-to-device copies per step cost more than
-    the step itself on mid-size graphs).  Same caveat as whole_epoch: for loops that leave Python's `random` alone."""
+EPOCH_CHUNK_BATCHES = 512        # batches per chunk of device_epoch's producer
+
+
+def device_epoch(data, batch_size, device, n_users=None, n_items=None, chunk_batches=None, stats=None):
+    """One epoch of next_batch_pairwise as DEVICE int32 tensors, the sampler running BEHIND the consumer: the epoch's shuffle is the only
+    serial part; the negatives are then drawn in chunks of `chunk_batches` batches by ONE producer thread (the MT state is single-owner; the
+    native call releases the GIL), range-checked, staged in one of two pinned host buffers and copied to their slice of the epoch's [3, nnz]
+    device image on a copy stream of their own -- while the consumer's GPU steps run on the chunks already there.  The consumer's stream waits
+    for a chunk's copy event, never the host for the device.  The numbers are those of the reference's generator (util/sampler.py:4-30: the
+    stream is consumed sample by sample in the same order); Python's `random` state is written back when the generator ends or is closed --
+    having consumed the WHOLE epoch, also after an early close -- so, as with whole_epoch=True, this is for loops that leave `random` alone
+    between batches (our training loops).  stats (optional dict): 'first_batch_seconds' = shuffle + first chunk, 'chunks', 'producer_seconds'."""
+    import queue
+    import threading
+    import time
     import torch
-    parts = list(next_batch_pairwise(data, batch_size, whole_epoch=True))
-    if not parts:
+    t_begin = time.perf_counter()
+    sh, mt = _begin_epoch(data)
+    nnz = sh.nnz
+    if nnz == 0:
+        mt.to_python()
         return
-    u = np.concatenate([b[0] for b in parts]); p = np.concatenate([b[1] for b in parts]); n = np.concatenate([b[2] for b in parts])
-    if n_users is not None and (int(u.max()) >= n_users or int(u.min()) < 0):
-        raise IndexError('sampler produced a user index outside the embedding table')
-    if n_items is not None and (int(max(p.max(), n.max())) >= n_items or int(min(p.min(), n.min())) < 0):
-        raise IndexError('sampler produced an item index outside the embedding table')
-    dev = torch.from_numpy(np.stack([u, p, n])).to(device)
-    b = 0
-    for part in parts:
-        cnt = len(part[0])
-        yield dev[0, b:b + cnt], dev[1, b:b + cnt], dev[2, b:b + cnt]
-        b += cnt
+    dev = torch.device(device)
+    cuda = dev.type == 'cuda'
+    if cuda and dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    B = int(batch_size)
+    n_batches = (nnz + B - 1) // B
+    cb = int(chunk_batches or EPOCH_CHUNK_BATCHES)
+    n_chunks = (n_batches + cb - 1) // cb
+    image = torch.empty(3, nnz, dtype=torch.int32, device=dev)
+    span = min(cb * B, nnz)
+    stage = [torch.empty(3, span, dtype=torch.int32, pin_memory=cuda) for _ in range(min(2, n_chunks))]
+    side = torch.cuda.Stream(device=dev) if cuda else None
+    if cuda:
+        # the image's block may be one the consumer's stream is still reading under its previous owner (the last steps of the previous epoch
+        # read THAT epoch's image): uploads start behind everything the consumer has enqueued so far, and the block is not handed out again
+        # before the copy stream is done with it
+        side.wait_stream(torch.cuda.current_stream(dev))
+        image.record_stream(side)
+    copied = [None] * len(stage)                      # event of the last copy out of each staging buffer
+    ready = queue.Queue()
+    cancel = threading.Event()                        # (never skips sampling: the RNG stream must end where the reference's does)
+    t_prod = [0.0]
+
+    def produce():
+        try:
+            if cuda:
+                torch.cuda.set_device(dev)
+            for c in range(n_chunks):
+                t0 = time.perf_counter()
+                b0 = c * cb * B
+                cnt = min(cb * B, nnz - b0)
+                buf = stage[c % len(stage)]
+                if copied[c % len(stage)] is not None:
+                    copied[c % len(stage)].synchronize()          # the copy that last read this staging buffer (blocks the producer only)
+                out = buf.numpy()[:, :cnt] if cnt == span else np.empty((3, cnt), np.int32)
+                sh.batch(mt, b0, cnt, out=out)
+                if n_users is not None and (int(out[0].max()) >= n_users or int(out[0].min()) < 0):
+                    raise IndexError('sampler produced a user index outside the embedding table')
+                if n_items is not None and (int(out[1:].max()) >= n_items or int(out[1:].min()) < 0):
+                    raise IndexError('sampler produced an item index outside the embedding table')
+                if cnt != span:
+                    buf.numpy()[:, :cnt] = out
+                ev = None
+                if not cancel.is_set():                           # a closed consumer needs no more uploads
+                    if cuda:
+                        with torch.cuda.stream(side):
+                            image[:, b0:b0 + cnt].copy_(buf[:, :cnt], non_blocking=True)
+                            ev = side.record_event()
+                        copied[c % len(stage)] = ev
+                    else:
+                        image[:, b0:b0 + cnt].copy_(buf[:, :cnt])
+                t_prod[0] += time.perf_counter() - t0
+                ready.put((c, ev))
+            ready.put(('done', None))
+        except BaseException as e:                                # surfaces in the consumer
+            ready.put(('error', e))
+
+    def drain():
+        """Let the producer finish the epoch (the RNG stream's end point), then hand the state back to Python's `random`."""
+        if th is not None:
+            cancel.set()
+            th.join()
+        mt.to_python()
+        if stats is not None:
+            stats['producer_seconds'] = t_prod[0]
+            stats['chunks'] = n_chunks
+
+    th = None
+    try:
+        if n_chunks == 1:
+            produce()                                             # small epochs: no thread
+        else:
+            th = threading.Thread(target=produce, name='arl-sampler', daemon=True)
+            th.start()
+        b = 0
+        for c in range(n_chunks):
+            tag, ev = ready.get()
+            if tag == 'error':
+                raise ev
+            if ev is not None:
+                torch.cuda.current_stream(dev).wait_event(ev)     # the consumer's stream, not the host, waits for the upload
+            if c == 0 and stats is not None:
+                stats['first_batch_seconds'] = time.perf_counter() - t_begin
+            end = min(b + cb * B, nnz)
+            while b < end:
+                cnt = min(B, nnz - b)
+                yield image[0, b:b + cnt], image[1, b:b + cnt], image[2, b:b + cnt]
+                b += cnt
+    finally:
+        drain()

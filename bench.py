@@ -48,7 +48,8 @@ def parse():
     ap.add_argument('--clear-steps', type=int, default=15, help='CLeaR surrogate steps to time at N=1 (median and spread are printed)')
     ap.add_argument('--schedule', default='auto', choices=['auto', 'csr', 'blocked'], help='full-graph hop schedule (engine.PropagationEngine)')
     ap.add_argument('--repeats', type=int, default=3, help='timed regions of K steps each: the first is the contract figure (`value`), all are listed with median and spread')
-    ap.add_argument('--api-steps', type=int, default=200, help='steps of LightGCN(args, DataLoader).train() to time through the class API at N=1 (0 disables)')
+    ap.add_argument('--api-steps', type=int, default=600, help='steps of LightGCN(args, DataLoader).train() to time through the class API at N=1 (0 disables)')
+    ap.add_argument('--model-steps', type=int, default=20, help='steps of the SimGCL (L=2) and NGCF (d=128, L=3) training steps to time at N=1 on the same graph (0 disables)')
     ap.add_argument('--l2-ceiling', type=int, default=1, help='measure the hop with every gather an L2 hit (roofline.attainable); 0 disables')
     ap.add_argument('--dense-step', action='store_true', help='time the reference-shaped step (all 2L hops on the full graph) as the main number')
     return ap.parse_args()
@@ -217,11 +218,21 @@ def attack_leg(torch, ops, data, E0_dev, args):
     Pu_all, Pi_all = out[:U + F].contiguous(), out[U + F:].contiguous()
     ops.score_mask_topk(Pu_all[:256].contiguous(), Pi_all, 50)      # first call of the process: code-object load of the kernel and of torch's sort (not timed)
     topk_all = []
+    ops.TOPK_STATS['record_exit'], ops.TOPK_STATS['exit'] = True, []      # early-exit counters of every pass (16-byte device copies; read after the timing)
     for _ in range(3):                               # three passes (the GPU has idled through the host-side set-up above: the first one also pays the clock ramp)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         top_idx, _ = ops.score_mask_topk(Pu_all, Pi_all, 50)
         torch.cuda.synchronize(); topk_all.append(time.perf_counter() - t1)
     topk_s = sorted(topk_all)[1]                     # the median is the figure
+    skipped_trained = ops.topk_exit_fractions()
+    # the same pass on RANDOM tables of the same shape (no norm structure: the exit bound never holds, expected share skipped = 0)
+    gr = torch.Generator(device=E0_dev.device).manual_seed(args.seed)
+    Ru = torch.randn(Pu_all.shape, generator=gr, device=E0_dev.device); Ri = torch.randn(Pi_all.shape, generator=gr, device=E0_dev.device)
+    ops.score_mask_topk(Ru, Ri, 50); torch.cuda.synchronize(); t1 = time.perf_counter()
+    ops.score_mask_topk(Ru, Ri, 50); torch.cuda.synchronize(); topk_random_s = time.perf_counter() - t1
+    skipped_random = ops.topk_exit_fractions()
+    ops.TOPK_STATS['record_exit'] = False
+    del Ru, Ri
     del Pu_all, Pi_all
     M = cw_operator(U + F + I, U + F, *cw_pairs(top_idx, U, targets, pop=True), device=E0.device)
 
@@ -265,6 +276,9 @@ def attack_leg(torch, ops, data, E0_dev, args):
                                              'note': 'fp16 matrix flops executed by the stream: ONE fp16 product per (user, item, k) -- the high pieces; the two other products of '
                                                      'the split form run only for queued candidates (a 16 x 16 tile per merge) and are not counted; dense fp16/bf16 MFMA peak. '
                                                      'The pass is bound by its ring / candidate handling, not by the matrix pipe (DESIGN 3b)'},
+                                'stages_skipped_frac': {'trained_propagated_tables': skipped_trained, 'random_tables': skipped_random,
+                                                        'what': 'share of (workgroup, 64-item stage) pairs of the norm-ordered item stream the exact early exit never scored'},
+                                'random_tables_seconds': topk_random_s,
                                 'note': '`tflops` = fp32-equivalent (2 U I d); once per inner epoch, not per step'},
             'setup_seconds': setup_s}
 
@@ -324,12 +338,14 @@ def clear_leg(torch, ops, data, A, E0_dev, args):
     # host thread wakes up after a 45 ms kernel: 58 ms per step on some boxes, 80-100 ms in 10 ms quanta on others, with the same device-side spans.)
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
     ops.TOPK_STATS['record_events'], ops.TOPK_STATS['events'], ops.TOPK_STATS['flags'] = True, [], []      # device-side span of every scoring pass of the timed steps
+    ops.TOPK_STATS['record_exit'], ops.TOPK_STATS['exit'] = True, []
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for k in range(n):
         cw, sfa = step(evs[k])
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    ops.TOPK_STATS['record_events'] = False
+    ops.TOPK_STATS['record_events'] = ops.TOPK_STATS['record_exit'] = False
+    skipped = ops.topk_exit_fractions()
     topk_dev = [a.elapsed_time(b) for a, b in ops.TOPK_STATS.pop('events', [])]
     cold_repeats = int(sum(int(f) != 0 for f in ops.TOPK_STATS.pop('flags', [])))
     per = [evs[k][0].elapsed_time(evs[k + 1][0]) * 1e-3 for k in range(n - 1)] + [evs[n - 1][0].elapsed_time(evs[n - 1][2]) * 1e-3]      # step start to next step start
@@ -337,7 +353,7 @@ def clear_leg(torch, ops, data, A, E0_dev, args):
     return {'metric': 'attack-grad steps/sec (CLeaR surrogate step: CW + SFA, LightGCN d=%d L=%d)' % (d, L), 'value': 1.0 / dt, 'unit': 'steps/s',
             'ms_per_step': 1e3 * dt, 'steps_timed': n, 'ms_per_step_median': 1e3 * float(np.median(per)), 'ms_per_step_min': 1e3 * min(per), 'ms_per_step_max': 1e3 * max(per),
             'ms_per_step_all': [round(1e3 * x, 2) for x in per], 'topk_device_ms_all': [round(x, 2) for x in topk_dev], 'topk_device_ms_median': float(np.median(topk_dev)) if topk_dev else None,
-            **({'trace_cw_sfa_umax_imax': trace} if trace else {}), 'topk_cold_repeats': cold_repeats,
+            **({'trace_cw_sfa_umax_imax': trace} if trace else {}), 'topk_cold_repeats': cold_repeats, 'topk_stages_skipped_frac_all': [round(x, 4) for x in skipped],
             'ms_forward_topk_loss': float(np.mean(fwd)), 'targets': 5, 'pairs': U * 5,
             'cw_loss': float(cw), 'sfa_loss': float(sfa), 'score_flops_per_step': 2.0 * U * I * d,
             'timing': '`ms_per_step` = wall clock over the %d steps between two device synchronisations / %d; per-step figures = HIP events at the step boundaries on the launch stream' % (n, n),
@@ -372,6 +388,59 @@ def ncl_structure_leg(torch, E0_dev, args, reps=10):
     return out
 
 
+def model_legs(torch, ops, engine, data, A, dev_batches, args, steps=20):
+    """Driver-visible steps of BASELINE configs 4 and 5 on ONE GPU, same cfg2 graph and batches as the headline:
+      simgcl_step -- SimGCL (recommender/SimGCL.py:51-70,198-219): three forwards (clean + two perturbed views, noise drawn inside the perturbation
+                     kernel), BPR + L2 + InfoNCE at the batch's unique users / positive items, one backward, dense Adam; L = 2 (the reference hard-codes it, Q14);
+      ngcf_step   -- NGCF d = 128, L = 3 (recommender/NGCF.py:47-64,197-212): per layer one hop + the fp32-MFMA dense part, BPR + L2, backward, Adam on
+                     both tables and the 2L weight matrices.
+    Algorithmic bytes per step (E = 2 nnz, N = U + I): SimGCL `3 L (16E + 8N + 24Nd) + 28Nd + 24Bd + 16 n^2` (n = batch size as the bound on the unique
+    rows); NGCF `L (2 (8E + 4N + 8Nd) + 52Nd) + 28Nd + 24Bd` (per layer: the hop forward and backward, the dense part's 12Nd forward + 28Nd dgrad + 12Nd wgrad)."""
+    U, I, nnz = data.training_size()
+    N, E, B = U + I, 2 * nnz, args.batch
+    dev = dev_batches.device
+    out = {}
+    g = torch.Generator().manual_seed(args.seed)
+
+    def run(step_fn):
+        for k in range(3):
+            step_fn(k)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for k in range(3, 3 + steps):
+            last = step_fn(k % dev_batches.shape[0])
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps, last
+
+    # ---- SimGCL, d = args.emb, L = 2
+    d, L = args.emb, 2
+    E0 = torch.cat([torch.nn.init.xavier_uniform_(torch.empty(U, d), generator=g), torch.nn.init.xavier_uniform_(torch.empty(I, d), generator=g)], 0).to(dev)
+    eng = engine.PropagationEngine(A, U, I, d, L, 1e-4, 0.005, dev, skip_layer0=True, table=E0)
+    dt, last = run(lambda k: eng.step_simgcl(dev_batches[k, 0], dev_batches[k, 1], dev_batches[k, 2]))
+    by = 3 * L * (16 * E + 8 * N + 24 * N * d) + 28 * N * d + 24 * B * d + 16 * B * B
+    out['simgcl_step'] = {'metric': 'BPR-train interactions/sec (SimGCL d=%d L=%d: 3 forwards + InfoNCE + Adam, B=%d)' % (d, L, B), 'value': B / dt, 'unit': 'interactions/s',
+                          'ms_per_step': 1e3 * dt, 'steps_timed': steps, 'algorithmic_bytes_per_step': by, 'hbm_frac': by / dt / 1e9 / HBM_PEAK_GBS,
+                          'rec_loss': float(last[0][0] + last[0][1]), 'cl_loss': float(last[1]),
+                          'note': 'cfg2 graph; noise drawn in the perturbation kernel (the reference draws rand_like per hop and view); the shared first hop, row-subset last '
+                                  'hops and the single backward pass make it 2 full hops + 1 masked + 3 row-subset hops instead of 12 full hops'}
+    del eng, E0
+    torch.cuda.empty_cache()
+    # ---- NGCF, d = 128, L = 3
+    d, L = 128, 3
+    E0 = torch.cat([torch.nn.init.xavier_uniform_(torch.empty(U, d), generator=g), torch.nn.init.xavier_uniform_(torch.empty(I, d), generator=g)], 0).to(dev)
+    eng = engine.PropagationEngine(A, U, I, d, L, 1e-4, 0.005, dev, table=E0)
+    eng.init_ngcf([(torch.nn.init.xavier_uniform_(torch.empty(d, d), generator=g).to(dev), torch.nn.init.xavier_uniform_(torch.empty(d, d), generator=g).to(dev)) for _ in range(L)])
+    rows = torch.cat([dev_batches[:, 0], dev_batches[:, 1] + U, dev_batches[:, 2] + U], 1).contiguous()
+    dt, last = run(lambda k: eng.step_ngcf(dev_batches[k, 0], dev_batches[k, 1], dev_batches[k, 2], rows=rows[k]))
+    by = L * (2 * (8 * E + 4 * N + 8 * N * d) + 52 * N * d) + 28 * N * d + 24 * B * d
+    out['ngcf_step'] = {'metric': 'BPR-train interactions/sec (NGCF d=%d L=%d + BPR/L2 + Adam, B=%d)' % (d, L, B), 'value': B / dt, 'unit': 'interactions/s',
+                        'ms_per_step': 1e3 * dt, 'steps_timed': steps, 'algorithmic_bytes_per_step': by, 'hbm_frac': by / dt / 1e9 / HBM_PEAK_GBS,
+                        'loss': float(last[0] + last[1]), 'peak_memory_GB': torch.cuda.max_memory_allocated() / 1e9,
+                        'note': 'cfg2 graph at the width of BASELINE config 5 (d = 128); fused route (engine.step_ngcf): no autograd, no torch optimizer'}
+    del eng, E0, rows
+    torch.cuda.empty_cache()
+    return out
+
+
 def class_api_leg(torch, data, args, engine_ms):
     """The same training step through the reference's class surface: LightGCN(args, DataLoader).train(Epoch=1) on the same graph
     (recommender/LightGCN.py:17-80), array-native DataLoader, the drop-in sampler drawing the epoch from Python's RNG, the fused engine
@@ -402,11 +471,22 @@ def class_api_leg(torch, data, args, engine_ms):
         epoch_wall = time.perf_counter() - t2
     st = rec.last_train_stats
     ms = 1e3 * st['loop_seconds'] / max(1, st['steps'])
+    # End-to-end epoch figure, sampler INSIDE the clock (reference step = sampler + forward/backward/Adam, recommender/LightGCN.py:47-64): the epoch's
+    # serial sampler part (in-place shuffle + first chunk of negatives, measured) + every batch at the measured loop pace -- the loop's clock holds whatever
+    # time the steps waited for the producer thread that draws the later chunks behind the GPU (util/sampler.device_epoch)
+    n_epoch = -(-len(p) // args.batch)
+    epoch_s = st['first_batch_seconds'] + n_epoch * st['loop_seconds'] / max(1, st['steps'])
     return {'what': 'LightGCN(args, DataLoader.from_arrays(...)).train(Epoch=1) on the same cfg2 graph, first %d batches of the epoch' % st['steps'],
             'ms_per_step': ms, 'value': args.batch * st['steps'] / st['loop_seconds'], 'unit': 'interactions/s', 'steps': st['steps'], 'fused_engine': st['fused'],
             'engine_step_ms': engine_ms, 'gap_vs_engine_step': ms / engine_ms - 1.0,
             'dataloader_build_seconds': build_s, 'model_init_seconds': init_s,
-            'train_call_wall_seconds': epoch_wall, 'note': 'train() wall also holds the epoch shuffle + all negatives of the epoch (host, one native call) and the epoch-end full forward'}
+            'epoch_wall_interactions_per_s': len(p) / epoch_s,
+            'epoch_wall': {'seconds_per_epoch': epoch_s, 'batches_per_epoch': n_epoch, 'serial_sampler_seconds': st['first_batch_seconds'],
+                           'producer_thread_seconds_whole_epoch': st.get('sampler_producer_seconds'), 'chunks': st.get('sampler_chunks'),
+                           'how': 'serial_sampler_seconds (measured: epoch shuffle + first chunk) + batches_per_epoch x measured loop pace over %d steps; the '
+                                  'negatives of later chunks are drawn by one host thread while the GPU steps run (the loop pace includes any wait for it)' % st['steps']},
+            'train_call_wall_seconds': epoch_wall, 'note': 'train() wall also holds the epoch shuffle, the wait for the producer to finish the WHOLE epoch\'s negatives '
+                                                           '(the loop stops after %d of %d batches) and the epoch-end full forward' % (st['steps'], n_epoch)}
 
 
 def self_launch(n, result_out):
@@ -655,7 +735,15 @@ def main():
                                    'schedule': 'blocked' if A.blocked is not None else 'csr',
                                    'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': spmm_bytes,
                                    'per_variant_ms': {k: v[0] for k, v in evs.items()},
-                                   'gather_model_bytes_per_launch': E * (8 + 4 * d) + 4 * N * d}
+                                   'gather_model_bytes_per_launch': E * (8 + 4 * d) + 4 * N * d,
+                                   # ceilings from the chip's own figures (MI355X_MICROARCH.md), independent of this implementation: a pull SpMM moves one
+                                   # 4d-byte row per edge through the vector L1s whatever the HBM-side traffic
+                                   'chip_ceilings': {'row_gather_bytes_per_launch': E * 4 * d,
+                                                     'ms_at_L2_peak_34.5TBs': E * 4 * d / 34.5e12 * 1e3,
+                                                     'ms_at_guide_L2_resident_row_gather_16.8_to_18.8TBs': [E * 4 * d / 18.8e12 * 1e3, E * 4 * d / 16.8e12 * 1e3],
+                                                     'ms_for_measured_fabric_traffic_at_6.3TBs_achievable_HBM': (traffic / 6.3e12 * 1e3) if traffic else None,
+                                                     'frac_of_peak_if_at_guide_gather_rate': spmm_bytes / (E * 4 * d / 16.8e12) / 1e9 / HBM_PEAK_GBS,
+                                                     'note': '`attainable` above is THIS kernel with every gather an L2 hit; these are the guide\'s rates for the same bytes'}}
             else:
                 res['spmm_events_ms'] = {k: v[0] for k, v in evs.items()}
         if comm_info is not None:
@@ -687,6 +775,10 @@ def main():
         if not sharded and args.attack_steps > 0 and d in (16, 32, 64, 128):
             torch.cuda.empty_cache()
             res['ncl_structure_term'] = ncl_structure_leg(torch, E0_snapshot, args)
+        if not sharded and args.model_steps > 0 and args.emb in (64, 128):
+            E0_snapshot = None
+            torch.cuda.empty_cache()
+            res.update(model_legs(torch, ops, engine, data, eng.A, dev_batches, args, steps=args.model_steps))
         if not sharded and args.api_steps > 0:
             torch.cuda.empty_cache()
             res['class_api'] = class_api_leg(torch, data, args, float(np.median(region_s)) * 1e3 / args.steps)

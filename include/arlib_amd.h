@@ -148,7 +148,9 @@ int arl_zero_rows_f32(float *dst, const int32_t *idx, int64_t n, int64_t d, arl_
  * bit-identical from run to run.
  * dup_bits (optional, a second bitmap of the size of `bits`, all-zero on entry like `bits`): a first launch records in it the rows the list
  * names more than once, so that only those are summed by the ordered scan and every other row is a plain add (44 -> ~10 us at cfg2); the
- * clearing call takes the same pointer and zeroes it again. */
+ * clearing call takes the same pointer and zeroes it again.
+ * An entry with row_scale[t] == 0 is ABSENT: nothing is added, its row is neither flagged nor marked nor counted as a duplicate (the user-sharded
+ * step gives foreign samples factor 0 on a clamped row to keep static shapes: they must not pile up on that row). */
 int arl_batch_rows_set_f32(float *G, uint8_t *flags, uint32_t *bits, const int32_t *idx, int64_t n, int64_t d,
                            const float *src, float scale, const float *row_scale, uint32_t *dup_bits, arl_stream_t stream);
 int arl_batch_rows_clear_f32(float *G, uint8_t *flags, uint32_t *bits, const int32_t *idx, int64_t n, int64_t d,
@@ -411,8 +413,14 @@ int arl_pga_update_f32(float *S, const float *grad, const float *dinv_rows, cons
  * item_order (optional, used on the fp16 matrix path; a permutation of [0, I)): the items are STREAMED in this order instead of table
  * order -- typically by descending row norm, so that the items most users rank high come first and the thresholds rise early (6-20 %
  * less time at 1 M x 100 K).  Masks, warm_idx, top_idx and the tie order (lower item id first) are in item ids as always: the result is
- * the one of the table order, bit for bit. */
+ * the one of the table order, bit for bit.
+ * Early exit (fp16 matrix path): with the stream in descending row-norm order a workgroup stops streaming once, for each of its users,
+ * |a_u| * (largest norm of any later item) lies below the user's current k-th best score by more than the pre-filter's slack (Cauchy-Schwarz:
+ * no later item can enter a list) -- the stages skipped cannot change the result, which stays that of the full stream bit for bit.  What was
+ * skipped is readable after the pass: two uint64 counters at byte arl_score_mask_topk_stats_offset(I, d) of the workspace,
+ * [stream stages consumed summed over workgroups, workgroups]. */
 int64_t arl_score_mask_topk_workspace_bytes(int64_t I, int64_t d);
+int64_t arl_score_mask_topk_stats_offset(int64_t I, int64_t d);
 int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t I, int64_t d,
                             const int32_t *mask_rowptr, const int32_t *mask_col, int64_t k, int32_t *top_idx,
                             float *top_val, void *workspace, const int32_t *warm_idx, int32_t *underflow,
@@ -464,7 +472,8 @@ int arl_normalize_rows_bwd_f32(const float *Y, const float *nrm, const float *dY
 typedef void *arl_comm_t;
 int arl_comm_load(const char *rccl_path);
 int arl_comm_unique_id(void *id128);
-int arl_comm_init(const void *id128, int64_t rank, int64_t world, arl_comm_t *out);
+/* device: HIP device index the communicator binds to (made current for the call and restored); < 0 = the calling thread's current device */
+int arl_comm_init(const void *id128, int64_t rank, int64_t world, int64_t device, arl_comm_t *out);
 int arl_comm_destroy(arl_comm_t comm);
 int arl_item_exchange_range(int64_t n_elems, int64_t world, int64_t n_chunks, int64_t shard, int64_t chunk, int64_t *lo, int64_t *hi);
 int64_t arl_allreduce_item_workspace_bytes(int64_t n_elems, int64_t world, int64_t n_chunks);

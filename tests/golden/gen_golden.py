@@ -1306,6 +1306,51 @@ def gen_adjgrad():
              item=rec.model.embedding_dict['item_emb'].detach().numpy().copy(), next_random=np.array([random.random()], np.float64), **extra)
 
 
+def gen_adjgrad_simgcl():
+    """Reference `SimGCL.train(requires_adjgrad=True)` (recommender/SimGCL.py:36-85): `sparse_norm_adj` takes gradient from all THREE forwards of a step
+    (the clean one and the two perturbed views of cal_cl_loss, :212-219; the perturbation itself carries none).  The views' noise is injected:
+    the k-th torch.rand_like call of the run returns torch.rand(N, d, generator=manual_seed(5000 + k)) -- the product's test regenerates the same
+    sequence instead of storing 88 tables.  Captured: the first step's gradient, the returned block after one epoch (22 steps, running-sum quirk as
+    in g21), the tables, the RNG stream."""
+    import io, contextlib
+    args = rec_args(emb_size=16, n_layers=2, model_name='SimGCL')
+    seedSet(2018)
+    data = DataLoader(args)
+    rec = SimGCL(args, data)
+    u0 = rec.model.embedding_dict['user_emb'].detach().numpy().copy(); i0 = rec.model.embedding_dict['item_emb'].detach().numpy().copy()
+    first, calls = {}, [0]
+    orig_backward, orig_rand_like = torch.Tensor.backward, torch.rand_like
+
+    def rand_like(x, *a, **k):
+        g = torch.Generator().manual_seed(5000 + calls[0])
+        calls[0] += 1
+        return torch.rand(x.shape, generator=g)
+
+    def backward_and_capture(self, *a, **k):
+        out = orig_backward(self, *a, **k)
+        if not first:
+            gr = rec.model.sparse_norm_adj.grad.coalesce()
+            first['idx'], first['val'] = gr.indices().numpy().copy(), gr.values().numpy().copy()
+        return out
+    torch.Tensor.backward, torch.rand_like = backward_and_capture, rand_like
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            block = rec.train(requires_adjgrad=True, Epoch=1, gradIterationNum=10, evalNum=1)
+    finally:
+        torch.Tensor.backward, torch.rand_like = orig_backward, orig_rand_like
+    U = data.user_num
+    N = U + data.item_num
+    M1 = sp.coo_matrix((first['val'], (first['idx'][0], first['idx'][1])), shape=(N, N)).tocsr()
+    B1 = (M1 + M1.T).tocsr()[:U, U:].tocoo()
+    block = block.detach().numpy()
+    r, c = np.nonzero(block)
+    save('g23_adjgrad_simgcl.npz', user0=u0, item0=i0, block_row=r.astype(np.int32), block_col=c.astype(np.int32), block_val=block[r, c].astype(np.float32),
+         first_row=B1.row.astype(np.int32), first_col=B1.col.astype(np.int32), first_val=B1.data.astype(np.float32),
+         block_shape=np.array(block.shape, np.int64), user=rec.model.embedding_dict['user_emb'].detach().numpy().copy(),
+         item=rec.model.embedding_dict['item_emb'].detach().numpy().copy(), next_random=np.array([random.random()], np.float64),
+         noise_calls=np.array([calls[0]], np.int64), noise_seed0=np.array([5000], np.int64))
+
+
 if __name__ == '__main__':
     only = set(sys.argv[1:])                          # e.g. `gen_golden.py xsimgcl` regenerates that fixture alone
     if only:
@@ -1335,6 +1380,8 @@ if __name__ == '__main__':
             gen_fake_rows()
         if 'adjgrad' in only:
             gen_adjgrad()
+        if 'adjgrad_simgcl' in only:
+            gen_adjgrad_simgcl()
         sys.exit(0)
     gen_dataset()
     data = gen_sampler()
@@ -1361,4 +1408,5 @@ if __name__ == '__main__':
     gen_victims()
     gen_fake_rows()
     gen_adjgrad()
+    gen_adjgrad_simgcl()
     print('done; scratch dir', SCRATCH)

@@ -39,6 +39,11 @@ def test_bench_json_contract_small_instance():
     assert r['cpu_baseline_torch']['value'] > 0 and r['cpu_baseline_torch']['steps_timed'] >= 1      # reference-shaped stock-PyTorch step, on by default
     assert 'traffic_source' in roof
     assert r['class_api']['steps'] == 5 and r['class_api']['fused_engine'] and r['class_api']['ms_per_step'] > 0
+    assert r['class_api']['epoch_wall_interactions_per_s'] > 0 and r['class_api']['epoch_wall']['serial_sampler_seconds'] > 0
+    for leg in ('simgcl_step', 'ngcf_step'):                      # BASELINE configs 4 and 5 on one GPU
+        assert r[leg]['value'] > 0 and r[leg]['algorithmic_bytes_per_step'] > 0 and 0 < r[leg]['hbm_frac'] < 1
+    sk = r['attack']['score_topk_pass']['stages_skipped_frac']
+    assert all(0.0 <= x <= 1.0 for x in sk['trained_propagated_tables'] + sk['random_tables'])
 
 
 def test_bench_gpus2_plain_invocation_self_launches():

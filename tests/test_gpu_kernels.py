@@ -351,6 +351,15 @@ def test_nce_allrows_against_float64(ops, nA, nV, d):
     assert rel_err(dA3.cpu().numpy(), (P @ V.double()).cpu().numpy()) < 1e-5 and torch.equal(dV3, dV)
     with pytest.raises(ValueError):
         ops.nce_allrows(A[:, :8].contiguous(), V[:, :8].contiguous(), tau)
+    # the kernels shift by the constant 1 (no running maximum): at the smallest temperature they accept, a batch row whose best cosine is NEGATIVE
+    # still has a finite log-sum-exp and finite gradients; anything smaller is refused (callers take the panel form with a running maximum)
+    Aneg = torch.nn.functional.normalize(-V[:nA if nA <= nV else nV].mean(0, keepdim=True).repeat(min(nA, 16), 1) + 0.01 * torch.randn(min(nA, 16), d, generator=g).to(DEV), dim=1).contiguous()
+    l4, dA4, dV4 = ops.nce_allrows(Aneg, V, ops.NCE_ALLROWS_MIN_TAU)
+    S4 = (Aneg.double() @ V.double().T) / ops.NCE_ALLROWS_MIN_TAU
+    assert float(S4.max()) < 0.5 / ops.NCE_ALLROWS_MIN_TAU and bool(torch.isfinite(l4).all()) and bool(torch.isfinite(dA4).all()) and bool(torch.isfinite(dV4).all())
+    assert float((l4.double() - torch.logsumexp(S4, dim=1)).abs().max()) < 1e-4
+    with pytest.raises(ValueError):
+        ops.nce_allrows(A, V, 0.01)
 
 
 @pytest.mark.parametrize('n,d', [(1000, 64), (37, 16), (513, 128), (90, 100), (5, 256)])
@@ -469,6 +478,37 @@ def test_ordered_accumulation_is_sequential_and_bit_exact(ops, n, d):
     assert np.array_equal(((dn[np.arange(N) >> 5] >> (np.arange(N) & 31)) & 1).astype(bool), cnt > 1)
     ops.batch_rows_clear_(G2, flags2, bits2, T(idx), dup_bits=dup)
     assert int(flags2.max()) == 0 and int(bits2.abs().max()) == 0 and int(dup.abs().max()) == 0
+
+
+def test_batch_rows_set_zero_factor_entries_are_absent(ops):
+    """The user-sharded step keeps static shapes by giving every foreign sample factor 0 on a clamped local row (arl_shard_batch_prep_i32): such entries
+    are ABSENT -- they add nothing, mark nothing, are no duplicates -- so ~7/8 of a batch's user entries at 8 ranks do not pile up on one row."""
+    rng = np.random.default_rng(5)
+    N, n, d = 300, 4096, 64
+    idx = rng.integers(1, N - 1, n).astype(np.int32)
+    rs = np.ones(n, np.float32)
+    foreign = rng.random(n) < 0.875
+    idx[foreign] = np.where(rng.random(int(foreign.sum())) < 0.5, 0, N - 1)         # clamped rows 0 and N - 1, named by foreign entries only
+    rs[foreign] = 0.0
+    src = rng.standard_normal((n, d)).astype(np.float32)
+    src[foreign] = np.nan                                                           # an absent entry's payload is never read into the sum
+    base = rng.standard_normal((N, d)).astype(np.float32)
+    own = ~foreign
+    want = _seq_add(base, idx[own], src[own], 0.5)
+    for with_dup in (False, True):
+        G = T(base.copy()); flags = torch.zeros(N, dtype=torch.uint8, device=DEV); bits = torch.zeros((N + 31) // 32, dtype=torch.int32, device=DEV)
+        dup = torch.zeros_like(bits) if with_dup else None
+        ops.batch_rows_set_(G, flags, bits, T(idx), T(src), 0.5, row_scale=T(rs), dup_bits=dup)
+        assert np.array_equal(G.cpu().numpy(), want)
+        wantf = np.zeros(N, np.uint8); wantf[idx[own]] = 1
+        assert np.array_equal(flags.cpu().numpy(), wantf) and wantf[0] == 0 and wantf[N - 1] == 0
+        bn = bits.cpu().numpy().view(np.uint32)
+        assert np.array_equal(((bn[np.arange(N) >> 5] >> (np.arange(N) & 31)) & 1).astype(np.uint8), wantf)
+        if with_dup:
+            dn = dup.cpu().numpy().view(np.uint32)
+            assert np.array_equal(((dn[np.arange(N) >> 5] >> (np.arange(N) & 31)) & 1).astype(bool), np.bincount(idx[own], minlength=N) > 1)
+        ops.batch_rows_clear_(G, flags, bits, T(idx), dup_bits=dup)
+        assert int(flags.max()) == 0 and int(bits.abs().max()) == 0
 
 
 def test_bpr_backward_ordered(ops):
@@ -699,6 +739,59 @@ def test_score_mask_topk_item_stream_order_is_result_neutral(ops, d, k, masked):
         assert torch.equal(i3, base_i) and torch.equal(v3, base_v)
     with pytest.raises(ValueError):
         ops.score_mask_topk(T(Pu), T(Pi), k, item_order=T(np.arange(5, dtype=np.int32)))
+
+
+@pytest.mark.parametrize('d,k,masked', [(64, 50, False), (64, 50, True), (128, 20, False)])
+def test_score_mask_topk_early_exit_is_exact_and_one_user_keeps_the_stream_alive(ops, d, k, masked):
+    """Exact early exit of the norm-ordered item stream (arl_kernels.hip: EXIT): a workgroup stops once |a_u| * (largest later item norm) is below
+    every one of its users' k-th best scores (Cauchy-Schwarz).  Items here fall steeply in norm and point along +e1, users along +e1: every
+    list is complete after the first few stages and most of the stream is skipped.  ONE user of the first workgroup points along -e1: its best
+    items are the 100 SMALLEST-norm items at the very end of the stream, so that workgroup must stream to the end -- and the user's list must
+    hold exactly those items.  Lists and values equal the table-order call's (no exit there) bit for bit and float64's."""
+    rng = np.random.default_rng(4100 + d + k + masked)
+    U, I = 700, 66000
+    e1 = np.zeros(d); e1[0] = 1.0
+    norms = np.concatenate([np.geomspace(8.0, 0.05, I - 100), np.full(100, 1e-3)])
+    sign = np.concatenate([np.ones(I - 100), -np.ones(100)])
+    Pi = (norms[:, None] * (sign[:, None] * e1[None, :] + 0.05 * rng.standard_normal((I, d)))).astype(np.float32)
+    Pi = Pi[rng.permutation(I)]                                  # table order is not norm order
+    Pu = (e1[None, :] + 0.05 * rng.standard_normal((U, d))).astype(np.float32)
+    lone = 37
+    Pu[lone] = (-e1 + 0.01 * rng.standard_normal(d)).astype(np.float32)
+    scores = Pu.astype(np.float64) @ Pi.astype(np.float64).T
+    rp = mc = None
+    if masked:
+        cols = [np.unique(np.concatenate([np.argsort(-scores[u])[:int(rng.integers(0, 20))], rng.choice(I, size=10, replace=False)])).astype(np.int32) for u in range(U)]
+        for u in range(U):
+            scores[u, cols[u]] = -10e8
+        rp = T(np.concatenate([[0], np.cumsum([len(c) for c in cols])]).astype(np.int32)); mc = T(np.concatenate(cols))
+    ridx = np.argsort(-scores, axis=1, kind='stable')[:, :k]
+    rval = np.take_along_axis(scores, ridx, 1)
+    small = set(np.nonzero(np.linalg.norm(Pi, axis=1) < 5e-3)[0].tolist())
+    assert set(ridx[lone].tolist()) <= small                      # the lone user's list = items of the stream's last two stages
+    ops.TOPK_STATS['record_exit'] = True; ops.TOPK_STATS['exit'] = []
+    try:
+        base_i, base_v = ops.score_mask_topk(T(Pu), T(Pi), k, rp, mc, item_order=None)        # table order: suffix maxima stay high, nothing is skipped
+        i2, v2 = ops.score_mask_topk(T(Pu), T(Pi), k, rp, mc, item_order='norm')
+        i3, v3 = ops.score_mask_topk(T(Pu), T(Pi), k, rp, mc, item_order='norm', warm_idx=base_i)
+        Pu2 = Pu.copy(); Pu2[lone] = Pu[lone + 1]
+        ops.score_mask_topk(T(Pu2), T(Pi), k, rp, mc, item_order='norm')                       # the same call without the lone user
+        frac = ops.topk_exit_fractions()
+    finally:
+        ops.TOPK_STATS['record_exit'] = False
+    assert torch.equal(i2, base_i) and torch.equal(v2, base_v) and torch.equal(i3, base_i) and torch.equal(v3, base_v)
+    idx, val = i2.cpu().numpy(), v2.cpu().numpy()
+    assert set(idx[lone].tolist()) == set(ridx[lone].tolist())
+    same = idx == ridx
+    assert same.mean() > 0.999
+    for r, c in np.argwhere(~same):
+        assert abs(rval[r, c] - val[r, c]) <= 2e-6 * max(abs(rval[r, c]), 1e-3)
+    assert np.abs(val[:, -1] - rval[:, -1]).max() <= 2e-6 * np.abs(rval[:, -1]).max()
+    n_wg = -(-U // (256 if d == 64 else 192))
+    assert frac[0] < 0.01                                          # table order: large items until the last stages, nothing to skip
+    # norm order with the lone user: its workgroup consumes every stage, the others leave early; without it all of them do
+    assert frac[1] > 0.5 * (n_wg - 1) / n_wg and frac[1] < (n_wg - 1) / n_wg + 1e-9, frac
+    assert frac[3] > frac[1] + 0.5 / n_wg and frac[3] > 0.8, frac
 
 
 @pytest.mark.parametrize('F,I,d', [(64, 100000, 64), (5, 777, 32), (130, 301, 128), (64, 1000, 16), (1, 4, 4), (7, 12345, 256)])

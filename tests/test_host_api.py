@@ -208,6 +208,38 @@ def test_whole_epoch_sampling_is_the_same_stream(ml100k):
     assert random.random() == float(g['next_random'][0])
 
 
+@pytest.mark.parametrize('chunk_batches', [None, 3, 1])
+def test_device_epoch_producer_thread_is_the_same_stream(ml100k, chunk_batches):
+    """device_epoch (what train() iterates): the epoch's negatives are drawn in chunks by a producer thread behind the consumer.  Same batches as the
+    reference's generator captured in g1 (two epochs, carry-over), Python's RNG left where the reference leaves it -- for one chunk (no thread), chunks of
+    3 batches and of 1 -- and also when the consumer stops after two batches: the producer still finishes the epoch's RNG stream."""
+    import torch
+    from arlib_amd.util.sampler import device_epoch
+    g = golden('g1_sampler.npz')
+    data = make_data()
+    random.seed(2018)
+    for ep in range(2):
+        st = {}
+        bs = list(device_epoch(data, 2048, 'cpu', ml100k['U'], ml100k['I'], chunk_batches=chunk_batches, stats=st))
+        assert [len(bs), len(bs[-1][0])] == list(g['ep%d_nb' % ep])
+        for k, key in enumerate(('u', 'p', 'n')):
+            assert np.array_equal(torch.cat([b[k] for b in bs]).numpy(), g['ep%d_%s' % (ep, key)])
+        assert st['chunks'] == (1 if chunk_batches is None else -(-len(bs) // chunk_batches)) and st['first_batch_seconds'] > 0
+    assert random.random() == float(g['next_random'][0])
+    # early close: same RNG end point
+    data2 = make_data()
+    random.seed(2018)
+    for ep in range(2):
+        it = device_epoch(data2, 2048, 'cpu', chunk_batches=chunk_batches)
+        first = [next(it), next(it)]
+        it.close()
+        assert np.array_equal(first[1][2].numpy(), g['ep%d_n' % ep][2048:4096])
+    assert random.random() == float(g['next_random'][0])
+    # a sampler result outside the tables surfaces in the consumer
+    with pytest.raises(IndexError):
+        list(device_epoch(make_data(), 2048, 'cpu', n_users=10, chunk_batches=chunk_batches))
+
+
 @pytest.mark.parametrize('n,k', [(44212, 39790), (943, 94), (100000, 17), (30, 5), (10, 10), (5, 0)])
 def test_native_sample_range_is_pythons(n, k):
     """random.sample(range(n), k) natively: both of CPython's algorithms (pool / rejection), same values, same RNG consumption."""
