@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ARLIB_AMD_LIB') or os.path.join(_HERE, 'lib', 'libarlib_amd.so')      # override: developer builds (e.g. `make prof`)
-ABI_VERSION = 22
+ABI_VERSION = 23
 _lib = None
 
 
@@ -100,6 +100,8 @@ _SIGS = {
     'arl_fake_block_rows_workspace_bytes': (_i64, [_i64, _i64, _i64]),
     'arl_fake_block_rows_f32': (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, C.c_float, _vp, _vp, _vp]),
     'arl_fake_block_cols_f32': (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, C.c_float, _vp, _vp]),
+    'arl_cw_topk_term_workspace_bytes': (_i64, [_i64, _i64, _i64, _i64]),
+    'arl_cw_topk_term_f32': (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _i64, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     'arl_score_mask_topk_workspace_bytes': (_i64, [_i64, _i64]),
     'arl_score_mask_topk_stats_offset': (_i64, [_i64, _i64]),
     'arl_score_mask_topk_f32': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -12,23 +12,21 @@ from ... import ops
 from ._bilevel import ScheduledBiLevel
 from .CLeaR import _packed
 from .DLAttack import masked_topk
-from .PGA import cw_operator_from_topk
 
 
 class _CwLoss(torch.autograd.Function):
-    """CW loss as 1/2 X^T M X with the operator of PGA.cw_operator_from_topk (no U*T index lists, no atomics)."""
+    """CW loss and its gradient on the packed table straight from the top-k lists (ops.cw_topk_term: no U*T index lists, no operator build,
+    deterministic)."""
 
     @staticmethod
     def forward(ctx, Pu, Pi, top_idx, n_real, targets):
         X = _packed(Pu, Pi)
-        Up, T = Pu.shape[0], len(targets)
-        ranks = top_idx.shape[1] - 1 - torch.arange(T, device=X.device)
-        neg = top_idx[:n_real][:, ranks].long()
-        M, _ = cw_operator_from_topk(Up + Pi.shape[0], Up, n_real, targets, neg, X.device)
-        G = ops.spmm(M, X)
+        Up = Pu.shape[0]
+        tg = targets.to(X.device, torch.int64) if isinstance(targets, torch.Tensor) else torch.as_tensor(targets, device=X.device, dtype=torch.int64)
+        loss, G, _ = ops.cw_topk_term(X.contiguous(), Up, n_real, top_idx.contiguous(), tg, want_w=False, check_range=False)
         ctx.save_for_backward(G)
         ctx.Up = Up
-        return 0.5 * (X * G).sum()
+        return loss[0]
 
     @staticmethod
     def backward(ctx, g):

@@ -19,7 +19,6 @@ from ...util.metrics import AttackMetric
 from .._common import AttackBase, DEVICE, symmetric_adjacency, init_graph, rebuild_interaction_matrix, reinit_with_tables, cw_pairs, with_fake_rows, append_rows
 from ...util.optim import Adam        # torch.optim.Adam, stepped by arl_adam_dense_f32
 from .DLAttack import masked_topk, device_mask
-from .PGA import cw_operator_from_topk
 
 
 def _packed(Pu, Pi):
@@ -35,23 +34,18 @@ class _CwSfaLoss(torch.autograd.Function):
     """(CWloss, sfaloss) of CLeaR.py:89-126 from the propagated tables and the users' top-k lists.
 
     H = cat(Pu[users], Pi[pos], Pi[neg]) has 3*U*T rows but only U + I distinct ones, so neither it nor the U*T index lists
-    are gathered: the CW term is bilinear in the packed table (one SpMM with the operator of PGA.cw_operator) and the SFA
+    are gathered: the CW term is bilinear in the packed table (ops.cw_topk_term: user rows gather, item rows sum in 64-bit fixed point) and the SFA
     term is three weighted passes over the table (ops.sfa_l1, row weight = multiplicity in H)."""
 
     @staticmethod
     def forward(ctx, Pu, Pi, top_idx, n_real, targets, r0):
         X = _packed(Pu, Pi)
         Up, I, d, T = Pu.shape[0], Pi.shape[0], Pu.shape[1], len(targets)
-        ranks = top_idx.shape[1] - 1 - torch.arange(T, device=X.device)                 # successive .pop()s (CLeaR.py:84-88)
-        neg = top_idx[:n_real][:, ranks].long()                                         # [n_real, T]
-        M, neg_cnt = cw_operator_from_topk(Up + I, Up, n_real, targets, neg, X.device)
-        G_cw = ops.spmm(M, X)
-        cw = 0.5 * (X * G_cw).sum()
-        w = torch.zeros(Up + I, dtype=torch.float32, device=X.device)
-        w[:n_real] = float(T)
-        w[Up:] = neg_cnt.to(torch.float32)
         tg = targets.to(X.device, torch.int64) if isinstance(targets, torch.Tensor) else torch.as_tensor(targets, device=X.device, dtype=torch.int64)
-        w.index_add_(0, tg + Up, torch.full((T,), float(n_real), device=X.device))
+        # one hand-written kernel group (arl_cw_topk_term_f32): the loss, its gradient on every row and the SFA term's row multiplicities straight from the
+        # top-k lists -- no operator build (sort, searchsorted, scatters), no ATen launches between the scoring pass and the SFA kernels, deterministic
+        cw1, G_cw, w = ops.cw_topk_term(X.contiguous(), Up, n_real, top_idx.contiguous(), tg, check_range=False)
+        cw = cw1[0]
         sfa, G_sfa = ops.sfa_l1(X, w, r0.to(X.device, torch.float32).contiguous(), 3 * n_real * T * d)
         ctx.save_for_backward(G_cw, G_sfa)
         ctx.Up = Up

@@ -2330,10 +2330,32 @@ __global__ __launch_bounds__(kWave) void stage_norm_kernel(const float *__restri
     }
 }
 
+#ifndef ARL_TOPK_EXIT
+#define ARL_TOPK_EXIT 1                          // exact early exit of the norm-ordered stream (see the kernel); 0 = the round-3 form
+#endif
+#ifndef ARL_TOPK_EXIT_EVERY
+#define ARL_TOPK_EXIT_EVERY 8                    // a wave tests its 16 users' bound every this-many stages (a power of two)
+#endif
 // suffix maxima of the per-stage norms: out[s] = max(sn[s..nst)), out[nst] = 0 -- the largest scaled item norm any LATER stage of the stream can hold
 // (the early exit's bound; for a norm-ordered stream it equals sn).  One wave.
-__global__ __launch_bounds__(kWave) void stage_sufmax_kernel(const float *__restrict__ sn, int nst, float *__restrict__ out) {
+// pick[0] / pick[1] (optional): 1 / 0 when the early exit can pay on this norm profile, 0 / 1 otherwise (the gates of the two kernel builds).  A row can
+// only finish when the remaining items' norms have fallen below cos * (norm of its k-th best item), cos = the cosine of that pair -- well under 1.  The
+// exit is enabled when the stage at 7/8 of the stream lies below half of the stage that holds the 4096th largest norm (where the bootstrap sample ends:
+// the region the first thresholds come from): measured on 1 M x 100 K, i.i.d. normal tables (ratio 0.73) and one-hop propagated tables (0.58) skip nothing
+// and keep the plain build; log-normal item norms (0.05) skip 84 % of the stream.
+__global__ __launch_bounds__(kWave) void stage_sufmax_kernel(const float *__restrict__ sn, int nst, float *__restrict__ out, int mst, int *__restrict__ pick) {
     const int lane = threadIdx.x;
+    if (pick != nullptr) {                                          // (suffix maxima of the two stages, so that a stream in any other order than by norm keeps the plain build)
+        const int head = min(nst - 1, 4096 / mst), tail = min(nst - 1, nst - nst / 8);
+        float mh = 0.f, mt = 0.f;
+        for (int s = head + lane; s < nst; s += kWave) { const float v = sn[s]; mh = fmaxf(mh, v); if (s >= tail) mt = fmaxf(mt, v); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { mh = fmaxf(mh, __shfl_xor(mh, off)); mt = fmaxf(mt, __shfl_xor(mt, off)); }
+        if (lane == 0) {
+            const int on = (ARL_TOPK_EXIT != 0) && head < tail && mt < 0.5f * mh;
+            pick[0] = on; pick[1] = !on;
+        }
+    }
     float carry = 0.f;
     for (int base = ((nst - 1) / kWave) * kWave; base >= 0; base -= kWave) {
         const int s = base + lane;
@@ -2350,15 +2372,15 @@ __global__ __launch_bounds__(kWave) void stage_sufmax_kernel(const float *__rest
     if (lane == 0) out[nst] = 0.f;
 }
 
-#ifndef ARL_TOPK_EXIT
-#define ARL_TOPK_EXIT 1                          // exact early exit of the norm-ordered stream (see the kernel); 0 = the round-3 form
-#endif
-#ifndef ARL_TOPK_EXIT_EVERY
-#define ARL_TOPK_EXIT_EVERY 4                    // a wave tests its 16 users' bound every this-many stages (a power of two)
-#endif
-constexpr int kExitWords = 4;                    // LDS words behind the ring counters: [0] stop stage, [1] votes
+constexpr int kExitWords = 20;                   // LDS words behind the ring counters: [0] stop stage, [4 .. 4 + waves) one "finished" word per wave
+// Early exit bound.  A high-piece score is <ah, bh> accumulated in fp32: |score| <= |ah| |bh| (1 + 2^-18) (Cauchy-Schwarz; 64 or 128 exact products,
+// fp32 adds) <= |a'| |b'| (1 + 2^-10 + 2^-17) + Eabs (each piece within 2^-11 relative of its element, or 2^-25 absolute when subnormal: that part is
+// what Eabs bounds).  With 1.05 * 2^-10 instead of 2^-10 covering the roundings of the two norms themselves, an item of scaled norm n cannot pass the
+// pre-filter `score >= threshold - (Ereg n + Eabs)`, Ereg = ESCALE * 2^-10 |a'|, of a row with  (|a'| (1 + 1.05 * 2^-10) + Ereg) n + 2 Eabs < threshold.
+// No register is spent on |a'|: it is Ereg / (ESCALE * 2^-10), so the bound is kExitK * Ereg * n + 2 Eabs (the kernel runs at 128 VGPRs with no slack).
+constexpr float kExitK = (1.f + 1.05f * 0.0009765625f) / (ARL_TOPK_ESCALE * 0.0009765625f > 0.f ? ARL_TOPK_ESCALE * 0.0009765625f : 1.f) + 1.f;
 
-template <int D, bool SPLIT, bool WARM>
+template <int D, bool SPLIT, bool WARM, bool XIT = false>
 __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfma16_kernel(const float *__restrict__ Pu, const void *__restrict__ Pi_image, int U, int I,
                                                                             const int32_t *__restrict__ mrp, const int32_t *__restrict__ mcol, int k,
                                                                             int32_t *__restrict__ top_idx, float *__restrict__ top_val,
@@ -2366,10 +2388,14 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
                                                                             int *__restrict__ underflow, const unsigned *__restrict__ table_max_bits,
                                                                             const int32_t *__restrict__ item_order, const int32_t *__restrict__ item_pos,
                                                                             const int *__restrict__ gate, const float *__restrict__ stage_norm,
-                                                                            unsigned long long *__restrict__ stats) {
+                                                                            unsigned long long *__restrict__ stats, const int *__restrict__ gate2) {
     // gate (optional): the launch is the cold repeat of a warm-started call and runs only if that call raised its underflow flag -- decided here,
     // on the device, so that the host never waits for the flag (every thread of the grid takes the same branch)
     if (gate != nullptr && *gate == 0) return;
+    // gate2 (optional): which BUILD of the kernel runs this call.  XIT = true carries the early exit of the norm-ordered stream; its extra code costs ~5 % on
+    // tables where nothing can be skipped (the stream loop has no register to spare), so both builds are launched and the device picks one from the
+    // items' norm profile (stage_sufmax_kernel) -- the other returns here.
+    if (gate2 != nullptr && *gate2 == 0) return;
     // item_order / item_pos (both or neither): the staged image holds table row item_order[p] at position p (item_pos = the inverse).  Scores,
     // stages and the bootstrap sample are in POSITIONS; a candidate becomes an item id when it is packed into a key, so masks, keys (ties:
     // lower item id first) and results are those of the table order -- only the order in which thresholds rise changes.
@@ -2412,7 +2438,6 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     constexpr bool F16 = SPLIT && kSplitMode == 2;
     constexpr bool REFINE = F16 && ARL_TOPK_REFINE && ARL_TOPK_QUEUE;      // see the staging constants below
     float Ereg[4] = {0.f, 0.f, 0.f, 0.f};                          // REFINE: E of user rows 4g + reg for an item of scaled norm n is Ereg * n + Eabs
-    [[maybe_unused]] float Nreg[4] = {0.f, 0.f, 0.f, 0.f};         // early exit: no later item passes row 4g + reg's pre-filter once Nreg * (largest later norm) + 2 Eabs < threshold
     float Eabs = 0.f;
     bf16x8 af[3][KS];
     f16x8 ah[2][KS];
@@ -2440,14 +2465,6 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
             const float Ec = ARL_TOPK_ESCALE * 0.0009765625f * sqrtf(n2);
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) Ereg[reg] = __shfl(Ec, 4 * g + reg);
-            // Early exit.  A high-piece score is <ah, bh> accumulated in fp32: |score| <= |ah| |bh| (1 + 2^-18) (Cauchy-Schwarz; 64 or 128 exact
-            // products, fp32 adds) <= |a'| |b'| (1 + 2^-10 + 2^-17) + Eabs (each piece within 2^-11 relative of its element, or 2^-25 absolute when
-            // subnormal: that part is what Eabs bounds).  With the 1.05 below covering the roundings of the two norms themselves, an item of
-            // scaled norm n cannot pass the pre-filter `score >= threshold - (Ereg n + Eabs)` of a row with
-            //     (|a'| (1 + 1.05 * 2^-10) + Ereg) * n + 2 Eabs < threshold.
-            const float Nc = fmaf(sqrtf(n2), 1.f + 1.05f * 0.0009765625f, Ec);
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) Nreg[reg] = __shfl(Nc, 4 * g + reg);
         }
     } else if constexpr (SPLIT) {
 #pragma unroll
@@ -2534,12 +2551,12 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     constexpr int STAGEB = 2 * HALF;
     unsigned *ring_ctr = reinterpret_cast<unsigned *>(bt + kTopkRing * STAGEB);                             // fill[kTopkRing], done[kTopkRing]
     constexpr int kQAll = ARL_TOPK_QUEUE ? kQWords * (kM16Block / kWave) : 0;
-    unsigned *exit_st = ring_ctr + 2 * kTopkRing;                                                            // [0] stop stage (virtual index), [1] waves that voted
+    unsigned *exit_st = ring_ctr + 2 * kTopkRing;                                                            // [0] stop stage (virtual index), [4 + w] wave w's rows are finished
     unsigned *qcnt = ring_ctr + 2 * kTopkRing + kExitWords + wv * kQWords;                                                // this wave's 16 queue counters ...
     unsigned long long *qkey = reinterpret_cast<unsigned long long *>(qcnt + 16);                           // ... and its [16][kQCap] keys (8-byte aligned)
     unsigned *bloom = ring_ctr + 2 * kTopkRing + kExitWords + kQAll + wv * 16 * kBloomWords;                             // [16][kBloomWords]
     if (tid < 2 * kTopkRing) ring_ctr[tid] = 0u;
-    if (tid == 0) { exit_st[0] = 0x7fffffffu; exit_st[1] = 0u; }
+    if (tid < kExitWords) exit_st[tid] = tid == 0 ? 0x7fffffffu : 0u;
     if (ARL_TOPK_QUEUE && lane < 16) qcnt[lane] = 0u;
     if (mrp) {
         for (int t = lane; t < 16 * kBloomWords; t += kWave) bloom[t] = 0u;
@@ -3061,43 +3078,40 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
     unsigned *fill_ctr = ring_ctr, *done_ctr = ring_ctr + kTopkRing;
     constexpr unsigned NWV = kM16Block / kWave;
     // ---- Exact early exit (REFINE, with per-stage norms; pays on a norm-ordered stream).  Row r is FINISHED at stage s when no item of a later
-    // stage can pass its pre-filter: Nreg_r * sufmax[s + 1] + 2 Eabs < threshold_r (Cauchy-Schwarz, see Nreg).  Thresholds only rise and the suffix
-    // maxima only fall, so a finished row stays finished.  A wave whose 16 rows are finished VOTES once; the wave casting the last of the
-    // workgroup's votes, in its step s, publishes stop = s + lead + 1; every wave reads `stop` in the same LDS instruction as the fill counter it
-    // waits for before consuming a stage, and leaves the loop at stage `stop` without consuming it.  Why that stage is safe: the fill counter of
-    // stage t completes only when every wave has run step t - lead, so (1) no wave has consumed stage s + lead + 1 when the last vote is cast in step s,
-    // and (2) a wave that sees stage `stop` filled sees a counter the voter raised in its step s + 1, after it stored `stop` (one wave's LDS operations
-    // execute in order).  All waves leave at the same stage, the counters of every stage below it complete as before; the stages skipped could
-    // not have produced a candidate, so lists, values and tie order are those of the full stream, bit for bit.
-    constexpr bool EXIT = REFINE && ARL_TOPK_EXIT && !ARL_TOPK_POLL8 && !ARL_TOPK_PAIRS;
-    [[maybe_unused]] const float *sufmax = stage_norm ? stage_norm + nstages + 1 : nullptr;      // [nstages + 1], behind the stage norms and the table's maximum
-    [[maybe_unused]] bool voted = false;                               // wave-uniform
-    [[maybe_unused]] int stop_seen = 0x7fffffff;
-    [[maybe_unused]] auto wait_fill_stop = [&](unsigned *ctr, unsigned want) -> int {      // wait_ge(ctr, want); returns the stop stage read with the counter
-        const lds_u32 *p = (const lds_u32 *)(lane < 32 ? ctr : exit_st);                   // (different banks: one pass of the LDS)
+    // stage can pass its pre-filter: kExitK * Ereg_r * sufmax[s + 1] + 2 Eabs < threshold_r (Cauchy-Schwarz, see kExitK).  Thresholds only rise and the
+    // suffix maxima only fall, so a finished row stays finished.  Every ARL_TOPK_EXIT_EVERY stages a wave whose 16 rows are finished sets ITS word
+    // (idempotent) and looks at all of them; a wave that finds every word set, in its step s, lowers `stop` to s + lead + 1 (atomic minimum).  Every wave
+    // reads `stop` in the same LDS instruction as the fill counter it waits for before consuming a stage, and leaves the loop at the first stage
+    // >= stop without consuming it.  Why that is safe for whichever wave publishes: the fill counter of stage t completes only when every wave has run
+    // step t - lead, so (1) no wave has consumed stage s + lead + 1 while the publisher is in step s, and (2) a wave that sees stage s + lead + 1 filled
+    // sees a counter the publisher raised in its step s + 1, after its atomic on `stop` (one wave's LDS operations execute in order).  All waves leave at the
+    // same stage, the counters of every stage below it complete as before; the stages skipped could not have produced a candidate, so lists, values
+    // and tie order are those of the full stream, bit for bit.  (No per-wave state in registers: the kernel has none to spare.)
+    constexpr bool EXIT = XIT && REFINE && ARL_TOPK_EXIT && !ARL_TOPK_POLL8 && !ARL_TOPK_PAIRS && (ARL_TOPK_ESCALE >= 1.05f);
+    // The poll of the fill counter is the plain wait_ge() with the counter's top bit masked off: the publisher of `stop` sets that bit on all fill
+    // counters AFTER storing `stop` and BEFORE its next fill signal, so a wave that sees stage s + lead + 1 (or any later one) filled sees the bit on the
+    // counter it just polled and only then -- once per workgroup and kernel -- reads the stop stage itself.
+    [[maybe_unused]] auto wait_fill_stop = [&](unsigned *ctr, unsigned want) -> bool {     // true: the top bit is set (a stop stage has been published)
         unsigned v;
         int spins = 0;
-        while (v = *(volatile const lds_u32 *)p, (unsigned)__builtin_amdgcn_readfirstlane((int)v) < want) {
+        while (v = (unsigned)__builtin_amdgcn_readfirstlane((int)*(volatile lds_u32 *)ctr), (v & 0x7fffffffu) < want) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1 << 26)) __builtin_trap();
         }
         asm volatile("" ::: "memory");
-        return __builtin_amdgcn_readlane((int)v, 32);
+        return (v >> 31) != 0u;
     };
-    [[maybe_unused]] auto vote = [&](int st) {                         // after stage st (virtual index, a stream stage) has been consumed
-        const float sx = sufmax[st - NB + 1];                          // wave-uniform scalar load
-        bool fin = true;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) fin = fin && (fmaf(Nreg[reg], sx, 2.f * Eabs) < thrf[reg]);       // (+inf for rows past U; NaN never finishes)
-        if (__builtin_amdgcn_ballot_w64(!fin) == 0ull) {
-            voted = true;
-            if (lane == 0) {
-                const unsigned before = __hip_atomic_fetch_add((lds_u32 *)(exit_st + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (before == NWV - 1u) __hip_atomic_store((lds_u32 *)exit_st, (unsigned)(st + kTopkLead + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+    [[maybe_unused]] auto vote = [&](int st) {                         // this wave's rows are finished after stage st (virtual index)
+        unsigned *fw = ring_ctr + 2 * kTopkRing + 4;
+        int lv = lane;
+        asm volatile("" : "+v"(lv));                                   // (opaque copy: the per-lane LDS addresses below are formed HERE, not hoisted into registers held over the whole stream)
+        if (lv == 0) *(volatile lds_u32 *)(fw + wv) = 1u;
+        const unsigned seen = lv < (int)NWV ? *(volatile lds_u32 *)(fw + lv) : 1u;      // (after this wave's own store: LDS operations of a wave execute in order)
+        if (__builtin_amdgcn_ballot_w64(seen == 0u) == 0ull) {
+            if (lv == 0) __hip_atomic_fetch_min((lds_u32 *)(ring_ctr + 2 * kTopkRing), (unsigned)(st + kTopkLead + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lv < kTopkRing) __hip_atomic_fetch_or((lds_u32 *)(ring_ctr + lv), 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (issued after the minimum: in order)
         }
     };
-    static_assert(kTopkLead >= 2 && kTopkLead % 2 == 0 && kTopkLead < kTopkRing && (kTopkRing & (kTopkRing - 1)) == 0, "two register sets alternate: the lead is even");
     __syncthreads();                                               // counters zeroed (the only block barrier of the kernel)
     // one step of the pipeline: stage st + 2 goes from register set r to LDS, set r is refilled with stage st + 4, stage st is consumed
     [[maybe_unused]] auto step = [&](auto boot_tag, int st, f32x4 (&r)[PER]) -> bool {
@@ -3136,17 +3150,26 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
         }
         asm volatile("" ::: "memory");
 #else
-        if constexpr (EXIT) {
-            if (sufmax != nullptr) {
-                stop_seen = wait_fill_stop(fill_ctr + (st & (kTopkRing - 1)), NWV * (unsigned)(st / kTopkRing + 1));
-                if (st >= stop_seen) return true;                      // wave-uniform; every wave of the workgroup leaves at this stage
-            } else wait_ge(fill_ctr + (st & (kTopkRing - 1)), NWV * (unsigned)(st / kTopkRing + 1));
+        if constexpr (EXIT && !decltype(boot_tag)::value) {
+            if (wait_fill_stop(fill_ctr + (st & (kTopkRing - 1)), NWV * (unsigned)(st / kTopkRing + 1))) {
+                const int stop = __builtin_amdgcn_readfirstlane((int)*(volatile lds_u32 *)(ring_ctr + 2 * kTopkRing));
+                if (st >= stop) return true;                           // wave-uniform; every wave of the workgroup leaves at this stage
+            }
         } else wait_ge(fill_ctr + (st & (kTopkRing - 1)), NWV * (unsigned)(st / kTopkRing + 1));
 #endif
         ARL_PROF_TICK(3)
         compute(boot_tag, slot(st), st, done_ctr + (st & (kTopkRing - 1)));
         if constexpr (EXIT && !decltype(boot_tag)::value) {
-            if (sufmax != nullptr && !voted && (st & (ARL_TOPK_EXIT_EVERY - 1)) == ARL_TOPK_EXIT_EVERY - 1) vote(st);
+            // are this wave's 16 rows finished -- can no item of a LATER stage pass their pre-filter?  Tested every ARL_TOPK_EXIT_EVERY-th stage, here, after
+            // the stage's accumulators have died (the kernel runs at 128 VGPRs with none to spare; the constant rides on the wave-uniform factor so that
+            // the compiler has no per-lane product to hoist into a register held over the whole stream)
+            if ((st & (ARL_TOPK_EXIT_EVERY - 1)) == ARL_TOPK_EXIT_EVERY - 1) {
+                const float kx = kExitK * stage_norm[nstages + 1 + (st - NB) + 1];      // suffix maximum: the largest scaled norm of any later stage (scalar load)
+                bool f = true;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) f = f && (fmaf(Ereg[reg], kx, 2.f * Eabs) < thrf[reg]);       // (+inf for rows past U; NaN never finishes)
+                if (__builtin_amdgcn_ballot_w64(!f) == 0ull) vote(st);
+            }
         }
         return false;
     };
@@ -3201,12 +3224,13 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
         step(std::true_type{}, st + 1, nc);
     }
     if (NB > 0) boot_finish();
-    for (int st = NB; st < nvirt; st += 2) {
-        if (step(std::false_type{}, st, nb)) break;
-        if (st + 1 < nvirt && step(std::false_type{}, st + 1, nc)) break;
+    int st_end = NB;
+    for (; st_end < nvirt; st_end += 2) {
+        if (step(std::false_type{}, st_end, nb)) break;
+        if (st_end + 1 < nvirt && step(std::false_type{}, st_end + 1, nc)) { st_end += 1; break; }
     }
     if (stats != nullptr && tid == 0) {                            // stream stages this workgroup consumed (all of them without an exit), and one workgroup
-        atomicAdd(stats, (unsigned long long)(min(stop_seen, nvirt) - NB));
+        atomicAdd(stats, (unsigned long long)(min(st_end, nvirt) - NB));
         atomicAdd(stats + 1, 1ull);
     }
 #endif
@@ -3234,6 +3258,203 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
         o[6] = (float)P_acc[4]; o[7] = (float)P_acc[5]; o[8] = (float)P_acc[6];
     }
 #endif
+}
+
+// ================================================================================================
+// CW term of the attacks' surrogate loss from the users' top-k lists (attack/White/CLeaR.py:83-95, PGA.py:104-116):
+//     L = c * sum over real users u and targets t of  <X_u, X_neg(u,t)> - <X_u, X_tg(t)>,   neg(u, t) = top_idx[u][k - 1 - t]  (successive .pop()s)
+// and G = dL/dX on the packed table X = [user rows | item rows]: L is bilinear, L = 1/2 X^T M X, G = M X.  Round 3 built M as a CSR per step from ~25
+// ATen launches (radix sort, searchsorted, cumsum, scatters) and ran an SpMM; here the term is five launches of its own and deterministic:
+//   1 cw_user_kernel    user rows:  G_u = c (sum_t X_neg - sum_t X_tg), the loss terms <X_u, G_u>, column sums of the real users' rows, |X| maximum,
+//                       and the histogram of the negatives (integer atomics: order-free);
+//   2 cw_scan_kernel    folds the partials in a fixed order, cuts the items into groups of IPG rows and the groups' entries into slices, fixes the scale;
+//   3 cw_fill_kernel    every (user, negative) entry goes to its group's bucket (slot by an integer atomic: the ORDER inside a bucket varies from run to
+//                       run -- it does not matter, see 4);
+//   4 cw_item_kernel    item rows:  sum over the entries of an item of X_u.  One workgroup per slice keeps the group's rows in LDS as 64-bit FIXED-POINT
+//                       accumulators (value * 2^e, e chosen from the table's largest magnitude and the entry count so that no sum can overflow): integer
+//                       addition is associative, so the sums are bit-identical whatever the order and exact to 2^-e (far below fp32 rounding of the
+//                       same sum) -- no float atomics, no sort.  A slice's partial goes to the global accumulator by 64-bit integer atomics;
+//   5 cw_finish_kernel  G_i = c (sum - [i is a target] * column sum) in fp32, and the SFA term's row multiplicities w (CLeaR.py:98-103).
+// ================================================================================================
+constexpr int kCwParts = 1024;       // workgroups of cw_user_kernel = partial sums folded by cw_scan_kernel
+constexpr int kCwSlice = 8192;       // entries per workgroup of cw_item_kernel
+constexpr int kCwItemThreads = 1024;
+__host__ __device__ inline int cw_ipg(int d) { const int a = 16384 / d; return a >= 256 ? 256 : (a >= 128 ? 128 : 64); }      // item rows per group: IPG * d * 8 B of LDS <= 128 KB
+
+struct CwWs {                        // carved out of the caller's workspace (arl_cw_topk_term_workspace_bytes)
+    float *part;                     // [kCwParts][d + 2]: column sums, loss terms, |x| maximum
+    float *colsum;                   // [d]
+    double *scale;                   // [0] 2^e, [1] 2^-e
+    int32_t *neg_cnt;                // [I]
+    int32_t *grp_off;                // [G + 1]
+    int32_t *cursor;                 // [G]
+    int32_t *slices;                 // [max_slices][4]: group, begin, end, -
+    int32_t *n_slices;               // [1]
+    int2 *bucket;                    // [n_real * T]: (user, item)
+    long long *acc;                  // [I * d]
+};
+
+__global__ __launch_bounds__(kBlock) void cw_user_kernel(const float *__restrict__ X, int d, long long Up, int n_real, const int32_t *__restrict__ top_idx, int k,
+                                                         const long long *__restrict__ targets, int T, float c, float *__restrict__ G, float *__restrict__ w,
+                                                         CwWs W, int rows_per_wg) {
+    __shared__ float red[kWavesPerBlock][256 + 2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int MC = 4;                                          // columns per lane: d <= 256
+    float tgs[MC], cs[MC];
+#pragma unroll
+    for (int j = 0; j < MC; ++j) { tgs[j] = 0.f; cs[j] = 0.f; }
+    for (int t = 0; t < T; ++t) {
+        const float *xr = X + (size_t)(Up + targets[t]) * d;
+#pragma unroll
+        for (int j = 0; j < MC; ++j) { const int col = lane + 64 * j; if (col < d) tgs[j] += xr[col]; }
+    }
+    float dot = 0.f, amax = 0.f;
+    const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, Up);
+    for (long long r = r0 + wv; r < r1; r += kWavesPerBlock) {
+        float *g = G + (size_t)r * d;
+        if (r >= n_real) {                                         // fake users take no part in the CW pairs
+#pragma unroll
+            for (int j = 0; j < MC; ++j) { const int col = lane + 64 * j; if (col < d) g[col] = 0.f; }
+            if (w && lane == 0) w[r] = 0.f;
+            continue;
+        }
+        const int32_t *tl = top_idx + (size_t)r * k + (k - 1);
+        float acc[MC];
+#pragma unroll
+        for (int j = 0; j < MC; ++j) acc[j] = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float *xr = X + (size_t)(Up + tl[-t]) * d;       // wave-uniform row: one 4d-byte gather
+#pragma unroll
+            for (int j = 0; j < MC; ++j) { const int col = lane + 64 * j; if (col < d) acc[j] += xr[col]; }
+        }
+        if (lane < T) atomicAdd(W.neg_cnt + tl[-lane], 1);
+        const float *xu = X + (size_t)r * d;
+#pragma unroll
+        for (int j = 0; j < MC; ++j) {
+            const int col = lane + 64 * j;
+            if (col < d) {
+                const float x = xu[col], gv = c * (acc[j] - tgs[j]);
+                g[col] = gv;
+                dot = fmaf(x, gv, dot);
+                cs[j] += x;
+                amax = fmaxf(amax, fabsf(x));
+            }
+        }
+        if (w && lane == 0) w[r] = (float)T;
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+#pragma unroll
+    for (int j = 0; j < MC; ++j) { const int col = lane + 64 * j; if (col < d) red[wv][col] = cs[j]; }
+    if (lane == 0) { red[wv][256] = dot; red[wv][257] = amax; }
+    __syncthreads();
+    float *out = W.part + (size_t)blockIdx.x * (d + 2);
+    for (int col = threadIdx.x; col < d + 2; col += kBlock) {
+        const int src = col < d ? col : 256 + (col - d);
+        float v = red[0][src];
+        for (int q = 1; q < kWavesPerBlock; ++q) v = (col == d + 1) ? fmaxf(v, red[q][src]) : v + red[q][src];      // waves in a fixed order
+        out[col] = v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void cw_scan_kernel(CwWs W, int d, int n_items, int n_groups, int ipg, int n_parts, int count_log2, float *__restrict__ loss) {
+    __shared__ int tot[1024];
+    __shared__ float fin[2];
+    for (int col = threadIdx.x; col < d + 2; col += kBlock) {
+        float v = W.part[col];
+        for (int p = 1; p < n_parts; ++p) { const float x = W.part[(size_t)p * (d + 2) + col]; v = (col == d + 1) ? fmaxf(v, x) : v + x; }       // parts in a fixed order
+        if (col < d) W.colsum[col] = v;
+        else fin[col - d] = v;
+    }
+    for (int g = threadIdx.x; g < n_groups; g += kBlock) {
+        int s = 0;
+        for (int i = g * ipg, e = min(i + ipg, n_items); i < e; ++i) s += W.neg_cnt[i];
+        tot[g] = s;
+        W.cursor[g] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        loss[0] = fin[0];
+        // scale 2^e with |x| < 2^(ea + 1) for every element and at most 2^count_log2 addends per sum: |sum * 2^e| < 2^(ea + 1 + count_log2 + e) = 2^61
+        const float amax = fin[1];
+        int e = 0;
+        if (amax > 0.f && amax < INFINITY) e = 61 - (ilogbf(amax) + 1) - count_log2;
+        e = max(min(e, 1000), -1000);
+        W.scale[0] = ldexp(1.0, e); W.scale[1] = ldexp(1.0, -e);
+        int off = 0, ns = 0;
+        for (int g = 0; g < n_groups; ++g) {
+            W.grp_off[g] = off;
+            for (int b = 0; b < tot[g]; b += kCwSlice) {
+                int32_t *sl = W.slices + 4 * ns++;
+                sl[0] = g; sl[1] = off + b; sl[2] = off + min(b + kCwSlice, tot[g]);
+            }
+            off += tot[g];
+        }
+        W.grp_off[n_groups] = off;
+        W.n_slices[0] = ns;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void cw_fill_kernel(const int32_t *__restrict__ top_idx, int k, int T, long long n_entries, int ipg, CwWs W) {
+    const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n_entries) return;
+    const int u = (int)(e / T), t = (int)(e - (long long)u * T);
+    const int item = top_idx[(size_t)u * k + (k - 1 - t)];
+    const int g = item / ipg;
+    const int slot = atomicAdd(W.cursor + g, 1);
+    W.bucket[W.grp_off[g] + slot] = make_int2(u, item);
+}
+
+__global__ __launch_bounds__(kCwItemThreads) void cw_item_kernel(const float *__restrict__ X, int d, int n_items, int ipg, CwWs W) {
+    extern __shared__ unsigned long long cw_acc[];                 // [ipg][d] fixed-point sums of this slice
+    const int s = blockIdx.x;
+    if (s >= W.n_slices[0]) return;                                // (the grid is the static upper bound of the slice count)
+    const int grp = W.slices[4 * s], begin = W.slices[4 * s + 1], end = W.slices[4 * s + 2];
+    const int cells = ipg * d;
+    for (int i = threadIdx.x; i < cells; i += kCwItemThreads) cw_acc[i] = 0ull;
+    __syncthreads();
+    const double scale = W.scale[0];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int NW = kCwItemThreads / kWave, UNR = 4;
+    for (int e0 = begin + wv * UNR; e0 < end; e0 += NW * UNR) {
+        int2 en[UNR];
+        float x[UNR][4];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) en[q] = e0 + q < end ? W.bucket[e0 + q] : make_int2(-1, 0);        // wave-uniform
+#pragma unroll
+        for (int q = 0; q < UNR; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int col = lane + 64 * j; x[q][j] = (en[q].x >= 0 && col < d) ? X[(size_t)en[q].x * d + col] : 0.f; }
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+            if (en[q].x < 0) continue;
+            unsigned long long *row = cw_acc + (size_t)(en[q].y - grp * ipg) * d;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = lane + 64 * j;
+                if (col < d) atomicAdd(row + col, (unsigned long long)__double2ll_rn((double)x[q][j] * scale));
+            }
+        }
+    }
+    __syncthreads();
+    const long long base = (long long)grp * ipg * d, lim = (long long)n_items * d;
+    for (int i = threadIdx.x; i < cells; i += kCwItemThreads) {
+        const unsigned long long v = cw_acc[i];
+        if (v != 0ull && base + i < lim) atomicAdd(reinterpret_cast<unsigned long long *>(W.acc) + base + i, v);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void cw_finish_kernel(int d, long long Up, int n_items, int n_real, const long long *__restrict__ targets, int T, float c,
+                                                           float *__restrict__ G, float *__restrict__ w, CwWs W) {
+    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (long long)n_items * d) return;
+    const int i = (int)(t / d), col = (int)(t - (long long)i * d);
+    int tc = 0;
+    for (int q = 0; q < T; ++q) tc += targets[q] == i;
+    const float sum = (float)((double)W.acc[t] * W.scale[1]);
+    G[(size_t)(Up + i) * d + col] = c * (sum - (float)tc * W.colsum[col]);
+    if (w && col == 0) w[Up + i] = (float)W.neg_cnt[i] + (float)tc * (float)n_real;
 }
 
 // per-row top-n by n rounds of block arg-max over a scratch copy (n ~ average user degree, small)
@@ -4150,6 +4371,66 @@ int arl_fake_block_cols_f32(const float *S, int64_t F, int64_t I, const float *X
     return ARL_OK;
 }
 
+static int64_t cw_align(int64_t b) { return (b + 255) / 256 * 256; }
+static int64_t cw_layout(int64_t n_items, int64_t d, int64_t n_real, int64_t T, char *base, CwWs *W) {
+    const int64_t ipg = cw_ipg((int)d), G = (n_items + ipg - 1) / ipg, n_ent = n_real * T, max_sl = G + (n_ent + kCwSlice - 1) / kCwSlice + 1;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { char *p = base ? base + off : nullptr; off += cw_align(bytes); return p; };
+    char *p_part = take(sizeof(float) * kCwParts * (d + 2)), *p_col = take(sizeof(float) * d), *p_sc = take(sizeof(double) * 2), *p_neg = take(sizeof(int32_t) * n_items);
+    char *p_off = take(sizeof(int32_t) * (G + 1)), *p_cur = take(sizeof(int32_t) * G), *p_sl = take(sizeof(int32_t) * 4 * max_sl), *p_ns = take(sizeof(int32_t) * 4);
+    char *p_b = take(sizeof(int2) * (n_ent > 0 ? n_ent : 1)), *p_acc = take(sizeof(long long) * n_items * d);
+    if (W) {
+        W->part = (float *)p_part; W->colsum = (float *)p_col; W->scale = (double *)p_sc; W->neg_cnt = (int32_t *)p_neg; W->grp_off = (int32_t *)p_off;
+        W->cursor = (int32_t *)p_cur; W->slices = (int32_t *)p_sl; W->n_slices = (int32_t *)p_ns; W->bucket = (int2 *)p_b; W->acc = (long long *)p_acc;
+    }
+    return off;
+}
+
+int64_t arl_cw_topk_term_workspace_bytes(int64_t n_items, int64_t d, int64_t n_real, int64_t n_targets) {
+    if (n_items <= 0 || d <= 0 || n_real < 0 || n_targets <= 0) return 0;
+    return cw_layout(n_items, d, n_real, n_targets, nullptr, nullptr);
+}
+
+int arl_cw_topk_term_f32(const float *X, int64_t n_user_rows, int64_t n_items, int64_t d, int64_t n_real, const int32_t *top_idx, int64_t k,
+                         const int64_t *targets, int64_t n_targets, float c, float *G, float *loss, float *w_sfa, void *workspace, arl_stream_t stream) {
+    if (!X || !top_idx || !targets || !G || !loss || !workspace) return ARL_E_NULL;
+    if (d <= 0 || d > 256) return ARL_E_DIM;
+    if (n_user_rows <= 0 || n_items <= 0 || n_real < 0 || n_real > n_user_rows || n_targets <= 0 || n_targets > 64 || k < n_targets) return ARL_E_ARG;
+    if (n_user_rows + n_items > 0x7fffffffll || n_real * n_targets > 0x7fffffffll || n_items * d > 0x7fffffffffll) return ARL_E_RANGE;
+    if (((uintptr_t)workspace) & 7) return ARL_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    CwWs W;
+    cw_layout(n_items, d, n_real, n_targets, (char *)workspace, &W);
+    const int ipg = cw_ipg((int)d), n_groups = (int)((n_items + ipg - 1) / ipg);
+    if (n_groups > 1024) return ARL_E_RANGE;                          // (262 144 items at d <= 64; the scan kernel folds the groups in LDS)
+    const long long n_ent = (long long)n_real * n_targets;
+    if (hipMemsetAsync(W.neg_cnt, 0, sizeof(int32_t) * n_items, st) != hipSuccess) return ARL_E_ARG;
+    if (hipMemsetAsync(W.acc, 0, sizeof(long long) * n_items * d, st) != hipSuccess) return ARL_E_ARG;
+    const int rows_per_wg = (int)((n_user_rows + kCwParts - 1) / kCwParts);
+    const int n_parts = (int)((n_user_rows + rows_per_wg - 1) / rows_per_wg);
+    hipLaunchKernelGGL(cw_user_kernel, dim3((unsigned)n_parts), dim3(kBlock), 0, st, X, (int)d, (long long)n_user_rows, (int)n_real, top_idx, (int)k,
+                       (const long long *)targets, (int)n_targets, c, G, w_sfa, W, rows_per_wg);
+    ARL_LAUNCH_CHECK();
+    int count_log2 = 0;
+    while ((1ll << count_log2) < (n_ent > 1 ? n_ent : 1)) ++count_log2;
+    hipLaunchKernelGGL(cw_scan_kernel, dim3(1), dim3(kBlock), 0, st, W, (int)d, (int)n_items, n_groups, ipg, n_parts, count_log2, loss);
+    ARL_LAUNCH_CHECK();
+    if (n_ent > 0) {
+        hipLaunchKernelGGL(cw_fill_kernel, dim3((unsigned)((n_ent + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, top_idx, (int)k, (int)n_targets, n_ent, ipg, W);
+        ARL_LAUNCH_CHECK();
+        const size_t shm = sizeof(unsigned long long) * (size_t)ipg * (size_t)d;
+        hipError_t ea = hipFuncSetAttribute((const void *)cw_item_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (ea != hipSuccess) return (int)ea;
+        const unsigned max_sl = (unsigned)(n_groups + (n_ent + kCwSlice - 1) / kCwSlice + 1);
+        hipLaunchKernelGGL(cw_item_kernel, dim3(max_sl), dim3(kCwItemThreads), shm, st, X, (int)d, (int)n_items, ipg, W);
+        ARL_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(cw_finish_kernel, dim3((unsigned)((n_items * d + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (int)d, (long long)n_user_rows, (int)n_items,
+                       (int)n_real, (const long long *)targets, (int)n_targets, c, G, w_sfa, W);
+    ARL_LAUNCH_CHECK();
+    return ARL_OK;
+}
+
 int64_t arl_score_mask_topk_workspace_bytes(int64_t I, int64_t d) { return (I <= 0 || d <= 0) ? 0 : 6 * I * d + 64; }
 // byte offset, inside the workspace, of the pass's two 8-byte counters [stream stages consumed summed over workgroups, workgroups] (fp16 split path,
 // d = 64 / 128): consumed / (workgroups * ceil(I / stage items)) is the share of the item stream the early exit did not skip
@@ -4184,6 +4465,7 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
         int32_t *pos_d = nullptr;
         float *snorm_d = nullptr;
         unsigned long long *stats_d = nullptr;
+        int *pick_d = nullptr;
         if (split) {
             const long long n = (long long)I * d;
             if (kSplitMode == 2) {
@@ -4210,10 +4492,11 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
                     hipLaunchKernelGGL(stage_norm_kernel, dim3((unsigned)nst), dim3(kWave), 0, (hipStream_t)stream, Pi, (int)I, (int)d, mst, mb, order_d, nst, snorm_d);
                     ARL_LAUNCH_CHECK();
                     // behind them: the suffix maxima [nst + 1] (the early exit's bound) and two 8-byte counters (stream stages consumed, workgroups)
-                    hipLaunchKernelGGL(stage_sufmax_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)stream, snorm_d, nst, snorm_d + nst + 1);
-                    ARL_LAUNCH_CHECK();
                     stats_d = reinterpret_cast<unsigned long long *>(static_cast<char *>(workspace) + arl_score_mask_topk_stats_offset(I, d));
-                    if (hipMemsetAsync(stats_d, 0, 2 * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess) return ARL_E_ARG;
+                    pick_d = reinterpret_cast<int *>(stats_d + 2);     // [exit build, plain build]
+                    hipLaunchKernelGGL(stage_sufmax_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)stream, snorm_d, nst, snorm_d + nst + 1, mst, pick_d);
+                    ARL_LAUNCH_CHECK();
+                    if (hipMemsetAsync(stats_d, 0, 2 * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess) return ARL_E_ARG;      // (before the kernels; the two gate words behind them are written by stage_sufmax_kernel)
                 }
             } else {
                 hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, Pi, n, (int)d,
@@ -4222,24 +4505,30 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
             ARL_LAUNCH_CHECK();
             image = workspace;
         }
-#define ARL_TOPK_CASE2(DV, SP, WM, WARMP, GATE)                                                                                        \
+#define ARL_TOPK_CASE3(DV, SP, WM, XT, WARMP, GATE, GATE2)                                                                              \
         do {                                                                                                                           \
-            hipError_t em = hipFuncSetAttribute((const void *)score_mask_topk_mfma16_kernel<DV, SP, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m); \
+            hipError_t em = hipFuncSetAttribute((const void *)score_mask_topk_mfma16_kernel<DV, SP, WM, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m); \
             if (em != hipSuccess) return (int)em;                                                                                      \
-            hipLaunchKernelGGL((score_mask_topk_mfma16_kernel<DV, SP, WM>), dim3(grid_m), dim3(64 * topk_waves(DV, SP)), shm_m, (hipStream_t)stream, Pu, image, (int)U, (int)I, \
-                               mask_rowptr, mask_col, (int)k, top_idx, top_val, Pi, WARMP, underflow, max_bits, order_d, pos_d, GATE, (const float *)snorm_d, stats_d);  \
+            hipLaunchKernelGGL((score_mask_topk_mfma16_kernel<DV, SP, WM, XT>), dim3(grid_m), dim3(64 * topk_waves(DV, SP)), shm_m, (hipStream_t)stream, Pu, image, (int)U, (int)I, \
+                               mask_rowptr, mask_col, (int)k, top_idx, top_val, Pi, WARMP, underflow, max_bits, order_d, pos_d, GATE, (const float *)snorm_d, stats_d, GATE2);  \
         } while (0)
+        /* the fp16 split path launches both builds of the kernel (with / without the early exit); the device runs one (gate2), the other returns at once */
+#define ARL_TOPK_CASE2_true(DV, WM, WARMP, GATE)                                                                                       \
+        do { ARL_TOPK_CASE3(DV, true, WM, true, WARMP, GATE, (const int *)pick_d); ARL_TOPK_CASE3(DV, true, WM, false, WARMP, GATE, (const int *)(pick_d + 1)); } while (0)
+#define ARL_TOPK_CASE2_false(DV, WM, WARMP, GATE) ARL_TOPK_CASE3(DV, false, WM, false, WARMP, GATE, (const int *)nullptr)
         /* a warm-started call is followed by its own cold repeat, gated on the underflow flag on the device: valid results without a host round trip */
 #define ARL_TOPK_CASE(DV, SP)                                                                                                          \
         do {                                                                                                                           \
-            if (warm_idx) { ARL_TOPK_CASE2(DV, SP, true, warm_idx, (const int *)nullptr); ARL_TOPK_CASE2(DV, SP, false, (const int32_t *)nullptr, (const int *)underflow); } \
-            else ARL_TOPK_CASE2(DV, SP, false, (const int32_t *)nullptr, (const int *)nullptr);                                         \
+            if (warm_idx) { ARL_TOPK_CASE2_##SP(DV, true, warm_idx, (const int *)nullptr); ARL_TOPK_CASE2_##SP(DV, false, (const int32_t *)nullptr, (const int *)underflow); } \
+            else ARL_TOPK_CASE2_##SP(DV, false, (const int32_t *)nullptr, (const int *)nullptr);                                        \
         } while (0)
         if (d == 16) ARL_TOPK_CASE(16, false);
         else if (d == 32) ARL_TOPK_CASE(32, false);
         else if (d == 64) { if (split) ARL_TOPK_CASE(64, true); else ARL_TOPK_CASE(64, false); }
         else { if (split) ARL_TOPK_CASE(128, true); else ARL_TOPK_CASE(128, false); }
-#undef ARL_TOPK_CASE2
+#undef ARL_TOPK_CASE2_true
+#undef ARL_TOPK_CASE2_false
+#undef ARL_TOPK_CASE3
 #undef ARL_TOPK_CASE
         ARL_LAUNCH_CHECK();
         return ARL_OK;

@@ -222,7 +222,8 @@ class ShardedPropagationEngine:
         if schedule != 'csr' and hasattr(kernels, 'auto_blocked') and (schedule == 'blocked' or self.Au.nnz + self.Ai.nnz >= kernels.BLOCKED_MIN_NNZ):
             import os
             rpw = int(os.environ.get('ARL_SHARD_RPW', 32))             # developer knob (rows per wave of the shard plans)
-            kernels.auto_blocked(self.Au, self.d, force=True, rows_per_wave=rpw); kernels.auto_blocked(self.Ai, self.d, force=True, rows_per_wave=rpw)
+            kernels.auto_blocked(self.Au, self.d, force=True, rows_per_wave=rpw, small_launch='user')
+            kernels.auto_blocked(self.Ai, self.d, force=True, rows_per_wave=rpw, small_launch='item')
         for gph in (self.Au, self.Ai):                       # flag-masked hops take the rows sorted by length (ops.CSRGraph.enable_masked_order)
             if hasattr(gph, 'enable_masked_order') and gph.nnz >= 1_000_000:
                 gph.enable_masked_order()
@@ -332,10 +333,17 @@ class ShardedPropagationEngine:
         nl = int(min(max(int(n_real) - self.u0, 0), Ul))              # local real users: rows [0, nl)
         tg = torch.as_tensor(list(targets), dtype=torch.int64, device=dev)
         c = 1.0 / (float(n_real) * T)
-        G = torch.zeros_like(out)
-        w = torch.zeros(self.Nl, dtype=torch.float32, device=dev)
-        cw_local = torch.zeros((), dtype=torch.float32, device=dev)
-        if nl:
+        fused_cw = hasattr(k, 'cw_topk_term') and nl > 0               # the hand-written CW term (the oracle-backed CPU test double has none)
+        if fused_cw:
+            # local real users x targets against the replicated item rows: loss share, dL/d(out) (user rows complete, item rows this rank's partial)
+            # and the SFA multiplicities of the local rows, in one kernel group
+            lo, G, w = k.cw_topk_term(out.contiguous(), Ul, nl, top_idx.contiguous(), tg, c=c, check_range=False)
+            cw_local = lo[0]
+        else:
+            G = torch.zeros_like(out)
+            w = torch.zeros(self.Nl, dtype=torch.float32, device=dev)
+            cw_local = torch.zeros((), dtype=torch.float32, device=dev)
+        if nl and not fused_cw:
             ue = out[:nl]
             ranks = top_idx.shape[1] - 1 - torch.arange(T, device=dev)                  # successive .pop()s (CLeaR.py:84-88)
             neg = top_idx[:nl][:, ranks].long()                                         # [nl, T]
@@ -797,27 +805,32 @@ class ShardedPGA:
         self._dcol = self.dinv[:, None].contiguous()
 
     def _hop(self, X, alpha=1.0, beta=0.0, Z=None):
-        """alpha * (A_hat X) + beta * Z on the local rows (Z's item rows replicated)."""
+        """alpha * (A_hat X) + beta * Z on the local rows (Z's item rows replicated).  One element-wise pass (D^-1/2 X: the producer of X does not
+        know the degrees of this step) and, when beta != 0, one I x d add after the reduction; the output-side D^-1/2, alpha and the user rows'
+        beta * Z ride in the SpMM epilogues (row_scale), the fake block's products carry their own row scale."""
         k, Ul = self.k, self.Ul
         Xs = X * self._dcol
         Y = torch.empty_like(X)
-        k.spmm(self.Ai, Xs, out=Y[Ul:])                                 # partial over the local real users
+        du, di = self.dinv[:Ul], self.dinv[Ul:]
+        k.spmm(self.Ai, Xs, alpha, out=Y[Ul:], row_scale=di)            # alpha D_i^-1/2 (partial over the local real users)
         if self.owner and self.F:
             if hasattr(k, 'fake_block_cols_'):                          # + the fake users' contribution to every item row (hand-written product;
-                k.fake_block_cols_(self.S, Xs[self.f0:Ul], Y[Ul:])      #   the oracle-backed CPU test double has no such kernel)
+                k.fake_block_cols_(self.S, Xs[self.f0:Ul], Y[Ul:], rscale=di, alpha=alpha)      #   the oracle-backed CPU test double has no such kernel)
             else:
-                Y[Ul:].addmm_(self.S.t(), Xs[self.f0:Ul])
+                Y[Ul:].add_((self.S.t() @ Xs[self.f0:Ul]) * di[:, None], alpha=alpha)
         work = self.comm.all_reduce_async(Y[Ul:])
-        k.spmm(self.Au, Xs, out=Y[:Ul])
+        if beta != 0.0:
+            k.spmm(self.Au, Xs, alpha, beta, Z[:Ul], out=Y[:Ul], row_scale=du)
+        else:
+            k.spmm(self.Au, Xs, alpha, out=Y[:Ul], row_scale=du)
         if self.owner and self.F:
             if hasattr(k, 'fake_block_rows_'):                          # the fake users' own rows
-                k.fake_block_rows_(self.S, Xs[Ul:], Y[self.f0:Ul])
+                k.fake_block_rows_(self.S, Xs[Ul:], Y[self.f0:Ul], rscale=du[self.f0:], alpha=alpha)
             else:
-                Y[self.f0:Ul] += self.S @ Xs[Ul:]
+                Y[self.f0:Ul].add_((self.S @ Xs[Ul:]) * du[self.f0:, None], alpha=alpha)
         work.wait()
-        Y.mul_(self._dcol * alpha)
         if beta != 0.0:
-            Y.add_(Z, alpha=beta)
+            Y[Ul:].add_(Z[Ul:], alpha=beta)                             # replicated rows: once, after the reduction
         return Y
 
     def forward(self):

@@ -403,13 +403,25 @@ BLOCKED_MIN_NNZ = 6_000_000      # measured cross-over (tools/blocked_bench.py):
 BLOCKED_MIN_WAVES = 1024         # a row set with fewer waves stays with the CSR kernel
 
 
-def auto_blocked(graph, d, split=None, force=False, rows_per_wave=32):
+def auto_blocked(graph, d, split=None, force=False, rows_per_wave=32, small_launch=None):
     """Attach the register-blocked plan to `graph` when it pays (d = 64 or 128, >= BLOCKED_MIN_NNZ edges) or when forced; no-op if the
-    graph already has one or cannot take one (other widths, 2^24 columns or more).  Returns the graph."""
+    graph already has one or cannot take one (other widths, 2^24 columns or more).  Returns the graph.
+    small_launch ('user' | 'item' | None): the graph is ONE rectangular block of the user-sharded step (a rank's user rows gathering item rows, or
+    the item rows gathering its users).  The plan's defaults were measured on 32 M-edge launches; on the ~4 M-edge blocks of N = 8
+    (tools/shard_hop_sweep.py, profiles/r04_c_shard_sweep.txt): item rows run better as twice as many waves of 16 rows, one wave per workgroup,
+    while a wave carries under 2 048 edges (108.2 -> 99.0 us); user rows with 16 loads in flight instead of 32 while the launch has under
+    8 192 waves (95.9 -> 91.6 us).  Larger blocks (N = 2, 4) keep the defaults."""
     if graph is None or graph.blocked is not None or int(d) not in (64, 128) or graph.n_cols >= (1 << 24):
         return graph
     if force or graph.nnz >= BLOCKED_MIN_NNZ:
-        graph.enable_blocked(split=split, rows_per_wave=rows_per_wave, min_waves=0 if force else BLOCKED_MIN_WAVES)
+        kw = {}
+        if small_launch is not None and not split and rows_per_wave == 32:
+            waves32 = max(1, (graph.n_rows + 31) // 32)
+            if small_launch == 'item' and graph.nnz < 2048 * waves32:
+                rows_per_wave, kw = 16, {'wpg': 1}
+            elif small_launch == 'user' and waves32 < 8192:
+                kw = {'unroll': 16}
+        graph.enable_blocked(split=split, rows_per_wave=rows_per_wave, min_waves=0 if force else BLOCKED_MIN_WAVES, **kw)
     return graph
 
 
@@ -1194,6 +1206,38 @@ def pga_update_(S, grad, dinv_rows=None, dinv_cols=None):
             raise ValueError('pga_update_: dinv_cols length')
     check(_lib.lib().arl_pga_update_f32(_ptr(S), _ptr(grad), _ptr(dinv_rows), _ptr(dinv_cols), S.shape[0], S.shape[1], _stream()), 'arl_pga_update_f32')
     return S
+
+
+_CW_WS = {}
+
+
+def cw_topk_term(X, n_user_rows, n_real, top_idx, targets, c=None, want_w=True, check_range=True):
+    """CW term of the attacks' surrogate loss from the users' top-k lists (attack/White/CLeaR.py:83-95, PGA.py:104-116) on the packed table
+    X [n_user_rows + I, d]: pairs (real user u < n_real) x (target t), negative = top_idx[u][k - 1 - t].  Returns (loss[1], G [like X], w) with
+    loss = c * sum <X_u, X_neg - X_tg> (c defaults to 1 / (n_real T): the reference's mean), G = d loss / d X, and w (want_w) the SFA term's row
+    multiplicities (CLeaR.py:98-103).  targets: int64 device tensor of item ids.  Deterministic (64-bit fixed-point item sums), five launches."""
+    _dev(X, torch.float32, 'X', 2); _dev(top_idx, torch.int32, 'top_idx', 2); _dev(targets, torch.int64, 'targets', 1)
+    N, d = X.shape
+    Up, n_real = int(n_user_rows), int(n_real)
+    I, k, T = N - Up, top_idx.shape[1], targets.numel()
+    if not (0 < Up < N) or not (0 <= n_real <= Up) or top_idx.shape[0] < n_real or not (0 < T <= min(k, 64)) or d > 256:
+        raise ValueError('cw_topk_term: X [n_user_rows + I, d], top_idx [>= n_real, k], 1 <= T <= min(k, 64), d <= 256')
+    if check_range and n_real and (int(top_idx[:n_real, k - T:].min()) < 0 or int(top_idx[:n_real, k - T:].max()) >= I or int(targets.min()) < 0 or int(targets.max()) >= I):
+        raise IndexError('cw_topk_term: item id out of range')
+    L = _lib.lib()
+    need = L.arl_cw_topk_term_workspace_bytes(I, d, n_real, T)
+    key = (X.device, need)
+    ws = _CW_WS.get(key)
+    if ws is None:
+        _CW_WS.clear()
+        ws = _CW_WS[key] = torch.empty(max(need, 8), dtype=torch.uint8, device=X.device)
+    G = torch.empty_like(X)
+    loss = torch.empty(1, dtype=torch.float32, device=X.device)
+    w = torch.empty(N, dtype=torch.float32, device=X.device) if want_w else None
+    c = 1.0 / (max(n_real, 1) * T) if c is None else float(c)
+    check(L.arl_cw_topk_term_f32(_ptr(X), Up, I, d, n_real, _ptr(top_idx), k, _ptr(targets), T, c, _ptr(G), _ptr(loss), _ptr(w), _ptr(ws), _stream()),
+          'arl_cw_topk_term_f32')
+    return loss, G, w
 
 
 TOPK_STATS = {'calls': 0, 'warm': 0, 'cold_repeats': 0}     # counters for benches: warm-started calls and how many of them had to be repeated cold

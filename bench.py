@@ -50,6 +50,7 @@ def parse():
     ap.add_argument('--repeats', type=int, default=3, help='timed regions of K steps each: the first is the contract figure (`value`), all are listed with median and spread')
     ap.add_argument('--api-steps', type=int, default=600, help='steps of LightGCN(args, DataLoader).train() to time through the class API at N=1 (0 disables)')
     ap.add_argument('--model-steps', type=int, default=20, help='steps of the SimGCL (L=2) and NGCF (d=128, L=3) training steps to time at N=1 on the same graph (0 disables)')
+    ap.add_argument('--share-steps', type=int, default=30, help='steps of ONE rank\'s share of the N=8 step to time alone on this GPU (projected_ceiling_8gpu; 0 disables)')
     ap.add_argument('--l2-ceiling', type=int, default=1, help='measure the hop with every gather an L2 hit (roofline.attainable); 0 disables')
     ap.add_argument('--dense-step', action='store_true', help='time the reference-shaped step (all 2L hops on the full graph) as the main number')
     return ap.parse_args()
@@ -231,6 +232,12 @@ def attack_leg(torch, ops, data, E0_dev, args):
     ops.score_mask_topk(Ru, Ri, 50); torch.cuda.synchronize(); t1 = time.perf_counter()
     ops.score_mask_topk(Ru, Ri, 50); torch.cuda.synchronize(); topk_random_s = time.perf_counter() - t1
     skipped_random = ops.topk_exit_fractions()
+    # ... and with the item rows' NORMS spread like a popularity-skewed model's (log-normal, sigma 1; same random directions): what the exit buys when the
+    # tables have the structure it needs -- the device picks the exit build of the kernel from the norm profile, the plain one otherwise
+    Ri *= torch.exp(torch.randn(Ri.shape[0], 1, generator=gr, device=E0_dev.device))
+    ops.score_mask_topk(Ru, Ri, 50); torch.cuda.synchronize(); t1 = time.perf_counter()
+    ops.score_mask_topk(Ru, Ri, 50); torch.cuda.synchronize(); topk_skewed_s = time.perf_counter() - t1
+    skipped_skewed = ops.topk_exit_fractions()
     ops.TOPK_STATS['record_exit'] = False
     del Ru, Ri
     del Pu_all, Pi_all
@@ -276,9 +283,9 @@ def attack_leg(torch, ops, data, E0_dev, args):
                                              'note': 'fp16 matrix flops executed by the stream: ONE fp16 product per (user, item, k) -- the high pieces; the two other products of '
                                                      'the split form run only for queued candidates (a 16 x 16 tile per merge) and are not counted; dense fp16/bf16 MFMA peak. '
                                                      'The pass is bound by its ring / candidate handling, not by the matrix pipe (DESIGN 3b)'},
-                                'stages_skipped_frac': {'trained_propagated_tables': skipped_trained, 'random_tables': skipped_random,
+                                'stages_skipped_frac': {'trained_propagated_tables': skipped_trained, 'random_tables': skipped_random, 'lognormal_item_norms': skipped_skewed,
                                                         'what': 'share of (workgroup, 64-item stage) pairs of the norm-ordered item stream the exact early exit never scored'},
-                                'random_tables_seconds': topk_random_s,
+                                'random_tables_seconds': topk_random_s, 'lognormal_item_norms_seconds': topk_skewed_s,
                                 'note': '`tflops` = fp32-equivalent (2 U I d); once per inner epoch, not per step'},
             'setup_seconds': setup_s}
 
@@ -439,6 +446,69 @@ def model_legs(torch, ops, engine, data, A, dev_batches, args, steps=20):
     del eng, E0, rows
     torch.cuda.empty_cache()
     return out
+
+
+class _NullWork:
+    def wait(self):
+        return True
+
+
+class _NullComm:
+    """Stand-in collective for ONE rank's share timed alone on this GPU: the buffers are left as they are (the values of the item rows are then this
+    rank's partials -- the kernels' cost does not depend on them), nothing is exchanged, nothing waits."""
+    measure = False
+    item_exchange = 'none'
+
+    def all_reduce_async(self, t):
+        return _NullWork()
+
+    def all_reduce(self, t):
+        return t
+
+
+def share_leg(torch, data, E0, dev_batches, args, ms_1gpu, world=8, steps=30):
+    """What bounds the 8-GPU speed-up before a byte crosses xGMI: rank 0's share of the cfg2 step at N = 8 (125 K local users x 100 K items: its two
+    rectangular blocks, its batch samples, the replicated item table and Adam state) run through the SAME code path `bench.py --gpus 8` runs
+    (dist_engine.ShardedPropagationEngine.step_sparse) with a no-op collective, timed alone on this GPU.  projected_ceiling_8gpu = t_1gpu / t_share: the
+    strong-scaling speed-up with zero exposed communication and perfectly balanced ranks (SYN-v1 users are i.i.d., the blocks have equal size)."""
+    from arlib_amd import dist_engine
+    U, I, nnz = data.training_size()
+    dev = dev_batches.device
+    t0 = time.perf_counter()
+    eng = dist_engine.ShardedPropagationEngine.from_pairs(data.pairs0, U, I, args.emb, args.layers, 1e-4, 0.005, dev, 0, world, table=E0, chunk=args.chunk,
+                                                           schedule=args.schedule, comm=_NullComm())
+    build_s = time.perf_counter() - t0
+    nb = dev_batches.shape[0]
+    for k in range(5):
+        eng.step_sparse(dev_batches[k % nb, 0], dev_batches[k % nb, 1], dev_batches[k % nb, 2])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    th = time.perf_counter(); e0.record()
+    for k in range(steps):
+        eng.step_sparse(dev_batches[k % nb, 0], dev_batches[k % nb, 1], dev_batches[k % nb, 2])
+    e1.record(); t_enq = time.perf_counter() - th
+    torch.cuda.synchronize()
+    span_ms = e0.elapsed_time(e1) / steps
+    # GPU-busy time and launch count per step from the profiler's device records (the span above also holds launch gaps)
+    busy_ms = launches = None
+    try:
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            for k in range(3):
+                eng.step_sparse(dev_batches[k % nb, 0], dev_batches[k % nb, 1], dev_batches[k % nb, 2])
+            torch.cuda.synchronize()
+        ev = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+        busy_ms, launches = sum(e.device_time for e in ev) / 3e3, len(ev) / 3.0
+    except Exception as e:                                   # the figure of merit below falls back to the event span
+        busy_ms = None
+    t_share = busy_ms if busy_ms else span_ms
+    del eng
+    torch.cuda.empty_cache()
+    return {'what': 'rank 0 of %d: %d local users x %d items, same step as --gpus %d (step_sparse), no-op collective, alone on this GPU' % (world, U // world, I, world),
+            'gpu_busy_ms_per_step': busy_ms, 'launches_per_step': launches, 'event_span_ms_per_step': span_ms, 'host_enqueue_ms_per_step': 1e3 * t_enq / steps,
+            'steps_timed': steps, 'build_seconds': build_s, 't_1gpu_ms': ms_1gpu,
+            'projected_ceiling_8gpu': ms_1gpu / t_share, 'projected_ceiling_8gpu_from_event_span': ms_1gpu / span_ms,
+            'note': 'ceiling of the strong-scaling speed-up at %d GPUs with ZERO exposed communication; a measured SCALE run can only be below it' % world}
 
 
 def class_api_leg(torch, data, args, engine_ms):
@@ -779,6 +849,11 @@ def main():
             E0_snapshot = None
             torch.cuda.empty_cache()
             res.update(model_legs(torch, ops, engine, data, eng.A, dev_batches, args, steps=args.model_steps))
+        if not sharded and args.share_steps > 0 and U >= 8 * 64:
+            torch.cuda.empty_cache()
+            sh = share_leg(torch, data, E0, dev_batches, args, float(np.median(region_s)) * 1e3 / args.steps, steps=args.share_steps)
+            res['rank_share_n8'] = sh
+            res['projected_ceiling_8gpu'] = sh['projected_ceiling_8gpu']
         if not sharded and args.api_steps > 0:
             torch.cuda.empty_cache()
             res['class_api'] = class_api_leg(torch, data, args, float(np.median(region_s)) * 1e3 / args.steps)

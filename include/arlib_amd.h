@@ -425,6 +425,21 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
                             const int32_t *mask_rowptr, const int32_t *mask_col, int64_t k, int32_t *top_idx,
                             float *top_val, void *workspace, const int32_t *warm_idx, int32_t *underflow,
                             const int32_t *item_order, arl_stream_t stream);
+/* CW term of the white-box attacks' surrogate loss, from the users' top-k lists (attack/White/CLeaR.py:83-95, PGA.py:104-116; the reference builds
+ * three Python lists of U*T ids and gathers a [U*T, d] matrix per side).  X [n_user_rows + n_items, d] = the packed propagated tables (users first);
+ * pairs = (real user u < n_real) x (target t): negative item neg(u, t) = top_idx[u][k - 1 - t] (the successive .pop()s of CLeaR.py:84-88), positive
+ * = targets[t] (item ids, int64, on the device).
+ *     *loss = c * sum_{u,t} <X_u, X_neg(u,t)> - <X_u, X_tg(t)>          (c = 1 / (n_real * T) gives the reference's mean)
+ *     G     = d loss / d X on every row of X (rows of fake users n_real <= r < n_user_rows: zero)
+ *     w_sfa (optional, [n_user_rows + n_items]) = how often each row occurs in H = cat(users, positives, negatives) of CLeaR.py:98-103: T per real
+ *             user, n_real per target occurrence, the negatives' histogram -- the row weights of arl_sfa_l1_fwd_bwd_f32.
+ * Deterministic: the item-side sums run in 64-bit fixed point (integer addition is associative; scale chosen on the device so that no sum can
+ * overflow, resolution far below fp32 rounding of the same sum); no float atomics, no sort.  top_idx entries must be item ids in [0, n_items)
+ * (the caller's own arl_score_mask_topk_f32 output).  T <= 64 <= ... k >= T, d <= 256, n_items <= 1024 * (256 | 128 | 64 rows for d <= 64 | 128 | 256). */
+int64_t arl_cw_topk_term_workspace_bytes(int64_t n_items, int64_t d, int64_t n_real, int64_t n_targets);
+int arl_cw_topk_term_f32(const float *X, int64_t n_user_rows, int64_t n_items, int64_t d, int64_t n_real, const int32_t *top_idx, int64_t k,
+                         const int64_t *targets, int64_t n_targets, float c, float *G, float *loss, float *w_sfa, void *workspace,
+                         arl_stream_t stream);
 /* Per-row top-n -> {0,1} rows (+ indices, descending value, ties ascending column).  Replaces project()
  * (attack/White/PGA.py:153-158, CLeaR.py:161-166, DLAttack.py:127-132).  scratch: [rows*cols] fp32. */
 int arl_topn_project_rows_f32(const float *M, int64_t rows, int64_t cols, int64_t n, float *out, int32_t *idx,

@@ -16,9 +16,15 @@ class CSRGraph:
         assert self.nnz == 0 or (self.col.min() >= 0 and self.col.max() < self.n_cols)
 
 
-def spmm(A, X, alpha=1.0, beta=0.0, Z=None, out=None):
+def spmm(A, X, alpha=1.0, beta=0.0, Z=None, out=None, row_scale=None, rows_from=0):
     assert X.shape[0] == A.n_cols
-    y = O.spmm((A.rowptr, A.col, A.val), X.numpy(), alpha, beta, Z.numpy() if (Z is not None and beta != 0.0) else None)
+    if row_scale is not None:       # alpha * diag(row_scale) (A X) + beta * Z
+        y = O.spmm((A.rowptr, A.col, A.val), X.numpy()).astype(np.float64) * (alpha * row_scale.numpy().astype(np.float64))[:, None]
+        if Z is not None and beta != 0.0:
+            y += beta * Z.numpy()
+        y = y.astype(np.float32)
+    else:
+        y = O.spmm((A.rowptr, A.col, A.val), X.numpy(), alpha, beta, Z.numpy() if (Z is not None and beta != 0.0) else None)
     if out is None:
         return torch.from_numpy(y)
     out.copy_(torch.from_numpy(y))

@@ -42,6 +42,7 @@ def test_bench_json_contract_small_instance():
     assert r['class_api']['epoch_wall_interactions_per_s'] > 0 and r['class_api']['epoch_wall']['serial_sampler_seconds'] > 0
     for leg in ('simgcl_step', 'ngcf_step'):                      # BASELINE configs 4 and 5 on one GPU
         assert r[leg]['value'] > 0 and r[leg]['algorithmic_bytes_per_step'] > 0 and 0 < r[leg]['hbm_frac'] < 1
+    assert r['projected_ceiling_8gpu'] > 0 and r['rank_share_n8']['launches_per_step'] is None or r['rank_share_n8']['launches_per_step'] > 0      # one rank's share of the N = 8 step, alone
     sk = r['attack']['score_topk_pass']['stages_skipped_frac']
     assert all(0.0 <= x <= 1.0 for x in sk['trained_propagated_tables'] + sk['random_tables'])
 

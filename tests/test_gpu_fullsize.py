@@ -289,7 +289,11 @@ def test_simgcl_fused_step_full_size_equals_autograd_route(cfg2):
     s.shuffle(mt)
     b = torch.from_numpy(s.batch(mt, 0, B)).to(DEV)
     # fused
-    eng = engine.PropagationEngine(Ab, U, I, d, L, 1e-4, 0.005, DEV, skip_layer0=True, table=E0.clone())
+    # Adam with eps = 1e-3 on both routes: the FIRST Adam step is lr g / (|g| + eps), and two hops away from the batch |g| ~ 1e-8 = the default eps, where
+    # d(update)/dg = lr / (4 eps) ~ 1e5 turns the routes' 1e-11 rounding differences in g into 7e-6 in the table (measured: 5.7e-4 of the table's
+    # maximum).  With eps >> |g| the update is linear in g, so comparing the UPDATES at 1e-4 compares the gradients at 1e-4.
+    AEPS = 1e-3
+    eng = engine.PropagationEngine(Ab, U, I, d, L, 1e-4, 0.005, DEV, skip_layer0=True, table=E0.clone(), eps=AEPS)
     lo, cl = eng.step_simgcl(b[0], b[1], b[2], cl_rate=0.2, tau=0.2, eps=0.1, noises=noises)
     fused = eng.E0.clone(); lo = lo.cpu().numpy(); cl = float(cl)
     del eng
@@ -304,7 +308,7 @@ def test_simgcl_fused_step_full_size_equals_autograd_route(cfg2):
     adj = SparseNormAdj.__new__(SparseNormAdj)
     adj.shape, adj.indptr, adj.indices, adj.values, adj._graph = (N, N), None, None, Ab.val, Ab
     enc.sparse_norm_adj = adj
-    opt = torch.optim.Adam(enc.parameters(), lr=0.005)
+    opt = torch.optim.Adam(enc.parameters(), lr=0.005, eps=AEPS)
     ue, ie = enc()
     ul, pl, nl = b[0].long(), b[1].long(), b[2].long()
     rec = bpr_l2_loss(ue[ul], ie[pl], ie[nl], 1e-4)
@@ -313,11 +317,13 @@ def test_simgcl_fused_step_full_size_equals_autograd_route(cfg2):
     (rec + cl2).backward()
     opt.step()
     ref = torch.cat([enc.embedding_dict['user_emb'].detach(), enc.embedding_dict['item_emb'].detach()], 0)
-    assert abs(float(lo[0] + lo[1]) - float(rec)) <= 1e-4 * abs(float(rec)) and abs(cl - float(cl2)) <= 1e-4 * abs(float(cl2))
-    assert ((fused - ref).abs().max() / ref.abs().max()).item() < 1e-4
+    assert abs(float(lo[0] + lo[1]) - float(rec.detach())) <= 1e-4 * abs(float(rec.detach())) and abs(cl - float(cl2.detach())) <= 1e-4 * abs(float(cl2.detach()))
+    uf, ur = fused - E0, ref - E0                                                      # the step's updates
+    assert ((uf - ur).abs().max() / ur.abs().max()).item() < 1e-4
+    assert ((fused - ref).abs().max() / ref.abs().max()).item() < 1e-5                 # (and the tables themselves)
     rows = torch.from_numpy(np.random.default_rng(1).choice(N, 200_000, replace=False)).to(DEV)
-    rn = ref[rows].norm(dim=1)
-    assert (((fused[rows] - ref[rows]).norm(dim=1)) / torch.clamp(rn, min=1e-3 * float(rn.max()))).max().item() < 1e-4       # sampled rows, each at its own magnitude
+    rn = ur[rows].norm(dim=1)
+    assert (((uf[rows] - ur[rows]).norm(dim=1)) / torch.clamp(rn, min=1e-3 * float(rn.max()))).max().item() < 1e-4       # sampled rows, each at its own magnitude
     moved = ((ref - E0).abs().max(dim=1)[0] > 0).float().mean().item()
     assert moved > 0.1                                                                 # dense Adam: two hops from the 6 K batch rows reach a large part of the graph, all of it moves
     del enc, opt, ref, fused

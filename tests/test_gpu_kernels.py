@@ -356,7 +356,7 @@ def test_nce_allrows_against_float64(ops, nA, nV, d):
     Aneg = torch.nn.functional.normalize(-V[:nA if nA <= nV else nV].mean(0, keepdim=True).repeat(min(nA, 16), 1) + 0.01 * torch.randn(min(nA, 16), d, generator=g).to(DEV), dim=1).contiguous()
     l4, dA4, dV4 = ops.nce_allrows(Aneg, V, ops.NCE_ALLROWS_MIN_TAU)
     S4 = (Aneg.double() @ V.double().T) / ops.NCE_ALLROWS_MIN_TAU
-    assert float(S4.max()) < 0.5 / ops.NCE_ALLROWS_MIN_TAU and bool(torch.isfinite(l4).all()) and bool(torch.isfinite(dA4).all()) and bool(torch.isfinite(dV4).all())
+    assert bool(torch.isfinite(l4).all()) and bool(torch.isfinite(dA4).all()) and bool(torch.isfinite(dV4).all())
     assert float((l4.double() - torch.logsumexp(S4, dim=1)).abs().max()) < 1e-4
     with pytest.raises(ValueError):
         ops.nce_allrows(A, V, 0.01)
@@ -509,6 +509,47 @@ def test_batch_rows_set_zero_factor_entries_are_absent(ops):
             assert np.array_equal(((dn[np.arange(N) >> 5] >> (np.arange(N) & 31)) & 1).astype(bool), np.bincount(idx[own], minlength=N) > 1)
         ops.batch_rows_clear_(G, flags, bits, T(idx), dup_bits=dup)
         assert int(flags.max()) == 0 and int(bits.abs().max()) == 0
+
+
+@pytest.mark.parametrize('U,F,I,d,k,nT', [(3000, 7, 900, 64, 50, 5), (500, 0, 70, 16, 8, 3), (1200, 3, 5000, 128, 20, 1), (257, 1, 300, 100, 64, 64)])
+def test_cw_topk_term_against_float64_and_deterministic(ops, U, F, I, d, k, nT):
+    """arl_cw_topk_term_f32 (attack/White/CLeaR.py:83-95): loss, gradient on every row of the packed table and the SFA row multiplicities against a
+    float64 restatement of the pair lists (negative = successive .pop()s from the tail of the top-k list), the oracle's cw_loss_grad, and two runs
+    bit for bit -- with the negatives concentrated on a handful of items (thousands of addends per item row: the order-free fixed-point sums)."""
+    from arlib_amd.attack._common import cw_pairs
+    rng = np.random.default_rng(U + I + d)
+    Up = U + F
+    X = (rng.standard_normal((Up + I, d)) * 10.0 ** rng.integers(-3, 1, (Up + I, 1))).astype(np.float32)
+    top = np.stack([rng.choice(I, size=k, replace=False) for _ in range(Up)]).astype(np.int32)
+    hot = rng.choice(I, size=3, replace=False)
+    top[: U // 2, k - 1] = hot[0]; top[U // 4: U, max(k - 2, 0)] = hot[1]                     # heavy rows (a distinct-list violation does not matter to the term)
+    targets = rng.choice(I, size=nT, replace=False).astype(np.int64)
+    c = 1.0 / (U * nT)
+    Xd = X.astype(np.float64)
+    neg = top[:U][:, [k - 1 - t for t in range(nT)]].astype(np.int64)                          # [U, nT]
+    loss_ref = c * sum(((Xd[:U] * Xd[Up + neg[:, t]]).sum() - (Xd[:U] * Xd[Up + targets[t]]).sum()) for t in range(nT))
+    G_ref = np.zeros_like(Xd)
+    for t in range(nT):
+        G_ref[:U] += c * (Xd[Up + neg[:, t]] - Xd[Up + targets[t]])
+        np.add.at(G_ref, Up + neg[:, t], c * Xd[:U])
+        G_ref[Up + targets[t]] -= c * Xd[:U].sum(0)
+    w_ref = np.zeros(Up + I); w_ref[:U] = nT
+    np.add.at(w_ref, Up + neg.reshape(-1), 1.0); np.add.at(w_ref, Up + targets, float(U))
+    outs = []
+    for _ in range(2):
+        loss, G, w = ops.cw_topk_term(T(X), Up, U, T(top), torch.from_numpy(targets).to(DEV))
+        outs.append((loss.clone(), G.clone(), w.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    loss, G, w = (t.cpu().numpy() for t in outs[0])
+    assert abs(loss[0] - loss_ref) <= 1e-5 * max(abs(loss_ref), np.abs(G_ref).max())
+    assert rel_err(G, G_ref) < 5e-6 and row_err(G, G_ref) < 2e-5
+    assert np.array_equal(w, w_ref.astype(np.float32)) and float(np.abs(G[U:Up]).max() if F else 0.0) == 0.0
+    users, pos, ng = cw_pairs(T(top).long(), U, [int(t) for t in targets], pop=True)
+    lo, Go = O.cw_loss_grad(X, Up, users.cpu().numpy(), pos.cpu().numpy(), ng.cpu().numpy())
+    assert abs(loss[0] - lo) <= 1e-4 * max(abs(lo), np.abs(Go).max()) and close(G, Go)
+    with pytest.raises(IndexError):
+        bad = top.copy(); bad[0, k - 1] = I
+        ops.cw_topk_term(T(X), Up, U, T(bad), torch.from_numpy(targets).to(DEV))
 
 
 def test_bpr_backward_ordered(ops):

@@ -51,7 +51,7 @@ print('blocked hop (RPW=%d HUB=%d UB=%d): %.3f ms' % (RPW, HUB, UB, t(lambda: op
 import ctypes as C
 from arlib_amd import _lib
 st = ops._stream()
-for k, s in enumerate(bp.structs):
+for k, s in enumerate([bp.struct(j, d) for j in range(len(bp.sets))]):
     print('  row set %d: %.3f ms' % (k, t(lambda: _lib.check(_lib.lib().arl_spmm_blocked_f32(C.byref(s), X.data_ptr(), d, 1.0, 0.0, None, None, Yb.data_ptr(), st), 'blocked'))))
 if bp.hub is not None:
     print('  hub rows (chunked CSR kernel): %.3f ms' % t(lambda: _lib.check(_lib.lib().arl_spmm_csr_f32(C.byref(bp.hub._struct(d)), X.data_ptr(), d, 1.0, 0.0, None, Yb.data_ptr(), st), 'csr')))
