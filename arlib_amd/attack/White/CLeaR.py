@@ -54,7 +54,7 @@ class _CwSfaLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_cw, g_sfa):
         G_cw, G_sfa = ctx.saved_tensors
-        G = g_cw * G_cw + g_sfa * G_sfa
+        G = torch.addcmul(g_cw * G_cw, G_sfa, g_sfa)              # g_cw G_cw + g_sfa G_sfa in two passes
         return G[:ctx.Up], G[ctx.Up:], None, None, None, None
 
 

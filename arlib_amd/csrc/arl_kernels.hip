@@ -3279,13 +3279,16 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfm
 constexpr int kCwParts = 1024;       // workgroups of cw_user_kernel = partial sums folded by cw_scan_kernel
 constexpr int kCwSlice = 8192;       // entries per workgroup of cw_item_kernel
 constexpr int kCwItemThreads = 1024;
-__host__ __device__ inline int cw_ipg(int d) { const int a = 16384 / d; return a >= 256 ? 256 : (a >= 128 ? 128 : 64); }      // item rows per group: IPG * d * 8 B of LDS <= 128 KB
+constexpr int kCwMaxGroups = 8192;   // item groups (LDS histograms of that many bins)
+// item rows per group: IPG * d * 8 B of LDS accumulators -- 64 KB at d = 64 (two workgroups of cw_item_kernel per CU), 128 KB at d = 128 / 256
+__host__ __device__ inline int cw_ipg(int d) { return d <= 128 ? 128 : 64; }
 
 struct CwWs {                        // carved out of the caller's workspace (arl_cw_topk_term_workspace_bytes)
     float *part;                     // [kCwParts][d + 2]: column sums, loss terms, |x| maximum
     float *colsum;                   // [d]
     double *scale;                   // [0] 2^e, [1] 2^-e
-    int32_t *neg_cnt;                // [I]
+    int32_t *neg_cnt;                // [I]: filled by cw_item_kernel (per-slice counts)
+    int32_t *grp_tot;                // [G]: entries per item group, filled by cw_user_kernel (per-workgroup counts)
     int32_t *grp_off;                // [G + 1]
     int32_t *cursor;                 // [G]
     int32_t *slices;                 // [max_slices][4]: group, begin, end, -
@@ -3294,87 +3297,124 @@ struct CwWs {                        // carved out of the caller's workspace (ar
     long long *acc;                  // [I * d]
 };
 
-__global__ __launch_bounds__(kBlock) void cw_user_kernel(const float *__restrict__ X, int d, long long Up, int n_real, const int32_t *__restrict__ top_idx, int k,
-                                                         const long long *__restrict__ targets, int T, float c, float *__restrict__ G, float *__restrict__ w,
-                                                         CwWs W, int rows_per_wg) {
-    __shared__ float red[kWavesPerBlock][256 + 2];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    constexpr int MC = 4;                                          // columns per lane: d <= 256
-    float tgs[MC], cs[MC];
-#pragma unroll
-    for (int j = 0; j < MC; ++j) { tgs[j] = 0.f; cs[j] = 0.f; }
-    for (int t = 0; t < T; ++t) {
-        const float *xr = X + (size_t)(Up + targets[t]) * d;
-#pragma unroll
-        for (int j = 0; j < MC; ++j) { const int col = lane + 64 * j; if (col < d) tgs[j] += xr[col]; }
-    }
+// LPR lanes x float4 own one user row (d = 64: 16 lanes, four rows per wave in flight); d % 4 == 0.
+template <int LPR>
+__global__ __launch_bounds__(kCwItemThreads) void cw_user_kernel(const float *__restrict__ X, int d, long long Up, int n_real, const int32_t *__restrict__ top_idx, int k,
+                                                                 const long long *__restrict__ targets, int T, float c, float *__restrict__ G, float *__restrict__ w,
+                                                                 CwWs W, int rows_per_wg, int ipg, int n_groups) {
+    constexpr int NW = kCwItemThreads / kWave, RPV = kWave / LPR;  // waves per workgroup, rows per wave
+    __shared__ float red[NW][256 + 2];
+    __shared__ int ghist[kCwMaxGroups];                            // entries per item group seen by this workgroup (same-address GLOBAL atomics serialise: the
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;      //   tails of everybody's lists fall on few popular items -- counted in LDS, flushed once)
+    const int q = lane % LPR, grp = lane / LPR;
+    const bool act = q * 4 < d;
+    for (int gI = threadIdx.x; gI < n_groups; gI += kCwItemThreads) ghist[gI] = 0;
+    __syncthreads();
+    float4 tgs = make_float4(0.f, 0.f, 0.f, 0.f), cs = tgs;
+    if (act)
+        for (int t = 0; t < T; ++t) tgs = add4(tgs, *reinterpret_cast<const float4 *>(X + (size_t)(Up + targets[t]) * d + q * 4));
     float dot = 0.f, amax = 0.f;
     const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, Up);
-    for (long long r = r0 + wv; r < r1; r += kWavesPerBlock) {
-        float *g = G + (size_t)r * d;
+    for (long long r = r0 + wv * RPV + grp; r < r1; r += NW * RPV) {
+        float4 *g = reinterpret_cast<float4 *>(G + (size_t)r * d + q * 4);
         if (r >= n_real) {                                         // fake users take no part in the CW pairs
-#pragma unroll
-            for (int j = 0; j < MC; ++j) { const int col = lane + 64 * j; if (col < d) g[col] = 0.f; }
-            if (w && lane == 0) w[r] = 0.f;
+            if (act) *g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (w && q == 0) w[r] = 0.f;
             continue;
         }
         const int32_t *tl = top_idx + (size_t)r * k + (k - 1);
-        float acc[MC];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t0 = 0; t0 < T; t0 += 8) {                        // eight gathers in flight per lane
+            int it[8]; float4 x[8];
 #pragma unroll
-        for (int j = 0; j < MC; ++j) acc[j] = 0.f;
-        for (int t = 0; t < T; ++t) {
-            const float *xr = X + (size_t)(Up + tl[-t]) * d;       // wave-uniform row: one 4d-byte gather
+            for (int j = 0; j < 8; ++j) it[j] = t0 + j < T ? tl[-(t0 + j)] : -1;
 #pragma unroll
-            for (int j = 0; j < MC; ++j) { const int col = lane + 64 * j; if (col < d) acc[j] += xr[col]; }
+            for (int j = 0; j < 8; ++j) x[j] = (it[j] >= 0 && act) ? *reinterpret_cast<const float4 *>(X + (size_t)(Up + it[j]) * d + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = add4(acc, x[j]);     // t ascending
         }
-        if (lane < T) atomicAdd(W.neg_cnt + tl[-lane], 1);
-        const float *xu = X + (size_t)r * d;
-#pragma unroll
-        for (int j = 0; j < MC; ++j) {
-            const int col = lane + 64 * j;
-            if (col < d) {
-                const float x = xu[col], gv = c * (acc[j] - tgs[j]);
-                g[col] = gv;
-                dot = fmaf(x, gv, dot);
-                cs[j] += x;
-                amax = fmaxf(amax, fabsf(x));
-            }
+        for (int t = q; t < T; t += LPR) atomicAdd(&ghist[tl[-t] / ipg], 1);
+        if (act) {
+            const float4 x = *reinterpret_cast<const float4 *>(X + (size_t)r * d + q * 4);
+            const float4 gv = make_float4(c * (acc.x - tgs.x), c * (acc.y - tgs.y), c * (acc.z - tgs.z), c * (acc.w - tgs.w));
+            *g = gv;
+            dot = fmaf(x.x, gv.x, dot); dot = fmaf(x.y, gv.y, dot); dot = fmaf(x.z, gv.z, dot); dot = fmaf(x.w, gv.w, dot);
+            cs = add4(cs, x);
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(x.x), fabsf(x.y))), fmaxf(fabsf(x.z), fabsf(x.w)));
         }
-        if (w && lane == 0) w[r] = (float)T;
+        if (w && q == 0) w[r] = (float)T;
     }
     dot = wave_sum(dot);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
 #pragma unroll
-    for (int j = 0; j < MC; ++j) { const int col = lane + 64 * j; if (col < d) red[wv][col] = cs[j]; }
+    for (int off = LPR; off < kWave; off <<= 1) {                  // the wave's row groups, fixed butterfly order
+        cs.x += __shfl_xor(cs.x, off); cs.y += __shfl_xor(cs.y, off); cs.z += __shfl_xor(cs.z, off); cs.w += __shfl_xor(cs.w, off);
+    }
+    if (grp == 0 && act) { red[wv][q * 4] = cs.x; red[wv][q * 4 + 1] = cs.y; red[wv][q * 4 + 2] = cs.z; red[wv][q * 4 + 3] = cs.w; }
     if (lane == 0) { red[wv][256] = dot; red[wv][257] = amax; }
     __syncthreads();
+    for (int gI = threadIdx.x; gI < n_groups; gI += kCwItemThreads)
+        if (ghist[gI]) atomicAdd(W.grp_tot + gI, ghist[gI]);
     float *out = W.part + (size_t)blockIdx.x * (d + 2);
-    for (int col = threadIdx.x; col < d + 2; col += kBlock) {
+    for (int col = threadIdx.x; col < d + 2; col += kCwItemThreads) {
         const int src = col < d ? col : 256 + (col - d);
         float v = red[0][src];
-        for (int q = 1; q < kWavesPerBlock; ++q) v = (col == d + 1) ? fmaxf(v, red[q][src]) : v + red[q][src];      // waves in a fixed order
+        for (int qq = 1; qq < NW; ++qq) v = (col == d + 1) ? fmaxf(v, red[qq][src]) : v + red[qq][src];      // waves in a fixed order
         out[col] = v;
     }
 }
 
-__global__ __launch_bounds__(kBlock) void cw_scan_kernel(CwWs W, int d, int n_items, int n_groups, int ipg, int n_parts, int count_log2, float *__restrict__ loss) {
-    __shared__ int tot[1024];
+__global__ __launch_bounds__(kCwItemThreads) void cw_scan_kernel(CwWs W, int d, int n_groups, int n_parts, int count_log2, float *__restrict__ loss) {
+    __shared__ int s_tot[kCwItemThreads], s_sl[kCwItemThreads];
     __shared__ float fin[2];
-    for (int col = threadIdx.x; col < d + 2; col += kBlock) {
-        float v = W.part[col];
-        for (int p = 1; p < n_parts; ++p) { const float x = W.part[(size_t)p * (d + 2) + col]; v = (col == d + 1) ? fmaxf(v, x) : v + x; }       // parts in a fixed order
-        if (col < d) W.colsum[col] = v;
-        else fin[col - d] = v;
+    const int tid = threadIdx.x;
+    if (tid < d + 2) {                                             // fold the workgroups' partials, parts in a fixed order, eight loads in flight
+        float v = tid == d + 1 ? 0.f : 0.f;
+        for (int p0 = 0; p0 < n_parts; p0 += 8) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = p0 + j < n_parts ? W.part[(size_t)(p0 + j) * (d + 2) + tid] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v = (tid == d + 1) ? fmaxf(v, x[j]) : v + x[j];
+        }
+        if (tid < d) W.colsum[tid] = v;
+        else fin[tid - d] = v;
     }
-    for (int g = threadIdx.x; g < n_groups; g += kBlock) {
-        int s = 0;
-        for (int i = g * ipg, e = min(i + ipg, n_items); i < e; ++i) s += W.neg_cnt[i];
-        tot[g] = s;
-        W.cursor[g] = 0;
+    // groups: thread t owns groups [t * GPT, (t + 1) * GPT); block-wide exclusive scan of (entries, slices)
+    constexpr int GPT = kCwMaxGroups / kCwItemThreads;
+    int tot[GPT], my_tot = 0, my_sl = 0;
+#pragma unroll
+    for (int j = 0; j < GPT; ++j) {
+        const int g = tid * GPT + j;
+        tot[j] = g < n_groups ? W.grp_tot[g] : 0;
+        my_tot += tot[j];
+        my_sl += (tot[j] + kCwSlice - 1) / kCwSlice;
     }
+    s_tot[tid] = my_tot; s_sl[tid] = my_sl;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    for (int off = 1; off < kCwItemThreads; off <<= 1) {
+        const int a = tid >= off ? s_tot[tid - off] : 0, b = tid >= off ? s_sl[tid - off] : 0;
+        __syncthreads();
+        s_tot[tid] += a; s_sl[tid] += b;
+        __syncthreads();
+    }
+    int off_e = s_tot[tid] - my_tot, off_s = s_sl[tid] - my_sl;   // exclusive prefixes
+#pragma unroll
+    for (int j = 0; j < GPT; ++j) {
+        const int g = tid * GPT + j;
+        if (g < n_groups) {
+            W.grp_off[g] = off_e;
+            W.cursor[g] = 0;
+            for (int b = 0; b < tot[j]; b += kCwSlice) {
+                int32_t *sl = W.slices + 4 * off_s++;
+                sl[0] = g; sl[1] = off_e + b; sl[2] = off_e + min(b + kCwSlice, tot[j]);
+            }
+            off_e += tot[j];
+        }
+    }
+    if (tid == kCwItemThreads - 1) { W.grp_off[n_groups] = s_tot[tid]; W.n_slices[0] = s_sl[tid]; }
+    if (tid == 0) {
         loss[0] = fin[0];
         // scale 2^e with |x| < 2^(ea + 1) for every element and at most 2^count_log2 addends per sum: |sum * 2^e| < 2^(ea + 1 + count_log2 + e) = 2^61
         const float amax = fin[1];
@@ -3382,59 +3422,61 @@ __global__ __launch_bounds__(kBlock) void cw_scan_kernel(CwWs W, int d, int n_it
         if (amax > 0.f && amax < INFINITY) e = 61 - (ilogbf(amax) + 1) - count_log2;
         e = max(min(e, 1000), -1000);
         W.scale[0] = ldexp(1.0, e); W.scale[1] = ldexp(1.0, -e);
-        int off = 0, ns = 0;
-        for (int g = 0; g < n_groups; ++g) {
-            W.grp_off[g] = off;
-            for (int b = 0; b < tot[g]; b += kCwSlice) {
-                int32_t *sl = W.slices + 4 * ns++;
-                sl[0] = g; sl[1] = off + b; sl[2] = off + min(b + kCwSlice, tot[g]);
-            }
-            off += tot[g];
-        }
-        W.grp_off[n_groups] = off;
-        W.n_slices[0] = ns;
     }
 }
 
-__global__ __launch_bounds__(kBlock) void cw_fill_kernel(const int32_t *__restrict__ top_idx, int k, int T, long long n_entries, int ipg, CwWs W) {
-    const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (e >= n_entries) return;
-    const int u = (int)(e / T), t = (int)(e - (long long)u * T);
-    const int item = top_idx[(size_t)u * k + (k - 1 - t)];
-    const int g = item / ipg;
-    const int slot = atomicAdd(W.cursor + g, 1);
-    W.bucket[W.grp_off[g] + slot] = make_int2(u, item);
+// One slot per entry inside its group's bucket.  The slot comes from an LDS counter per group (1 024 entries per workgroup), and ONE global atomic per
+// workgroup and touched group reserves the workgroup's range: the lists' tails concentrate on few groups, and 5 M global atomics on a handful of addresses
+// serialise (~12 ns each: +15 ms on the CLeaR step in the first version of this kernel).
+__global__ __launch_bounds__(kCwItemThreads) void cw_fill_kernel(const int32_t *__restrict__ top_idx, int k, int T, long long n_entries, int ipg, int n_groups, CwWs W) {
+    __shared__ int cnt[kCwMaxGroups], base[kCwMaxGroups];
+    for (int g = threadIdx.x; g < n_groups; g += kCwItemThreads) cnt[g] = 0;
+    __syncthreads();
+    const long long e = (long long)blockIdx.x * kCwItemThreads + threadIdx.x;
+    int u = 0, item = 0, g = 0, slot = 0;
+    if (e < n_entries) {
+        u = (int)(e / T);
+        item = top_idx[(size_t)u * k + (k - 1 - (int)(e - (long long)u * T))];
+        g = item / ipg;
+        slot = atomicAdd(&cnt[g], 1);
+    }
+    __syncthreads();
+    for (int qg = threadIdx.x; qg < n_groups; qg += kCwItemThreads)
+        if (cnt[qg]) base[qg] = atomicAdd(W.cursor + qg, cnt[qg]);
+    __syncthreads();
+    if (e < n_entries) W.bucket[W.grp_off[g] + base[g] + slot] = make_int2(u, item);
 }
 
 __global__ __launch_bounds__(kCwItemThreads) void cw_item_kernel(const float *__restrict__ X, int d, int n_items, int ipg, CwWs W) {
     extern __shared__ unsigned long long cw_acc[];                 // [ipg][d] fixed-point sums of this slice
+    __shared__ int icnt[128];                                      // entries per item of the group in this slice (the negatives' histogram)
     const int s = blockIdx.x;
     if (s >= W.n_slices[0]) return;                                // (the grid is the static upper bound of the slice count)
     const int grp = W.slices[4 * s], begin = W.slices[4 * s + 1], end = W.slices[4 * s + 2];
     const int cells = ipg * d;
     for (int i = threadIdx.x; i < cells; i += kCwItemThreads) cw_acc[i] = 0ull;
+    if (threadIdx.x < 128) icnt[threadIdx.x] = 0;
     __syncthreads();
     const double scale = W.scale[0];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    constexpr int NW = kCwItemThreads / kWave, UNR = 4;
+    constexpr int NW = kCwItemThreads / kWave, UNR = 8;            // 16 waves x 8 row gathers in flight
     for (int e0 = begin + wv * UNR; e0 < end; e0 += NW * UNR) {
         int2 en[UNR];
-        float x[UNR][4];
 #pragma unroll
         for (int q = 0; q < UNR; ++q) en[q] = e0 + q < end ? W.bucket[e0 + q] : make_int2(-1, 0);        // wave-uniform
+        for (int c0 = 0; c0 < d; c0 += 64) {                       // one pass per 64 columns (d = 64: one)
+            const int col = c0 + lane;
+            float x[UNR];
 #pragma unroll
-        for (int q = 0; q < UNR; ++q)
+            for (int q = 0; q < UNR; ++q) x[q] = (en[q].x >= 0 && col < d) ? X[(size_t)en[q].x * d + col] : 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const int col = lane + 64 * j; x[q][j] = (en[q].x >= 0 && col < d) ? X[(size_t)en[q].x * d + col] : 0.f; }
-#pragma unroll
-        for (int q = 0; q < UNR; ++q) {
-            if (en[q].x < 0) continue;
-            unsigned long long *row = cw_acc + (size_t)(en[q].y - grp * ipg) * d;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = lane + 64 * j;
-                if (col < d) atomicAdd(row + col, (unsigned long long)__double2ll_rn((double)x[q][j] * scale));
-            }
+            for (int q = 0; q < UNR; ++q)
+                if (en[q].x >= 0 && col < d)
+                    atomicAdd(cw_acc + (size_t)(en[q].y - grp * ipg) * d + col, (unsigned long long)__double2ll_rn((double)x[q] * scale));
+        }
+        if (lane < UNR) {
+            const int2 mine = e0 + lane < end ? W.bucket[e0 + lane] : make_int2(-1, 0);
+            if (mine.x >= 0) atomicAdd(&icnt[mine.y - grp * ipg], 1);
         }
     }
     __syncthreads();
@@ -3443,6 +3485,7 @@ __global__ __launch_bounds__(kCwItemThreads) void cw_item_kernel(const float *__
         const unsigned long long v = cw_acc[i];
         if (v != 0ull && base + i < lim) atomicAdd(reinterpret_cast<unsigned long long *>(W.acc) + base + i, v);
     }
+    if ((int)threadIdx.x < ipg && icnt[threadIdx.x] && grp * ipg + (int)threadIdx.x < n_items) atomicAdd(W.neg_cnt + grp * ipg + threadIdx.x, icnt[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(kBlock) void cw_finish_kernel(int d, long long Up, int n_items, int n_real, const long long *__restrict__ targets, int T, float c,
@@ -4377,10 +4420,10 @@ static int64_t cw_layout(int64_t n_items, int64_t d, int64_t n_real, int64_t T, 
     int64_t off = 0;
     auto take = [&](int64_t bytes) { char *p = base ? base + off : nullptr; off += cw_align(bytes); return p; };
     char *p_part = take(sizeof(float) * kCwParts * (d + 2)), *p_col = take(sizeof(float) * d), *p_sc = take(sizeof(double) * 2), *p_neg = take(sizeof(int32_t) * n_items);
-    char *p_off = take(sizeof(int32_t) * (G + 1)), *p_cur = take(sizeof(int32_t) * G), *p_sl = take(sizeof(int32_t) * 4 * max_sl), *p_ns = take(sizeof(int32_t) * 4);
+    char *p_tot = take(sizeof(int32_t) * G), *p_off = take(sizeof(int32_t) * (G + 1)), *p_cur = take(sizeof(int32_t) * G), *p_sl = take(sizeof(int32_t) * 4 * max_sl), *p_ns = take(sizeof(int32_t) * 4);
     char *p_b = take(sizeof(int2) * (n_ent > 0 ? n_ent : 1)), *p_acc = take(sizeof(long long) * n_items * d);
     if (W) {
-        W->part = (float *)p_part; W->colsum = (float *)p_col; W->scale = (double *)p_sc; W->neg_cnt = (int32_t *)p_neg; W->grp_off = (int32_t *)p_off;
+        W->part = (float *)p_part; W->colsum = (float *)p_col; W->scale = (double *)p_sc; W->neg_cnt = (int32_t *)p_neg; W->grp_tot = (int32_t *)p_tot; W->grp_off = (int32_t *)p_off;
         W->cursor = (int32_t *)p_cur; W->slices = (int32_t *)p_sl; W->n_slices = (int32_t *)p_ns; W->bucket = (int2 *)p_b; W->acc = (long long *)p_acc;
     }
     return off;
@@ -4394,29 +4437,36 @@ int64_t arl_cw_topk_term_workspace_bytes(int64_t n_items, int64_t d, int64_t n_r
 int arl_cw_topk_term_f32(const float *X, int64_t n_user_rows, int64_t n_items, int64_t d, int64_t n_real, const int32_t *top_idx, int64_t k,
                          const int64_t *targets, int64_t n_targets, float c, float *G, float *loss, float *w_sfa, void *workspace, arl_stream_t stream) {
     if (!X || !top_idx || !targets || !G || !loss || !workspace) return ARL_E_NULL;
-    if (d <= 0 || d > 256) return ARL_E_DIM;
+    if (d <= 0 || d > 256 || (d & 3)) return ARL_E_DIM;
     if (n_user_rows <= 0 || n_items <= 0 || n_real < 0 || n_real > n_user_rows || n_targets <= 0 || n_targets > 64 || k < n_targets) return ARL_E_ARG;
     if (n_user_rows + n_items > 0x7fffffffll || n_real * n_targets > 0x7fffffffll || n_items * d > 0x7fffffffffll) return ARL_E_RANGE;
-    if (((uintptr_t)workspace) & 7) return ARL_E_ARG;
+    if ((((uintptr_t)workspace) & 7) || (((uintptr_t)X | (uintptr_t)G) & 15)) return ARL_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     CwWs W;
     cw_layout(n_items, d, n_real, n_targets, (char *)workspace, &W);
     const int ipg = cw_ipg((int)d), n_groups = (int)((n_items + ipg - 1) / ipg);
-    if (n_groups > 1024) return ARL_E_RANGE;                          // (262 144 items at d <= 64; the scan kernel folds the groups in LDS)
+    if (n_groups > kCwMaxGroups) return ARL_E_RANGE;                  // (1 048 576 items at d <= 128; the group histograms live in LDS)
     const long long n_ent = (long long)n_real * n_targets;
     if (hipMemsetAsync(W.neg_cnt, 0, sizeof(int32_t) * n_items, st) != hipSuccess) return ARL_E_ARG;
+    if (hipMemsetAsync(W.grp_tot, 0, sizeof(int32_t) * n_groups, st) != hipSuccess) return ARL_E_ARG;
     if (hipMemsetAsync(W.acc, 0, sizeof(long long) * n_items * d, st) != hipSuccess) return ARL_E_ARG;
     const int rows_per_wg = (int)((n_user_rows + kCwParts - 1) / kCwParts);
     const int n_parts = (int)((n_user_rows + rows_per_wg - 1) / rows_per_wg);
-    hipLaunchKernelGGL(cw_user_kernel, dim3((unsigned)n_parts), dim3(kBlock), 0, st, X, (int)d, (long long)n_user_rows, (int)n_real, top_idx, (int)k,
-                       (const long long *)targets, (int)n_targets, c, G, w_sfa, W, rows_per_wg);
+#define ARL_CW_USER(LPRV) hipLaunchKernelGGL((cw_user_kernel<LPRV>), dim3((unsigned)n_parts), dim3(kCwItemThreads), 0, st, X, (int)d, (long long)n_user_rows, (int)n_real, \
+                                             top_idx, (int)k, (const long long *)targets, (int)n_targets, c, G, w_sfa, W, rows_per_wg, ipg, n_groups)
+    if (d <= 16) ARL_CW_USER(4);
+    else if (d <= 32) ARL_CW_USER(8);
+    else if (d <= 64) ARL_CW_USER(16);
+    else if (d <= 128) ARL_CW_USER(32);
+    else ARL_CW_USER(64);
+#undef ARL_CW_USER
     ARL_LAUNCH_CHECK();
     int count_log2 = 0;
     while ((1ll << count_log2) < (n_ent > 1 ? n_ent : 1)) ++count_log2;
-    hipLaunchKernelGGL(cw_scan_kernel, dim3(1), dim3(kBlock), 0, st, W, (int)d, (int)n_items, n_groups, ipg, n_parts, count_log2, loss);
+    hipLaunchKernelGGL(cw_scan_kernel, dim3(1), dim3(kCwItemThreads), 0, st, W, (int)d, n_groups, n_parts, count_log2, loss);
     ARL_LAUNCH_CHECK();
     if (n_ent > 0) {
-        hipLaunchKernelGGL(cw_fill_kernel, dim3((unsigned)((n_ent + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, top_idx, (int)k, (int)n_targets, n_ent, ipg, W);
+        hipLaunchKernelGGL(cw_fill_kernel, dim3((unsigned)((n_ent + kCwItemThreads - 1) / kCwItemThreads)), dim3(kCwItemThreads), 0, st, top_idx, (int)k, (int)n_targets, n_ent, ipg, n_groups, W);
         ARL_LAUNCH_CHECK();
         const size_t shm = sizeof(unsigned long long) * (size_t)ipg * (size_t)d;
         hipError_t ea = hipFuncSetAttribute((const void *)cw_item_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -4442,7 +4492,7 @@ int64_t arl_score_mask_topk_stats_offset(int64_t I, int64_t d) {
 
 int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t I, int64_t d, const int32_t *mask_rowptr, const int32_t *mask_col,
                             int64_t k, int32_t *top_idx, float *top_val, void *workspace, const int32_t *warm_idx, int32_t *underflow,
-                            const int32_t *item_order, arl_stream_t stream) {
+                            const int32_t *item_order, int32_t exit_mode, arl_stream_t stream) {
     if (!Pu || !Pi || !top_idx || !top_val) return ARL_E_NULL;
     if (warm_idx && !underflow) return ARL_E_NULL;
     if (mask_rowptr && !mask_col) return ARL_E_NULL;
@@ -4514,7 +4564,10 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
         } while (0)
         /* the fp16 split path launches both builds of the kernel (with / without the early exit); the device runs one (gate2), the other returns at once */
 #define ARL_TOPK_CASE2_true(DV, WM, WARMP, GATE)                                                                                       \
-        do { ARL_TOPK_CASE3(DV, true, WM, true, WARMP, GATE, (const int *)pick_d); ARL_TOPK_CASE3(DV, true, WM, false, WARMP, GATE, (const int *)(pick_d + 1)); } while (0)
+        do {                                                                                                                           \
+            if (exit_mode != 0) { ARL_TOPK_CASE3(DV, true, WM, true, WARMP, GATE, (const int *)pick_d); ARL_TOPK_CASE3(DV, true, WM, false, WARMP, GATE, (const int *)(pick_d + 1)); } \
+            else ARL_TOPK_CASE3(DV, true, WM, false, WARMP, GATE, (const int *)nullptr);                                                \
+        } while (0)
 #define ARL_TOPK_CASE2_false(DV, WM, WARMP, GATE) ARL_TOPK_CASE3(DV, false, WM, false, WARMP, GATE, (const int *)nullptr)
         /* a warm-started call is followed by its own cold repeat, gated on the underflow flag on the device: valid results without a host round trip */
 #define ARL_TOPK_CASE(DV, SP)                                                                                                          \

@@ -1243,6 +1243,43 @@ def cw_topk_term(X, n_user_rows, n_real, top_idx, targets, c=None, want_w=True, 
 TOPK_STATS = {'calls': 0, 'warm': 0, 'cold_repeats': 0}     # counters for benches: warm-started calls and how many of them had to be repeated cold
 
 
+_EXIT_PROBE = {}          # (U, I, d, k, masked) -> adaptive use of the kernel's early-exit build (see score_mask_topk)
+EXIT_REPROBE = 32         # calls between two probes of the exit build on tables where it skipped nothing
+
+
+def _exit_mode(key, ws, off, nst, device):
+    """Which build the next pass over tables of this shape should launch: 1 = let the device pick (exit build where the norm profile allows), 0 = plain.
+    The exit build costs ~5 % when nothing is skipped, and whether anything is depends on the tables (thresholds vs norms), which only the pass itself
+    finds out: after a pass in mode 1 its 24 bytes of counters are copied to pinned memory asynchronously; a later call that finds the copy complete and
+    the exit build picked but nothing skipped switches to the plain build for EXIT_REPROBE calls.  Never waits for the device."""
+    st = _EXIT_PROBE.setdefault(key, {'off': 0, 'pending': None})
+    p = st['pending']
+    if p is not None and p[1].query():
+        consumed, wgs = (int(x) for x in p[0][:2].tolist())
+        picked = int(p[0][2].item()) & 0xffffffff
+        if picked == 1 and wgs > 0 and consumed >= wgs * p[2]:
+            st['off'] = EXIT_REPROBE
+        st['pending'] = None
+    if st['off'] > 0:
+        st['off'] -= 1
+        return 0, st
+    return 1, st
+
+
+def reset_exit_probe():
+    """Forget what earlier passes learnt about the early exit (new tables of a shape already seen: benches, tests)."""
+    _EXIT_PROBE.clear()
+
+
+def _exit_probe_record(st, ws, off, nst):
+    if st['pending'] is None:
+        host = torch.empty(3, dtype=torch.int64).pin_memory()
+        host.copy_(ws[off:off + 24].view(torch.int64), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st['pending'] = (host, ev, nst)
+
+
 def score_mask_topk(Pu, Pi, k, mask_rowptr=None, mask_col=None, exact=False, warm_idx=None, item_order='norm'):
     """top-k of Pu @ Pi.T per user with an optional interacted-item mask (CSR over users), streamed.
     exact=True: scores are the exact fp32 contraction; default: split-fp16 matrix path (two fp16 pieces of the power-of-two-scaled operands, three products) for d in {64, 128} (scores within
@@ -1295,8 +1332,15 @@ def score_mask_topk(Pu, Pi, k, mask_rowptr=None, mask_col=None, exact=False, war
         evs[0].record()
     if timed:
         torch.cuda.synchronize(); t0 = time.perf_counter()
+    mode, probe = 0, None
+    if ws is not None and order is not None:               # the early exit needs the norm-ordered stream
+        soff = _lib.lib().arl_score_mask_topk_stats_offset(I, d)
+        nst = (I + (64 if d <= 64 else 32) - 1) // (64 if d <= 64 else 32)
+        mode, probe = _exit_mode((U, I, d, k, mask_rowptr is not None), ws, soff, nst, Pu.device)
     check(_lib.lib().arl_score_mask_topk_f32(_ptr(Pu), _ptr(Pi), U, I, d, _ptr(mask_rowptr), _ptr(mask_col), k, _ptr(idx), _ptr(val), _ptr(ws),
-                                             _ptr(warm_idx), _ptr(flag), _ptr(order), _stream()), 'arl_score_mask_topk_f32')
+                                             _ptr(warm_idx), _ptr(flag), _ptr(order), mode, _stream()), 'arl_score_mask_topk_f32')
+    if mode == 1:
+        _exit_probe_record(probe, ws, soff, nst)
     if timed:
         torch.cuda.synchronize(); TOPK_STATS.setdefault('ms', []).append(1e3 * (time.perf_counter() - t0))
     if evs is not None:

@@ -418,13 +418,17 @@ int arl_pga_update_f32(float *S, const float *grad, const float *dinv_rows, cons
  * |a_u| * (largest norm of any later item) lies below the user's current k-th best score by more than the pre-filter's slack (Cauchy-Schwarz:
  * no later item can enter a list) -- the stages skipped cannot change the result, which stays that of the full stream bit for bit.  What was
  * skipped is readable after the pass: two uint64 counters at byte arl_score_mask_topk_stats_offset(I, d) of the workspace,
- * [stream stages consumed summed over workgroups, workgroups]. */
+ * [stream stages consumed summed over workgroups, workgroups], followed by two int32 [exit build picked, plain build picked].
+ * The exit's code costs the stream loop ~5 % where nothing can be skipped (the loop has no register to spare), so it lives in a second BUILD of
+ * the kernel.  exit_mode = 1: both builds are launched and the device runs one of them, chosen from the items' norm profile (the exit build iff the
+ * norms at 7/8 of the stream are below half of the 4096th largest); exit_mode = 0: the plain build alone (a caller that has seen the counters report
+ * nothing skipped on these tables saves the 5 %).  Results are identical in every case. */
 int64_t arl_score_mask_topk_workspace_bytes(int64_t I, int64_t d);
 int64_t arl_score_mask_topk_stats_offset(int64_t I, int64_t d);
 int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t I, int64_t d,
                             const int32_t *mask_rowptr, const int32_t *mask_col, int64_t k, int32_t *top_idx,
                             float *top_val, void *workspace, const int32_t *warm_idx, int32_t *underflow,
-                            const int32_t *item_order, arl_stream_t stream);
+                            const int32_t *item_order, int32_t exit_mode, arl_stream_t stream);
 /* CW term of the white-box attacks' surrogate loss, from the users' top-k lists (attack/White/CLeaR.py:83-95, PGA.py:104-116; the reference builds
  * three Python lists of U*T ids and gathers a [U*T, d] matrix per side).  X [n_user_rows + n_items, d] = the packed propagated tables (users first);
  * pairs = (real user u < n_real) x (target t): negative item neg(u, t) = top_idx[u][k - 1 - t] (the successive .pop()s of CLeaR.py:84-88), positive
@@ -435,7 +439,8 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
  *             user, n_real per target occurrence, the negatives' histogram -- the row weights of arl_sfa_l1_fwd_bwd_f32.
  * Deterministic: the item-side sums run in 64-bit fixed point (integer addition is associative; scale chosen on the device so that no sum can
  * overflow, resolution far below fp32 rounding of the same sum); no float atomics, no sort.  top_idx entries must be item ids in [0, n_items)
- * (the caller's own arl_score_mask_topk_f32 output).  T <= 64 <= ... k >= T, d <= 256, n_items <= 1024 * (256 | 128 | 64 rows for d <= 64 | 128 | 256). */
+ * (the caller's own arl_score_mask_topk_f32 output).  1 <= T <= 64, k >= T, d <= 256 with d % 4 == 0, X and G 16-byte aligned,
+ * n_items <= 8192 * 128 (d <= 128) or 8192 * 64 (d = 256). */
 int64_t arl_cw_topk_term_workspace_bytes(int64_t n_items, int64_t d, int64_t n_real, int64_t n_targets);
 int arl_cw_topk_term_f32(const float *X, int64_t n_user_rows, int64_t n_items, int64_t d, int64_t n_real, const int32_t *top_idx, int64_t k,
                          const int64_t *targets, int64_t n_targets, float c, float *G, float *loss, float *w_sfa, void *workspace,

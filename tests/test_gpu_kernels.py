@@ -3,7 +3,7 @@ against the golden fixtures captured from the reference.  Bar: fp32 within 1e-4 
 import numpy as np
 import pytest
 import torch
-from conftest import golden, rel_err, RTOL
+from conftest import golden, rel_err, row_err, close, RTOL
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -811,6 +811,7 @@ def test_score_mask_topk_early_exit_is_exact_and_one_user_keeps_the_stream_alive
     small = set(np.nonzero(np.linalg.norm(Pi, axis=1) < 5e-3)[0].tolist())
     assert set(ridx[lone].tolist()) <= small                      # the lone user's list = items of the stream's last two stages
     ops.TOPK_STATS['record_exit'] = True; ops.TOPK_STATS['exit'] = []
+    ops.reset_exit_probe()
     try:
         base_i, base_v = ops.score_mask_topk(T(Pu), T(Pi), k, rp, mc, item_order=None)        # table order: suffix maxima stay high, nothing is skipped
         i2, v2 = ops.score_mask_topk(T(Pu), T(Pi), k, rp, mc, item_order='norm')

@@ -49,6 +49,7 @@ print('lib', os.environ.get('ARLIB_AMD_LIB', 'default'), ' U=%d I=%d d=%d k=%d' 
 ops.score_mask_topk(torch.randn(256, d, device=dev), torch.randn(I, d, device=dev), k); torch.cuda.synchronize()
 for kind in kinds:
     Pu, Pi = tables(kind)
+    ops.reset_exit_probe()
     nrm = torch.linalg.vector_norm(Pi, dim=1)
     ops.TOPK_STATS['record_exit'], ops.TOPK_STATS['exit'] = True, []
     cold, (idx, val) = timed(lambda: ops.score_mask_topk(Pu, Pi, k))
