@@ -241,22 +241,7 @@ def attack_leg(torch, ops, data, E0_dev, args):
     ops.score_mask_topk(Ru, Ri, 50); torch.cuda.synchronize(); topk_skewed_s = time.perf_counter() - t1
     skipped_skewed = ops.topk_exit_fractions()
     del Ru, Ri
-    # ... and on the LightGCN-propagated tables of an UNTRAINED model (xavier tables through the same poisoned graph): item norms follow popularity, as they
-    # do early in a surrogate's training (and in converged models); the 210 dense-Adam steps behind `trained_propagated_tables` have flattened them
-    g0 = torch.Generator().manual_seed(args.seed + 7)
-    X0 = torch.cat([torch.nn.init.xavier_uniform_(torch.empty(U + F, d), generator=g0), torch.nn.init.xavier_uniform_(torch.empty(I, d), generator=g0)], 0).to(E0_dev.device)
-    out0 = X0.clone(); Ek = X0
-    for k in range(L):
-        Ek = _hop(graph, Ek); out0 += Ek
-    out0 /= (L + 1)
-    P0u, P0i = out0[:U + F].contiguous(), out0[U + F:].contiguous()
-    del X0, Ek, out0
-    ops.reset_exit_probe()
-    ops.score_mask_topk(P0u, P0i, 50); torch.cuda.synchronize(); t1 = time.perf_counter()
-    ops.score_mask_topk(P0u, P0i, 50); torch.cuda.synchronize(); topk_init_s = time.perf_counter() - t1
-    skipped_init = ops.topk_exit_fractions()
     ops.TOPK_STATS['record_exit'] = False
-    del P0u, P0i
     ops.reset_exit_probe()
     del Pu_all, Pi_all
     M = cw_operator(U + F + I, U + F, *cw_pairs(top_idx, U, targets, pop=True), device=E0.device)
@@ -301,9 +286,9 @@ def attack_leg(torch, ops, data, E0_dev, args):
                                              'note': 'fp16 matrix flops executed by the stream: ONE fp16 product per (user, item, k) -- the high pieces; the two other products of '
                                                      'the split form run only for queued candidates (a 16 x 16 tile per merge) and are not counted; dense fp16/bf16 MFMA peak. '
                                                      'The pass is bound by its ring / candidate handling, not by the matrix pipe (DESIGN 3b)'},
-                                'stages_skipped_frac': {'trained_propagated_tables': skipped_trained, 'random_tables': skipped_random, 'lognormal_item_norms': skipped_skewed, 'untrained_propagated_tables': skipped_init,
+                                'stages_skipped_frac': {'trained_propagated_tables': skipped_trained, 'random_tables': skipped_random, 'lognormal_item_norms': skipped_skewed,
                                                         'what': 'share of (workgroup, 64-item stage) pairs of the norm-ordered item stream the exact early exit never scored'},
-                                'random_tables_seconds': topk_random_s, 'lognormal_item_norms_seconds': topk_skewed_s, 'untrained_propagated_tables_seconds': topk_init_s,
+                                'random_tables_seconds': topk_random_s, 'lognormal_item_norms_seconds': topk_skewed_s,
                                 'note': '`tflops` = fp32-equivalent (2 U I d); once per inner epoch, not per step'},
             'setup_seconds': setup_s}
 
