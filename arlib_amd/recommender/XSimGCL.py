@@ -25,7 +25,7 @@ class _PropagateX(torch.autograd.Function):
             if k == enc.layer_cl - 1:
                 cl = cur if k < L - 1 else cur.clone()
         acc.mul_(1.0 / L)
-        ctx.enc = enc
+        ctx.enc, ctx.noises = enc, noises
         return acc[:U], acc[U:], cl[:U], cl[U:]
 
     @staticmethod
@@ -35,10 +35,22 @@ class _PropagateX(torch.autograd.Function):
         L = enc.n_prop_layers
         G = (torch.cat([g_mu, g_mi], 0) * (1.0 / L)).contiguous()
         Gcl = torch.cat([g_cu, g_ci], 0).contiguous()
+        sink = getattr(enc, '_adj_sink', None)
+        E = None
+        if sink is not None:
+            # train(requires_adjgrad=True): the stored entries of A receive sum_k <dE_k[row], E_{k-1}[col]> with dE_k = acc_k below and E_k the
+            # perturbed layer tables of THIS forward (recomputed from its noise; XSimGCL.py:205-216)
+            E, cur = [eng.E0], eng.E0
+            for k in range(L - 1):
+                cur = ops.spmm(eng.A, cur)
+                ops.simgcl_perturb_(cur, ctx.noises[k], enc.eps)
+                E.append(cur)
         acc = None
         for k in range(L, 0, -1):
             c = G + Gcl if k == enc.layer_cl else G
             acc = c if acc is None else ops.spmm(eng.A, acc, 1.0, 1.0, c)
+            if sink is not None:
+                ops.sddmm_csr(eng.A, acc.contiguous(), E[k - 1], 1.0, out=sink)
         dE0 = ops.spmm(eng.A, acc.contiguous())
         U = g_mu.shape[0]
         return dE0[:U], dE0[U:], None, None
@@ -46,6 +58,7 @@ class _PropagateX(torch.autograd.Function):
 
 class XSimGCL_Encoder(GraphEncoder):
     skip_layer0 = True
+    adjgrad_sink_capable = True         # every training forward runs through _PropagateX, whose backward feeds the encoder's adjacency-gradient sink
 
     def __init__(self, data, emb_size, eps, n_layers, layer_cl):
         super().__init__(data, emb_size)
@@ -72,6 +85,7 @@ class XSimGCL(Recommender):
     print_every = 100
     has_extra_loss = True
     fused_extra_loss = True
+    adjgrad_through_views = True
     train_forward_perturbed = True          # the BPR term reads the PERTURBED pass (XSimGCL.py:66-68)
 
     def __init__(self, args, data):

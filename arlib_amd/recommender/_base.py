@@ -421,7 +421,7 @@ class Recommender:
             # recommender/LightGCN.py:41-43: sparse_norm_adj.requires_grad = True, Matgrad = zeros(N, N).  The gradient of a sparse operand lives on its
             # stored entries, so Matgrad is kept as one value per entry of the pattern (CSR order) instead of N x N.
             if self.has_extra_loss and not self.adjgrad_through_views:
-                raise NotImplementedError('requires_adjgrad is implemented for LightGCN, NGCF and SimGCL')
+                raise NotImplementedError('requires_adjgrad is implemented for LightGCN, NGCF, SimGCL and XSimGCL')
             self._adjgrad_begin(model)
             adj = model.sparse_norm_adj
             adj.requires_grad = True
@@ -536,8 +536,8 @@ class Recommender:
         """Prepare the encoder for train(requires_adjgrad=True).  The base form covers every encoder whose forwards all run through _Propagate
         (GraphEncoder.forward: LightGCN's mean over layers 0..L, SimGCL's clean pass and perturbed views over layers 1..L): each backward of such a
         forward adds its share of the adjacency's gradient to the encoder's sink (engine.adjacency_gradient)."""
-        if type(model).forward is not GraphEncoder.forward:
-            raise NotImplementedError('requires_adjgrad is implemented for the LightGCN, NGCF and SimGCL propagations')
+        if not getattr(model, 'adjgrad_sink_capable', type(model).forward is GraphEncoder.forward):
+            raise NotImplementedError('requires_adjgrad is implemented for the LightGCN, NGCF, SimGCL and XSimGCL propagations')
         nnz = model._engine().A.col.numel()
         model._adj_sink = torch.zeros(nnz, dtype=torch.float32, device=DEVICE)
 

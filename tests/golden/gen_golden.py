@@ -1306,17 +1306,23 @@ def gen_adjgrad():
              item=rec.model.embedding_dict['item_emb'].detach().numpy().copy(), next_random=np.array([random.random()], np.float64), **extra)
 
 
-def gen_adjgrad_simgcl():
-    """Reference `SimGCL.train(requires_adjgrad=True)` (recommender/SimGCL.py:36-85): `sparse_norm_adj` takes gradient from all THREE forwards of a step
+def gen_adjgrad_simgcl(which='simgcl'):
+    """(which = 'xsimgcl': the same capture for `XSimGCL.train(requires_adjgrad=True)`, recommender/XSimGCL.py:46-85 -- ONE perturbed forward per step, two noise
+    draws; written to g24_adjgrad_xsimgcl.npz.)
+    Reference `SimGCL.train(requires_adjgrad=True)` (recommender/SimGCL.py:36-85): `sparse_norm_adj` takes gradient from all THREE forwards of a step
     (the clean one and the two perturbed views of cal_cl_loss, :212-219; the perturbation itself carries none).  The views' noise is injected:
     the k-th torch.rand_like call of the run returns torch.rand(N, d, generator=manual_seed(5000 + k)) -- the product's test regenerates the same
     sequence instead of storing 88 tables.  Captured: the first step's gradient, the returned block after one epoch (22 steps, running-sum quirk as
     in g21), the tables, the RNG stream."""
     import io, contextlib
-    args = rec_args(emb_size=16, n_layers=2, model_name='SimGCL')
+    if which == 'xsimgcl':
+        from recommender.XSimGCL import XSimGCL as Cls
+    else:
+        Cls = SimGCL
+    args = rec_args(emb_size=16, n_layers=2, model_name=Cls.__name__)
     seedSet(2018)
     data = DataLoader(args)
-    rec = SimGCL(args, data)
+    rec = Cls(args, data)
     u0 = rec.model.embedding_dict['user_emb'].detach().numpy().copy(); i0 = rec.model.embedding_dict['item_emb'].detach().numpy().copy()
     first, calls = {}, [0]
     orig_backward, orig_rand_like = torch.Tensor.backward, torch.rand_like
@@ -1344,7 +1350,7 @@ def gen_adjgrad_simgcl():
     B1 = (M1 + M1.T).tocsr()[:U, U:].tocoo()
     block = block.detach().numpy()
     r, c = np.nonzero(block)
-    save('g23_adjgrad_simgcl.npz', user0=u0, item0=i0, block_row=r.astype(np.int32), block_col=c.astype(np.int32), block_val=block[r, c].astype(np.float32),
+    save('g24_adjgrad_xsimgcl.npz' if which == 'xsimgcl' else 'g23_adjgrad_simgcl.npz', user0=u0, item0=i0, block_row=r.astype(np.int32), block_col=c.astype(np.int32), block_val=block[r, c].astype(np.float32),
          first_row=B1.row.astype(np.int32), first_col=B1.col.astype(np.int32), first_val=B1.data.astype(np.float32),
          block_shape=np.array(block.shape, np.int64), user=rec.model.embedding_dict['user_emb'].detach().numpy().copy(),
          item=rec.model.embedding_dict['item_emb'].detach().numpy().copy(), next_random=np.array([random.random()], np.float64),
@@ -1382,6 +1388,8 @@ if __name__ == '__main__':
             gen_adjgrad()
         if 'adjgrad_simgcl' in only:
             gen_adjgrad_simgcl()
+        if 'adjgrad_xsimgcl' in only:
+            gen_adjgrad_simgcl('xsimgcl')
         sys.exit(0)
     gen_dataset()
     data = gen_sampler()
@@ -1409,4 +1417,5 @@ if __name__ == '__main__':
     gen_fake_rows()
     gen_adjgrad()
     gen_adjgrad_simgcl()
+    gen_adjgrad_simgcl('xsimgcl')
     print('done; scratch dir', SCRATCH)

@@ -148,16 +148,23 @@ def test_train_requires_adjgrad_matches_reference_run(array_native):
     assert close(rec.model.embedding_dict['item_emb'].detach().cpu().numpy(), g['item'])
 
 
-def test_simgcl_train_requires_adjgrad_matches_reference_run():
-    """SimGCL.train(requires_adjgrad=True) against the reference's own run (g23, recommender/SimGCL.py:36-85): `sparse_norm_adj` takes gradient from
+@pytest.mark.parametrize('which', ['simgcl', 'xsimgcl'])
+def test_simgcl_train_requires_adjgrad_matches_reference_run(which):
+    """(which = 'xsimgcl': the same for XSimGCL.train(requires_adjgrad=True), g24, recommender/XSimGCL.py:46-85 -- one perturbed forward per step whose
+    backward, _PropagateX, feeds the sink with its own perturbed layer tables.)
+    SimGCL.train(requires_adjgrad=True) against the reference's own run (g23, recommender/SimGCL.py:36-85): `sparse_norm_adj` takes gradient from
     the step's THREE forwards -- the clean pass and the two perturbed views of cal_cl_loss (the perturbation carries none) -- each through
     engine.adjacency_gradient with that forward's own layer tables.  Noise injected on both sides: the k-th draw of the run is
     torch.rand(N, d, generator=manual_seed(5000 + k)) (the reference's torch.rand_like patched by the golden harness, the product's torch.rand here).
     First step's gradient, the returned block after the 22-step epoch (running-sum quirk as in g21), the tables and the random stream; then a
     foreign optimizer (quirk Q4): the loop still runs forward / backward and returns the accumulated gradients (recommender/LightGCN.py:45-59)."""
     from arlib_amd.util.tool import seedSet
-    from arlib_amd.recommender.SimGCL import SimGCL
-    g = golden('g23_adjgrad_simgcl.npz')
+    if which == 'xsimgcl':
+        from arlib_amd.recommender.XSimGCL import XSimGCL as SimGCL
+        g, per_step = golden('g24_adjgrad_xsimgcl.npz'), 2
+    else:
+        from arlib_amd.recommender.SimGCL import SimGCL
+        g, per_step = golden('g23_adjgrad_simgcl.npz'), 4
     calls = [0]
     orig_rand = torch.rand
 
@@ -169,14 +176,14 @@ def test_simgcl_train_requires_adjgrad_matches_reference_run():
 
     def fresh():
         seedSet(2018)
-        rec = SimGCL(rec_args(emb_size=16, n_layers=2, model_name='SimGCL'), make_data())
+        rec = SimGCL(rec_args(emb_size=16, n_layers=2, model_name=SimGCL.__name__), make_data())
         assert close(rec.model.embedding_dict['user_emb'].detach().cpu().numpy(), g['user0'])
         calls[0] = 0
         return rec
     torch.rand = rand
     try:
         got1, ref1 = _first_step_block(fresh(), g)
-        assert calls[0] == 4 and close(got1, ref1)                     # two views x two hops per step
+        assert calls[0] == per_step and close(got1, ref1)              # SimGCL: two views x two hops per step; XSimGCL: one pass x two hops
         rec = fresh()
         with contextlib.redirect_stdout(io.StringIO()):
             block = rec.train(requires_adjgrad=True, Epoch=1, gradIterationNum=10, evalNum=1)

@@ -55,6 +55,7 @@ for kind in kinds:
     cold, (idx, val) = timed(lambda: ops.score_mask_topk(Pu, Pi, k))
     warm, _ = timed(lambda: ops.score_mask_topk(Pu, Pi, k, warm_idx=idx))
     fr = ops.topk_exit_fractions()
+    digest = '%d/%.6e' % (int(idx.long().sum()), float(val.double().sum()))       # same lists and values across builds
     line = '%-10s item-norm min/median/max %.3g/%.3g/%.3g: cold %.1f ms (skipped %.3f), warm %.1f ms (skipped %.3f)' % (
         kind, nrm.min().item(), nrm.median().item(), nrm.max().item(), cold, fr[1], warm, fr[4])
     if os.environ.get('ORDER_USERS') == '1':
@@ -67,7 +68,7 @@ for kind in kinds:
         fr2 = ops.topk_exit_fractions()
         assert torch.equal(i2, idx2) and torch.equal(v2, val[perm])
         line += ' | users ordered: cold %.1f (skipped %.3f), warm %.1f (skipped %.3f)' % (c2, fr2[1], w2, fr2[4])
-    print(line, flush=True)
+    print(line + '  [digest ' + digest + ']', flush=True)
     ops.TOPK_STATS['record_exit'] = False
     del Pu, Pi
     torch.cuda.empty_cache()
