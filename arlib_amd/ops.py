@@ -1266,9 +1266,15 @@ def _exit_mode(key, ws, off, nst, device):
     return 1, st
 
 
+_ORDER_CACHE = {}         # (I, d, device) -> [item order of the last 'norm' call, calls served]
+ORDER_REFRESH = 8         # calls that may reuse one norm order
+
+
 def reset_exit_probe():
-    """Forget what earlier passes learnt about the early exit (new tables of a shape already seen: benches, tests)."""
+    """Forget what earlier passes learnt about the tables of a shape already seen (benches, tests; a caller that switches to unrelated tables):
+    the early-exit probe state and the cached item order."""
     _EXIT_PROBE.clear()
+    _ORDER_CACHE.clear()
 
 
 def _exit_probe_record(st, ws, off, nst):
@@ -1322,7 +1328,16 @@ def score_mask_topk(Pu, Pi, k, mask_rowptr=None, mask_col=None, exact=False, war
                 raise ValueError('score_mask_topk: item_order must be a permutation of the I items')
         elif item_order == 'norm':
             if I >= 32768:                                 # shorter streams run without a bootstrap pass: nothing to gain
-                order = torch.argsort(torch.linalg.vector_norm(Pi, dim=1), descending=True).to(torch.int32)
+                # The order is a heuristic of the STREAM only (thresholds rise earlier, the early exit can bite): the result does not depend on it, the
+                # exit's bound is computed from the norms of whatever order is streamed.  A loop that scores slowly moving tables again and again
+                # (CLeaR's surrogate steps) therefore reuses the last order and re-sorts every ORDER_REFRESH-th call instead of a radix sort per step.
+                okey = (I, d, str(Pu.device))
+                ent = _ORDER_CACHE.get(okey)
+                if ent is None or ent[1] >= ORDER_REFRESH:
+                    order = torch.argsort(torch.linalg.vector_norm(Pi, dim=1), descending=True).to(torch.int32)
+                    _ORDER_CACHE[okey] = [order, 1]
+                else:
+                    order = ent[0]; ent[1] += 1
         elif item_order is not None:
             raise ValueError("score_mask_topk: item_order must be 'norm', None or an int32 permutation")
     timed = os.environ.get('ARL_TOPK_TIME') == '1'          # diagnostics: wall time of the pass itself, between device synchronisations

@@ -66,4 +66,7 @@ def _deterministic_torch_rng():
     so a tolerance that holds holds on every run."""
     import torch
     torch.manual_seed(20260)
+    ops = sys.modules.get('arlib_amd.ops')
+    if ops is not None and hasattr(ops, 'reset_exit_probe'):
+        ops.reset_exit_probe()            # what earlier tests' scoring passes learnt about tables of the same shape (exit probe, cached item order) stays with them
     yield

@@ -240,3 +240,22 @@ def sddmm_rows_dense(dY, X, rows, col_off, n_cols, out=None):
 def pga_update_(S, grad, dinv_rows=None, dinv_cols=None):
     S.copy_(torch.from_numpy(O.pga_update(S.numpy(), grad.numpy(), None if dinv_rows is None else dinv_rows.numpy(), None if dinv_cols is None else dinv_cols.numpy())))
     return S
+
+
+def cw_topk_term(X, n_user_rows, n_real, top_idx, targets, c=None, want_w=True, check_range=True):
+    """float64 restatement of ops.cw_topk_term (attack/White/CLeaR.py:83-95): loss, dL/dX on every row, SFA row multiplicities."""
+    Xn = X.numpy().astype(np.float64)
+    Up, n_real = int(n_user_rows), int(n_real)
+    k, tg = top_idx.shape[1], targets.numpy().astype(np.int64)
+    T = len(tg)
+    c = 1.0 / (max(n_real, 1) * T) if c is None else float(c)
+    neg = top_idx.numpy()[:n_real][:, [k - 1 - t for t in range(T)]].astype(np.int64).reshape(n_real, T)
+    G = np.zeros_like(Xn); loss = 0.0
+    for t in range(T):
+        G[:n_real] += c * (Xn[Up + neg[:, t]] - Xn[Up + tg[t]])
+        np.add.at(G, Up + neg[:, t], c * Xn[:n_real])
+        G[Up + tg[t]] -= c * Xn[:n_real].sum(0)
+        loss += c * ((Xn[:n_real] * Xn[Up + neg[:, t]]).sum() - (Xn[:n_real] * Xn[Up + tg[t]]).sum())
+    w = np.zeros(Xn.shape[0]); w[:n_real] = T
+    np.add.at(w, Up + neg.reshape(-1), 1.0); np.add.at(w, Up + tg, float(n_real))
+    return (torch.tensor([loss], dtype=torch.float32), torch.from_numpy(G.astype(np.float32)), torch.from_numpy(w.astype(np.float32)) if want_w else None)

@@ -100,5 +100,33 @@ for case in range(n_cases):
         gP, gE = ops.ngcf_combine_bwd(gST, Pn, En)
         report(case, 'ngcf d=%d' % d, {'combine': rel(ST, torch.cat([Pn + En, Pn * En], 1)), 'act': rel(Zc, F.leaky_relu(P, 0.01)), 'acc': rel(acc, g + F.leaky_relu(P, 0.01)),
                                         'act_bwd': rel(gz, g * torch.where(Zc > 0, 1.0, 0.01)), 'gP': rel(gP, gST[:, :d] + gST[:, d:] * En), 'gE': rel(gE, gST[:, :d] + gST[:, d:] * Pn)})
+    # ---- CW term from top-k lists (arl_cw_topk_term_f32): loss, gradient on every row, SFA multiplicities vs float64; two runs bit-identical
+    if d % 4 == 0:
+        Uc, Fc, Ic = int(rng.integers(1, 1500)), int(rng.integers(0, 5)), int(rng.integers(8, 3000))
+        kc = int(rng.integers(1, min(Ic, 64) + 1)); Tc = int(rng.integers(1, min(kc, 8) + 1))
+        Upc = Uc + Fc
+        Xc = (rng.standard_normal((Upc + Ic, d)) * float(rng.choice([1e-3, 0.1, 5.0]))).astype(np.float32)
+        hot = int(rng.integers(0, Ic))
+        top = rng.integers(0, Ic, (Upc, kc)).astype(np.int32)
+        if rng.random() < 0.5:
+            top[: max(1, Uc // 2), kc - 1] = hot                        # most negatives on one item
+        tgc = rng.choice(Ic, size=Tc, replace=False).astype(np.int64)
+        cc = 1.0 / (Uc * Tc)
+        Xd = Xc.astype(np.float64)
+        neg = top[:Uc][:, [kc - 1 - t_ for t_ in range(Tc)]].astype(np.int64)
+        Gr = np.zeros_like(Xd); lr = 0.0
+        for t_ in range(Tc):
+            Gr[:Uc] += cc * (Xd[Upc + neg[:, t_]] - Xd[Upc + tgc[t_]])
+            np.add.at(Gr, Upc + neg[:, t_], cc * Xd[:Uc])
+            Gr[Upc + tgc[t_]] -= cc * Xd[:Uc].sum(0)
+            lr += cc * ((Xd[:Uc] * Xd[Upc + neg[:, t_]]).sum() - (Xd[:Uc] * Xd[Upc + tgc[t_]]).sum())
+        wr = np.zeros(Upc + Ic); wr[:Uc] = Tc
+        np.add.at(wr, Upc + neg.reshape(-1), 1.0); np.add.at(wr, Upc + tgc, float(Uc))
+        l1, G1, w1 = ops.cw_topk_term(T(Xc), Upc, Uc, T(top), T(tgc))
+        l2, G2, w2 = ops.cw_topk_term(T(Xc), Upc, Uc, T(top), T(tgc))
+        same = torch.equal(l1, l2) and torch.equal(G1, G2) and torch.equal(w1, w2)
+        report(case, 'cw_topk_term U=%d I=%d d=%d k=%d T=%d' % (Uc, Ic, d, kc, Tc),
+               {'loss': abs(l1.item() - lr) / max(abs(lr), float(np.abs(Gr).max()), 1e-30), 'G': rel(G1, torch.from_numpy(Gr).to(dev)),
+                'w': float(np.abs(w1.cpu().numpy() - wr).max()), 'rerun': 0.0 if same else 1.0}, 2e-5)
 print('%d cases: %d mismatches' % (n_cases, bad))
 sys.exit(1 if bad else 0)
