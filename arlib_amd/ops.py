@@ -1279,7 +1279,9 @@ def reset_exit_probe():
 
 def _exit_probe_record(st, ws, off, nst):
     if st['pending'] is None:
-        host = torch.empty(3, dtype=torch.int64).pin_memory()
+        host = st.get('host')
+        if host is None:
+            host = st['host'] = torch.empty(3, dtype=torch.int64).pin_memory()       # one pinned slot per shape, reused (no copy is in flight while `pending` is None)
         host.copy_(ws[off:off + 24].view(torch.int64), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()

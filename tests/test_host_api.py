@@ -208,6 +208,26 @@ def test_whole_epoch_sampling_is_the_same_stream(ml100k):
     assert random.random() == float(g['next_random'][0])
 
 
+@pytest.mark.parametrize('n', [0, 1, 2, 511, 512, 513, 1025, 5000])
+def test_native_shuffle_is_random_shuffle_across_the_lookahead_block(n):
+    """arl_sampler_shuffle draws the swap partners a block of 512 ahead (to prefetch their rows) and then swaps in random.shuffle's order: same
+    permutation and same RNG end point as CPython for sizes around the block size, from an 8-byte- and a 4-byte-aligned buffer."""
+    import ctypes as C
+    from arlib_amd import _lib
+    for shift in (0, 1):
+        raw = np.zeros(2 * max(n, 1) + 2, np.int32)
+        pairs = raw[shift:shift + 2 * n].reshape(n, 2) if n else raw[:0].reshape(0, 2)
+        if n:
+            pairs[:, 0] = np.arange(n); pairs[:, 1] = 7 * np.arange(n)
+        random.seed(99)
+        st = np.array(random.getstate()[1], dtype=np.uint32)
+        ptr = C.c_void_p(pairs.ctypes.data) if n else C.c_void_p(raw.ctypes.data)
+        _lib.check(_lib.lib().arl_sampler_shuffle(st.ctypes.data_as(C.c_void_p), ptr, n), 'arl_sampler_shuffle')
+        ref = list(range(n)); random.shuffle(ref)
+        assert pairs[:, 0].tolist() == ref and pairs[:, 1].tolist() == [7 * x for x in ref]
+        assert np.array_equal(st, np.array(random.getstate()[1], dtype=np.uint32))
+
+
 @pytest.mark.parametrize('chunk_batches', [None, 3, 1])
 def test_device_epoch_producer_thread_is_the_same_stream(ml100k, chunk_batches):
     """device_epoch (what train() iterates): the epoch's negatives are drawn in chunks by a producer thread behind the consumer.  Same batches as the

@@ -34,6 +34,18 @@ for n in (0, 1, 2, 7, 1000, 44212):
     ref = list(range(n)); random.shuffle(ref)
     assert pairs[:n, 0].tolist() == ref, n
     assert np.array_equal(st, mt_from_python())
+# the same from a buffer that is only 4-byte aligned (the swap then moves the two int32 halves separately), across the block size of the look-ahead
+for n in (3, 511, 512, 513, 5000):
+    random.seed(6)
+    st = mt_from_python()
+    raw = np.zeros(2 * n + 1, np.int32)
+    pairs = raw[1:].reshape(n, 2)
+    pairs[:, 0] = np.arange(n); pairs[:, 1] = np.arange(n) * 3
+    assert pairs.ctypes.data % 8 == 4
+    assert H.arl_sampler_shuffle(vp(st), C.c_void_p(pairs.ctypes.data), i64(n)) == 0
+    ref = list(range(n)); random.shuffle(ref)
+    assert pairs[:, 0].tolist() == ref and pairs[:, 1].tolist() == [3 * x for x in ref], n
+    assert np.array_equal(st, mt_from_python())
 # next_batch: rejection against membership, users without any item, window at the very end
 rng = np.random.default_rng(0)
 U, I, nnz = 50, 40, 600
