@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-TRAFFIC_BLOCKED, TRAFFIC_CSR = 'r03_pmc_traffic_blocked.json', 'r01_pmc_traffic.json'      # PMC passes `roofline.traffic` quotes (tools/pmc_traffic.py)
+TRAFFIC_BLOCKED, TRAFFIC_CSR = 'r04_pmc_traffic_blocked.json', 'r01_pmc_traffic.json'      # PMC passes `roofline.traffic` quotes (tools/pmc_traffic.py)
 
 
 def parse():
