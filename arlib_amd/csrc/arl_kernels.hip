@@ -2154,6 +2154,9 @@ __global__ __launch_bounds__(kBlock) void score_mask_topk_kernel(const float *__
 #ifndef ARL_TOPK_D64_WAVES
 #define ARL_TOPK_D64_WAVES 16
 #endif
+#ifndef ARL_TOPK_MIN_WAVES_EU
+#define ARL_TOPK_MIN_WAVES_EU 1                   // (developer knob: smaller workgroups, e.g. -DARL_TOPK_D64_WAVES=8, need 4 here to stay at 128 registers = two workgroups per CU)
+#endif
 constexpr int topk_waves(int D, bool SPLIT) { return (SPLIT && ARL_TOPK_SPLIT_MODE == 2) ? (D == 64 ? ARL_TOPK_D64_WAVES : (D == 128 ? ARL_TOPK_D128_WAVES : 8)) : 8; }
 #ifdef ARL_TOPK_PROF
 #define ARL_PROF_DECL long long P_acc[7] = {0, 0, 0, 0, 0, 0, 0}, P_t0 = clock64(); const long long P_start = P_t0;
@@ -2381,7 +2384,7 @@ constexpr int kExitWords = 20;                   // LDS words behind the ring co
 constexpr float kExitK = (1.f + 1.05f * 0.0009765625f) / (ARL_TOPK_ESCALE * 0.0009765625f > 0.f ? ARL_TOPK_ESCALE * 0.0009765625f : 1.f) + 1.f;
 
 template <int D, bool SPLIT, bool WARM, bool XIT = false>
-__global__ __launch_bounds__(64 * topk_waves(D, SPLIT)) void score_mask_topk_mfma16_kernel(const float *__restrict__ Pu, const void *__restrict__ Pi_image, int U, int I,
+__global__ __launch_bounds__(64 * topk_waves(D, SPLIT), ARL_TOPK_MIN_WAVES_EU) void score_mask_topk_mfma16_kernel(const float *__restrict__ Pu, const void *__restrict__ Pi_image, int U, int I,
                                                                             const int32_t *__restrict__ mrp, const int32_t *__restrict__ mcol, int k,
                                                                             int32_t *__restrict__ top_idx, float *__restrict__ top_val,
                                                                             const float *__restrict__ Pi_f32, const int32_t *__restrict__ warm_idx,
