@@ -130,6 +130,7 @@ class NCL(Recommender):
     has_extra_loss = True
     fused_extra_loss = False
     l2_on_negatives = True
+    adjgrad_through_views = True      # train(requires_adjgrad=True): only the main forward runs on sparse_norm_adj (NCL.py:134); the structure term's hops use a fresh tensor (:135)
 
     def __init__(self, args, data):
         self._common_init(args, data, 'NCL')

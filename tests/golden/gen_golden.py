@@ -1317,12 +1317,17 @@ def gen_adjgrad_simgcl(which='simgcl'):
     import io, contextlib
     if which == 'xsimgcl':
         from recommender.XSimGCL import XSimGCL as Cls
+    elif which == 'ncl':
+        # NCL (recommender/NCL.py:114-186), one warm-up epoch (no k-means before epoch 5): sparse_norm_adj takes gradient from the main forward only -- the
+        # structure term propagates over a FRESH tensor built per step (:135), which carries none; no noise draws; g25_adjgrad_ncl.npz
+        from recommender.NCL import NCL as Cls
     else:
         Cls = SimGCL
     args = rec_args(emb_size=16, n_layers=2, model_name=Cls.__name__)
     seedSet(2018)
     data = DataLoader(args)
-    rec = Cls(args, data)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rec = Cls(args, data)
     u0 = rec.model.embedding_dict['user_emb'].detach().numpy().copy(); i0 = rec.model.embedding_dict['item_emb'].detach().numpy().copy()
     first, calls = {}, [0]
     orig_backward, orig_rand_like = torch.Tensor.backward, torch.rand_like
@@ -1350,7 +1355,7 @@ def gen_adjgrad_simgcl(which='simgcl'):
     B1 = (M1 + M1.T).tocsr()[:U, U:].tocoo()
     block = block.detach().numpy()
     r, c = np.nonzero(block)
-    save('g24_adjgrad_xsimgcl.npz' if which == 'xsimgcl' else 'g23_adjgrad_simgcl.npz', user0=u0, item0=i0, block_row=r.astype(np.int32), block_col=c.astype(np.int32), block_val=block[r, c].astype(np.float32),
+    save({'xsimgcl': 'g24_adjgrad_xsimgcl.npz', 'ncl': 'g25_adjgrad_ncl.npz'}.get(which, 'g23_adjgrad_simgcl.npz'), user0=u0, item0=i0, block_row=r.astype(np.int32), block_col=c.astype(np.int32), block_val=block[r, c].astype(np.float32),
          first_row=B1.row.astype(np.int32), first_col=B1.col.astype(np.int32), first_val=B1.data.astype(np.float32),
          block_shape=np.array(block.shape, np.int64), user=rec.model.embedding_dict['user_emb'].detach().numpy().copy(),
          item=rec.model.embedding_dict['item_emb'].detach().numpy().copy(), next_random=np.array([random.random()], np.float64),
@@ -1390,6 +1395,8 @@ if __name__ == '__main__':
             gen_adjgrad_simgcl()
         if 'adjgrad_xsimgcl' in only:
             gen_adjgrad_simgcl('xsimgcl')
+        if 'adjgrad_ncl' in only:
+            gen_adjgrad_simgcl('ncl')
         sys.exit(0)
     gen_dataset()
     data = gen_sampler()
@@ -1418,4 +1425,5 @@ if __name__ == '__main__':
     gen_adjgrad()
     gen_adjgrad_simgcl()
     gen_adjgrad_simgcl('xsimgcl')
+    gen_adjgrad_simgcl('ncl')
     print('done; scratch dir', SCRATCH)

@@ -148,7 +148,7 @@ def test_train_requires_adjgrad_matches_reference_run(array_native):
     assert close(rec.model.embedding_dict['item_emb'].detach().cpu().numpy(), g['item'])
 
 
-@pytest.mark.parametrize('which', ['simgcl', 'xsimgcl'])
+@pytest.mark.parametrize('which', ['simgcl', 'xsimgcl', 'ncl'])
 def test_simgcl_train_requires_adjgrad_matches_reference_run(which):
     """(which = 'xsimgcl': the same for XSimGCL.train(requires_adjgrad=True), g24, recommender/XSimGCL.py:46-85 -- one perturbed forward per step whose
     backward, _PropagateX, feeds the sink with its own perturbed layer tables.)
@@ -162,6 +162,9 @@ def test_simgcl_train_requires_adjgrad_matches_reference_run(which):
     if which == 'xsimgcl':
         from arlib_amd.recommender.XSimGCL import XSimGCL as SimGCL
         g, per_step = golden('g24_adjgrad_xsimgcl.npz'), 2
+    elif which == 'ncl':            # g25, recommender/NCL.py:114-186, one warm-up epoch: the gradient comes from the main forward alone (the structure term propagates over a fresh tensor), no noise
+        from arlib_amd.recommender.NCL import NCL as SimGCL
+        g, per_step = golden('g25_adjgrad_ncl.npz'), 0
     else:
         from arlib_amd.recommender.SimGCL import SimGCL
         g, per_step = golden('g23_adjgrad_simgcl.npz'), 4
