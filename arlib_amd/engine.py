@@ -19,6 +19,27 @@ import torch
 from . import ops
 
 
+def mean_adjacency_gradient(A, E0, G, L, s, out, noises=None, eps=0.1):
+    """out[e] += dL/d(value of stored entry e of the symmetric graph A) for out_tables = s * sum of layers E_k (k >= 1 always in the sum), E_{k+1} = A E_k
+    (+ a gradient-free perturbation when `noises` is given), from G = dL/d(out_tables): dE_L = s G, dE_k = s G + A dE_{k+1}, entry (i, j) receives
+    sum_{k=0}^{L-1} <dE_{k+1}[i], E_k[j]>.  L - 1 forward hops, L - 1 backward hops, L products over the pattern (ops.sddmm_csr)."""
+    if L == 0:
+        return out
+    E = [E0]
+    for k in range(L - 1):
+        nxt = ops.spmm(A, E[-1])
+        if noises is not None:
+            ops.simgcl_perturb_(nxt, noises[k], eps)
+        E.append(nxt)
+    G = G.contiguous()
+    acc = G
+    for j in range(L):
+        ops.sddmm_csr(A, acc, E[L - 1 - j], s, out=out)
+        if j < L - 1:
+            acc = ops.spmm(A, acc, 1.0, 1.0, G)
+    return out
+
+
 class PropagationEngine:
     def __init__(self, graph, n_users, n_items, emb_size, n_layers, reg, lr, device, skip_layer0=False,
                  optimizer='adam', betas=(0.9, 0.999), eps=1e-8, table=None, schedule='auto'):
@@ -135,22 +156,7 @@ class PropagationEngine:
         L, A = self.L, self.A
         if out is None:
             out = torch.zeros(A.col.numel(), dtype=torch.float32, device=G.device)
-        if L == 0:
-            return out
-        s = 1.0 / L if self.skip0 else 1.0 / (L + 1)
-        E = [self.E0]
-        for k in range(L - 1):
-            nxt = ops.spmm(A, E[-1])
-            if noises is not None:
-                ops.simgcl_perturb_(nxt, noises[k], eps)
-            E.append(nxt)
-        G = G.contiguous()
-        acc = G
-        for j in range(L):
-            ops.sddmm_csr(A, acc, E[L - 1 - j], s, out=out)
-            if j < L - 1:
-                acc = ops.spmm(A, acc, 1.0, 1.0, G)
-        return out
+        return mean_adjacency_gradient(A, self.E0, G, L, 1.0 / L if self.skip0 else 1.0 / (L + 1), out, noises, eps)
 
     # ---- the propagated mean on a row subset, with its backward: the sparse-batch schedule of step() for callers that keep autograd and
     # their own optimiser (an extra loss term, an optimiser over one table only, gradient capture)

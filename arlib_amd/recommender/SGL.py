@@ -57,7 +57,7 @@ class _PropagateOn(torch.autograd.Function):
             cur = ops.spmm(graph, cur)
             acc.add_(cur)
         acc.mul_(1.0 / (L + 1))
-        ctx.graph, ctx.L = graph, L
+        ctx.graph, ctx.L, ctx.E0 = graph, L, E
         U = user_emb.shape[0]
         return acc[:U], acc[U:]
 
@@ -66,6 +66,10 @@ class _PropagateOn(torch.autograd.Function):
         L = ctx.L
         G = torch.cat([g_u, g_i], 0).contiguous()
         s = 1.0 / (L + 1)
+        sink = getattr(ctx.graph, 'grad_sink', None)
+        if sink is not None:            # train(requires_adjgrad=True): this VIEW's stored entries receive their gradient (the reference sets dropped_adj*.requires_grad, SGL.py:56-63)
+            from ..engine import mean_adjacency_gradient
+            mean_adjacency_gradient(ctx.graph, ctx.E0, G, L, s, sink)
         acc = G
         for k in range(L):
             a = s if k == L - 1 else 1.0
@@ -139,13 +143,62 @@ class SGL(Recommender):
         self.temp = 0.2
         self.model = SGL_Encoder(self.data, self.args.emb_size, self.drop_rate, self.n_layers, self.temp, self.aug_type)
 
-    def _on_epoch_start(self, model):
-        self.dropped_adj1 = model.graph_reconstruction()      # two fresh views per epoch (SGL.py:50-51)
-        self.dropped_adj2 = model.graph_reconstruction()
-
     def _extra_loss(self, model, user_idx, pos_idx):
         return self.cl_rate * model.cal_cl_loss([user_idx, pos_idx], self.dropped_adj1, self.dropped_adj2)
 
+    # ---- train(requires_adjgrad / requires_embgrad) the way the reference's SGL does it (recommender/SGL.py:39-95), which is NOT the other models' way:
+    #   * the adjacency gradient is taken w.r.t. the two DROPPED graphs of the epoch; per step grad_mat* += dropped_adj*.grad, and `.grad` is never zeroed
+    #     inside the epoch, so grad_mat adds the running sum; at the END of the epoch gradAll[U, I] += upper-right block of (grad_mat1 + grad_mat2)
+    #     (no transpose added), while maxEpoch - epoch < gradIterationNum;
+    #   * `elif requires_embgrad`: the tables' `.grad` of the epoch's LAST step is added once per epoch (both flags: the adjacency branch wins);
+    #   * the two flags are independent `if`s at set-up, so both together work (the other models fail there).
+    _grad_req = None
+
+    def _on_epoch_start(self, model):
+        self.dropped_adj1 = model.graph_reconstruction()      # two fresh views per epoch (SGL.py:50-51)
+        self.dropped_adj2 = model.graph_reconstruction()
+        if self._grad_req is not None and self._grad_req[0]:
+            for g in (self.dropped_adj1, self.dropped_adj2):
+                z = lambda: torch.zeros(g.col.numel(), dtype=torch.float32, device=g.col.device)
+                g.grad_sink, g.grad_run, g.grad_mat = z(), z(), z()
+
+    def _after_backward(self, model, epoch, maxEpoch, gradIterationNum):
+        if self._grad_req is not None and self._grad_req[0]:
+            for g in (self.dropped_adj1, self.dropped_adj2):
+                g.grad_run += g.grad_sink                      # dropped_adj.grad: the running sum of the epoch's steps
+                g.grad_sink.zero_()
+                g.grad_mat += g.grad_run                       # grad_mat += dropped_adj.grad (SGL.py:75-77)
+
+    def _on_epoch_end(self, model, epoch, maxEpoch, gradIterationNum):
+        if self._grad_req is None or not maxEpoch - epoch < gradIterationNum:
+            return
+        U, I = self.data.user_num, self.data.item_num
+        if self._grad_req[0]:
+            for g in (self.dropped_adj1, self.dropped_adj2):
+                nu = int(g.rowptr[U])                          # the user rows' entries come first: (u, U + i)
+                rows = torch.repeat_interleave(torch.arange(U, device=g.col.device), (g.rowptr[1:U + 1] - g.rowptr[:U]).long(), output_size=nu)
+                self.gradAll.index_put_((rows, g.col[:nu].long() - U), g.grad_mat[:nu], accumulate=True)
+                g.grad_sink = None
+        elif self._grad_req[1]:
+            self.usergrad += model.embedding_dict['user_emb'].grad
+            self.itemgrad += model.embedding_dict['item_emb'].grad
+
     def train(self, requires_adjgrad=False, requires_embgrad=False, gradIterationNum=10, Epoch=0, optimizer=None, evalNum=5):
-        return self._train_loop(Epoch, optimizer, evalNum, requires_embgrad=requires_embgrad, requires_adjgrad=requires_adjgrad,
-                                gradIterationNum=gradIterationNum)
+        if not requires_adjgrad and not requires_embgrad:
+            return self._train_loop(Epoch, optimizer, evalNum)
+        U, I = self.data.user_num, self.data.item_num
+        if requires_adjgrad:
+            self.gradAll = torch.zeros(U, I, dtype=torch.float32, device=DEVICE)
+        if requires_embgrad:
+            self.usergrad = torch.zeros((U, self.args.emb_size), device=DEVICE)
+            self.itemgrad = torch.zeros((self.data.item_num, self.args.emb_size), device=DEVICE)
+        self._grad_req = (bool(requires_adjgrad), bool(requires_embgrad))
+        try:
+            self._train_loop(Epoch, optimizer, evalNum, gradIterationNum=gradIterationNum, force_autograd=True)
+        finally:
+            self._grad_req = None
+        if requires_adjgrad and requires_embgrad:
+            return self.gradAll, self.user_emb, self.item_emb, self.usergrad, self.itemgrad
+        if requires_adjgrad:
+            return self.gradAll
+        return self.user_emb, self.item_emb, self.usergrad, self.itemgrad

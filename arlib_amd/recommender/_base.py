@@ -401,13 +401,19 @@ class Recommender:
     def _on_epoch_start(self, model):
         pass
 
-    def _train_loop(self, Epoch, optimizer, evalNum, requires_embgrad=False, requires_adjgrad=False, gradIterationNum=10):
+    def _after_backward(self, model, epoch, maxEpoch, gradIterationNum):
+        pass
+
+    def _on_epoch_end(self, model, epoch, maxEpoch, gradIterationNum):
+        pass
+
+    def _train_loop(self, Epoch, optimizer, evalNum, requires_embgrad=False, requires_adjgrad=False, gradIterationNum=10, force_autograd=False):
         self.bestPerformance = []
         model = self.model.cuda()
         fused_kind = None
         if optimizer is None:
             optimizer = torch.optim.Adam(model.parameters(), lr=self.args.lRate)
-        if not requires_embgrad and not requires_adjgrad:
+        if not requires_embgrad and not requires_adjgrad and not force_autograd:      # (force_autograd: a model that captures gradients its own way, SGL)
             fused_kind = self._fusable(optimizer)
             if self.has_extra_loss and not (fused_kind == 'adam' and self.fused_extra_loss):
                 fused_kind = None
@@ -436,7 +442,7 @@ class Recommender:
         # nothing -- it only consumes the sampler's random stream and runs the per-epoch evaluation.  Same here,
         # without spending the forward/backward.
         mine = self._params()
-        inert = not requires_embgrad and not requires_adjgrad and not any(p is q for g in optimizer.param_groups for p in g['params'] for q in mine)
+        inert = not requires_embgrad and not requires_adjgrad and not force_autograd and not any(p is q for g in optimizer.param_groups for p in g['params'] for q in mine)
         eng = None
         if fused_kind:
             eng = model._engine(self.args.reg, self.args.lRate, fused_kind)
@@ -502,6 +508,7 @@ class Recommender:
                 if requires_embgrad and maxEpoch - epoch < gradIterationNum:
                     self.usergrad += model.embedding_dict['user_emb'].grad
                     self.itemgrad += model.embedding_dict['item_emb'].grad
+                self._after_backward(model, epoch, maxEpoch, gradIterationNum)
                 optimizer.step()
                 if n % self.print_every == 0:
                     print('training:', epoch + 1, 'batch', n, 'batch_loss:', batch_loss.item())
@@ -517,6 +524,7 @@ class Recommender:
                 self.last_train_stats.update({'sampler_' + k: v for k, v in samp.items()})
             if eng is not None:
                 self._sync_optimizer_step(eng, optimizer, fused_kind)
+            self._on_epoch_end(model, epoch, maxEpoch, gradIterationNum)
             model.eval()
             with torch.no_grad():
                 self.user_emb, self.item_emb = self._detached_forward()

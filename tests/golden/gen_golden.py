@@ -1362,6 +1362,71 @@ def gen_adjgrad_simgcl(which='simgcl'):
          noise_calls=np.array([calls[0]], np.int64), noise_seed0=np.array([5000], np.int64))
 
 
+SGL_SGD_LR = 20.0
+
+
+def gen_adjgrad_sgl():
+    """Reference `SGL.train(requires_adjgrad=True)` / `(requires_embgrad=True)` (recommender/SGL.py:39-95): unlike the other models the gradient is taken
+    w.r.t. the two DROPPED graphs of the epoch (`dropped_adj*.requires_grad`), summed per step into grad_mat* -- `.grad` is never zeroed inside the epoch, so
+    grad_mat adds the running sum -- and folded into gradAll[U, I] = the upper-right block of grad_mat1 + grad_mat2 at the END of the epoch; with
+    requires_embgrad the tables' `.grad` of the epoch's LAST step is added at the end of the epoch (:82-84).  One epoch each; the first step's gradient of view 1
+    is captured through the adjacency handed to cal_cl_loss."""
+    import io, contextlib
+    from recommender.SGL import SGL
+    args = rec_args(emb_size=16, n_layers=2, model_name='SGL')
+    out = {}
+    for mode in ('adj', 'emb', 'sgd'):
+        seedSet(2018)
+        data = DataLoader(args)
+        rec = SGL(args, data)
+        U, I = data.user_num, data.item_num
+        if mode == 'sgd':
+            # the same adjacency-gradient run under plain SGD (train()'s `optimizer` argument): Adam's g / sqrt(v) amplifies rounding-level differences in
+            # small gradients to +-lr per step (tools/sgl_adjgrad_conditioning.py), SGD does not, so this trajectory pins the 22-step accumulation at 1e-4
+            with contextlib.redirect_stdout(io.StringIO()):
+                res = rec.train(requires_adjgrad=True, Epoch=1, gradIterationNum=10, evalNum=1, optimizer=torch.optim.SGD(rec.model.parameters(), lr=SGL_SGD_LR))
+            block = res.detach().numpy()
+            r, c = np.nonzero(block)
+            moved = (rec.model.embedding_dict['item_emb'].detach() - torch.from_numpy(out['item0'])).norm() / torch.from_numpy(out['item0']).norm()
+            print('  SGL under SGD(lr=%g): item table moved by %.3f of its norm in one epoch' % (SGL_SGD_LR, float(moved)))
+            out.update(sgd_block_row=r.astype(np.int32), sgd_block_col=c.astype(np.int32), sgd_block_val=block[r, c].astype(np.float32), sgd_lr=np.array([SGL_SGD_LR]),
+                       sgd_user=rec.model.embedding_dict['user_emb'].detach().numpy().copy(), sgd_item=rec.model.embedding_dict['item_emb'].detach().numpy().copy())
+            continue
+        if mode == 'adj':
+            out['user0'] = rec.model.embedding_dict['user_emb'].detach().numpy().copy(); out['item0'] = rec.model.embedding_dict['item_emb'].detach().numpy().copy()
+        first, seen = {}, {}
+        orig_cl, orig_backward = rec.model.cal_cl_loss, torch.Tensor.backward
+
+        def cl_wrap(idx, a1, a2):
+            seen['a1'] = a1
+            return orig_cl(idx, a1, a2)
+
+        def backward_and_capture(self, *a, **k):
+            res = orig_backward(self, *a, **k)
+            if mode == 'adj' and not first and 'a1' in seen and seen['a1'].grad is not None:
+                gr = seen['a1'].grad.coalesce()
+                first['idx'], first['val'] = gr.indices().numpy().copy(), gr.values().numpy().copy()
+            return res
+        rec.model.cal_cl_loss = cl_wrap
+        torch.Tensor.backward = backward_and_capture
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                res = rec.train(requires_adjgrad=(mode == 'adj'), requires_embgrad=(mode == 'emb'), Epoch=1, gradIterationNum=10, evalNum=1)
+        finally:
+            torch.Tensor.backward = orig_backward
+        if mode == 'adj':
+            block = res.detach().numpy()
+            r, c = np.nonzero(block)
+            sel = first['idx'][0] < U
+            out.update(block_row=r.astype(np.int32), block_col=c.astype(np.int32), block_val=block[r, c].astype(np.float32), block_shape=np.array(block.shape, np.int64),
+                       first_row=first['idx'][0][sel].astype(np.int32), first_col=(first['idx'][1][sel] - U).astype(np.int32), first_val=first['val'][sel].astype(np.float32),
+                       user=rec.model.embedding_dict['user_emb'].detach().numpy().copy(), item=rec.model.embedding_dict['item_emb'].detach().numpy().copy(),
+                       next_random=np.array([random.random()], np.float64))
+        else:
+            out.update(emb_usergrad=res[2].detach().numpy().copy(), emb_itemgrad=res[3].detach().numpy().copy(), emb_next_random=np.array([random.random()], np.float64))
+    save('g26_adjgrad_sgl.npz', **out)
+
+
 if __name__ == '__main__':
     only = set(sys.argv[1:])                          # e.g. `gen_golden.py xsimgcl` regenerates that fixture alone
     if only:
@@ -1397,6 +1462,8 @@ if __name__ == '__main__':
             gen_adjgrad_simgcl('xsimgcl')
         if 'adjgrad_ncl' in only:
             gen_adjgrad_simgcl('ncl')
+        if 'adjgrad_sgl' in only:
+            gen_adjgrad_sgl()
         sys.exit(0)
     gen_dataset()
     data = gen_sampler()
@@ -1426,4 +1493,5 @@ if __name__ == '__main__':
     gen_adjgrad_simgcl()
     gen_adjgrad_simgcl('xsimgcl')
     gen_adjgrad_simgcl('ncl')
+    gen_adjgrad_sgl()
     print('done; scratch dir', SCRATCH)
