@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ARLIB_AMD_LIB') or os.path.join(_HERE, 'lib', 'libarlib_amd.so')      # override: developer builds (e.g. `make prof`)
-ABI_VERSION = 23
+ABI_VERSION = 24
 _lib = None
 
 
@@ -104,7 +104,8 @@ _SIGS = {
     'arl_cw_topk_term_f32': (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _i64, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     'arl_score_mask_topk_workspace_bytes': (_i64, [_i64, _i64]),
     'arl_score_mask_topk_stats_offset': (_i64, [_i64, _i64]),
-    'arl_score_mask_topk_f32': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp]),
+    'arl_score_mask_topk_user_workspace_bytes': (_i64, [_i64, _i64]),
+    'arl_score_mask_topk_f32': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp, _vp]),
     'arl_normalize_rows_f32': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     'arl_normalize_rows_bwd_f32': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _f, _vp, _vp, _vp]),
     'arl_nce_allrows_workspace_bytes': (_i64, [_i64, _i64, _i64]),

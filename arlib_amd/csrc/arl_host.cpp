@@ -90,7 +90,7 @@ inline bool user_has_item(const int64_t *rowptr, const int32_t *items, int64_t r
 
 extern "C" {
 
-int arl_abi_version(void) { return 23; }
+int arl_abi_version(void) { return 24; }
 
 int arl_mt_seed(uint32_t *mt_state, const uint32_t *key, int64_t key_len) {
     if (!mt_state || !key) return ARL_E_NULL;

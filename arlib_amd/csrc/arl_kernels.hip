@@ -3264,6 +3264,387 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT), ARL_TOPK_MIN_WAVES_EU) v
 }
 
 // ================================================================================================
+// score_mask_topk, second form of the fp16 split path's stream (round 4; d = 64 / 128, k <= 64, needs the caller's USER workspace).
+// The first form (above) spends its time on issue slots, not on products: 104 vector + 130 scalar instructions per wave and 64-item stage of
+// 16 users, a counter ring polled five times per stage, MFMA busy 15 %.  This form turns the tile around:
+//   * a wave owns 32 users and contracts with v_mfma_f32_32x32x16_f16, ITEMS as rows and USERS as columns: all 16 accumulators of a lane belong
+//     to ONE user (column lane % 32), so the pre-filter is one subtract + one v_alignbit per score against one threshold register, collected
+//     into a per-lane bit mask -- no per-score scalar mask, no per-(sub-tile, row) branch;
+//   * 16 waves = 512 users share a staged tile (half the staging traffic per score of the first form's 256), stages are 128 items (d = 64)
+//     behind ONE workgroup barrier each (double-buffered tiles) instead of the ring's counters;
+//   * the sorted lists live IN THE OUTPUT ARRAYS (top_val = mapped score bits, top_idx = ~item while the kernel runs; L2-resident) and not in
+//     registers: a merge loads / stores 8 B per lane, and the kernel fits 128 registers with four waves per SIMD;
+//   * starting thresholds come from two small kernels of their own (bootstrap sample / warm-start candidates) through the user workspace.
+// What reaches the lists is unchanged: a queued candidate gets the first form's exact three-product score (the same v_mfma_f32_16x16x32_f16
+// sequence on the same pieces, user row against candidate columns) when its row's queue is merged, keys and tie order are the same, so the
+// results are bit-identical to the first form's (and the bound behind the pre-filter is the same E: any fp32-accumulated contraction of the
+// high pieces lies within it).
+// ================================================================================================
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef ARL_TOPK2
+#define ARL_TOPK2 1                                // 0: the first form everywhere (A/B builds)
+#endif
+#ifndef ARL_TOPK2_D128
+#define ARL_TOPK2_D128 0
+#endif
+constexpr int kT2Waves = 16;                       // waves per workgroup
+constexpr int kT2Users = 32 * kT2Waves;            // users per workgroup
+constexpr int kT2QCap = 16;                        // queue slots per user (the candidates of one merge are the columns of one 16 x 16 tile)
+#ifndef ARL_TOPK2_QFLUSH
+#define ARL_TOPK2_QFLUSH 12
+#endif
+constexpr int kT2QFlush = ARL_TOPK2_QFLUSH;        // a row's queue is merged at the end of a stage once it holds this many
+constexpr int kT2BootItems = 4096;                 // sample of the bootstrap kernel (streams of >= 32 768 items)
+__host__ __device__ constexpr int t2_mst(int D) { return D <= 64 ? 128 : 64; }       // items per stage
+__host__ __device__ constexpr int t2_rs(int D) { return D * 2 + 16; }                // LDS bytes per staged item row: the high pieces + 16 (conflict-free ds_read_b128 over 16 rows)
+__host__ __device__ constexpr size_t t2_lds_bytes(int D, bool masked) {
+    return 2 * (size_t)t2_mst(D) * t2_rs(D) + sizeof(unsigned) * kT2Users * (1 + kT2QCap) + (masked ? sizeof(unsigned) * kT2Users * kBloomWords : 0);
+}
+
+// starting thresholds from the warm-start candidates (first form: the WARM prologue): thr0[u] = the lowest of the k candidates' fp32 scores, lowered by
+// the bound on the difference to the streamed contraction, in the scaled domain
+__global__ __launch_bounds__(kBlock) void topk2_warm_kernel(const float *__restrict__ Pu, const float *__restrict__ Pi_f32, int U, int I, int D, int k,
+                                                            const int32_t *__restrict__ warm_idx, const unsigned *__restrict__ table_max_bits,
+                                                            float *__restrict__ thr0, const int *__restrict__ gate, const int *__restrict__ gate2) {
+    if (gate != nullptr && *gate == 0) return;
+    if (gate2 != nullptr && *gate2 == 0) return;
+    const int lane = threadIdx.x & 63;
+    const float score_scale = split_scale(table_max_bits[1]) * split_scale(table_max_bits[0]);
+    for (int u = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); u < U; u += gridDim.x * kWavesPerBlock) {
+        const float *pu = Pu + (size_t)u * D;
+        const int cand_j = lane < k ? min(max(warm_idx[(size_t)u * k + lane], 0), I - 1) : 0;
+        const float *pi = Pi_f32 + (size_t)cand_j * D;
+        float sdot = 0.f, ni = 0.f, nu = 0.f;
+        for (int t = 0; t < D; t += 4) {
+            const float4 x = *reinterpret_cast<const float4 *>(pu + t), y = *reinterpret_cast<const float4 *>(pi + t);
+            sdot = fmaf(x.x, y.x, sdot); sdot = fmaf(x.y, y.y, sdot); sdot = fmaf(x.z, y.z, sdot); sdot = fmaf(x.w, y.w, sdot);
+            ni = fmaf(y.x, y.x, ni); ni = fmaf(y.y, y.y, ni); ni = fmaf(y.z, y.z, ni); ni = fmaf(y.w, y.w, ni);
+            nu = fmaf(x.x, x.x, nu); nu = fmaf(x.y, x.y, nu); nu = fmaf(x.z, x.z, nu); nu = fmaf(x.w, x.w, nu);
+        }
+        float lb = lane < k ? (sdot - 8e-6f * sqrtf(nu * ni)) * score_scale - 1e-30f : INFINITY;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lb = fminf(lb, __shfl_xor(lb, off));
+        if (lane == 0) thr0[u] = lb;
+    }
+}
+
+// Bootstrap: starting thresholds from the first kT2BootItems items of the stream.  A lane scores its user (column lane % 32) against the sample and
+// keeps, in 32 registers, the maxima of 32 disjoint item groups (tile t of 32 items -> group t % 32; the two half-waves see different rows of a tile):
+// 64 group maxima of DISTINCT items per user.  The (k + m)-th largest of them -- m = the user's interacted items inside the sample, which the mask may
+// take out -- minus E is a lower bound of the user's final k-th best score.  Selected per lane pair by a 32-step bisection over the order-preserving
+// integer image of the floats.  combine != 0: thr0 = max(thr0, bound) (a warm-started call).
+template <int D>
+__global__ __launch_bounds__(kBlock) void topk2_boot_kernel(const _Float16 *__restrict__ uimg, const _Float16 *__restrict__ img, int U, int I,
+                                                            const int32_t *__restrict__ mrp, const int32_t *__restrict__ mcol, int k,
+                                                            const int32_t *__restrict__ item_pos, const unsigned *__restrict__ table_max_bits,
+                                                            const float *__restrict__ table_norm, float *__restrict__ thr0, int combine,
+                                                            const int *__restrict__ gate, const int *__restrict__ gate2) {
+    if (gate != nullptr && *gate == 0) return;
+    if (gate2 != nullptr && *gate2 == 0) return;
+    constexpr int KS = D / 16;
+    const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+    const int u = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * 32 + n;
+    const int uc = min(u, U - 1);
+    f16x8 bu[KS];
+    float n2 = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        bu[ks] = *reinterpret_cast<const f16x8 *>(uimg + (size_t)uc * 2 * D + 16 * ks + 8 * h);
+        const f16x8 lo = *reinterpret_cast<const f16x8 *>(uimg + (size_t)uc * 2 * D + D + 16 * ks + 8 * h);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { const float x = (float)bu[ks][t] + (float)lo[t]; n2 = fmaf(x, x, n2); }
+    }
+    n2 += __shfl_xor(n2, 32);
+    const float si = split_scale(table_max_bits[0]), su = split_scale(table_max_bits[1]);
+    const float Eabs = 1.1920929e-7f * (float)D * (__uint_as_float(table_max_bits[0]) * si + __uint_as_float(table_max_bits[1]) * su);
+    const float E = fmaf(ARL_TOPK_ESCALE * 0.0009765625f * sqrtf(n2) * 1.0000005f, *table_norm, Eabs);      // (|a'| from the pieces: within 2^-21 of the first form's)
+    float gm[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) gm[j] = -INFINITY;
+    const int ntile = kT2BootItems / 32;
+    for (int t0 = 0; t0 < ntile; t0 += 32) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const _Float16 *row = img + (size_t)((t0 + j) * 32 + n) * 2 * D + 8 * h;
+            f16x8 a[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const f16x8 *>(row + 16 * ks);
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], bu[ks], acc, 0, 0, 0);
+            float m = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+#pragma unroll
+            for (int i = 4; i < 16; i += 4) m = fmaxf(m, fmaxf(fmaxf(acc[i], acc[i + 1]), fmaxf(acc[i + 2], acc[i + 3])));
+            gm[j] = fmaxf(gm[j], m);
+        }
+    }
+    // m: this user's interacted items inside the sample (both lanes of the pair compute it)
+    int msk = 0;
+    if (mrp != nullptr && u < U) {
+        const int b0 = mrp[u], e0 = mrp[u + 1];
+        if (item_pos != nullptr) {
+            for (int e = b0; e < e0; ++e) msk += item_pos[mcol[e]] < kT2BootItems;
+        } else {
+            int lo = b0, hi = e0;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (mcol[mid] < kT2BootItems) lo = mid + 1; else hi = mid; }
+            msk = lo - b0;
+        }
+    }
+    const int K = k + msk;
+    unsigned key[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { const unsigned b = __float_as_uint(gm[j]); key[j] = (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+    unsigned T = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = T | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) cnt += key[j] >= cand;
+        cnt += __shfl_xor(cnt, 32);
+        if (cnt >= K) T = cand;
+    }
+    float bound = -INFINITY;
+    if (K <= 64 && T != 0u) {
+        const unsigned b = (T & 0x80000000u) ? (T & 0x7fffffffu) : ~T;
+        bound = __uint_as_float(b) - E;
+        if (!(bound == bound)) bound = -INFINITY;
+    }
+    if (h == 0 && u < U) thr0[u] = combine ? fmaxf(thr0[u], bound) : bound;
+}
+
+template <int D>
+__global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float16 *__restrict__ uimg, const _Float16 *__restrict__ img, int U, int I,
+                                                                  const int32_t *__restrict__ mrp, const int32_t *__restrict__ mcol, int k,
+                                                                  int32_t *__restrict__ top_idx, float *__restrict__ top_val, const float *__restrict__ thr0,
+                                                                  int *__restrict__ underflow, int warm, const unsigned *__restrict__ table_max_bits,
+                                                                  const int32_t *__restrict__ item_order, const int *__restrict__ gate,
+                                                                  const float *__restrict__ stage_norm, unsigned long long *__restrict__ stats,
+                                                                  const int *__restrict__ gate2) {
+    if (gate != nullptr && *gate == 0) return;
+    if (gate2 != nullptr && *gate2 == 0) return;
+    constexpr int MST = t2_mst(D), RS = t2_rs(D), TB = MST * RS, KS = D / 16, KS16 = D / 32, NT = 64 * kT2Waves;
+    constexpr int C16 = D * 2 / 16;                                // 16-byte pieces of an item row's high plane
+    constexpr int PER = MST * C16 / NT;
+    static_assert(MST * C16 % NT == 0 && PER >= 1, "every thread moves the same number of pieces");
+    extern __shared__ unsigned char smem_raw[];
+    unsigned *qcnt_all = reinterpret_cast<unsigned *>(smem_raw + 2 * TB);
+    unsigned *qpos_all = qcnt_all + kT2Users;
+    unsigned *bloom_all = qpos_all + kT2Users * kT2QCap;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 31, h = lane >> 5, c = lane & 15, g = lane >> 4;
+    const int u_base = blockIdx.x * kT2Users + wv * 32;
+    unsigned *qcnt = qcnt_all + wv * 32, *qpos = qpos_all + wv * 32 * kT2QCap, *bloom = bloom_all + wv * 32 * kBloomWords;
+    const int u = u_base + n, uc = min(u, U - 1);
+    const float su = split_scale(table_max_bits[1]), si = split_scale(table_max_bits[0]);
+    const float score_scale = su * si, score_unscale = (1.f / su) * (1.f / si);
+    const float Eabs = 1.1920929e-7f * (float)D * (__uint_as_float(table_max_bits[0]) * si + __uint_as_float(table_max_bits[1]) * su);
+    f16x8 bu[KS];
+    float Ereg;
+    {
+        float n2 = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bu[ks] = *reinterpret_cast<const f16x8 *>(uimg + (size_t)uc * 2 * D + 16 * ks + 8 * h);
+            const f16x8 lo = *reinterpret_cast<const f16x8 *>(uimg + (size_t)uc * 2 * D + D + 16 * ks + 8 * h);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { const float x = (float)bu[ks][t] + (float)lo[t]; n2 = fmaf(x, x, n2); }
+        }
+        n2 += __shfl_xor(n2, 32);
+        Ereg = ARL_TOPK_ESCALE * 0.0009765625f * sqrtf(n2) * 1.0000005f;
+    }
+    const float thr0v = u < U ? thr0[u] : INFINITY;               // lanes n and n + 32: user n's starting threshold
+    float thr = thr0v;                                             // running exact threshold of this lane's user (users past U never append)
+    // lists: empty
+    for (int r = 0; r < 32; ++r) {
+        const int ur = u_base + r;
+        if (ur < U && lane < k) { top_idx[(size_t)ur * k + lane] = 0; reinterpret_cast<unsigned *>(top_val)[(size_t)ur * k + lane] = 0u; }
+    }
+    if (lane < 32) qcnt[lane] = 0u;
+    if (mrp) {
+        for (int t = lane; t < 32 * kBloomWords; t += kWave) bloom[t] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        for (int r = 0; r < 32; ++r) {
+            const int ur = u_base + r;
+            if (ur >= U) break;
+            for (int e = mrp[ur] + lane, end = mrp[ur + 1]; e < end; e += kWave) {
+                const unsigned hb = bloom_hash(mcol[e]);
+                atomicOr(&bloom[r * kBloomWords + (hb >> 5)], 1u << (hb & 31u));
+            }
+        }
+    }
+    __threadfence();                                               // (the zeroed lists are read back by this wave only; L2 is the point of coherence)
+    const int nst = (I + MST - 1) / MST;
+
+    // merge the queue of user row r (wave-uniform) into its list
+    auto flush_row = [&](int r) {
+        const int cnt = __builtin_amdgcn_readfirstlane((int)*(volatile lds_u32 *)(qcnt + r));
+        const int m = min(cnt, kT2QCap);
+        const int ur = u_base + r;
+        unsigned pos_l = 0u;
+        if (lane < m) pos_l = *(volatile lds_u32 *)(qpos + r * kT2QCap + lane);
+        unsigned Kh = 0u, Kl = 0u;
+        if (lane < k) { Kh = reinterpret_cast<const unsigned *>(top_val)[(size_t)ur * k + lane]; Kl = (unsigned)top_idx[(size_t)ur * k + lane]; }
+        const int pos_c = __shfl((int)pos_l, c);                   // 0 for columns without a candidate: row 0 of the image, never read back
+        const _Float16 *src = img + (size_t)pos_c * 2 * D + g * (KS16 * 8);
+        const _Float16 *usr = uimg + (size_t)ur * 2 * D + g * (KS16 * 8);
+        f16x8 fb[2][KS16], ua[2][KS16];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < KS16; ++ks) {
+                fb[pl][ks] = *reinterpret_cast<const f16x8 *>(src + pl * D + ks * 8);
+                ua[pl][ks] = *reinterpret_cast<const f16x8 *>(usr + pl * D + ks * 8);
+            }
+        int item = 0;
+        if (lane < m) item = item_order ? item_order[pos_l] : (int)pos_l;
+        if (lane == 0) *(volatile lds_u32 *)(qcnt + r) = 0u;
+        constexpr int TA[3] = {0, 1, 0}, TB3[3] = {1, 0, 0};       // the first form's order: ah*bl, al*bh, ah*bh
+        f32x4 ca = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int ks = 0; ks < KS16; ++ks) ca = __builtin_amdgcn_mfma_f32_16x16x32_f16(ua[TA[term]][ks], fb[TB3[term]][ks], ca, 0, 0, 0);
+        // every row of the tile is user ur: lane j < 16 (k-group 0, register 0 = row 0) holds candidate j's score
+        unsigned long long cj = 0ull;
+        if (lane < m) {
+            float sc = ca[0];
+            if (mrp) {
+                const unsigned hb = bloom_hash(item);
+                if ((bloom[r * kBloomWords + (hb >> 5)] >> (hb & 31u)) & 1u) {
+                    int lo = mrp[ur], hi = mrp[ur + 1];
+                    const int end = hi;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (mcol[mid] < item) lo = mid + 1; else hi = mid; }
+                    if (lo < end && mcol[lo] == item) sc = -10e8f * score_scale;
+                }
+            }
+            cj = pack_cand(sc, item);
+        }
+        const unsigned long long Kk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)Kh, k - 1) << 32) | (unsigned)__builtin_amdgcn_readlane((int)Kl, k - 1);
+        bool changed = false;
+        for (unsigned long long todo = __ballot(lane < m && cj > Kk); todo != 0ull; todo &= todo - 1ull) {
+            const int j = __ffsll((long long)todo) - 1;
+            const unsigned ch = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cj >> 32), j);
+            const unsigned cl = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cj, j);
+            const unsigned long long key = ((unsigned long long)ch << 32) | cl, K = ((unsigned long long)Kh << 32) | Kl;
+            const int pos = __popcll(__ballot(K > key));
+            if (pos < k) {
+                const unsigned sl = __builtin_amdgcn_update_dpp(Kl, Kl, 0x138, 0xf, 0xf, false);            // wave_shr:1
+                const unsigned sh = __builtin_amdgcn_update_dpp(Kh, Kh, 0x138, 0xf, 0xf, false);
+                Kl = lane < pos ? Kl : (lane == pos ? cl : sl);
+                Kh = lane < pos ? Kh : (lane == pos ? ch : sh);
+                changed = true;
+            }
+        }
+        if (changed) {
+            if (lane < k) { reinterpret_cast<unsigned *>(top_val)[(size_t)ur * k + lane] = Kh; top_idx[(size_t)ur * k + lane] = (int)Kl; }
+            const unsigned th = (unsigned)__builtin_amdgcn_readlane((int)Kh, k - 1);
+            const unsigned tl = (unsigned)__builtin_amdgcn_readlane((int)Kl, k - 1);
+            const float t0 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(thr0v), r));
+            const float nt = (th | tl) ? __builtin_fmaxf(cand_score((unsigned long long)th << 32), t0) : t0;
+            thr = (n == r) ? nt : thr;
+        }
+    };
+    auto flush_rows_with = [&](unsigned at_least) {
+        const unsigned cn = lane < 32 ? *(volatile lds_u32 *)(qcnt + lane) : 0u;
+        for (unsigned long long need = __ballot(cn >= at_least); need != 0ull; need &= need - 1ull) flush_row(__ffsll((long long)need) - 1);
+    };
+
+    // staging: global -> registers -> LDS, one stage ahead in registers, one in LDS
+    float4 stg[PER];
+    auto gload = [&](int s) {
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            const int f = tid + p * NT;
+            const int item = min(s * MST + f / C16, I - 1);        // clamped: rows past I are copies of item I - 1, masked out of the bit masks
+            stg[p] = *reinterpret_cast<const float4 *>(reinterpret_cast<const unsigned char *>(img) + (size_t)item * (4 * D) + (f % C16) * 16);
+        }
+    };
+    auto lwrite = [&](unsigned char *buf) {
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            const int f = tid + p * NT;
+            *reinterpret_cast<float4 *>(buf + (f / C16) * RS + (f % C16) * 16) = stg[p];
+        }
+    };
+    gload(0);
+    lwrite(smem_raw);
+    if (nst > 1) gload(1);
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+        const unsigned char *buf = smem_raw + (s & 1) * TB;
+        if (s + 1 < nst) lwrite(smem_raw + ((s + 1) & 1) * TB);
+        if (s + 2 < nst) gload(s + 2);
+        unsigned pm[MST / 64];                                     // bit 16 * (t & 1) + i of pm[t / 2]: accumulator i of tile t passed
+#pragma unroll
+        for (int t = 0; t < MST / 32; ++t) {
+            f16x8 a[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const f16x8 *>(buf + (t * 32 + n) * RS + ks * 32 + h * 16);
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], bu[ks], acc, 0, 0, 0);
+            const float sn = stage_norm[(s * MST + t * 32) >> (D <= 64 ? 6 : 5)];      // the largest scaled item norm of the tile's 64-item (32 at d = 128) stretch of the stream
+            const float tf = thr - fmaf(Ereg, sn, Eabs);
+            unsigned fails = 0u;
+#pragma unroll
+            for (int i = 15; i >= 0; --i) fails = __builtin_amdgcn_alignbit(fails, __float_as_uint(acc[i] - tf), 31);     // sign(score - threshold): NaN and -inf thresholds pass, +inf never
+            unsigned p16 = ~fails & 0xffffu;
+            if (s == nst - 1) {                                    // rows past I
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (s * MST + t * 32 + 8 * (i >> 2) + 4 * h + (i & 3) >= I) p16 &= ~(1u << i);
+            }
+            if (t & 1) pm[t / 2] |= p16 << 16; else pm[t / 2] = p16;
+        }
+        // appends: one candidate per lane and round
+        for (;;) {
+            bool have = false;
+#pragma unroll
+            for (int q = 0; q < MST / 64; ++q) have = have || pm[q] != 0u;
+            if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
+            bool ovf = false;
+            if (have) {
+                int q = 0;
+#pragma unroll
+                for (int x = MST / 64 - 1; x >= 0; --x) q = pm[x] != 0u ? x : q;
+                unsigned w = pm[0];
+#pragma unroll
+                for (int x = 1; x < MST / 64; ++x) w = q == x ? pm[x] : w;
+                const int b = __ffs(w) - 1;
+                const unsigned pos = (unsigned)(s * MST + q * 64 + (b >> 4) * 32 + 8 * ((b & 15) >> 2) + 4 * h + (b & 3));
+                const unsigned slot = __hip_atomic_fetch_add((lds_u32 *)(qcnt + n), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (slot < (unsigned)kT2QCap) {
+                    *(volatile lds_u32 *)(qpos + n * kT2QCap + slot) = pos;
+                    w &= w - 1u;
+#pragma unroll
+                    for (int x = 0; x < MST / 64; ++x) pm[x] = q == x ? w : pm[x];
+                } else ovf = true;
+            }
+            if (__builtin_amdgcn_ballot_w64(ovf) != 0ull) flush_rows_with((unsigned)kT2QCap);
+        }
+        flush_rows_with((unsigned)kT2QFlush);
+        __syncthreads();
+    }
+    flush_rows_with(1u);
+    if (stats != nullptr && tid == 0) {                            // (the first form's counters, in its 64- / 32-item stages: nothing skipped)
+        atomicAdd(stats, (unsigned long long)((I + (D <= 64 ? 64 : 32) - 1) / (D <= 64 ? 64 : 32)));
+        atomicAdd(stats + 1, 1ull);
+    }
+    __threadfence();
+    for (int r = 0; r < 32; ++r) {
+        const int ur = u_base + r;
+        if (ur < U && lane < k) {
+            const unsigned kh = reinterpret_cast<const unsigned *>(top_val)[(size_t)ur * k + lane], kl = (unsigned)top_idx[(size_t)ur * k + lane];
+            const unsigned long long key = ((unsigned long long)kh << 32) | kl;
+            top_idx[(size_t)ur * k + lane] = cand_item(key);
+            top_val[(size_t)ur * k + lane] = cand_score(key) * score_unscale;
+            if (warm && lane == k - 1 && key == 0ull) atomicOr(underflow, 1);
+        }
+    }
+}
+
+// ================================================================================================
 // CW term of the attacks' surrogate loss from the users' top-k lists (attack/White/CLeaR.py:83-95, PGA.py:104-116):
 //     L = c * sum over real users u and targets t of  <X_u, X_neg(u,t)> - <X_u, X_tg(t)>,   neg(u, t) = top_idx[u][k - 1 - t]  (successive .pop()s)
 // and G = dL/dX on the packed table X = [user rows | item rows]: L is bilinear, L = 1/2 X^T M X, G = M X.  Round 3 built M as a CSR per step from ~25
@@ -4493,9 +4874,11 @@ int64_t arl_score_mask_topk_stats_offset(int64_t I, int64_t d) {
     return (4 * I * d + 16 + 4 * I + 4 * (2 * nst + 2) + 7) / 8 * 8;
 }
 
+int64_t arl_score_mask_topk_user_workspace_bytes(int64_t U, int64_t d) { return (U <= 0 || d <= 0) ? 0 : 4 * U * d + 4 * U + 64; }
+
 int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t I, int64_t d, const int32_t *mask_rowptr, const int32_t *mask_col,
                             int64_t k, int32_t *top_idx, float *top_val, void *workspace, const int32_t *warm_idx, int32_t *underflow,
-                            const int32_t *item_order, int32_t exit_mode, arl_stream_t stream) {
+                            const int32_t *item_order, int32_t exit_mode, void *user_workspace, arl_stream_t stream) {
     if (!Pu || !Pi || !top_idx || !top_val) return ARL_E_NULL;
     if (warm_idx && !underflow) return ARL_E_NULL;
     if (mask_rowptr && !mask_col) return ARL_E_NULL;
@@ -4578,7 +4961,53 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
             if (warm_idx) { ARL_TOPK_CASE2_##SP(DV, true, warm_idx, (const int *)nullptr); ARL_TOPK_CASE2_##SP(DV, false, (const int32_t *)nullptr, (const int *)underflow); } \
             else ARL_TOPK_CASE2_##SP(DV, false, (const int32_t *)nullptr, (const int *)nullptr);                                        \
         } while (0)
-        if (d == 16) ARL_TOPK_CASE(16, false);
+        // second form of the fp16 split stream (topk2_*): needs the caller's user workspace ([U][2][d] fp16 image of the users, then [U] starting thresholds)
+        const bool form2 = split && kSplitMode == 2 && ARL_TOPK_REFINE && ARL_TOPK_QUEUE && ARL_TOPK2 && user_workspace != nullptr && (d == 64 || (d == 128 && ARL_TOPK2_D128));
+        if (form2) {
+            hipStream_t st = (hipStream_t)stream;
+            _Float16 *uimg = (_Float16 *)user_workspace;
+            float *thr0 = reinterpret_cast<float *>(static_cast<char *>(user_workspace) + 4 * (size_t)U * (size_t)d);
+            const long long nu = (long long)U * d;
+            hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)((nu + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, Pu, nu, (int)d, max_bits + 1, uimg, (const int32_t *)nullptr);
+            ARL_LAUNCH_CHECK();
+            const bool boot = I >= 32768;
+            const int nst1 = (int)((I + mst - 1) / mst);
+            const size_t shm2 = t2_lds_bytes((int)d, mask_rowptr != nullptr);
+            const unsigned grid2 = (unsigned)((U + kT2Users - 1) / kT2Users), gridb = (unsigned)((U + 32 * kWavesPerBlock - 1) / (32 * kWavesPerBlock));
+            const int *g2 = exit_mode != 0 ? (const int *)(pick_d + 1) : (const int *)nullptr;
+#define ARL_TOPK2_PASS(DV, WARMF, GATE)                                                                                                \
+            do {                                                                                                                       \
+                if (WARMF) {                                                                                                           \
+                    hipLaunchKernelGGL(topk2_warm_kernel, dim3(grid_for(U, kWavesPerBlock, 8192u)), dim3(kBlock), 0, st, Pu, Pi, (int)U, (int)I, (int)d, (int)k, warm_idx, max_bits, thr0, GATE, g2); \
+                } else if (!boot) {                                                                                                    \
+                    if (hipMemsetD32Async((hipDeviceptr_t)thr0, (int)0xff800000u, (size_t)U, st) != hipSuccess) return ARL_E_ARG;     \
+                }                                                                                                                      \
+                if (boot) hipLaunchKernelGGL((topk2_boot_kernel<DV>), dim3(gridb), dim3(kBlock), 0, st, (const _Float16 *)uimg, (const _Float16 *)workspace, (int)U, (int)I, mask_rowptr, mask_col, \
+                                             (int)k, (const int32_t *)pos_d, max_bits, (const float *)(snorm_d + nst1), thr0, (WARMF) ? 1 : 0, GATE, g2); \
+                ARL_LAUNCH_CHECK();                                                                                                    \
+                hipError_t em2 = hipFuncSetAttribute((const void *)topk2_main_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2); \
+                if (em2 != hipSuccess) return (int)em2;                                                                                \
+                hipLaunchKernelGGL((topk2_main_kernel<DV>), dim3(grid2), dim3(64 * kT2Waves), shm2, st, (const _Float16 *)uimg, (const _Float16 *)workspace, (int)U, (int)I, mask_rowptr, mask_col, \
+                                   (int)k, top_idx, top_val, (const float *)thr0, underflow, (WARMF) ? 1 : 0, max_bits, order_d, GATE, (const float *)snorm_d, stats_d, g2); \
+                ARL_LAUNCH_CHECK();                                                                                                    \
+            } while (0)
+#define ARL_TOPK2_CALL(DV)                                                                                                             \
+            do {                                                                                                                       \
+                if (warm_idx) {                                                                                                        \
+                    if (exit_mode != 0) ARL_TOPK_CASE3(DV, true, true, true, warm_idx, (const int *)nullptr, (const int *)pick_d);     \
+                    ARL_TOPK2_PASS(DV, true, (const int *)nullptr);                                                                    \
+                    if (exit_mode != 0) ARL_TOPK_CASE3(DV, true, false, true, (const int32_t *)nullptr, (const int *)underflow, (const int *)pick_d); \
+                    ARL_TOPK2_PASS(DV, false, (const int *)underflow);                                                                 \
+                } else {                                                                                                               \
+                    if (exit_mode != 0) ARL_TOPK_CASE3(DV, true, false, true, (const int32_t *)nullptr, (const int *)nullptr, (const int *)pick_d); \
+                    ARL_TOPK2_PASS(DV, false, (const int *)nullptr);                                                                   \
+                }                                                                                                                      \
+            } while (0)
+            if (d == 64) ARL_TOPK2_CALL(64); else ARL_TOPK2_CALL(128);
+#undef ARL_TOPK2_CALL
+#undef ARL_TOPK2_PASS
+        }
+        else if (d == 16) ARL_TOPK_CASE(16, false);
         else if (d == 32) ARL_TOPK_CASE(32, false);
         else if (d == 64) { if (split) ARL_TOPK_CASE(64, true); else ARL_TOPK_CASE(64, false); }
         else { if (split) ARL_TOPK_CASE(128, true); else ARL_TOPK_CASE(128, false); }

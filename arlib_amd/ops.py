@@ -1240,6 +1240,7 @@ def cw_topk_term(X, n_user_rows, n_real, top_idx, targets, c=None, want_w=True, 
     return loss, G, w
 
 
+TOPK_FORM2 = os.environ.get('ARL_TOPK_FORM2', '1') != '0'      # (A/B: ARL_TOPK_FORM2=0 keeps the first form of score_mask_topk's fp16 stream)
 TOPK_STATS = {'calls': 0, 'warm': 0, 'cold_repeats': 0}     # counters for benches: warm-started calls and how many of them had to be repeated cold
 
 
@@ -1354,8 +1355,11 @@ def score_mask_topk(Pu, Pi, k, mask_rowptr=None, mask_col=None, exact=False, war
         soff = _lib.lib().arl_score_mask_topk_stats_offset(I, d)
         nst = (I + (64 if d <= 64 else 32) - 1) // (64 if d <= 64 else 32)
         mode, probe = _exit_mode((U, I, d, k, mask_rowptr is not None), ws, soff, nst, Pu.device)
+    uws = None
+    if ws is not None and d == 64 and TOPK_FORM2:           # the second form of the stream (32 users per wave, lists kept in the outputs): needs the user workspace
+        uws = torch.empty(_lib.lib().arl_score_mask_topk_user_workspace_bytes(U, d), dtype=torch.uint8, device=Pu.device)
     check(_lib.lib().arl_score_mask_topk_f32(_ptr(Pu), _ptr(Pi), U, I, d, _ptr(mask_rowptr), _ptr(mask_col), k, _ptr(idx), _ptr(val), _ptr(ws),
-                                             _ptr(warm_idx), _ptr(flag), _ptr(order), mode, _stream()), 'arl_score_mask_topk_f32')
+                                             _ptr(warm_idx), _ptr(flag), _ptr(order), mode, _ptr(uws), _stream()), 'arl_score_mask_topk_f32')
     if mode == 1:
         _exit_probe_record(probe, ws, soff, nst)
     if timed:
