@@ -3284,6 +3284,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef ARL_TOPK2
 #define ARL_TOPK2 1                                // 0: the first form everywhere (A/B builds)
 #endif
+#ifndef ARL_TOPK2_EXP
+#define ARL_TOPK2_EXP 0                            // developer probes (results wrong by construction)
+#endif
+#ifndef ARL_TOPK2_UA_LATE
+#define ARL_TOPK2_UA_LATE 1                        // the user's pieces of a merge are loaded when it completes (1) or carried with the pending state (0: 16 registers more)
+#endif
 #ifndef ARL_TOPK2_D128
 #define ARL_TOPK2_D128 0
 #endif
@@ -3308,108 +3314,27 @@ __global__ __launch_bounds__(kBlock) void topk2_warm_kernel(const float *__restr
                                                             float *__restrict__ thr0, const int *__restrict__ gate, const int *__restrict__ gate2) {
     if (gate != nullptr && *gate == 0) return;
     if (gate2 != nullptr && *gate2 == 0) return;
-    const int lane = threadIdx.x & 63;
+    // D / 4 lanes x float4 own one candidate row (d = 64: 16 lanes, four candidates per pass): a load instruction touches whole 256-byte rows
+    const int lane = threadIdx.x & 63, LPR = D >> 2, RPP = 64 / LPR, sub = lane / LPR, ch = lane % LPR;
     const float score_scale = split_scale(table_max_bits[1]) * split_scale(table_max_bits[0]);
     for (int u = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); u < U; u += gridDim.x * kWavesPerBlock) {
-        const float *pu = Pu + (size_t)u * D;
-        const int cand_j = lane < k ? min(max(warm_idx[(size_t)u * k + lane], 0), I - 1) : 0;
-        const float *pi = Pi_f32 + (size_t)cand_j * D;
-        float sdot = 0.f, ni = 0.f, nu = 0.f;
-        for (int t = 0; t < D; t += 4) {
-            const float4 x = *reinterpret_cast<const float4 *>(pu + t), y = *reinterpret_cast<const float4 *>(pi + t);
-            sdot = fmaf(x.x, y.x, sdot); sdot = fmaf(x.y, y.y, sdot); sdot = fmaf(x.z, y.z, sdot); sdot = fmaf(x.w, y.w, sdot);
-            ni = fmaf(y.x, y.x, ni); ni = fmaf(y.y, y.y, ni); ni = fmaf(y.z, y.z, ni); ni = fmaf(y.w, y.w, ni);
-            nu = fmaf(x.x, x.x, nu); nu = fmaf(x.y, x.y, nu); nu = fmaf(x.z, x.z, nu); nu = fmaf(x.w, x.w, nu);
+        const float4 x = *reinterpret_cast<const float4 *>(Pu + (size_t)u * D + 4 * ch);
+        float nu = fmaf(x.x, x.x, fmaf(x.y, x.y, fmaf(x.z, x.z, x.w * x.w)));
+        for (int off = 1; off < LPR; off <<= 1) nu += __shfl_xor(nu, off);
+        float lb = INFINITY;
+        for (int j0 = 0; j0 < k; j0 += RPP) {
+            const int j = j0 + sub;
+            const int cand = j < k ? min(max(warm_idx[(size_t)u * k + j], 0), I - 1) : 0;
+            const float4 y = *reinterpret_cast<const float4 *>(Pi_f32 + (size_t)cand * D + 4 * ch);
+            float sd = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, x.w * y.w)));
+            float ni = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, y.w * y.w)));
+            for (int off = 1; off < LPR; off <<= 1) { sd += __shfl_xor(sd, off); ni += __shfl_xor(ni, off); }
+            const float v = (sd - 8e-6f * sqrtf(nu * ni)) * score_scale - 1e-30f;       // (the slack covers any fp32 summation order of the two contractions)
+            if (j < k) lb = fminf(lb, v);
         }
-        float lb = lane < k ? (sdot - 8e-6f * sqrtf(nu * ni)) * score_scale - 1e-30f : INFINITY;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) lb = fminf(lb, __shfl_xor(lb, off));
+        for (int off = LPR; off < 64; off <<= 1) lb = fminf(lb, __shfl_xor(lb, off));
         if (lane == 0) thr0[u] = lb;
     }
-}
-
-// Bootstrap: starting thresholds from the first kT2BootItems items of the stream.  A lane scores its user (column lane % 32) against the sample and
-// keeps, in 32 registers, the maxima of 32 disjoint item groups (tile t of 32 items -> group t % 32; the two half-waves see different rows of a tile):
-// 64 group maxima of DISTINCT items per user.  The (k + m)-th largest of them -- m = the user's interacted items inside the sample, which the mask may
-// take out -- minus E is a lower bound of the user's final k-th best score.  Selected per lane pair by a 32-step bisection over the order-preserving
-// integer image of the floats.  combine != 0: thr0 = max(thr0, bound) (a warm-started call).
-template <int D>
-__global__ __launch_bounds__(kBlock) void topk2_boot_kernel(const _Float16 *__restrict__ uimg, const _Float16 *__restrict__ img, int U, int I,
-                                                            const int32_t *__restrict__ mrp, const int32_t *__restrict__ mcol, int k,
-                                                            const int32_t *__restrict__ item_pos, const unsigned *__restrict__ table_max_bits,
-                                                            const float *__restrict__ table_norm, float *__restrict__ thr0, int combine,
-                                                            const int *__restrict__ gate, const int *__restrict__ gate2) {
-    if (gate != nullptr && *gate == 0) return;
-    if (gate2 != nullptr && *gate2 == 0) return;
-    constexpr int KS = D / 16;
-    const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
-    const int u = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * 32 + n;
-    const int uc = min(u, U - 1);
-    f16x8 bu[KS];
-    float n2 = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        bu[ks] = *reinterpret_cast<const f16x8 *>(uimg + (size_t)uc * 2 * D + 16 * ks + 8 * h);
-        const f16x8 lo = *reinterpret_cast<const f16x8 *>(uimg + (size_t)uc * 2 * D + D + 16 * ks + 8 * h);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) { const float x = (float)bu[ks][t] + (float)lo[t]; n2 = fmaf(x, x, n2); }
-    }
-    n2 += __shfl_xor(n2, 32);
-    const float si = split_scale(table_max_bits[0]), su = split_scale(table_max_bits[1]);
-    const float Eabs = 1.1920929e-7f * (float)D * (__uint_as_float(table_max_bits[0]) * si + __uint_as_float(table_max_bits[1]) * su);
-    const float E = fmaf(ARL_TOPK_ESCALE * 0.0009765625f * sqrtf(n2) * 1.0000005f, *table_norm, Eabs);      // (|a'| from the pieces: within 2^-21 of the first form's)
-    float gm[32];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) gm[j] = -INFINITY;
-    const int ntile = kT2BootItems / 32;
-    for (int t0 = 0; t0 < ntile; t0 += 32) {
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const _Float16 *row = img + (size_t)((t0 + j) * 32 + n) * 2 * D + 8 * h;
-            f16x8 a[KS];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const f16x8 *>(row + 16 * ks);
-            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], bu[ks], acc, 0, 0, 0);
-            float m = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
-#pragma unroll
-            for (int i = 4; i < 16; i += 4) m = fmaxf(m, fmaxf(fmaxf(acc[i], acc[i + 1]), fmaxf(acc[i + 2], acc[i + 3])));
-            gm[j] = fmaxf(gm[j], m);
-        }
-    }
-    // m: this user's interacted items inside the sample (both lanes of the pair compute it)
-    int msk = 0;
-    if (mrp != nullptr && u < U) {
-        const int b0 = mrp[u], e0 = mrp[u + 1];
-        if (item_pos != nullptr) {
-            for (int e = b0; e < e0; ++e) msk += item_pos[mcol[e]] < kT2BootItems;
-        } else {
-            int lo = b0, hi = e0;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (mcol[mid] < kT2BootItems) lo = mid + 1; else hi = mid; }
-            msk = lo - b0;
-        }
-    }
-    const int K = k + msk;
-    unsigned key[32];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) { const unsigned b = __float_as_uint(gm[j]); key[j] = (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
-    unsigned T = 0u;
-    for (int bit = 31; bit >= 0; --bit) {
-        const unsigned cand = T | (1u << bit);
-        int cnt = 0;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) cnt += key[j] >= cand;
-        cnt += __shfl_xor(cnt, 32);
-        if (cnt >= K) T = cand;
-    }
-    float bound = -INFINITY;
-    if (K <= 64 && T != 0u) {
-        const unsigned b = (T & 0x80000000u) ? (T & 0x7fffffffu) : ~T;
-        bound = __uint_as_float(b) - E;
-        if (!(bound == bound)) bound = -INFINITY;
-    }
-    if (h == 0 && u < U) thr0[u] = combine ? fmaxf(thr0[u], bound) : bound;
 }
 
 template <int D>
@@ -3419,7 +3344,7 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
                                                                   int *__restrict__ underflow, int warm, const unsigned *__restrict__ table_max_bits,
                                                                   const int32_t *__restrict__ item_order, const int *__restrict__ gate,
                                                                   const float *__restrict__ stage_norm, unsigned long long *__restrict__ stats,
-                                                                  const int *__restrict__ gate2) {
+                                                                  const int *__restrict__ gate2, int boot, const int32_t *__restrict__ item_pos) {
     if (gate != nullptr && *gate == 0) return;
     if (gate2 != nullptr && *gate2 == 0) return;
     constexpr int MST = t2_mst(D), RS = t2_rs(D), TB = MST * RS, KS = D / 16, KS16 = D / 32, NT = 64 * kT2Waves;
@@ -3452,7 +3377,7 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
         n2 += __shfl_xor(n2, 32);
         Ereg = ARL_TOPK_ESCALE * 0.0009765625f * sqrtf(n2) * 1.0000005f;
     }
-    const float thr0v = u < U ? thr0[u] : INFINITY;               // lanes n and n + 32: user n's starting threshold
+    float thr0v = u < U ? (thr0 != nullptr ? thr0[u] : -INFINITY) : INFINITY;      // lanes n and n + 32: user n's starting threshold (warm start; the bootstrap below raises it)
     float thr = thr0v;                                             // running exact threshold of this lane's user (users past U never append)
     // lists: empty
     for (int r = 0; r < 32; ++r) {
@@ -3476,39 +3401,84 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
     __threadfence();                                               // (the zeroed lists are read back by this wave only; L2 is the point of coherence)
     const int nst = (I + MST - 1) / MST;
 
-    // merge the queue of user row r (wave-uniform) into its list
-    auto flush_row = [&](int r) {
+    // Merging the queue of user row r (wave-uniform) into its list, in two halves so that the global round trips (the candidates' rows of the image, the
+    // user's pieces, the list, the item ids) run behind a stage of matrix work: flush_issue() snapshots the queue into registers, frees it and issues
+    // the loads; flush_complete() -- one stage later for the stage-end merges, at once for a full queue -- scores, packs, merges and stores.  One merge
+    // may be pending per wave; a row whose queue fills while its own merge is pending is completed first (flush_row), so no list update is lost.
+#ifdef ARL_TOPK2_PROF
+    long long Q_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, Q_t0 = clock64();
+#define T2_TICK(SLOT) { const long long Q_t = clock64(); Q_acc[SLOT] += Q_t - Q_t0; Q_t0 = Q_t; }
+#define T2_COUNT(SLOT, N) { Q_acc[SLOT] += (N); }
+#else
+#define T2_TICK(SLOT)
+#define T2_COUNT(SLOT, N)
+#endif
+    int pend_r = -1, pend_m = 0;                                   // wave-uniform
+    unsigned p_pos = 0u, p_Kh = 0u, p_Kl = 0u;
+    int p_item = 0;
+    f16x8 p_fb[2][KS16];
+#if !ARL_TOPK2_UA_LATE
+    f16x8 p_ua[2][KS16];
+#endif
+    auto flush_issue = [&](int r) {
+#if ARL_TOPK2_EXP == 2
+        if (lane == 0) *(volatile lds_u32 *)(qcnt + r) = 0u;          // probe: appends only, queues dropped
+        return;
+#endif
         const int cnt = __builtin_amdgcn_readfirstlane((int)*(volatile lds_u32 *)(qcnt + r));
         const int m = min(cnt, kT2QCap);
         const int ur = u_base + r;
-        unsigned pos_l = 0u;
-        if (lane < m) pos_l = *(volatile lds_u32 *)(qpos + r * kT2QCap + lane);
-        unsigned Kh = 0u, Kl = 0u;
-        if (lane < k) { Kh = reinterpret_cast<const unsigned *>(top_val)[(size_t)ur * k + lane]; Kl = (unsigned)top_idx[(size_t)ur * k + lane]; }
-        const int pos_c = __shfl((int)pos_l, c);                   // 0 for columns without a candidate: row 0 of the image, never read back
+        p_pos = 0u;
+        if (lane < m) p_pos = *(volatile lds_u32 *)(qpos + r * kT2QCap + lane);
+        p_Kh = 0u; p_Kl = 0u;
+        if (lane < k) { p_Kh = reinterpret_cast<const unsigned *>(top_val)[(size_t)ur * k + lane]; p_Kl = (unsigned)top_idx[(size_t)ur * k + lane]; }
+        const int pos_c = __shfl((int)p_pos, c);                   // 0 for columns without a candidate: row 0 of the image, never read back
         const _Float16 *src = img + (size_t)pos_c * 2 * D + g * (KS16 * 8);
-        const _Float16 *usr = uimg + (size_t)ur * 2 * D + g * (KS16 * 8);
-        f16x8 fb[2][KS16], ua[2][KS16];
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-            for (int ks = 0; ks < KS16; ++ks) {
-                fb[pl][ks] = *reinterpret_cast<const f16x8 *>(src + pl * D + ks * 8);
-                ua[pl][ks] = *reinterpret_cast<const f16x8 *>(usr + pl * D + ks * 8);
-            }
-        int item = 0;
-        if (lane < m) item = item_order ? item_order[pos_l] : (int)pos_l;
+            for (int ks = 0; ks < KS16; ++ks) p_fb[pl][ks] = *reinterpret_cast<const f16x8 *>(src + pl * D + ks * 8);
+#if !ARL_TOPK2_UA_LATE
+        {
+            const _Float16 *usr = uimg + (size_t)ur * 2 * D + g * (KS16 * 8);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int ks = 0; ks < KS16; ++ks) p_ua[pl][ks] = *reinterpret_cast<const f16x8 *>(usr + pl * D + ks * 8);
+        }
+#endif
+        p_item = 0;
+        if (lane < m) p_item = item_order ? item_order[p_pos] : (int)p_pos;
         if (lane == 0) *(volatile lds_u32 *)(qcnt + r) = 0u;
+        pend_r = r; pend_m = m;
+    };
+    auto flush_complete = [&]() {
+        if (pend_r < 0) return;
+        const int r = pend_r, m = pend_m, ur = u_base + r;
+        pend_r = -1;
+        // the user's own pieces (every row of the 16 x 16 tile is this user; an L2 hit: the wave read these rows at its start): loaded here, not
+        // carried across the stage -- 16 registers the tile loop needs more
+#if ARL_TOPK2_UA_LATE
+        f16x8 p_ua[2][KS16];
+        {
+            const _Float16 *usr = uimg + (size_t)ur * 2 * D + g * (KS16 * 8);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int ks = 0; ks < KS16; ++ks) p_ua[pl][ks] = *reinterpret_cast<const f16x8 *>(usr + pl * D + ks * 8);
+        }
+#endif
         constexpr int TA[3] = {0, 1, 0}, TB3[3] = {1, 0, 0};       // the first form's order: ah*bl, al*bh, ah*bh
         f32x4 ca = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int term = 0; term < 3; ++term)
 #pragma unroll
-            for (int ks = 0; ks < KS16; ++ks) ca = __builtin_amdgcn_mfma_f32_16x16x32_f16(ua[TA[term]][ks], fb[TB3[term]][ks], ca, 0, 0, 0);
+            for (int ks = 0; ks < KS16; ++ks) ca = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_ua[TA[term]][ks], p_fb[TB3[term]][ks], ca, 0, 0, 0);
         // every row of the tile is user ur: lane j < 16 (k-group 0, register 0 = row 0) holds candidate j's score
         unsigned long long cj = 0ull;
         if (lane < m) {
             float sc = ca[0];
+            const int item = p_item;
             if (mrp) {
                 const unsigned hb = bloom_hash(item);
                 if ((bloom[r * kBloomWords + (hb >> 5)] >> (hb & 31u)) & 1u) {
@@ -3520,6 +3490,7 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
             }
             cj = pack_cand(sc, item);
         }
+        unsigned Kh = p_Kh, Kl = p_Kl;
         const unsigned long long Kk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)Kh, k - 1) << 32) | (unsigned)__builtin_amdgcn_readlane((int)Kl, k - 1);
         bool changed = false;
         for (unsigned long long todo = __ballot(lane < m && cj > Kk); todo != 0ull; todo &= todo - 1ull) {
@@ -3545,9 +3516,18 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
             thr = (n == r) ? nt : thr;
         }
     };
+    auto flush_row = [&](int r) { T2_TICK(1) flush_complete(); flush_issue(r); flush_complete(); T2_TICK(5) T2_COUNT(6, 1) };       // at once (a full queue; the end of the stream)
     auto flush_rows_with = [&](unsigned at_least) {
         const unsigned cn = lane < 32 ? *(volatile lds_u32 *)(qcnt + lane) : 0u;
         for (unsigned long long need = __ballot(cn >= at_least); need != 0ull; need &= need - 1ull) flush_row(__ffsll((long long)need) - 1);
+    };
+    // a slot of the pipelined merges (two per stage: after half of the tiles and at the end): the pending merge is completed, the next one -- a row whose
+    // queue has reached kT2QFlush -- is issued
+    auto flush_slot = [&]() {
+        flush_complete();
+        const unsigned cn = lane < 32 ? *(volatile lds_u32 *)(qcnt + lane) : 0u;
+        const unsigned long long need = __ballot(cn >= (unsigned)kT2QFlush);
+        if (need != 0ull) { flush_issue(__ffsll((long long)need) - 1); T2_COUNT(7, 1) }
     };
 
     // staging: global -> registers -> LDS, one stage ahead in registers, one in LDS
@@ -3567,28 +3547,87 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
             *reinterpret_cast<float4 *>(buf + (f / C16) * RS + (f % C16) * 16) = stg[p];
         }
     };
+    // Bootstrap (streams of >= 32 768 items): the first kT2BootItems items are scored once without lists.  A lane keeps the maxima of 32 disjoint item
+    // groups (its accumulator slots of a stage, over the sample's stages; the two half-waves see different rows): 64 group maxima of DISTINCT items per
+    // user.  The (k + m)-th largest -- m = the user's interacted items inside the sample, which the mask may take out -- minus E is a lower bound of the
+    // user's final k-th best score; selected per lane pair by a 32-step bisection over the order-preserving integer image of the floats.
+    if (boot) {
+        constexpr int NTL = MST / 32, GPT = 32 / NTL;              // tiles per stage, groups per tile and lane
+        float gm[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) gm[j] = -INFINITY;
+        const int nbs = kT2BootItems / MST;
+        gload(0);
+        lwrite(smem_raw);
+        gload(1);
+        __syncthreads();
+        for (int s = 0; s < nbs; ++s) {
+            const unsigned char *buf = smem_raw + (s & 1) * TB;
+            if (s + 1 < nbs) lwrite(smem_raw + ((s + 1) & 1) * TB);
+            if (s + 2 < nbs) gload(s + 2);
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) {
+                f16x8 af[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) af[ks] = *reinterpret_cast<const f16x8 *>(buf + (t * 32 + n) * RS + ks * 32 + h * 16);
+                f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bu[ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < GPT; ++q) {
+                    if constexpr (GPT == 8) gm[t * GPT + q] = fmaxf(gm[t * GPT + q], fmaxf(acc[2 * q], acc[2 * q + 1]));
+                    else gm[t * GPT + q] = fmaxf(gm[t * GPT + q], acc[q]);
+                }
+            }
+            __syncthreads();
+        }
+        int msk = 0;                                               // this user's interacted items inside the sample (both lanes of the pair compute it)
+        if (mrp != nullptr && u < U) {
+            const int b0 = mrp[u], e0 = mrp[u + 1];
+            if (item_pos != nullptr) {
+                for (int e = b0; e < e0; ++e) msk += item_pos[mcol[e]] < kT2BootItems;
+            } else {
+                int lo = b0, hi = e0;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (mcol[mid] < kT2BootItems) lo = mid + 1; else hi = mid; }
+                msk = lo - b0;
+            }
+        }
+        const int K = k + msk;
+        unsigned T = 0u;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned cand = T | (1u << bit);
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) { const unsigned b = __float_as_uint(gm[j]); cnt += ((b & 0x80000000u) ? ~b : (b | 0x80000000u)) >= cand; }
+            cnt += __shfl_xor(cnt, 32);
+            if (cnt >= K) T = cand;
+        }
+        float bound = -INFINITY;
+        if (K <= 64 && T != 0u) {
+            const unsigned b = (T & 0x80000000u) ? (T & 0x7fffffffu) : ~T;
+            bound = __uint_as_float(b) - fmaf(Ereg, stage_norm[(I + (D <= 64 ? 64 : 32) - 1) / (D <= 64 ? 64 : 32)], Eabs);
+            if (!(bound == bound)) bound = -INFINITY;
+        }
+        if (u < U) { thr0v = fmaxf(thr0v, bound); thr = thr0v; }
+    }
     gload(0);
     lwrite(smem_raw);
     if (nst > 1) gload(1);
     __syncthreads();
+    [[maybe_unused]] int exp_cnt = 0;
+    T2_TICK(9)
     for (int s = 0; s < nst; ++s) {
         const unsigned char *buf = smem_raw + (s & 1) * TB;
         if (s + 1 < nst) lwrite(smem_raw + ((s + 1) & 1) * TB);
         if (s + 2 < nst) gload(s + 2);
         unsigned pm[MST / 64];                                     // bit 16 * (t & 1) + i of pm[t / 2]: accumulator i of tile t passed
-#pragma unroll
-        for (int t = 0; t < MST / 32; ++t) {
-            f16x8 a[KS];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const f16x8 *>(buf + (t * 32 + n) * RS + ks * 32 + h * 16);
-            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], bu[ks], acc, 0, 0, 0);
+        constexpr int NTL = MST / 32;
+        auto masks = [&](int t, const f32x16 &acc) {
             const float sn = stage_norm[(s * MST + t * 32) >> (D <= 64 ? 6 : 5)];      // the largest scaled item norm of the tile's 64-item (32 at d = 128) stretch of the stream
             const float tf = thr - fmaf(Ereg, sn, Eabs);
             unsigned fails = 0u;
 #pragma unroll
-            for (int i = 15; i >= 0; --i) fails = __builtin_amdgcn_alignbit(fails, __float_as_uint(acc[i] - tf), 31);     // sign(score - threshold): NaN and -inf thresholds pass, +inf never
+            for (int i = 15; i >= 0; --i) fails = __builtin_amdgcn_alignbit(fails, __float_as_uint(acc[i] - tf), 31);     // sign(score - threshold): -inf thresholds pass, +inf never
             unsigned p16 = ~fails & 0xffffu;
             if (s == nst - 1) {                                    // rows past I
 #pragma unroll
@@ -3596,7 +3635,24 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
                     if (s * MST + t * 32 + 8 * (i >> 2) + 4 * h + (i & 3) >= I) p16 &= ~(1u << i);
             }
             if (t & 1) pm[t / 2] |= p16 << 16; else pm[t / 2] = p16;
+        };
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+            f16x8 af[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) af[ks] = *reinterpret_cast<const f16x8 *>(buf + (t * 32 + n) * RS + ks * 32 + h * 16);
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bu[ks], acc, 0, 0, 0);
+            masks(t, acc);
+            if (NTL >= 4 && t == NTL / 2 - 1) flush_slot();        // mid-stage slot: the pending merge has had half a stage of matrix work to land
         }
+        // (a software pipeline over the tiles -- two accumulator sets, the pre-filter of tile t - 1 behind the MFMAs of tile t -- was tried: 61 ms, the
+        // second set does not fit 128 registers beside a pending merge)
+        T2_TICK(0)
+#ifdef ARL_TOPK2_PROF
+        { int pc = 0; for (int q = 0; q < MST / 64; ++q) pc += __popc(pm[q]); for (int off = 32; off > 0; off >>= 1) pc += __shfl_xor(pc, off); T2_COUNT(8, pc) Q_t0 = clock64(); }
+#endif
         // appends: one candidate per lane and round
         for (;;) {
             bool have = false;
@@ -3623,15 +3679,28 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
             }
             if (__builtin_amdgcn_ballot_w64(ovf) != 0ull) flush_rows_with((unsigned)kT2QCap);
         }
-        flush_rows_with((unsigned)kT2QFlush);
+        // stage end: the merge issued a stage ago is completed, the next one (a row whose queue has reached kT2QFlush) is issued
+        T2_TICK(1)
+        flush_slot();
+        T2_TICK(3)
         __syncthreads();
+        T2_TICK(4)
     }
+    flush_complete();
     flush_rows_with(1u);
+#if ARL_TOPK2_EXP == 1
+    if (u < U && h == 0) top_idx[(size_t)u * k] = exp_cnt;
+    return;
+#endif
     if (stats != nullptr && tid == 0) {                            // (the first form's counters, in its 64- / 32-item stages: nothing skipped)
         atomicAdd(stats, (unsigned long long)((I + (D <= 64 ? 64 : 32) - 1) / (D <= 64 ? 64 : 32)));
         atomicAdd(stats + 1, 1ull);
     }
     __threadfence();
+#ifdef ARL_TOPK2_PROF
+    if (lane < 10 && u_base < U) top_val[(size_t)u_base * k + lane] = (float)Q_acc[0 + lane];      // (dynamic index: the compiler keeps the array in scratch -- a profiling build)
+    return;
+#endif
     for (int r = 0; r < 32; ++r) {
         const int ur = u_base + r;
         if (ur < U && lane < k) {
@@ -4971,24 +5040,20 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
             hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)((nu + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, Pu, nu, (int)d, max_bits + 1, uimg, (const int32_t *)nullptr);
             ARL_LAUNCH_CHECK();
             const bool boot = I >= 32768;
-            const int nst1 = (int)((I + mst - 1) / mst);
             const size_t shm2 = t2_lds_bytes((int)d, mask_rowptr != nullptr);
-            const unsigned grid2 = (unsigned)((U + kT2Users - 1) / kT2Users), gridb = (unsigned)((U + 32 * kWavesPerBlock - 1) / (32 * kWavesPerBlock));
+            const unsigned grid2 = (unsigned)((U + kT2Users - 1) / kT2Users);
             const int *g2 = exit_mode != 0 ? (const int *)(pick_d + 1) : (const int *)nullptr;
 #define ARL_TOPK2_PASS(DV, WARMF, GATE)                                                                                                \
             do {                                                                                                                       \
                 if (WARMF) {                                                                                                           \
                     hipLaunchKernelGGL(topk2_warm_kernel, dim3(grid_for(U, kWavesPerBlock, 8192u)), dim3(kBlock), 0, st, Pu, Pi, (int)U, (int)I, (int)d, (int)k, warm_idx, max_bits, thr0, GATE, g2); \
-                } else if (!boot) {                                                                                                    \
-                    if (hipMemsetD32Async((hipDeviceptr_t)thr0, (int)0xff800000u, (size_t)U, st) != hipSuccess) return ARL_E_ARG;     \
+                    ARL_LAUNCH_CHECK();                                                                                                \
                 }                                                                                                                      \
-                if (boot) hipLaunchKernelGGL((topk2_boot_kernel<DV>), dim3(gridb), dim3(kBlock), 0, st, (const _Float16 *)uimg, (const _Float16 *)workspace, (int)U, (int)I, mask_rowptr, mask_col, \
-                                             (int)k, (const int32_t *)pos_d, max_bits, (const float *)(snorm_d + nst1), thr0, (WARMF) ? 1 : 0, GATE, g2); \
-                ARL_LAUNCH_CHECK();                                                                                                    \
                 hipError_t em2 = hipFuncSetAttribute((const void *)topk2_main_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2); \
                 if (em2 != hipSuccess) return (int)em2;                                                                                \
                 hipLaunchKernelGGL((topk2_main_kernel<DV>), dim3(grid2), dim3(64 * kT2Waves), shm2, st, (const _Float16 *)uimg, (const _Float16 *)workspace, (int)U, (int)I, mask_rowptr, mask_col, \
-                                   (int)k, top_idx, top_val, (const float *)thr0, underflow, (WARMF) ? 1 : 0, max_bits, order_d, GATE, (const float *)snorm_d, stats_d, g2); \
+                                   (int)k, top_idx, top_val, (WARMF) ? (const float *)thr0 : (const float *)nullptr, underflow, (WARMF) ? 1 : 0, max_bits, order_d, GATE, (const float *)snorm_d, \
+                                   stats_d, g2, boot ? 1 : 0, (const int32_t *)pos_d);                                                 \
                 ARL_LAUNCH_CHECK();                                                                                                    \
             } while (0)
 #define ARL_TOPK2_CALL(DV)                                                                                                             \
