@@ -3295,16 +3295,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 constexpr int kT2Waves = 16;                       // waves per workgroup
 constexpr int kT2Users = 32 * kT2Waves;            // users per workgroup
+constexpr int kT2Ring = 3;                         // staged item tiles in LDS
 constexpr int kT2QCap = 16;                        // queue slots per user (the candidates of one merge are the columns of one 16 x 16 tile)
 #ifndef ARL_TOPK2_QFLUSH
 #define ARL_TOPK2_QFLUSH 12
 #endif
 constexpr int kT2QFlush = ARL_TOPK2_QFLUSH;        // a row's queue is merged at the end of a stage once it holds this many
-constexpr int kT2BootItems = 4096;                 // sample of the bootstrap kernel (streams of >= 32 768 items)
+#ifndef ARL_TOPK2_BOOT_ITEMS
+#define ARL_TOPK2_BOOT_ITEMS 16384
+#endif
+constexpr int kT2BootItems = ARL_TOPK2_BOOT_ITEMS; // sample of the bootstrap phase (streams of >= 32 768 items; a multiple of 128)
 __host__ __device__ constexpr int t2_mst(int D) { return D <= 64 ? 128 : 64; }       // items per stage
 __host__ __device__ constexpr int t2_rs(int D) { return D * 2 + 16; }                // LDS bytes per staged item row: the high pieces + 16 (conflict-free ds_read_b128 over 16 rows)
 __host__ __device__ constexpr size_t t2_lds_bytes(int D, bool masked) {
-    return 2 * (size_t)t2_mst(D) * t2_rs(D) + sizeof(unsigned) * kT2Users * (1 + kT2QCap) + (masked ? sizeof(unsigned) * kT2Users * kBloomWords : 0);
+    return kT2Ring * (size_t)t2_mst(D) * t2_rs(D) + 64 + sizeof(unsigned) * kT2Users * (1 + kT2QCap) + (masked ? sizeof(unsigned) * kT2Users * kBloomWords : 0);
 }
 
 // starting thresholds from the warm-start candidates (first form: the WARM prologue): thr0[u] = the lowest of the k candidates' fp32 scores, lowered by
@@ -3352,7 +3356,8 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
     constexpr int PER = MST * C16 / NT;
     static_assert(MST * C16 % NT == 0 && PER >= 1, "every thread moves the same number of pieces");
     extern __shared__ unsigned char smem_raw[];
-    unsigned *qcnt_all = reinterpret_cast<unsigned *>(smem_raw + 2 * TB);
+    unsigned *ring_ctr = reinterpret_cast<unsigned *>(smem_raw + kT2Ring * TB);      // fill[kT2Ring], done[kT2Ring] (the main stream's ring, below)
+    unsigned *qcnt_all = ring_ctr + 16;
     unsigned *qpos_all = qcnt_all + kT2Users;
     unsigned *bloom_all = qpos_all + kT2Users * kT2QCap;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -3556,7 +3561,7 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
         float gm[32];
 #pragma unroll
         for (int j = 0; j < 32; ++j) gm[j] = -INFINITY;
-        const int nbs = kT2BootItems / MST;
+        const int nbs = boot / MST;                                // boot = the sample's size in items (a multiple of 128)
         gload(0);
         lwrite(smem_raw);
         gload(1);
@@ -3585,10 +3590,10 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
         if (mrp != nullptr && u < U) {
             const int b0 = mrp[u], e0 = mrp[u + 1];
             if (item_pos != nullptr) {
-                for (int e = b0; e < e0; ++e) msk += item_pos[mcol[e]] < kT2BootItems;
+                for (int e = b0; e < e0; ++e) msk += item_pos[mcol[e]] < boot;
             } else {
                 int lo = b0, hi = e0;
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (mcol[mid] < kT2BootItems) lo = mid + 1; else hi = mid; }
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (mcol[mid] < boot) lo = mid + 1; else hi = mid; }
                 msk = lo - b0;
             }
         }
@@ -3610,16 +3615,43 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
         }
         if (u < U) { thr0v = fmaxf(thr0v, bound); thr = thr0v; }
     }
+    // The stream: a RING of kT2Ring staged tiles, no workgroup barrier in the loop.  Every wave writes ITS share of stage s + 1 into slot (s + 1) % ring once all
+    // waves have read the stage that occupied it (`done` counter), and consumes stage s once all shares of it are there (`fill` counter); counters only
+    // grow (stage t expects (t / ring + 1) * waves).  A wave may run up to ring - 1 stages ahead of the slowest: the merges come at random moments and take
+    // thousands of cycles -- behind a barrier per stage every one of them stalled the other fifteen waves (a third of the kernel was barrier wait).
+    // LDS executes one wave's operations in order, so a wave's tile writes are in place before its `fill` increment, its fragment reads before `done`'s.
+    unsigned *fill_ctr = ring_ctr, *done_ctr = ring_ctr + kT2Ring;
+    if (tid < 2 * kT2Ring) ring_ctr[tid] = 0u;
+    __syncthreads();                                               // (also: the bootstrap's last tile has been read by every wave)
+    auto ring_wait = [&](unsigned *ctr, unsigned want) {
+        int spins = 0;
+        while ((unsigned)__builtin_amdgcn_readfirstlane((int)*(volatile lds_u32 *)ctr) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 26)) __builtin_trap();             // never reached: every wave signals every stage; a trap beats a hang
+        }
+        asm volatile("" ::: "memory");
+    };
+    auto ring_signal = [&](unsigned *ctr) {
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add((lds_u32 *)ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     gload(0);
     lwrite(smem_raw);
+    ring_signal(fill_ctr + 0);
     if (nst > 1) gload(1);
-    __syncthreads();
     [[maybe_unused]] int exp_cnt = 0;
     T2_TICK(9)
     for (int s = 0; s < nst; ++s) {
-        const unsigned char *buf = smem_raw + (s & 1) * TB;
-        if (s + 1 < nst) lwrite(smem_raw + ((s + 1) & 1) * TB);
+        const unsigned char *buf = smem_raw + (s % kT2Ring) * TB;
+        if (s + 1 < nst) {
+            const int t = s + 1, sl = t % kT2Ring;
+            ring_wait(done_ctr + sl, (unsigned)kT2Waves * (unsigned)(t / kT2Ring));      // the stage that held this slot has been read by every wave
+            lwrite(smem_raw + sl * TB);
+            ring_signal(fill_ctr + sl);
+        }
         if (s + 2 < nst) gload(s + 2);
+        ring_wait(fill_ctr + s % kT2Ring, (unsigned)kT2Waves * (unsigned)(s / kT2Ring + 1));
+        T2_TICK(4)
         unsigned pm[MST / 64];                                     // bit 16 * (t & 1) + i of pm[t / 2]: accumulator i of tile t passed
         constexpr int NTL = MST / 32;
         auto masks = [&](int t, const f32x16 &acc) {
@@ -3647,11 +3679,15 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
             masks(t, acc);
             if (NTL >= 4 && t == NTL / 2 - 1) flush_slot();        // mid-stage slot: the pending merge has had half a stage of matrix work to land
         }
+        ring_signal(done_ctr + s % kT2Ring);                        // this wave's fragment reads of the stage are done
         // (a software pipeline over the tiles -- two accumulator sets, the pre-filter of tile t - 1 behind the MFMAs of tile t -- was tried: 61 ms, the
         // second set does not fit 128 registers beside a pending merge)
         T2_TICK(0)
 #ifdef ARL_TOPK2_PROF
         { int pc = 0; for (int q = 0; q < MST / 64; ++q) pc += __popc(pm[q]); for (int off = 32; off > 0; off >>= 1) pc += __shfl_xor(pc, off); T2_COUNT(8, pc) Q_t0 = clock64(); }
+#endif
+#if ARL_TOPK2_EXP == 1
+        { for (int q = 0; q < MST / 64; ++q) exp_cnt += __popc(pm[q]); continue; }      // probe: scores + masks only
 #endif
         // appends: one candidate per lane and round
         for (;;) {
@@ -3683,8 +3719,6 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
         T2_TICK(1)
         flush_slot();
         T2_TICK(3)
-        __syncthreads();
-        T2_TICK(4)
     }
     flush_complete();
     flush_rows_with(1u);
@@ -3697,10 +3731,6 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
         atomicAdd(stats + 1, 1ull);
     }
     __threadfence();
-#ifdef ARL_TOPK2_PROF
-    if (lane < 10 && u_base < U) top_val[(size_t)u_base * k + lane] = (float)Q_acc[0 + lane];      // (dynamic index: the compiler keeps the array in scratch -- a profiling build)
-    return;
-#endif
     for (int r = 0; r < 32; ++r) {
         const int ur = u_base + r;
         if (ur < U && lane < k) {
@@ -3711,6 +3741,9 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
             if (warm && lane == k - 1 && key == 0ull) atomicOr(underflow, 1);
         }
     }
+#ifdef ARL_TOPK2_PROF
+    if (lane < 10 && u_base < U) top_val[(size_t)u_base * k + lane] = (float)Q_acc[0 + lane];      // (over the first user's values; top_idx stays valid.  Dynamic index: the array lives in scratch -- a profiling build)
+#endif
 }
 
 // ================================================================================================
@@ -4943,6 +4976,13 @@ int64_t arl_score_mask_topk_stats_offset(int64_t I, int64_t d) {
     return (4 * I * d + 16 + 4 * I + 4 * (2 * nst + 2) + 7) / 8 * 8;
 }
 
+static int t2_env_items(const char *name, int dflt) {     // developer knob: bootstrap sample in items (0 or a multiple of 128, at most 32 768)
+    const char *e = getenv(name);
+    if (!e) return dflt;
+    const int v = atoi(e);
+    return (v < 0 || v > 32768 || (v & 127)) ? dflt : v;
+}
+
 int64_t arl_score_mask_topk_user_workspace_bytes(int64_t U, int64_t d) { return (U <= 0 || d <= 0) ? 0 : 4 * U * d + 4 * U + 64; }
 
 int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t I, int64_t d, const int32_t *mask_rowptr, const int32_t *mask_col,
@@ -5040,6 +5080,9 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
             hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)((nu + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, Pu, nu, (int)d, max_bits + 1, uimg, (const int32_t *)nullptr);
             ARL_LAUNCH_CHECK();
             const bool boot = I >= 32768;
+            // bootstrap sample: a cold pass gains from a large one (fewer candidates, no burst of merges while the sample is re-scored); a warm-started
+            // pass already has near-final thresholds and takes the small one as a safety net against stale candidates
+            static const int boot_cold = t2_env_items("ARL_TOPK2_BOOT_COLD", kT2BootItems), boot_warm = t2_env_items("ARL_TOPK2_BOOT_WARM", 4096);
             const size_t shm2 = t2_lds_bytes((int)d, mask_rowptr != nullptr);
             const unsigned grid2 = (unsigned)((U + kT2Users - 1) / kT2Users);
             const int *g2 = exit_mode != 0 ? (const int *)(pick_d + 1) : (const int *)nullptr;
@@ -5053,7 +5096,7 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
                 if (em2 != hipSuccess) return (int)em2;                                                                                \
                 hipLaunchKernelGGL((topk2_main_kernel<DV>), dim3(grid2), dim3(64 * kT2Waves), shm2, st, (const _Float16 *)uimg, (const _Float16 *)workspace, (int)U, (int)I, mask_rowptr, mask_col, \
                                    (int)k, top_idx, top_val, (WARMF) ? (const float *)thr0 : (const float *)nullptr, underflow, (WARMF) ? 1 : 0, max_bits, order_d, GATE, (const float *)snorm_d, \
-                                   stats_d, g2, boot ? 1 : 0, (const int32_t *)pos_d);                                                 \
+                                   stats_d, g2, boot ? ((WARMF) ? boot_warm : boot_cold) : 0, (const int32_t *)pos_d);                 \
                 ARL_LAUNCH_CHECK();                                                                                                    \
             } while (0)
 #define ARL_TOPK2_CALL(DV)                                                                                                             \

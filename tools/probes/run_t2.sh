@@ -14,7 +14,7 @@ import collections
 d = collections.defaultdict(list)
 for r in rows:
     nm = r['Kernel_Name']
-    if 'topk' in nm or 'split_f16' in nm:
+    if "topk" in nm:
         d[nm.split('(')[0][-60:]].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6)
 for k, v in d.items():
     print('   %-62s %s' % (k, ' '.join('%.2f' % x for x in v)))
