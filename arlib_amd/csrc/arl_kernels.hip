@@ -3251,7 +3251,9 @@ __global__ __launch_bounds__(64 * topk_waves(D, SPLIT), ARL_TOPK_MIN_WAVES_EU) v
             const unsigned long long key = ((unsigned long long)tk_hi[r] << 32) | tk_lo[r];
             top_idx[(size_t)u * k + lane] = cand_item(key);
             top_val[(size_t)u * k + lane] = cand_score(key) * score_unscale;
-            if (WARM && lane == k - 1 && key == 0ull) atomicOr(underflow, 1);          // the warm threshold excluded too much
+            // the warm threshold excluded too much: the list ends short -- or with an interacted item's -10e8, which only belongs there when fewer than k
+            // other items exist (a warm candidate that has become interacted can set a threshold above every free item; the repeat is then cold)
+            if (WARM && lane == k - 1 && (key == 0ull || cand_score(key) <= -5e8f * score_scale)) atomicOr(underflow, 1);
         }
     }
 #ifdef ARL_TOPK_PROF
@@ -3738,7 +3740,7 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
             const unsigned long long key = ((unsigned long long)kh << 32) | kl;
             top_idx[(size_t)ur * k + lane] = cand_item(key);
             top_val[(size_t)ur * k + lane] = cand_score(key) * score_unscale;
-            if (warm && lane == k - 1 && key == 0ull) atomicOr(underflow, 1);
+            if (warm && lane == k - 1 && (key == 0ull || cand_score(key) <= -5e8f * score_scale)) atomicOr(underflow, 1);      // (as the first form)
         }
     }
 #ifdef ARL_TOPK2_PROF

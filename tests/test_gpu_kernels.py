@@ -836,6 +836,52 @@ def test_score_mask_topk_early_exit_is_exact_and_one_user_keeps_the_stream_alive
     assert frac[3] > frac[1] + 0.5 / n_wg and frac[3] > 0.8, frac
 
 
+@pytest.mark.parametrize('I', [5000, 40000])
+@pytest.mark.parametrize('k', [1, 50, 64])
+@pytest.mark.parametrize('masked', [False, True])
+def test_score_mask_topk_second_form_equals_first_form(ops, I, k, masked):
+    """The two forms of the fp16 split stream at d = 64 (arl_kernels.hip: score_mask_topk_mfma16_kernel / topk2_main_kernel; the second needs the user
+    workspace): 32 users per wave on 32 x 32 tiles with the items as rows, bit-mask pre-filter, counter ring of three tiles, lists kept in the outputs,
+    bootstrap by group maxima, pipelined merges -- same candidates' exact three-product scores, same keys: indices AND values bit-identical, cold and
+    warm-started (also from deliberately stale candidates), masked or not, with and without the bootstrap phase (I >= 32 768), a ragged last workgroup
+    (1 300 users = 2 x 512 + 276), and popularity-skewed norms so that thresholds differ wildly between users."""
+    rng = np.random.default_rng(9100 + I + k + masked)
+    U, d = 1300, 64
+    Pu = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    Pi = (rng.standard_normal((I, d)) * 0.1 * (rng.pareto(2.0, I) + 0.1)[:, None]).astype(np.float32)
+    rp = mc = None
+    if masked:
+        sc = Pu @ Pi.T
+        cols = [np.unique(np.concatenate([np.argsort(-sc[u])[:int(rng.integers(0, 40))], rng.choice(I, size=int(rng.integers(0, 30)), replace=False)])).astype(np.int32) for u in range(U)]
+        rp = T(np.concatenate([[0], np.cumsum([len(c) for c in cols])]).astype(np.int32)); mc = T(np.concatenate(cols) if sum(len(c) for c in cols) else np.zeros(0, np.int32))
+    out = {}
+    for form2 in (False, True):
+        ops.TOPK_FORM2 = form2
+        ops.reset_exit_probe()
+        try:
+            i_c, v_c = ops.score_mask_topk(T(Pu), T(Pi), k, rp, mc)
+            i_w, v_w = ops.score_mask_topk(T(Pu), T(Pi), k, rp, mc, warm_idx=i_c)
+            stale = torch.from_numpy(np.stack([rng.choice(I, size=k, replace=False) for _ in range(U)]).astype(np.int32)).cuda()      # random candidates: valid but useless thresholds
+            i_s, v_s = ops.score_mask_topk(T(Pu), T(Pi), k, rp, mc, warm_idx=stale)
+            i_t, v_t = ops.score_mask_topk(T(Pu), T(Pi), k, rp, mc, item_order=None)
+        finally:
+            ops.TOPK_FORM2 = True
+        out[form2] = (i_c, v_c)
+        for i_x, v_x in ((i_w, v_w), (i_s, v_s), (i_t, v_t)):
+            assert torch.equal(i_x, i_c) and torch.equal(v_x, v_c)
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+    ref = torch.topk((T(Pu).double() @ T(Pi).double().T) if not masked else _masked_scores(Pu, Pi, rp, mc), k, dim=1)
+    got_v = out[True][1].double()
+    assert (got_v - ref.values).abs().max().item() <= 2e-6 * max(1e-3, ref.values.abs().max().item())      # and float64's values (at least k unmasked items everywhere)
+
+
+def _masked_scores(Pu, Pi, rp, mc):
+    sc = T(Pu).double() @ T(Pi).double().T
+    rows = torch.repeat_interleave(torch.arange(sc.shape[0], device=sc.device), (rp[1:] - rp[:-1]).long())
+    sc[rows, mc.long()] = -10e8
+    return sc
+
+
 @pytest.mark.parametrize('F,I,d', [(64, 100000, 64), (5, 777, 32), (130, 301, 128), (64, 1000, 16), (1, 4, 4), (7, 12345, 256)])
 def test_fake_block_products(ops, F, I, d):
     """The F x I fake-user block of the poisoned adjacency as two dense products (attack/White/PGA.py:118-134) against float64."""
