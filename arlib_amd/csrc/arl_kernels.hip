@@ -3292,6 +3292,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef ARL_TOPK2_UA_LATE
 #define ARL_TOPK2_UA_LATE 1                        // the user's pieces of a merge are loaded when it completes (1) or carried with the pending state (0: 16 registers more)
 #endif
+#ifndef ARL_TOPK2_PREFETCH
+#define ARL_TOPK2_PREFETCH 0
+#endif
 #ifndef ARL_TOPK2_D128
 #define ARL_TOPK2_D128 0
 #endif
@@ -3670,6 +3673,27 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
             }
             if (t & 1) pm[t / 2] |= p16 << 16; else pm[t / 2] = p16;
         };
+#if ARL_TOPK2_PREFETCH
+        // the fragment reads of tile t + 1 are issued right behind the MFMAs of tile t, into the same registers (the hardware orders the overwrite behind
+        // the MFMAs' operand reads): their LDS latency runs under the matrix work and the pre-filter of tile t
+        f16x8 af[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) af[ks] = *reinterpret_cast<const f16x8 *>(buf + n * RS + ks * 32 + h * 16);
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bu[ks], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < NTL) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) af[ks] = *reinterpret_cast<const f16x8 *>(buf + ((t + 1) * 32 + n) * RS + ks * 32 + h * 16);
+            } else ring_signal(done_ctr + s % kT2Ring);            // this wave's fragment reads of the stage are done (issued: LDS executes a wave's operations in order)
+            __builtin_amdgcn_sched_barrier(0);
+            masks(t, acc);
+            if (NTL >= 4 && t == NTL / 2 - 1) flush_slot();        // mid-stage slot: the pending merge has had half a stage of matrix work to land
+        }
+#else
 #pragma unroll
         for (int t = 0; t < NTL; ++t) {
             f16x8 af[KS];
@@ -3682,6 +3706,7 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
             if (NTL >= 4 && t == NTL / 2 - 1) flush_slot();        // mid-stage slot: the pending merge has had half a stage of matrix work to land
         }
         ring_signal(done_ctr + s % kT2Ring);                        // this wave's fragment reads of the stage are done
+#endif
         // (a software pipeline over the tiles -- two accumulator sets, the pre-filter of tile t - 1 behind the MFMAs of tile t -- was tried: 61 ms, the
         // second set does not fit 128 registers beside a pending merge)
         T2_TICK(0)

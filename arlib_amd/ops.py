@@ -1356,7 +1356,7 @@ def score_mask_topk(Pu, Pi, k, mask_rowptr=None, mask_col=None, exact=False, war
         nst = (I + (64 if d <= 64 else 32) - 1) // (64 if d <= 64 else 32)
         mode, probe = _exit_mode((U, I, d, k, mask_rowptr is not None), ws, soff, nst, Pu.device)
     uws = None
-    if ws is not None and d == 64 and TOPK_FORM2:           # the second form of the stream (32 users per wave, lists kept in the outputs): needs the user workspace
+    if ws is not None and TOPK_FORM2 and (d == 64 or (d == 128 and os.environ.get('ARL_TOPK_FORM2_D128') == '1')):      # (d = 128: developer builds with -DARL_TOPK2_D128=1 only)           # the second form of the stream (32 users per wave, lists kept in the outputs): needs the user workspace
         uws = torch.empty(_lib.lib().arl_score_mask_topk_user_workspace_bytes(U, d), dtype=torch.uint8, device=Pu.device)
     check(_lib.lib().arl_score_mask_topk_f32(_ptr(Pu), _ptr(Pi), U, I, d, _ptr(mask_rowptr), _ptr(mask_col), k, _ptr(idx), _ptr(val), _ptr(ws),
                                              _ptr(warm_idx), _ptr(flag), _ptr(order), mode, _ptr(uws), _stream()), 'arl_score_mask_topk_f32')
