@@ -3313,7 +3313,7 @@ constexpr int kT2BootItems = ARL_TOPK2_BOOT_ITEMS; // sample of the bootstrap ph
 __host__ __device__ constexpr int t2_mst(int D) { return D <= 64 ? 128 : 64; }       // items per stage
 __host__ __device__ constexpr int t2_rs(int D) { return D * 2 + 16; }                // LDS bytes per staged item row: the high pieces + 16 (conflict-free ds_read_b128 over 16 rows)
 __host__ __device__ constexpr size_t t2_lds_bytes(int D, bool masked) {
-    return kT2Ring * (size_t)t2_mst(D) * t2_rs(D) + 64 + sizeof(unsigned) * kT2Users * (1 + kT2QCap) + (masked ? sizeof(unsigned) * kT2Users * kBloomWords : 0);
+    return kT2Ring * (size_t)t2_mst(D) * t2_rs(D) + 128 + sizeof(unsigned) * kT2Users * (1 + kT2QCap) + (masked ? sizeof(unsigned) * kT2Users * kBloomWords : 0);
 }
 
 // starting thresholds from the warm-start candidates (first form: the WARM prologue): thr0[u] = the lowest of the k candidates' fp32 scores, lowered by
@@ -3346,7 +3346,7 @@ __global__ __launch_bounds__(kBlock) void topk2_warm_kernel(const float *__restr
     }
 }
 
-template <int D>
+template <int D, bool XIT>
 __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float16 *__restrict__ uimg, const _Float16 *__restrict__ img, int U, int I,
                                                                   const int32_t *__restrict__ mrp, const int32_t *__restrict__ mcol, int k,
                                                                   int32_t *__restrict__ top_idx, float *__restrict__ top_val, const float *__restrict__ thr0,
@@ -3362,7 +3362,7 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
     static_assert(MST * C16 % NT == 0 && PER >= 1, "every thread moves the same number of pieces");
     extern __shared__ unsigned char smem_raw[];
     unsigned *ring_ctr = reinterpret_cast<unsigned *>(smem_raw + kT2Ring * TB);      // fill[kT2Ring], done[kT2Ring] (the main stream's ring, below)
-    unsigned *qcnt_all = ring_ctr + 16;
+    unsigned *qcnt_all = ring_ctr + 32;                            // ([6] the early exit's stop stage, [8 .. 8 + waves) one "finished" word per wave)
     unsigned *qpos_all = qcnt_all + kT2Users;
     unsigned *bloom_all = qpos_all + kT2Users * kT2QCap;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -3626,8 +3626,25 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
     // thousands of cycles -- behind a barrier per stage every one of them stalled the other fifteen waves (a third of the kernel was barrier wait).
     // LDS executes one wave's operations in order, so a wave's tile writes are in place before its `fill` increment, its fragment reads before `done`'s.
     unsigned *fill_ctr = ring_ctr, *done_ctr = ring_ctr + kT2Ring;
-    if (tid < 2 * kT2Ring) ring_ctr[tid] = 0u;
+    if (tid < 32) ring_ctr[tid] = tid == 6 ? 0x7fffffffu : 0u;
     __syncthreads();                                               // (also: the bootstrap's last tile has been read by every wave)
+    // XIT: the exact early exit of the norm-ordered stream, as in the first form (bound: kExitK above).  Row r is FINISHED at stage s when no item of a later
+    // stage can pass its pre-filter: kExitK * Ereg_r * sufmax(next stage) + 2 Eabs < threshold_r; thresholds only rise, suffix maxima only fall.  Every 8th
+    // stage a wave whose 32 rows are finished sets its word and looks at all 16; a wave that finds them all set, at the END of its step s, lowers `stop` to
+    // s + 2 (atomic minimum) and then sets the top bit of the fill counters.  Stage s + 2 is filled only once every wave has run the head of step s + 1 --
+    // the publisher after its atomics (one wave's LDS operations execute in order) -- so nobody has consumed it yet, and whoever polls its fill counter sees
+    // the bit, reads `stop` and leaves the loop there: all waves consume exactly the stages below `stop`, the shares of every such stage are written by
+    // every wave as before, and the stages skipped could not have produced a candidate -- lists, values and tie order are the full stream's.
+    [[maybe_unused]] auto ring_wait_flag = [&](unsigned *ctr, unsigned want) -> bool {
+        unsigned v;
+        int spins = 0;
+        while (v = (unsigned)__builtin_amdgcn_readfirstlane((int)*(volatile lds_u32 *)ctr), (v & 0x7fffffffu) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 26)) __builtin_trap();
+        }
+        asm volatile("" ::: "memory");
+        return (v >> 31) != 0u;
+    };
     auto ring_wait = [&](unsigned *ctr, unsigned want) {
         int spins = 0;
         while ((unsigned)__builtin_amdgcn_readfirstlane((int)*(volatile lds_u32 *)ctr) < want) {
@@ -3646,6 +3663,7 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
     if (nst > 1) gload(1);
     [[maybe_unused]] int exp_cnt = 0;
     T2_TICK(9)
+    int s_end = nst;                                               // stages consumed (XIT: the stop stage)
     for (int s = 0; s < nst; ++s) {
         const unsigned char *buf = smem_raw + (s % kT2Ring) * TB;
         if (s + 1 < nst) {
@@ -3655,7 +3673,12 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
             ring_signal(fill_ctr + sl);
         }
         if (s + 2 < nst) gload(s + 2);
-        ring_wait(fill_ctr + s % kT2Ring, (unsigned)kT2Waves * (unsigned)(s / kT2Ring + 1));
+        if constexpr (XIT) {
+            if (ring_wait_flag(fill_ctr + s % kT2Ring, (unsigned)kT2Waves * (unsigned)(s / kT2Ring + 1))) {
+                const int stop = __builtin_amdgcn_readfirstlane((int)*(volatile lds_u32 *)(ring_ctr + 6));
+                if (s >= stop) { s_end = s; break; }               // wave-uniform; every wave of the workgroup leaves at this stage
+            }
+        } else ring_wait(fill_ctr + s % kT2Ring, (unsigned)kT2Waves * (unsigned)(s / kT2Ring + 1));
         T2_TICK(4)
         unsigned pm[MST / 64];                                     // bit 16 * (t & 1) + i of pm[t / 2]: accumulator i of tile t passed
         constexpr int NTL = MST / 32;
@@ -3707,8 +3730,9 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
         }
         ring_signal(done_ctr + s % kT2Ring);                        // this wave's fragment reads of the stage are done
 #endif
-        // (a software pipeline over the tiles -- two accumulator sets, the pre-filter of tile t - 1 behind the MFMAs of tile t -- was tried: 61 ms, the
-        // second set does not fit 128 registers beside a pending merge)
+        // (tried and dropped, r04_experiments.md 5: a software pipeline over the tiles with two accumulator sets -- 61 ms, the second set does not fit 128
+        // registers beside a pending merge; a wave-uniform bit mask of the rows whose queue has reached kT2QFlush, kept by the appends, instead of reading
+        // the 32 counters back in every merge slot, with a 64-bit form of the append loop -- 28.8 vs 27.4 ms)
         T2_TICK(0)
 #ifdef ARL_TOPK2_PROF
         { int pc = 0; for (int q = 0; q < MST / 64; ++q) pc += __popc(pm[q]); for (int off = 32; off > 0; off >>= 1) pc += __shfl_xor(pc, off); T2_COUNT(8, pc) Q_t0 = clock64(); }
@@ -3746,6 +3770,23 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
         T2_TICK(1)
         flush_slot();
         T2_TICK(3)
+        if constexpr (XIT) {
+            if ((s & 7) == 7) {
+                const int nst64 = (I + (D <= 64 ? 64 : 32) - 1) / (D <= 64 ? 64 : 32);
+                const int nx = min(((s + 1) * MST) >> (D <= 64 ? 6 : 5), nst64);       // the first later stretch of the stream, in the norm arrays' stages
+                const float kx = kExitK * stage_norm[nst64 + 1 + nx];                   // suffix maximum: the largest scaled norm of any later item (0 behind the end)
+                const bool fin = fmaf(Ereg, kx, 2.f * Eabs) < thr;                      // (+inf thresholds of users past U: finished; NaN never)
+                if (__builtin_amdgcn_ballot_w64(!fin) == 0ull) {
+                    unsigned *fw = ring_ctr + 8;
+                    if (lane == 0) *(volatile lds_u32 *)(fw + wv) = 1u;
+                    const unsigned seen = lane < kT2Waves ? *(volatile lds_u32 *)(fw + lane) : 1u;      // (after this wave's own store: in order)
+                    if (__builtin_amdgcn_ballot_w64(seen == 0u) == 0ull) {
+                        if (lane == 0) __hip_atomic_fetch_min((lds_u32 *)(ring_ctr + 6), (unsigned)(s + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (lane < kT2Ring) __hip_atomic_fetch_or((lds_u32 *)(fill_ctr + lane), 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (issued after the minimum)
+                    }
+                }
+            }
+        }
     }
     flush_complete();
     flush_rows_with(1u);
@@ -3753,8 +3794,9 @@ __global__ __launch_bounds__(64 * kT2Waves) void topk2_main_kernel(const _Float1
     if (u < U && h == 0) top_idx[(size_t)u * k] = exp_cnt;
     return;
 #endif
-    if (stats != nullptr && tid == 0) {                            // (the first form's counters, in its 64- / 32-item stages: nothing skipped)
-        atomicAdd(stats, (unsigned long long)((I + (D <= 64 ? 64 : 32) - 1) / (D <= 64 ? 64 : 32)));
+    if (stats != nullptr && tid == 0) {                            // (the first form's counters, in its 64- / 32-item stages)
+        const int nst64 = (I + (D <= 64 ? 64 : 32) - 1) / (D <= 64 ? 64 : 32);
+        atomicAdd(stats, (unsigned long long)min(s_end * (MST / (D <= 64 ? 64 : 32)), nst64));
         atomicAdd(stats + 1, 1ull);
     }
     __threadfence();
@@ -5108,39 +5150,40 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
             ARL_LAUNCH_CHECK();
             const bool boot = I >= 32768;
             // bootstrap sample: a cold pass gains from a large one (fewer candidates, no burst of merges while the sample is re-scored); a warm-started
-            // pass already has near-final thresholds and takes the small one as a safety net against stale candidates
+            // pass already has near-final thresholds and takes the small one as a safety net against stale candidates, and so does the exit build (it runs
+            // where most of the stream is skipped: a 16 K sample would be as long as what is left)
             static const int boot_cold = t2_env_items("ARL_TOPK2_BOOT_COLD", kT2BootItems), boot_warm = t2_env_items("ARL_TOPK2_BOOT_WARM", 4096);
             const size_t shm2 = t2_lds_bytes((int)d, mask_rowptr != nullptr);
             const unsigned grid2 = (unsigned)((U + kT2Users - 1) / kT2Users);
-            const int *g2 = exit_mode != 0 ? (const int *)(pick_d + 1) : (const int *)nullptr;
+#define ARL_TOPK2_MAIN(DV, XT, WARMF, GATE, GATE2)                                                                                      \
+            do {                                                                                                                       \
+                hipError_t em2 = hipFuncSetAttribute((const void *)topk2_main_kernel<DV, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2); \
+                if (em2 != hipSuccess) return (int)em2;                                                                                \
+                hipLaunchKernelGGL((topk2_main_kernel<DV, XT>), dim3(grid2), dim3(64 * kT2Waves), shm2, st, (const _Float16 *)uimg, (const _Float16 *)workspace, (int)U, (int)I, mask_rowptr, mask_col, \
+                                   (int)k, top_idx, top_val, (WARMF) ? (const float *)thr0 : (const float *)nullptr, underflow, (WARMF) ? 1 : 0, max_bits, order_d, GATE, (const float *)snorm_d, \
+                                   stats_d, GATE2, boot ? (((WARMF) || (XT)) ? boot_warm : boot_cold) : 0, (const int32_t *)pos_d);       \
+                ARL_LAUNCH_CHECK();                                                                                                    \
+            } while (0)
+            /* exit_mode = 1: both builds of the kernel (with / without the early exit) are launched, the device runs one (pick_d, see stage_sufmax_kernel) */
 #define ARL_TOPK2_PASS(DV, WARMF, GATE)                                                                                                \
             do {                                                                                                                       \
                 if (WARMF) {                                                                                                           \
-                    hipLaunchKernelGGL(topk2_warm_kernel, dim3(grid_for(U, kWavesPerBlock, 8192u)), dim3(kBlock), 0, st, Pu, Pi, (int)U, (int)I, (int)d, (int)k, warm_idx, max_bits, thr0, GATE, g2); \
+                    hipLaunchKernelGGL(topk2_warm_kernel, dim3(grid_for(U, kWavesPerBlock, 8192u)), dim3(kBlock), 0, st, Pu, Pi, (int)U, (int)I, (int)d, (int)k, warm_idx, max_bits, thr0, GATE, \
+                                       (const int *)nullptr);                                                                          \
                     ARL_LAUNCH_CHECK();                                                                                                \
                 }                                                                                                                      \
-                hipError_t em2 = hipFuncSetAttribute((const void *)topk2_main_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2); \
-                if (em2 != hipSuccess) return (int)em2;                                                                                \
-                hipLaunchKernelGGL((topk2_main_kernel<DV>), dim3(grid2), dim3(64 * kT2Waves), shm2, st, (const _Float16 *)uimg, (const _Float16 *)workspace, (int)U, (int)I, mask_rowptr, mask_col, \
-                                   (int)k, top_idx, top_val, (WARMF) ? (const float *)thr0 : (const float *)nullptr, underflow, (WARMF) ? 1 : 0, max_bits, order_d, GATE, (const float *)snorm_d, \
-                                   stats_d, g2, boot ? ((WARMF) ? boot_warm : boot_cold) : 0, (const int32_t *)pos_d);                 \
-                ARL_LAUNCH_CHECK();                                                                                                    \
+                if (exit_mode != 0) { ARL_TOPK2_MAIN(DV, true, WARMF, GATE, (const int *)pick_d); ARL_TOPK2_MAIN(DV, false, WARMF, GATE, (const int *)(pick_d + 1)); } \
+                else ARL_TOPK2_MAIN(DV, false, WARMF, GATE, (const int *)nullptr);                                                     \
             } while (0)
 #define ARL_TOPK2_CALL(DV)                                                                                                             \
             do {                                                                                                                       \
-                if (warm_idx) {                                                                                                        \
-                    if (exit_mode != 0) ARL_TOPK_CASE3(DV, true, true, true, warm_idx, (const int *)nullptr, (const int *)pick_d);     \
-                    ARL_TOPK2_PASS(DV, true, (const int *)nullptr);                                                                    \
-                    if (exit_mode != 0) ARL_TOPK_CASE3(DV, true, false, true, (const int32_t *)nullptr, (const int *)underflow, (const int *)pick_d); \
-                    ARL_TOPK2_PASS(DV, false, (const int *)underflow);                                                                 \
-                } else {                                                                                                               \
-                    if (exit_mode != 0) ARL_TOPK_CASE3(DV, true, false, true, (const int32_t *)nullptr, (const int *)nullptr, (const int *)pick_d); \
-                    ARL_TOPK2_PASS(DV, false, (const int *)nullptr);                                                                   \
-                }                                                                                                                      \
+                if (warm_idx) { ARL_TOPK2_PASS(DV, true, (const int *)nullptr); ARL_TOPK2_PASS(DV, false, (const int *)underflow); }  \
+                else ARL_TOPK2_PASS(DV, false, (const int *)nullptr);                                                                  \
             } while (0)
             if (d == 64) ARL_TOPK2_CALL(64); else ARL_TOPK2_CALL(128);
 #undef ARL_TOPK2_CALL
 #undef ARL_TOPK2_PASS
+#undef ARL_TOPK2_MAIN
         }
         else if (d == 16) ARL_TOPK_CASE(16, false);
         else if (d == 32) ARL_TOPK_CASE(32, false);

@@ -829,7 +829,7 @@ def test_score_mask_topk_early_exit_is_exact_and_one_user_keeps_the_stream_alive
     for r, c in np.argwhere(~same):
         assert abs(rval[r, c] - val[r, c]) <= 2e-6 * max(abs(rval[r, c]), 1e-3)
     assert np.abs(val[:, -1] - rval[:, -1]).max() <= 2e-6 * np.abs(rval[:, -1]).max()
-    n_wg = -(-U // (256 if d == 64 else 192))
+    n_wg = -(-U // (512 if d == 64 else 192))                      # users per workgroup: the second form at d = 64 (512), the first at d = 128
     assert frac[0] < 0.01                                          # table order: large items until the last stages, nothing to skip
     # norm order with the lone user: its workgroup consumes every stage, the others leave early; without it all of them do
     assert frac[1] > 0.5 * (n_wg - 1) / n_wg and frac[1] < (n_wg - 1) / n_wg + 1e-9, frac
