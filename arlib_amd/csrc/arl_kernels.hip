@@ -5142,6 +5142,7 @@ int arl_score_mask_topk_f32(const float *Pu, const float *Pi, int64_t U, int64_t
         // second form of the fp16 split stream (topk2_*): needs the caller's user workspace ([U][2][d] fp16 image of the users, then [U] starting thresholds)
         const bool form2 = split && kSplitMode == 2 && ARL_TOPK_REFINE && ARL_TOPK_QUEUE && ARL_TOPK2 && user_workspace != nullptr && (d == 64 || (d == 128 && ARL_TOPK2_D128));
         if (form2) {
+            if (((uintptr_t)user_workspace | (uintptr_t)workspace) & 15) return ARL_E_ARG;      // 16-byte fragment loads from both images
             hipStream_t st = (hipStream_t)stream;
             _Float16 *uimg = (_Float16 *)user_workspace;
             float *thr0 = reinterpret_cast<float *>(static_cast<char *>(user_workspace) + 4 * (size_t)U * (size_t)d);

@@ -423,12 +423,12 @@ int arl_pga_update_f32(float *S, const float *grad, const float *dinv_rows, cons
  * the kernel.  exit_mode = 1: both builds are launched and the device runs one of them, chosen from the items' norm profile (the exit build iff the
  * norms at 7/8 of the stream are below half of the 4096th largest); exit_mode = 0: the plain build alone (a caller that has seen the counters report
  * nothing skipped on these tables saves the 5 %).  Results are identical in every case.
- * user_workspace (optional; arl_score_mask_topk_user_workspace_bytes(U, d) bytes, fp16 matrix path, d = 64): selects the SECOND FORM of the stream --
+ * user_workspace (optional; arl_score_mask_topk_user_workspace_bytes(U, d) bytes, 16-byte aligned like the workspace; fp16 matrix path, d = 64): selects the SECOND FORM of the stream --
  * a wave owns 32 users and contracts 32 x 32 tiles with the items as rows, so that all of a lane's scores belong to one user and the pre-filter is one
  * subtract + one bit shift per score; 512 users share a staged tile; the sorted lists are kept in top_idx / top_val themselves while the pass runs;
  * the starting thresholds (bootstrap sample, warm-start candidates) come from two small launches of their own.  The workspace receives the split
  * image of Pu and the starting thresholds.  Candidates, exact scores, keys and tie order are those of the first form: results identical bit for bit,
- * 2-3x less time at 1 M x 100 K.  NULL: the first form.  (With exit_mode = 1 the exit build is the first form's; the device picks as before.) */
+ * 1.6x less time at 1 M x 100 K.  NULL: the first form.  (exit_mode = 1 launches the second form's own two builds; the device picks as before.) */
 int64_t arl_score_mask_topk_workspace_bytes(int64_t I, int64_t d);
 int64_t arl_score_mask_topk_user_workspace_bytes(int64_t U, int64_t d);
 int64_t arl_score_mask_topk_stats_offset(int64_t I, int64_t d);

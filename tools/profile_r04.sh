@@ -19,15 +19,14 @@ for f in fs:
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
 out = open('gpurun_out/prof_$TAG/clear_leg_sequence.txt', 'w')
-idx = [i for i, n in enumerate(names) if 'score_mask_topk_mfma16_kernel' in n and 'Lb1ELb1E' not in n or ('score_mask_topk_mfma16_kernel<64, true, true' in n)]
 seen = 0
 for i, n in enumerate(names):
-    if 'score_mask_topk_mfma16_kernel<64, true, true' in n:      # a warm-started scoring pass = one CLeaR step
+    if 'topk2_warm_kernel' in n:      # a warm-started scoring pass (second form of the stream) = one CLeaR step
         seen += 1
         if seen > 6:
             break
         out.write('---- step (warm scoring pass at launch %d)\n' % i)
-        for m in names[i:i + 40]:
+        for m in names[i:i + 48]:
             out.write('  ' + m[:150] + '\n')
             if 'sfa_grad_kernel' in m:
                 break
