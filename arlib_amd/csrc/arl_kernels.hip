@@ -3300,7 +3300,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 constexpr int kT2Waves = 16;                       // waves per workgroup
 constexpr int kT2Users = 32 * kT2Waves;            // users per workgroup
-constexpr int kT2Ring = 3;                         // staged item tiles in LDS
+#ifndef ARL_TOPK2_RING
+#define ARL_TOPK2_RING 3
+#endif
+constexpr int kT2Ring = ARL_TOPK2_RING;                         // staged item tiles in LDS
 constexpr int kT2QCap = 16;                        // queue slots per user (the candidates of one merge are the columns of one 16 x 16 tile)
 #ifndef ARL_TOPK2_QFLUSH
 #define ARL_TOPK2_QFLUSH 12
