@@ -10,4 +10,4 @@ python3 tools/topk_fuzz.py 400 2>&1 | tail -1 > $O/${T}_fuzz.txt
 python3 tools/misc_fuzz.py 150 2>&1 | tail -1 >> $O/${T}_fuzz.txt
 python3 tools/engine_fuzz.py 40 2>&1 | tail -1 >> $O/${T}_fuzz.txt
 python3 tools/spmm_fuzz.py 150 2>&1 | tail -1 >> $O/${T}_fuzz.txt
-tail -4 $O/${T}_topk_first_form.txt $O/${T}_topk_second_form.txt $O/${T}_fuzz.txt | grep -v "^$"
+for f in $O/${T}_topk_first_form.txt $O/${T}_topk_second_form.txt $O/${T}_fuzz.txt; do tail -4 $f; done
