@@ -192,6 +192,18 @@ def test_score_mask_topk_full_size_against_dense_rows(cfg2):
     rv, ri = torch.topk(sc, 50)
     assert (ri == idx[sample].long()).float().mean().item() > 0.999           # ties / last-ulp orderings aside
     assert torch.allclose(rv, val[sample], rtol=1e-5, atol=1e-7)
+    # size-independent properties: a warm start from the result changes nothing; the two forms of the fp16 stream (32 users per wave with the lists in the
+    # outputs / 16 users per wave with the lists in registers) agree bit for bit on all 50 M entries; so does the table-order stream
+    i_w, v_w = ops.score_mask_topk(Pu, Pi, 50, rp, mc, warm_idx=idx)
+    assert torch.equal(i_w, idx) and torch.equal(v_w, val)
+    ops.TOPK_FORM2 = False
+    try:
+        i_1, v_1 = ops.score_mask_topk(Pu, Pi, 50, rp, mc)
+    finally:
+        ops.TOPK_FORM2 = True
+    assert torch.equal(i_1, idx) and torch.equal(v_1, val)
+    i_t, v_t = ops.score_mask_topk(Pu, Pi, 50, rp, mc, item_order=None)
+    assert torch.equal(i_t, idx) and torch.equal(v_t, val)
 
 
 def test_sfa_full_size_against_float64_closed_form(cfg2):
